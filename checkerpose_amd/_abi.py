@@ -1,0 +1,69 @@
+"""ctypes binding of libcheckerpose_hip.so (C ABI: include/checkerpose_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcheckerpose_hip.so")
+
+CP_F32, CP_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+class CpConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("out_f32", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cin", C.c_int32), ("in_cstride", C.c_int32), ("in_coff", C.c_int32),
+                ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+                ("o_base", C.c_int64), ("o_sb", C.c_int64), ("o_sy", C.c_int64), ("o_sx", C.c_int64),
+                ("o_sc", C.c_int64)]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+
+# name -> (restype, argtypes); exactly the symbols declared in include/checkerpose_hip.h
+SIGNATURES = {
+    "cp_version": (_I, []),
+    "cp_strerror": (C.c_char_p, [_I]),
+    "cp_chan_align": (_I, [_I]),
+    "cp_packed_weight_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
+    "cp_pack_conv_weight": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "cp_conv2d_igemm": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
+    "cp_upsample2x_bilinear_ac": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I]),
+    "cp_maxpool3x3s2": (_I, [_P, _I, _P, _P, _I, _I, _I, _I]),
+    "cp_edgeconv_gather_max": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_bits_decode": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
+    "cp_nchw_to_nhwc": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I]),
+    "cp_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),
+    "cp_graph_begin_capture": (_I, [_P]),
+    "cp_graph_end_capture": (_I, [_P, C.POINTER(_P)]),
+    "cp_graph_launch": (_I, [_P, _P]),
+    "cp_graph_destroy": (_I, [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly if it was not built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("checkerpose_amd: HIP library %s is missing -- build it with "
+                               "`make -C checkerpose_amd/csrc` (there is no CPU/PyTorch fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so is stale: also loud
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().cp_strerror(code).decode()
+        raise RuntimeError("checkerpose_hip %s failed: %s (code %d)" % (what, msg, code))

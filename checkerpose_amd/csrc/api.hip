@@ -1,0 +1,43 @@
+// Version / error strings and hipGraph capture helpers of the C ABI.
+#include "common.h"
+
+extern "C" int cp_version(void) { return 100; }   // 0.1.0
+
+extern "C" const char* cp_strerror(int code) {
+  switch (code) {
+    case CP_OK: return "ok";
+    case CP_ERR_INVALID: return "invalid argument or unsupported shape";
+    case CP_ERR_HIP: return "HIP runtime error (kernel launch / graph call failed)";
+    case CP_ERR_ALIGN: return "pointer, channel count or stride not aligned to 16 bytes / 4 channels";
+    case CP_ERR_RANGE: return "buffer exceeds 2 GiB 32-bit buffer addressing";
+    default: return "unknown checkerpose_hip error code";
+  }
+}
+
+// hipGraph: the forward is ~350 short launches; replaying them as one graph removes the per-launch host
+// cost.  Capture mode is thread-local so other threads (e.g. a data loader touching HIP) are not affected.
+extern "C" int cp_graph_begin_capture(cp_stream_t stream) {
+  return hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+
+extern "C" int cp_graph_end_capture(cp_stream_t stream, void** graph_exec_out) {
+  if (!graph_exec_out) return CP_ERR_INVALID;
+  hipGraph_t graph = nullptr;
+  if (hipStreamEndCapture((hipStream_t)stream, &graph) != hipSuccess || !graph) return CP_ERR_HIP;
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return CP_ERR_HIP;
+  *graph_exec_out = (void*)exec;
+  return CP_OK;
+}
+
+extern "C" int cp_graph_launch(void* graph_exec, cp_stream_t stream) {
+  if (!graph_exec) return CP_ERR_INVALID;
+  return hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+
+extern "C" int cp_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return CP_OK;
+  return hipGraphExecDestroy((hipGraphExec_t)graph_exec) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}

@@ -1,0 +1,69 @@
+// Shared device/host helpers for libcheckerpose_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/checkerpose_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// ---- bf16 <-> f32 on raw bits (round-to-nearest-even; NaN kept a NaN by the plain cast) --------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  __bf16 b = (__bf16)f;                      // v_cvt_pk_bf16_f32 on gfx950
+  return (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+// element type tags
+struct F32Tag { using elem = float; static constexpr int E = 4; static constexpr int dtype = CP_F32; };
+struct BF16Tag { using elem = uint16_t; static constexpr int E = 8; static constexpr int dtype = CP_BF16; };
+
+// 16-byte vector <-> E floats
+template <typename Tag> struct Vec16;
+template <> struct Vec16<F32Tag> {
+  static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    u32x4 v; v.x = __float_as_uint(f[0]); v.y = __float_as_uint(f[1]); v.z = __float_as_uint(f[2]); v.w = __float_as_uint(f[3]);
+    return v;
+  }
+};
+template <> struct Vec16<BF16Tag> {
+  static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    u32x4 v; v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+  }
+};
+
+template <typename Tag> __device__ __forceinline__ float load_elem(const void* p, size_t i);
+template <> __device__ __forceinline__ float load_elem<F32Tag>(const void* p, size_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float load_elem<BF16Tag>(const void* p, size_t i) {
+  return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+}
+template <typename Tag> __device__ __forceinline__ void store_elem(void* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_elem<F32Tag>(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void store_elem<BF16Tag>(void* p, size_t i, float v) {
+  ((uint16_t*)p)[i] = (uint16_t)f32_to_bf16_bits(v);
+}
+
+// ---- host side -------------------------------------------------------------------------------
+static inline int cp_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+static inline bool cp_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int cp_elem_size(int dtype) { return dtype == CP_BF16 ? 2 : 4; }

@@ -1,0 +1,262 @@
+// Implicit-GEMM convolution / linear layer on gfx950 MFMA.
+//
+// GEMM view:  D^T[channel][pixel] = sum_k Wp[channel][k] * im2col(X)[pixel][k]
+//   pixels  m = (b, oy, ox) flattened, channels-last input  X (B,H,W,Cstride)
+//   k       = (r, s, cin), cin padded to the physical channel count (multiple of E = 16B / sizeof(T))
+// One wave owns a (MT*16 pixel) x (NT*16 channel) tile; a 256-thread block = 4 waves stacked along
+// the pixel axis that share the same channel tiles (weight fragments hit in L1).
+//
+// Fragment shape (both dtypes): a K-chunk is 64 bytes per row (16 f32 / 32 bf16); lane (x = l&15,
+// q = l>>4) loads the 16-byte piece q of row x -- for activations straight from the channels-last
+// tensor (contiguous in cin, bounds-checked buffer load -> zero padding for free), for weights from
+// the pre-packed fragment-major image (one fully coalesced 1 KiB wave load per fragment).
+//   bf16: one v_mfma_f32_16x16x32_bf16 per fragment pair (lane holds k = 8q..8q+7, exactly its layout)
+//   f32 : four v_mfma_f32_16x16x4_f32; instruction j contracts k = {4q + j}: the same K permutation is
+//         applied to both operands, so the sum is unchanged and every load stays 16 bytes wide.
+// The weight fragment is the MFMA A operand and the activation fragment the B operand, so the
+// accumulator holds 4 CONSECUTIVE CHANNELS of one pixel per lane -> 16-byte (f32) / 8-byte (bf16)
+// epilogue stores into the channels-last output.
+//
+// Replaces (reference, relative to /root/reference/checkerpose): every nn.Conv2d/BatchNorm2d/ReLU,
+// nn.Linear/LeakyReLU on the path -- see include/checkerpose_hip.h for the file:line list.
+#include "common.h"
+
+struct ConvParams {
+  const void* in; const void* w; const float* scale; const float* shift; const void* res; void* out;
+  int M, H, W, HoWo, Wo;
+  int Cin, in_cs, in_coff;
+  int R, S, stride, pad;
+  int KC, Cout, n_tiles;
+  int act; float slope; int out_f32;
+  uint32_t in_bytes;
+  long long o_base, o_sb, o_sy, o_sx, o_sc;
+};
+
+template <typename Tag> struct Mma;
+template <> struct Mma<F32Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<BF16Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+  }
+};
+
+template <typename Tag, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+  constexpr int E = Tag::E;
+  constexpr int KCH = 4 * E;
+  constexpr int ES = 16 / E;  // sizeof(elem)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int m_wave = blockIdx.x * (4 * MT * 16) + wave * (MT * 16);
+  const int nt0 = blockIdx.y * NT;
+
+  // ---- per-(lane, mt) pixel decode: input window origin and element offset of (iy0, ix0)
+  int iy0[MT], ix0[MT], rowbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_wave + mt * 16 + x;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / p.HoWo;
+    const int rem = mm - b * p.HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    iy0[mt] = ok ? oy * p.stride - p.pad : -(1 << 28);   // out-of-range rows never pass the bounds test
+    ix0[mt] = ox * p.stride - p.pad;
+    rowbase[mt] = ((b * p.H + (ok ? iy0[mt] : 0)) * p.W + ix0[mt]) * p.in_cs + p.in_coff;
+  }
+  // ---- per-lane K state: this lane's 16-byte piece starts at k = kc*KCH + q*E -> (tap r,s ; cin c)
+  int kk = q * E;
+  int tap = kk / p.Cin;
+  int c = kk - tap * p.Cin;
+  int r = tap / p.S;
+  int s = tap - r * p.S;
+
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  // weight fragment pointers (tile index clamped: a partial last channel block recomputes a valid tile)
+  const u32x4* wp[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int t = nt0 + nt;
+    t = t < p.n_tiles ? t : p.n_tiles - 1;
+    wp[nt] = (const u32x4*)p.w + (size_t)t * p.KC * 64 + lane;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_chunk = [&](u32x4* a, u32x4* w, int kc) {
+    const int tapoff = (r * p.W + s) * p.in_cs + c;
+    const bool tap_ok = r < p.R;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bool ok = tap_ok && (unsigned)(iy0[mt] + r) < (unsigned)p.H && (unsigned)(ix0[mt] + s) < (unsigned)p.W;
+      const uint32_t off = ok ? (uint32_t)(rowbase[mt] + tapoff) * ES : 0x80000000u;
+      a[mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w[nt] = wp[nt][(size_t)kc * 64];
+    // advance the lane's K state by one chunk
+    c += KCH;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      if (++s == p.S) { s = 0; ++r; }
+    }
+  };
+  auto compute = [&](const u32x4* a, const u32x4* w) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) Mma<Tag>::run(w[nt], a[mt], acc[mt][nt]);
+  };
+
+  // ---- main loop, register double-buffered (chunk kc+1 in flight while chunk kc feeds the MFMAs)
+  u32x4 a0[MT], w0[NT], a1[MT], w1[NT];
+  load_chunk(a0, w0, 0);
+  int kc = 0;
+  for (; kc + 2 <= p.KC; kc += 2) {
+    load_chunk(a1, w1, kc + 1);
+    compute(a0, w0);
+    if (kc + 2 < p.KC) load_chunk(a0, w0, kc + 2);
+    compute(a1, w1);
+  }
+  if (kc < p.KC) compute(a0, w0);
+
+  // ---- epilogue: lane holds pixel (lane&15) x channels 4q..4q+3 of every (mt, nt) tile
+  const bool vec = (p.o_sc == 1);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_wave + mt * 16 + x;
+    if (m >= p.M) continue;
+    const int b = m / p.HoWo;
+    const int rem = m - b * p.HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    const long long pix = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (nt0 + nt) * 16 + q * 4;
+      if (nt0 + nt >= p.n_tiles || n >= p.Cout) continue;
+      const f32x4 sc = *(const f32x4*)(p.scale + n);
+      const f32x4 sh = *(const f32x4*)(p.shift + n);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * sc[j] + sh[j];
+      if (vec) {
+        const long long o = pix + n;
+        if (p.res) {
+          if (p.out_f32 || E == 4) {
+            const f32x4 rv = *(const f32x4*)((const float*)p.res + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rv[j];
+          } else {
+            const u32x2 rv = *(const u32x2*)((const uint16_t*)p.res + o);
+            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+          else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        }
+        if (p.out_f32 || E == 4) {
+          *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)((uint16_t*)p.out + o) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n + j >= p.Cout) continue;
+          const long long o = pix + (long long)(n + j) * p.o_sc;
+          float y = v[j];
+          if (p.res) y += (p.out_f32 || E == 4) ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
+          if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
+          else if (p.act == CP_ACT_LEAKY) y = y > 0.f ? y : y * p.slope;
+          if (p.out_f32 || E == 4) ((float*)p.out)[o] = y;
+          else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <typename Tag, int MT, int NT>
+static void launch(const ConvParams& p, hipStream_t st) {
+  dim3 grid((p.M + 4 * MT * 16 - 1) / (4 * MT * 16), (p.n_tiles + NT - 1) / NT);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tag, MT, NT>), grid, dim3(256), 0, st, p);
+}
+
+template <typename Tag, int MT>
+static void dispatch_nt(const ConvParams& p, int NT, hipStream_t st) {
+  switch (NT) {
+    case 1: launch<Tag, MT, 1>(p, st); break;
+    case 2: launch<Tag, MT, 2>(p, st); break;
+    case 3: launch<Tag, MT, 3>(p, st); break;
+    case 4: launch<Tag, MT, 4>(p, st); break;
+    default: launch<Tag, MT, 5>(p, st); break;
+  }
+}
+
+extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                               const float* scale, const float* shift, const void* residual, void* out) {
+  if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
+  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->R <= 0 || d->S <= 0 || d->stride <= 0)
+    return CP_ERR_INVALID;
+  if (d->Cin <= 0 || d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride)
+    return CP_ERR_ALIGN;
+  if (d->Cout <= 0 || (d->o_sc == 1 && d->Cout % 4)) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift))
+    return CP_ERR_ALIGN;
+  const long long in_bytes = (long long)d->B * d->H * d->W * d->in_cstride * es;
+  if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
+  const long long M = (long long)d->B * d->Ho * d->Wo;
+  if (M >= (1LL << 31)) return CP_ERR_RANGE;
+  if (d->o_sc == 1) {  // vector epilogue: 4 consecutive channels per store
+    const int oes = d->out_f32 ? 4 : es;
+    if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4)) return CP_ERR_ALIGN;
+    if (((uintptr_t)out % (4 * oes)) || (residual && ((uintptr_t)residual % (4 * oes)))) return CP_ERR_ALIGN;
+  }
+  ConvParams p;
+  p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
+  p.M = (int)M; p.H = d->H; p.W = d->W; p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo;
+  p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+  const int K = d->R * d->S * d->Cin, KCH = 4 * E;
+  p.KC = (K + KCH - 1) / KCH;
+  p.Cout = d->Cout; p.n_tiles = (d->Cout + 15) / 16;
+  p.act = d->act; p.slope = d->slope; p.out_f32 = d->out_f32;
+  p.in_bytes = (uint32_t)in_bytes;
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx; p.o_sc = d->o_sc;
+
+  // tile choice: NT minimises padded channel tiles (ties -> wider), MT=4 (256 pixels/block) unless the
+  // grid would leave most of the 256 CUs idle.
+  int NT = 1, best = 1 << 30;
+  for (int nt = 5; nt >= 1; --nt) {
+    const int padded = (p.n_tiles + nt - 1) / nt * nt;
+    if (padded < best) { best = padded; NT = nt; }
+  }
+  const long long blocks4 = ((M + 255) / 256) * ((p.n_tiles + NT - 1) / NT);
+  const int MT = blocks4 >= 512 ? 4 : 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CP_F32) { if (MT == 4) dispatch_nt<F32Tag, 4>(p, NT, st); else dispatch_nt<F32Tag, 2>(p, NT, st); }
+  else                    { if (MT == 4) dispatch_nt<BF16Tag, 4>(p, NT, st); else dispatch_nt<BF16Tag, 2>(p, NT, st); }
+  return cp_check_launch();
+}

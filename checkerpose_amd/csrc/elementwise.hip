@@ -1,0 +1,156 @@
+// Memory-bound channels-last helpers: bilinear x2 (align_corners), HRNet fuse sum, 3x3/s2 max pool.
+// One thread per 16-byte channel group (4 f32 / 8 bf16): every access is a coalesced 16-byte vector.
+#include "common.h"
+
+// ---- nn.UpsamplingBilinear2d(scale_factor=2)  (pipeline.py:199; == F.interpolate(align_corners=True)).
+// ATen (UpSample.h, align_corners): scale = (in-1)/(out-1); src = scale*dst; i0 = floor(src); i1 = i0 + (i0 < in-1);
+// l1 = src - i0; l0 = 1 - l1;  out = l0h*(l0w*x00 + l1w*x01) + l1h*(l0w*x10 + l1w*x11)   -- all in fp32.
+template <typename Tag>
+__global__ void upsample2x_bilinear_kernel(const void* __restrict__ in, void* __restrict__ out, int H, int W, int CG,
+                                           int in_cs, int in_coff, int out_cs, int out_coff, float sy, float sx,
+                                           size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * 2H * 2W * CG
+  if (i >= total) return;
+  const int g = (int)(i % CG);
+  size_t t = i / CG;
+  const int ox = (int)(t % (2 * W)); t /= (2 * W);
+  const int oy = (int)(t % (2 * H));
+  const size_t b = t / (2 * H);
+  const float fy = sy * oy, fx = sx * ox;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+  const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
+  const u32x4* src = (const u32x4*)in;
+  auto ld = [&](int y, int x, float* f) {
+    const size_t e = ((b * H + y) * W + x) * in_cs + in_coff + (size_t)g * E;
+    Vec16<Tag>::unpack(src[e / E], f);
+  };
+  float a[E], bb[E], c[E], d[E], o[E];
+  ld(y0, x0, a); ld(y0, x1, bb); ld(y1, x0, c); ld(y1, x1, d);
+#pragma unroll
+  for (int j = 0; j < E; ++j) o[j] = ly0 * (lx0 * a[j] + lx1 * bb[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
+  const size_t oe = ((b * 2 * H + oy) * 2 * W + ox) * out_cs + out_coff + (size_t)g * E;
+  ((u32x4*)out)[oe / E] = Vec16<Tag>::pack(o);
+}
+
+extern "C" int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,
+                                         int C, int in_cstride, int in_coff, int out_cstride, int out_coff) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (C % E || in_cstride % E || in_coff % E || out_cstride % E || out_coff % E) return CP_ERR_ALIGN;
+  if (in_coff + C > in_cstride || out_coff + C > out_cstride) return CP_ERR_INVALID;
+  if (!cp_aligned16(in) || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  const float sy = H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+  const float sx = W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+  const int CG = C / E;
+  const size_t total = (size_t)B * 2 * H * 2 * W * CG;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(upsample2x_bilinear_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+                       CG, in_cstride, in_coff, out_cstride, out_coff, sy, sx, total);
+  else
+    hipLaunchKernelGGL(upsample2x_bilinear_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+                       CG, in_cstride, in_coff, out_cstride, out_coff, sy, sx, total);
+  return cp_check_launch();
+}
+
+// ---- HRNet fuse: out = relu?( sum_t src_t[b, y>>sh_t, x>>sh_t, :] )   (timm HighResolutionModule.forward;
+// nn.Upsample(mode='nearest', scale 2^sh): src index = floor(dst / 2^sh)).  Summation order t = 0..nsrc-1
+// follows the reference's `y = y + fuse_outer[j](x[j])` loop.
+struct FuseSrcs { const void* p[4]; int sh[4]; };
+
+template <typename Tag>
+__global__ void fuse_sum_kernel(FuseSrcs s, int nsrc, void* __restrict__ out, int H, int W, int CG, int relu, size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W*CG
+  if (i >= total) return;
+  const int g = (int)(i % CG);
+  size_t t = i / CG;
+  const int x = (int)(t % W); t /= W;
+  const int y = (int)(t % H);
+  const size_t b = t / H;
+  float acc[E], f[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) acc[j] = 0.f;
+  for (int k = 0; k < nsrc; ++k) {
+    const int sh = s.sh[k];
+    const size_t v = ((b * (H >> sh) + (y >> sh)) * (W >> sh) + (x >> sh)) * CG + g;
+    Vec16<Tag>::unpack(((const u32x4*)s.p[k])[v], f);
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] = (k == 0) ? f[j] : acc[j] + f[j];
+  }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] = fmaxf(acc[j], 0.f);
+  }
+  ((u32x4*)out)[i] = Vec16<Tag>::pack(acc);
+}
+
+extern "C" int cp_fuse_sum_act(cp_stream_t stream, int dtype, int nsrc, const void* const* srcs, const int32_t* shifts,
+                               void* out, int B, int H, int W, int C, int relu) {
+  if (!srcs || !shifts || !out || nsrc < 1 || nsrc > 4 || B <= 0 || H <= 0 || W <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (C % E || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  FuseSrcs s;
+  for (int k = 0; k < 4; ++k) { s.p[k] = nullptr; s.sh[k] = 0; }
+  for (int k = 0; k < nsrc; ++k) {
+    if (!srcs[k] || !cp_aligned16(srcs[k]) || shifts[k] < 0 || shifts[k] > 5) return CP_ERR_INVALID;
+    if ((H >> shifts[k]) << shifts[k] != H || (W >> shifts[k]) << shifts[k] != W) return CP_ERR_INVALID;
+    s.p[k] = srcs[k]; s.sh[k] = shifts[k];
+  }
+  const int CG = C / E;
+  const size_t total = (size_t)B * H * W * CG;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(fuse_sum_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
+  else
+    hipLaunchKernelGGL(fuse_sum_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
+  return cp_check_launch();
+}
+
+// ---- F.max_pool2d(x, 3, 2, 1) (resnet34 stem). Padding is -inf, i.e. out-of-range taps are skipped.
+template <typename Tag>
+__global__ void maxpool3x3s2_kernel(const void* __restrict__ in, void* __restrict__ out, int H, int W, int CG, size_t total) {
+  constexpr int E = Tag::E;
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int g = (int)(i % CG);
+  size_t t = i / CG;
+  const int ox = (int)(t % Wo); t /= Wo;
+  const int oy = (int)(t % Ho);
+  const size_t b = t / Ho;
+  float m[E], f[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) m[j] = -INFINITY;
+  for (int r = 0; r < 3; ++r) {
+    const int y = 2 * oy - 1 + r;
+    if ((unsigned)y >= (unsigned)H) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int x = 2 * ox - 1 + s;
+      if ((unsigned)x >= (unsigned)W) continue;
+      Vec16<Tag>::unpack(((const u32x4*)in)[((b * H + y) * W + x) * CG + g], f);
+#pragma unroll
+      for (int j = 0; j < E; ++j) m[j] = fmaxf(m[j], f[j]);
+    }
+  }
+  ((u32x4*)out)[i] = Vec16<Tag>::pack(m);
+}
+
+extern "C" int cp_maxpool3x3s2(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W, int C) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (C % E || !cp_aligned16(in) || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  const int CG = C / E;
+  const size_t total = (size_t)B * (H / 2) * (W / 2) * CG;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W, CG, total);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W, CG, total);
+  return cp_check_launch();
+}

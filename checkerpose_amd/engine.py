@@ -1,0 +1,304 @@
+"""Host-side engine: turns a module tree (state dict + config) into a static launch program over the C ABI.
+
+Design: one process per GPU; a *program* is built once per (batch size, active stages, dtype):
+every op's arguments (pointers into ONE liveness-planned workspace, ctypes descriptors) are resolved ahead of
+time, so a forward is a flat loop of ~370 pre-bound C calls -- or one hipGraph replay of the captured loop.
+Nothing here computes: torch is used for device memory, parameter access and the stream handle only, and every
+arithmetic step is a HIP kernel behind include/checkerpose_hip.h.  No fallback path exists.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
+
+_TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
+DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class TBuf:
+    """A workspace tensor: `nbytes` at `offset` of the program's workspace; live over ops [first, last]."""
+    __slots__ = ("nbytes", "offset", "first", "last", "fixed")
+
+    def __init__(self, nbytes):
+        self.nbytes, self.offset, self.first, self.last, self.fixed = _rup(nbytes, 256), None, None, None, None
+
+
+class Act:
+    """Channels-last activation view: channels [coff, coff+Cphys) of a (B, H, W, cstride) tensor in `tbuf`."""
+    __slots__ = ("tbuf", "B", "H", "W", "C", "Cphys", "cstride", "coff")
+
+    def __init__(self, tbuf, B, H, W, C, Cphys, cstride, coff):
+        self.tbuf, self.B, self.H, self.W, self.C, self.Cphys, self.cstride, self.coff = tbuf, B, H, W, C, Cphys, cstride, coff
+
+    def slice(self, coff, C, Cphys=None):
+        return Act(self.tbuf, self.B, self.H, self.W, C, Cphys if Cphys is not None else C, self.cstride, self.coff + coff)
+
+
+class WeightStore:
+    """Packed (MFMA-fragment order) weights + folded per-channel affine vectors, built from a device state dict."""
+
+    def __init__(self, lib, sd, dtype, device):
+        self.lib, self.sd, self.dtype, self.device = lib, sd, dtype, device
+        self.E = lib.cp_chan_align(dtype)
+        self.cache = {}
+        self.keep = []   # keep temporaries alive until packing kernels ran
+
+    def _w(self, key):
+        t = self.sd[key]
+        if t.device != self.device or t.dtype != torch.float32:
+            raise RuntimeError("parameter %s must be an fp32 tensor on %s" % (key, self.device))
+        return t.detach().contiguous()
+
+    def pack(self, name, w, Cout, Cin, R, S, cin_phys, cout_rows, transposed=0, phase=0, row_map=None):
+        ck = (name, cin_phys, cout_rows, transposed, phase)
+        if ck in self.cache:
+            return self.cache[ck]
+        nbytes = self.lib.cp_packed_weight_bytes(self.dtype, cout_rows, cin_phys, R, S)
+        out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        rm = None
+        if row_map is not None:
+            rm = torch.tensor(row_map, dtype=torch.int32, device=self.device)
+            self.keep.append(rm)
+        w = w.contiguous()
+        self.keep.append(w)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _abi.check(self.lib.cp_pack_conv_weight(st, self.dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
+                                                rm.data_ptr() if rm is not None else None, cout_rows, out.data_ptr()),
+                   "cp_pack_conv_weight(%s)" % name)
+        self.cache[ck] = out
+        return out
+
+    def affine(self, name, scale, shift, rows):
+        """fp32 scale/shift vectors padded with zeros to a multiple of 16 entries (rows >= len)."""
+        ck = ("aff", name, rows)
+        if ck not in self.cache:
+            n = _rup(rows, 16)
+            s = torch.zeros(n, dtype=torch.float32, device=self.device)
+            t = torch.zeros(n, dtype=torch.float32, device=self.device)
+            s[: scale.numel()] = scale
+            t[: shift.numel()] = shift
+            self.cache[ck] = (s, t)
+        return self.cache[ck]
+
+    def bn_fold(self, bn, eps=1e-5):
+        """eval BatchNorm -> (scale, shift): y = x*scale + shift (nn.BatchNorm2d defaults, eps 1e-5)."""
+        s = self._w(bn + ".weight") / torch.sqrt(self._w(bn + ".running_var") + eps)
+        return s, self._w(bn + ".bias") - self._w(bn + ".running_mean") * s
+
+
+class Program:
+    """Static launch list for one (B, dtype).  Build with the op methods, then finalize(); run() replays it."""
+
+    def __init__(self, lib, ws: WeightStore, dtype, B, device):
+        self.lib, self.ws, self.dtype, self.B, self.device = lib, ws, dtype, B, device
+        self.E = lib.cp_chan_align(dtype)
+        self.es = 2 if dtype == CP_BF16 else 4
+        self.ops = []          # (fn, argbuilder(ptr_of) -> args tuple, name, reads, writes)
+        self.tbufs = []
+        self.keep = []
+        self.workspace = None
+        self.calls = None
+        self.flops = 0         # dense MACs*2 issued through cp_conv2d_igemm (algorithmic, unpadded)
+        self.conv_log = []     # (name, M, Cout, K, flops) per conv launch -- bench roofline uses it
+
+    # ---- tensors
+    def tensor(self, nelem, es=None):
+        t = TBuf(nelem * (es or self.es))
+        self.tbufs.append(t)
+        return t
+
+    def act(self, H, W, C, cstride_C=None):
+        Cphys = _rup(C, self.E)
+        cs = Cphys if cstride_C is None else cstride_C
+        return Act(self.tensor(self.B * H * W * cs), self.B, H, W, C, Cphys, cs, 0)
+
+    def fixed(self, torch_tensor):
+        t = TBuf(torch_tensor.numel() * torch_tensor.element_size())
+        t.fixed = torch_tensor
+        self.keep.append(torch_tensor)
+        return t
+
+    def _add(self, fn, argb, name, reads, writes):
+        i = len(self.ops)
+        for t in list(reads) + list(writes):
+            if t is None or t.fixed is not None:
+                continue
+            if t.first is None:
+                t.first = i
+            t.last = i
+        self.ops.append((fn, argb, name))
+
+    # ---- ops
+    def conv(self, x: Act, wkey, w, scale, shift, R, S, stride, pad, Cout, act=ACT_NONE, slope=0.0, residual: Act = None,
+             out: Act = None, transposed=0, phase=0, row_map=None, cout_rows=None, out_f32=False, ostr=None,
+             out_tbuf=None, out_hw=None, w_shape=None):
+        """Generic conv / linear.  `w` is the fp32 source weight in PyTorch layout; returns the output Act."""
+        E = self.E
+        wCout, wCin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+        rows = cout_rows if cout_rows is not None else wCout
+        if wCin != x.C:
+            raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
+        packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map)
+        sc, sh = self.ws.affine(wkey + "#" + str(phase), scale, shift, rows)
+        Ho, Wo = out_hw if out_hw is not None else ((x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1)
+        d = CpConvDesc()
+        d.dtype, d.out_f32 = self.dtype, 1 if out_f32 else 0
+        d.B, d.H, d.W = x.B, x.H, x.W
+        d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = R, S, stride, pad, Ho, Wo
+        d.act, d.slope = act, slope
+        if ostr is None:
+            if out is None:
+                out = self.act(Ho, Wo, Cout)
+            d.Cout = out.Cphys
+            d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
+            otb = out.tbuf
+        else:  # explicit element strides into `out_tbuf` (o_base, o_sb, o_sy, o_sx, o_sc)
+            d.Cout = Cout
+            d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = ostr
+            otb = out_tbuf
+        self.keep += [d, packed, sc, sh]
+        rtb = residual.tbuf if residual is not None else None
+        if residual is not None and ostr is None:
+            assert (residual.cstride, residual.coff, residual.H, residual.W) == (out.cstride, out.coff, out.H, out.W), \
+                "residual must share the output layout"
+        fn = self.lib.cp_conv2d_igemm
+        dref = C.byref(d)
+        pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        xtb = x.tbuf
+        self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(rtb) if rtb is not None else None, P(otb)),
+                  "conv:" + wkey, [xtb, rtb], [otb])
+        fl = 2 * x.B * Ho * Wo * R * S * wCin * wCout
+        self.flops += fl
+        self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl))
+        return out
+
+    def upsample2x(self, x: Act, out: Act):
+        fn = self.lib.cp_upsample2x_bilinear_ac
+        a = (self.dtype,)
+        xt, ot = x.tbuf, out.tbuf
+        tail = (x.B, x.H, x.W, x.Cphys, x.cstride, x.coff, out.cstride, out.coff)
+        self._add(fn, lambda P: a + (P(xt), P(ot)) + tail, "upsample2x", [xt], [ot])
+        return out
+
+    def fuse_sum(self, srcs, shifts, out: Act, relu=True):
+        n = len(srcs)
+        arr_p = (C.c_void_p * 4)()
+        arr_s = (C.c_int32 * 4)(*([int(s) for s in shifts] + [0] * (4 - n)))
+        self.keep += [arr_p, arr_s]
+        fn = self.lib.cp_fuse_sum_act
+        tbs = [s.tbuf for s in srcs]
+        for s in srcs:
+            assert s.coff == 0 and s.cstride == s.Cphys == out.Cphys
+        ot = out.tbuf
+
+        def argb(P):
+            for i, t in enumerate(tbs):
+                arr_p[i] = P(t)
+            return (self.dtype, n, arr_p, arr_s, P(ot), out.B, out.H, out.W, out.Cphys, 1 if relu else 0)
+
+        self._add(fn, argb, "fuse_sum", tbs, [ot])
+        return out
+
+    def maxpool(self, x: Act):
+        out = self.act(x.H // 2, x.W // 2, x.C)
+        fn = self.lib.cp_maxpool3x3s2
+        xt, ot = x.tbuf, out.tbuf
+        self._add(fn, lambda P: (self.dtype, P(xt), P(ot), x.B, x.H, x.W, x.Cphys), "maxpool", [xt], [ot])
+        return out
+
+    def edge_gather(self, pq: Act, idx_t, gids_t, out: Act, K, C_, G, slope):
+        fn = self.lib.cp_edgeconv_gather_max
+        pt, ot = pq.tbuf, out.tbuf
+        ip = idx_t.data_ptr()
+        gp = gids_t.data_ptr() if gids_t is not None else None
+        N = pq.W
+        self._add(fn, lambda P: (self.dtype, P(pt), ip, gp, P(ot), pq.B, N, K, C_, G, out.cstride, out.coff, slope),
+                  "edge_gather", [pt], [ot])
+        return out
+
+    def index2feat(self, patches: Act, xid_t, yid_t, mask_t, out: Act, N, E_ch, k):
+        fn = self.lib.cp_index2feat_gather
+        pt, ot = patches.tbuf, out.tbuf
+        args = (xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())
+        tail = (patches.B, N, patches.H, patches.W, E_ch, k, out.cstride, out.coff)
+        self._add(fn, lambda P: (self.dtype, P(pt)) + args + (P(ot),) + tail, "index2feat", [pt], [ot])
+        return out
+
+    def decode(self, bits_t, stage, mask_t, xid_t, yid_t, x64_t, y64_t, N):
+        fn = self.lib.cp_bits_decode
+        a = (bits_t.data_ptr(), stage, mask_t.data_ptr(), xid_t.data_ptr(), yid_t.data_ptr(), x64_t.data_ptr(),
+             y64_t.data_ptr(), self.B, N)
+        self._add(fn, lambda P: a, "decode", [], [])
+
+    def nchw_to_nhwc(self, img_t, Cc, H, W):
+        out = self.act(H, W, Cc)
+        fn = self.lib.cp_nchw_to_nhwc
+        ot = out.tbuf
+        ip = img_t.data_ptr()
+        self._add(fn, lambda P: (self.dtype, ip, P(ot), self.B, Cc, H, W, out.Cphys), "nchw_to_nhwc", [], [ot])
+        return out
+
+    def to_nchw_f32(self, x: Act, out_t):
+        fn = self.lib.cp_nhwc_to_nchw_f32
+        xt = x.tbuf
+        op = out_t.data_ptr()
+        self._add(fn, lambda P: (self.dtype, P(xt), op, x.B, x.C, x.H, x.W, x.cstride, x.coff), "to_nchw", [xt], [])
+
+    # ---- memory plan + argument binding
+    def finalize(self):
+        """Linear-scan placement of every workspace tensor by liveness (outputs are placed before the op's dead
+        inputs are released, so an op never aliases its own operands)."""
+        births, deaths = {}, {}
+        for t in self.tbufs:
+            if t.fixed is None and t.first is not None:
+                births.setdefault(t.first, []).append(t)
+                deaths.setdefault(t.last, []).append(t)
+        free, top = [], 0            # free: list of (offset, size)
+        for i in range(len(self.ops)):
+            for t in births.get(i, []):
+                best = None
+                for k, (off, sz) in enumerate(free):
+                    if sz >= t.nbytes and (best is None or sz < free[best][1]):
+                        best = k
+                if best is None:
+                    t.offset = top
+                    top += t.nbytes
+                else:
+                    off, sz = free.pop(best)
+                    t.offset = off
+                    if sz > t.nbytes:
+                        free.append((off + t.nbytes, sz - t.nbytes))
+            for t in deaths.get(i, []):
+                free.append((t.offset, t.nbytes))
+                free.sort()
+                merged = []
+                for off, sz in free:     # coalesce neighbours
+                    if merged and merged[-1][0] + merged[-1][1] == off:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                    else:
+                        merged.append((off, sz))
+                free = merged
+        self.workspace_bytes = top
+        self.workspace = torch.empty(max(top, 256), dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+
+        def P(t):
+            if t.fixed is not None:
+                return t.fixed.data_ptr()
+            return base + t.offset
+
+        self.calls = [(fn, (None,) + tuple(argb(P)), name) for fn, argb, name in self.ops]
+        return self
+
+    def run(self, stream_ptr):
+        for fn, args, name in self.calls:
+            rc = fn(stream_ptr, *args[1:])
+            if rc != 0:
+                _abi.check(rc, name)

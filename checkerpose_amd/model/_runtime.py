@@ -1,0 +1,155 @@
+"""Runtime glue shared by the drop-in modules: builds / caches the launch Program for a batch size, owns the
+persistent I/O tensors, captures the hipGraph and replays it.  Fails loudly -- no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from .. import _abi
+from ..engine import DTYPES, Program, WeightStore
+from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
+
+
+class HipForwardMixin:
+    def _init_runtime(self):
+        self._programs = {}
+        self._stores = {}
+        self._idx_dev = None
+        self.compute_dtype = os.environ.get("CHECKERPOSE_AMD_DTYPE", "fp32")
+        self.use_graph = os.environ.get("CHECKERPOSE_AMD_GRAPH", "1") != "0"
+        self.clone_outputs = True
+        self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
+
+    # ---- cache control
+    def invalidate(self):
+        """Drop packed weights / programs (called on load_state_dict, .to()/.cuda(), dtype change)."""
+        lib = _abi._lib
+        for pr in getattr(self, "_programs", {}).values():
+            if pr.get("graph") and lib is not None:
+                lib.cp_graph_destroy(pr["graph"])
+        self._programs, self._stores, self._idx_dev = {}, {}, None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if hasattr(self, "_programs"):
+            self.invalidate()
+        return r
+
+    def set_compute_dtype(self, name):
+        if name not in DTYPES:
+            raise ValueError("compute dtype must be one of %s" % sorted(DTYPES))
+        self.compute_dtype = name
+        self.invalidate()
+        return self
+
+    # ---- program construction
+    def _build(self, lib, B, size, stage, want_feats, want_graph, device):
+        dtype = DTYPES[self.compute_dtype]
+        cfg = self._net_cfg()
+        cfg["img_size"] = size
+        cfg["stage"] = stage
+        N = cfg["npoint"]
+        sd = self.state_dict()
+        if dtype not in self._stores:
+            self._stores[dtype] = WeightStore(lib, sd, dtype, device)
+        ws = self._stores[dtype]
+        ws.sd = sd
+        if self._idx_dev is None:
+            self._idx_dev = self._knn_table().to(torch.int32).contiguous().to(device)
+        idx = self._idx_dev
+        G = idx.shape[0]
+        io = dict(
+            img=torch.empty(B, 3, size, size, dtype=torch.float32, device=device),
+            bits=torch.zeros(B, 13, N, dtype=torch.float32, device=device),
+            mask=torch.zeros(B, N, dtype=torch.float32, device=device),
+            xid=torch.zeros(B, N, dtype=torch.int32, device=device),
+            yid=torch.zeros(B, N, dtype=torch.int32, device=device),
+            x64=torch.zeros(B, N, dtype=torch.int64, device=device),
+            y64=torch.zeros(B, N, dtype=torch.int64, device=device),
+            gids=torch.zeros(B, dtype=torch.int32, device=device) if self.LM else None,
+        )
+        prog = Program(lib, ws, dtype, B, device)
+        io["graph"] = dict(idx=idx, gids=io["gids"], K=idx.shape[2], G=G)
+        io["bits_tb"] = prog.fixed(io["bits"])
+        em = NetEmitter(prog, sd)
+        if cfg["kind"] == "init":
+            feats, g = emit_init_net(em, cfg, io, "")
+        else:
+            nref = cfg["res_log2"] - 3
+            fs = (size // 32) << (stage if stage is not None else nref)
+            io["seg"] = torch.zeros(B, cfg["seg_output_dim"], fs, fs, dtype=torch.float32, device=device)
+            io["seg_tb"] = prog.fixed(io["seg"])
+            feats, _ = emit_posenet(em, cfg, io)
+            g = None
+        if want_feats:
+            io["img_feats"] = []
+            for f in feats:
+                t = torch.empty(B, f.C, f.H, f.W, dtype=torch.float32, device=device)
+                prog.to_nchw_f32(f, t)
+                io["img_feats"].append(t)
+        if want_graph and g is not None:
+            io["graph_feats"] = torch.empty(B, g.C, N, dtype=torch.float32, device=device)
+            prog.to_nchw_f32(g, io["graph_feats"])
+        prog.finalize()
+        torch.cuda.current_stream(device).synchronize()      # weight packing done before temporaries die
+        ws.keep.clear()
+        return dict(prog=prog, io=io, graph=None, warm=False, side=None)
+
+    # ---- one forward
+    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False):
+        if self.training:
+            raise RuntimeError("checkerpose_amd: train-mode forward (batch-statistics BatchNorm + autograd) is not "
+                               "implemented; call .eval().  There is no PyTorch fallback.")
+        if not (torch.is_tensor(img) and img.is_cuda):
+            raise RuntimeError("checkerpose_amd: input must be a CUDA/HIP tensor on an MI355X; there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure only).")
+        if img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.shape[2] != 256:
+            raise ValueError("expected img of shape (B, 3, 256, 256), got %s" % (tuple(img.shape),))
+        lib = _abi.load()
+        device = img.device
+        p0 = next(self.parameters())
+        if p0.device != device:
+            raise RuntimeError("module parameters are on %s but the input is on %s" % (p0.device, device))
+        B, size = img.shape[0], img.shape[2]
+        key = (B, size, stage, self.compute_dtype, want_feats, want_graph)
+        pr = self._programs.get(key)
+        if pr is None:
+            with torch.cuda.device(device):
+                pr = self._build(lib, B, size, stage, want_feats, want_graph, device)
+            self._programs[key] = pr
+        io, prog = pr["io"], pr["prog"]
+        with torch.cuda.device(device):
+            io["img"].copy_(img)                              # boundary: stage the caller's NCHW fp32 batch
+            if self.LM:
+                if obj_ids is None:
+                    raise ValueError("obj_ids is required for the LM networks")
+                io["gids"].copy_((obj_ids.to(device) - 1).to(torch.int32))   # obj_ids start from 1 (init_lm.py:65)
+            cur = torch.cuda.current_stream(device)
+            if self.use_graph and pr["warm"]:
+                if pr["graph"] is None:
+                    side = torch.cuda.Stream(device)
+                    side.wait_stream(cur)
+                    _abi.check(lib.cp_graph_begin_capture(side.cuda_stream), "graph capture begin")
+                    try:
+                        prog.run(side.cuda_stream)
+                    finally:
+                        gx = C.c_void_p()
+                        rc = lib.cp_graph_end_capture(side.cuda_stream, C.byref(gx))
+                    _abi.check(rc, "graph capture end")
+                    pr["graph"], pr["side"] = gx, side
+                _abi.check(lib.cp_graph_launch(pr["graph"], cur.cuda_stream), "graph launch")
+            else:
+                prog.run(cur.cuda_stream)
+                pr["warm"] = True
+        out = {k: io[k] for k in ("bits", "seg", "x64", "y64", "img_feats", "graph_feats") if k in io}
+        if self.clone_outputs:
+            out = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in out.items()}
+        return out
+
+    def program_for(self, B, stage=None):
+        """Introspection for bench / tests: the cached Program of batch size B (after at least one forward)."""
+        for k, pr in self._programs.items():
+            if k[0] == B and k[2] == stage and k[3] == self.compute_dtype:
+                return pr["prog"]
+        return None

@@ -1,0 +1,144 @@
+"""Backbone feature extractors: parameter containers in timm's naming.
+
+Mirrors reference checkerpose/model/backbone.py:39-50 (`get_timm_backbone`), which obtains
+`timm.create_model(name, features_only=True, out_indices=(1,2,3,4))`.  timm is a third-party
+dependency absent from the reference tree, so the layouts below restate timm's published
+`HighResolutionNetFeatures(hrnet_w18, feature_location="incre")` and ResNet-34 (SURVEY.md
+Appendix A); the state-dict keys follow timm's so released checkpoints load unchanged.
+
+These classes only HOLD parameters (nn.Conv2d / nn.BatchNorm2d children are never called);
+the arithmetic runs in the HIP engine (checkerpose_amd/engine.py).  Calling forward() directly
+is not supported -- the owning InitNet_GNN drives the backbone as part of its fused program.
+"""
+import torch
+import torch.nn as nn
+
+
+def _conv(cin, cout, k, s=1, p=0):
+    return nn.Conv2d(cin, cout, k, s, p, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(cin, planes, 3, stride, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(cin, planes, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+
+def _down(cin, cout, stride=1):
+    return nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
+
+
+class HighResolutionModule(nn.Module):
+    def __init__(self, chans, nblocks=4):
+        super().__init__()
+        self.chans = tuple(chans)
+        self.branches = nn.ModuleList(
+            nn.Sequential(*[BasicBlock(c, c) for _ in range(nblocks)]) for c in chans)
+        fuse = []
+        for i, ci in enumerate(chans):
+            row = []
+            for j, cj in enumerate(chans):
+                if j > i:
+                    row.append(nn.Sequential(_conv(cj, ci, 1), nn.BatchNorm2d(ci),
+                                             nn.Upsample(scale_factor=2 ** (j - i), mode="nearest")))
+                elif j == i:
+                    row.append(nn.Identity())
+                else:
+                    steps = []
+                    for k in range(i - j):
+                        last = k == i - j - 1
+                        cout = ci if last else cj
+                        mods = [_conv(cj, cout, 3, 2, 1), nn.BatchNorm2d(cout)]
+                        if not last:
+                            mods.append(nn.ReLU(False))
+                        steps.append(nn.Sequential(*mods))
+                    row.append(nn.Sequential(*steps))
+            fuse.append(nn.ModuleList(row))
+        self.fuse_layers = nn.ModuleList(fuse)
+
+
+class HRNetW18Features(nn.Module):
+    """hrnet_w18 features_only: outputs [128@64^2, 256@32^2, 512@16^2, 1024@8^2] for a 256^2 crop."""
+    name = "hrnet_w18"
+    out_channels = (128, 256, 512, 1024)
+    STAGES = (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144)))
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _conv(3, 64, 3, 2, 1)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv2 = _conv(64, 64, 3, 2, 1)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.layer1 = nn.Sequential(Bottleneck(64, 64, _down(64, 256)), *[Bottleneck(256, 64) for _ in range(3)])
+        self.transition1 = nn.ModuleList([
+            nn.Sequential(_conv(256, 18, 3, 1, 1), nn.BatchNorm2d(18), nn.ReLU(False)),
+            nn.Sequential(nn.Sequential(_conv(256, 36, 3, 2, 1), nn.BatchNorm2d(36), nn.ReLU(False)))])
+        self.stage2 = nn.Sequential(HighResolutionModule((18, 36)))
+        self.transition2 = nn.ModuleList([nn.Identity(), nn.Identity(), nn.Sequential(
+            nn.Sequential(_conv(36, 72, 3, 2, 1), nn.BatchNorm2d(72), nn.ReLU(False)))])
+        self.stage3 = nn.Sequential(*[HighResolutionModule((18, 36, 72)) for _ in range(4)])
+        self.transition3 = nn.ModuleList([nn.Identity(), nn.Identity(), nn.Identity(), nn.Sequential(
+            nn.Sequential(_conv(72, 144, 3, 2, 1), nn.BatchNorm2d(144), nn.ReLU(False)))])
+        self.stage4 = nn.Sequential(*[HighResolutionModule((18, 36, 72, 144)) for _ in range(3)])
+        self.incre_modules = nn.ModuleList(
+            nn.Sequential(Bottleneck(c, p, _down(c, p * 4))) for c, p in zip((18, 36, 72, 144), (32, 64, 128, 256)))
+
+    def forward(self, x):
+        raise RuntimeError("checkerpose_amd backbones are parameter containers; run them through InitNet_GNN "
+                           "(HIP engine). There is no PyTorch fallback path.")
+
+
+class ResNet34Features(nn.Module):
+    """resnet34 features_only out_indices (1,2,3,4): [64@64^2, 128@32^2, 256@16^2, 512@8^2]."""
+    name = "resnet34"
+    out_channels = (64, 128, 256, 512)
+    LAYERS = (3, 4, 6, 3)
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _conv(3, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for li, (n, planes) in enumerate(zip(self.LAYERS, (64, 128, 256, 512))):
+            blocks = []
+            for k in range(n):
+                stride = 2 if (k == 0 and li > 0) else 1
+                ds = _down(cin, planes, stride) if (stride != 1 or cin != planes) else None
+                blocks.append(BasicBlock(cin, planes, stride, ds))
+                cin = planes
+            setattr(self, "layer%d" % (li + 1), nn.Sequential(*blocks))
+
+    def forward(self, x):
+        raise RuntimeError("checkerpose_amd backbones are parameter containers; run them through InitNet_GNN "
+                           "(HIP engine). There is no PyTorch fallback path.")
+
+
+def get_timm_backbone(model_name="resnet34", concat_decoder=True, pretrained=True):
+    """Same name/arguments as reference backbone.py:39.  `pretrained` weights cannot be downloaded
+    offline; parameters keep PyTorch's default init until load_state_dict()."""
+    if model_name == "hrnet_w18":
+        return HRNetW18Features()
+    if model_name == "resnet34":
+        return ResNet34Features()
+    raise ValueError("timm_backbone {} not supported yet".format(model_name))  # backbone.py:47

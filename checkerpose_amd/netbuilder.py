@@ -1,0 +1,229 @@
+"""Emit the CheckerPose forward as a Program (engine.py) -- the host-side restatement of the op ORDER of
+InitNet_GNN.forward (reference checkerpose/model/init.py:109-128) and PoseNet_GNNskip.forward
+(model/pipeline.py:351-384; LM twin model/pipeline_lm.py:392-425).  No arithmetic happens here: every step
+appends a C-ABI launch.  Layout: channels-last activations, graph features (B, N, C).
+"""
+import torch
+
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU
+from .engine import Act, Program, _rup
+
+HR_STAGES = (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144)))
+IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024]}   # pipeline.py:6-15
+
+
+class NetEmitter:
+    def __init__(self, prog: Program, sd):
+        self.p, self.ws, self.sd = prog, prog.ws, sd
+        self.ones = {}
+
+    def W(self, key):
+        return self.ws._w(key)
+
+    def _unit(self, n):
+        if n not in self.ones:
+            self.ones[n] = torch.ones(n, dtype=torch.float32, device=self.p.device)
+        return self.ones[n]
+
+    # ---- conv + folded BN (+residual) (+ReLU)
+    def conv_bn(self, x, conv, bn, k, stride, pad, relu=True, residual=None, out=None):
+        w = self.W(conv + ".weight")
+        s, t = self.ws.bn_fold(bn)
+        return self.p.conv(x, conv, w, s, t, k, k, stride, pad, w.shape[0], ACT_RELU if relu else ACT_NONE,
+                           residual=residual, out=out)
+
+    def linear(self, x, key, act=ACT_NONE, slope=0.0, out=None, **kw):
+        """nn.Linear / 1x1 conv with bias over a (B, 1, N, C) view."""
+        w = self.W(key + ".weight")
+        w4 = w.reshape(w.shape[0], w.shape[1], 1, 1)
+        b = self.W(key + ".bias")
+        return self.p.conv(x, key, w4, self._unit(w.shape[0]), b, 1, 1, 1, 0, w.shape[0], act, slope, out=out, **kw)
+
+    # ---- timm resnet blocks
+    def basic_block(self, pfx, x, stride=1):
+        y = self.conv_bn(x, pfx + ".conv1", pfx + ".bn1", 3, stride, 1)
+        sc = x
+        if (pfx + ".downsample.0.weight") in self.sd:
+            sc = self.conv_bn(x, pfx + ".downsample.0", pfx + ".downsample.1", 1, stride, 0, relu=False)
+        return self.conv_bn(y, pfx + ".conv2", pfx + ".bn2", 3, 1, 1, relu=True, residual=sc)
+
+    def bottleneck(self, pfx, x, out=None):
+        y = self.conv_bn(x, pfx + ".conv1", pfx + ".bn1", 1, 1, 0)
+        y = self.conv_bn(y, pfx + ".conv2", pfx + ".bn2", 3, 1, 1)
+        sc = x
+        if (pfx + ".downsample.0.weight") in self.sd:
+            sc = self.conv_bn(x, pfx + ".downsample.0", pfx + ".downsample.1", 1, 1, 0, relu=False, out=None)
+        return self.conv_bn(y, pfx + ".conv3", pfx + ".bn3", 1, 1, 0, relu=True, residual=sc, out=out)
+
+    # ---- HRNet-W18 features (timm HighResolutionNetFeatures)
+    def hr_module(self, pfx, xs):
+        nb = len(xs)
+        xs = list(xs)
+        for b in range(nb):
+            for k in range(4):
+                xs[b] = self.basic_block("%s.branches.%d.%d" % (pfx, b, k), xs[b])
+        outs = []
+        for i in range(nb):
+            terms, shifts = [], []
+            for j in range(nb):
+                q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+                if j == i:
+                    t = xs[j]
+                elif j > i:
+                    t = self.conv_bn(xs[j], q + ".0", q + ".1", 1, 1, 0, relu=False)
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        t = self.conv_bn(t, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), 3, 2, 1, relu=(k != i - j - 1))
+                terms.append(t)
+                shifts.append(max(j - i, 0))
+            out = self.p.act(xs[i].H, xs[i].W, xs[i].C)
+            outs.append(self.p.fuse_sum(terms, shifts, out, relu=True))
+        return outs
+
+    def hrnet(self, pfx, x, feat_outs=None):
+        x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 3, 2, 1)
+        x = self.conv_bn(x, pfx + "conv2", pfx + "bn2", 3, 2, 1)
+        for k in range(4):
+            x = self.bottleneck("%slayer1.%d" % (pfx, k), x)
+        xs = [self.conv_bn(x, pfx + "transition1.0.0", pfx + "transition1.0.1", 3, 1, 1),
+              self.conv_bn(x, pfx + "transition1.1.0.0", pfx + "transition1.1.0.1", 3, 2, 1)]
+        for si, (stage, nmod, chans) in enumerate(HR_STAGES):
+            if si > 0:
+                t = "%stransition%d.%d.0" % (pfx, si + 1, len(chans) - 1)
+                xs = xs + [self.conv_bn(xs[-1], t + ".0", t + ".1", 3, 2, 1)]
+            for m in range(nmod):
+                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs)
+        return [self.bottleneck("%sincre_modules.%d.0" % (pfx, i), f, out=(feat_outs[i] if feat_outs else None))
+                for i, f in enumerate(xs)]
+
+    def resnet34(self, pfx, x, feat_outs=None):
+        x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 7, 2, 3)
+        x = self.p.maxpool(x)
+        feats = []
+        for li, nblk in enumerate((3, 4, 6, 3)):
+            for k in range(nblk):
+                x = self.basic_block("%slayer%d.%d" % (pfx, li + 1, k), x, stride=2 if (k == 0 and li > 0) else 1)
+            feats.append(x)
+        return feats
+
+    # ---- EdgeConv: per-node GEMM to [P'|Q'] + neighbour gather-max (factored StaticGraph_module)
+    def edgeconv(self, pfx, x: Act, graph, slope, out: Act = None):
+        w = self.W(pfx + ".conv.0.weight")            # (C', 2C, 1, 1)
+        Co, C2 = w.shape[0], w.shape[1]
+        Cc = C2 // 2
+        ck = pfx + ".conv.0#pq"
+        if ck not in self.ws.cache:
+            w1, w2 = w[:, :Cc, 0, 0], w[:, Cc:, 0, 0]
+            s, t = self.ws.bn_fold(pfx + ".conv.1")
+            self.ws.cache[ck] = (torch.cat([w1, w2 - w1], 0).reshape(2 * Co, Cc, 1, 1).contiguous(),
+                                 torch.cat([s, s]), torch.cat([torch.zeros_like(t), t]))
+        wpq, sc, sh = self.ws.cache[ck]
+        pq = self.p.conv(x, ck, wpq, sc, sh, 1, 1, 1, 0, 2 * Co)
+        if out is None:
+            out = self.p.act(1, x.W, Co)
+        return self.p.edge_gather(pq, graph["idx"], graph["gids"], out, graph["K"], Co, graph["G"], slope)
+
+
+def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
+    """InitNet_GNN.forward init.py:109-128.  Returns (feats [Act], graph_feats Act)."""
+    p = em.p
+    N = cfg["npoint"]
+    x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
+    bb = pfx + "img_backbone."
+    feats = em.hrnet(bb, x) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
+    f = feats[-1]                                           # (B, 8, 8, Cb)
+    # conv1x1 Cb -> N, then `view(-1, N, 64).permute(0,2,1)` (init.py:112-114): keypoint n's 8x8 response map is its
+    # 64-d feature -> written straight into the (B, N, 64) graph layout through the epilogue strides.
+    w = em.W(pfx + "conv1x1.weight")
+    g0 = p.act(1, N, 64)
+    npix = f.H * f.W
+    p.conv(f, pfx + "conv1x1", w, em._unit(N), em.W(pfx + "conv1x1.bias"), 1, 1, 1, 0, N,
+           ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+    g = g0
+    ng = cfg["init_num_graph_module"]
+    for i in range(ng):
+        last = i == ng - 1
+        g = em.edgeconv("%spre_query_block.%d" % (pfx, i), g, io["graph"], cfg["init_graph_slope"],
+                        out=graph_out if (last and graph_out is not None) else None)
+    if ng == 0 and graph_out is not None:
+        raise RuntimeError("init_network_num_graph_module == 0 is not supported by the fused program")
+    # Linear(64 -> 7) (init.py:107,120-122) into the (B,13,N) logit block: rows [roi | x2 x1 x0 | . . . | y2 y1 y0]
+    wl = em.W(pfx + "mlp.weight")
+    p.conv(g, pfx + "mlp", wl.reshape(7, 64, 1, 1), em._unit(10),
+           torch.cat([em.W(pfx + "mlp.bias")[:4], torch.zeros(3, device=p.device), em.W(pfx + "mlp.bias")[4:]]),
+           1, 1, 1, 0, 10, row_map=[0, 1, 2, 3, -1, -1, -1, 4, 5, 6], cout_rows=10, out_f32=True,
+           ostr=(0, 13 * N, 0, 1, N), out_tbuf=io["bits_tb"])
+    return feats, g
+
+
+def emit_posenet(em: NetEmitter, cfg, io):
+    """PoseNet_GNNskip.forward pipeline.py:351-384."""
+    p = em.p
+    N, B = cfg["npoint"], p.B
+    nref = cfg["res_log2"] - 3
+    active = cfg["stage"] if cfg.get("stage") is not None else nref
+    ngs = cfg["num_graph_module"]
+    ngs = (ngs,) * nref if isinstance(ngs, int) else tuple(ngs)
+    nf = cfg["num_filters"]
+    qd = cfg["query_dims"] or (nf, 256, 64)
+    k = cfg["local_k"]
+    slope = cfg["leaky_slope"]
+
+    def local_buf(i):
+        gdim = 64 if i == 0 else qd[0]
+        return p.act(1, N, qd[0] + gdim)       # [local 4*E | previous graph feature]
+
+    L = local_buf(0) if active > 0 else None
+    feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None)
+    p.decode(io["bits"], -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
+    f = feats[-1]
+    for i in range(active):
+        up = "up_net.%d" % i
+        if i == 0:   # ConvTranspose2d(k3,s2,p1,op1)+BN+ReLU as 4 sub-pixel phase convs, then 2x conv3x3+BN+ReLU
+            wt = em.W(up + ".0.weight")                     # (Cin, Cout, 3, 3)
+            s, t = em.ws.bn_fold(up + ".1")
+            o = p.act(2 * f.H, 2 * f.W, nf)
+            for ph in range(4):
+                a, b = ph >> 1, ph & 1
+                p.conv(f, up + ".0", wt, s, t, 1 + a, 1 + b, 1, 0, nf, ACT_RELU, transposed=1, phase=ph,
+                       ostr=((a * o.W + b) * o.cstride, o.H * o.W * o.cstride, 2 * o.W * o.cstride, 2 * o.cstride, 1),
+                       out_tbuf=o.tbuf, out_hw=(f.H, f.W))
+            f = em.conv_bn(o, up + ".3", up + ".4", 3, 1, 1)
+            f = em.conv_bn(f, up + ".6", up + ".7", 3, 1, 1)
+        else:        # cat[img_feat, img_feats[-i-1]] -> bilinear x2 (align_corners) -> 2x conv3x3+BN+ReLU
+            sk = feats[-i - 1]
+            cat = p.act(2 * f.H, 2 * f.W, f.C + sk.C)
+            p.upsample2x(f, cat.slice(0, f.C))
+            p.upsample2x(sk, cat.slice(f.Cphys, sk.C))
+            f = em.conv_bn(cat, up + ".1", up + ".2", 3, 1, 1)
+            f = em.conv_bn(f, up + ".4", up + ".5", 3, 1, 1)
+        # ---- Refine_moduleGNN.forward pipeline.py:262-298
+        rp = "refine_net.%d" % i
+        wpg = em.W(rp + ".local_feat_ext_block.patch_generator.weight")     # (E, nf, k, k)
+        Ech = wpg.shape[0]
+        patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(rp + ".local_feat_ext_block.patch_generator.bias"),
+                         k, k, 1, k - 1, Ech)
+        p.index2feat(patches, io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, Ech, k)
+        h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)
+        h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope)
+        Lnext = local_buf(i + 1) if i + 1 < active else None
+        for gi in range(ngs[i]):
+            last = gi == ngs[i] - 1
+            h = em.edgeconv("%s.pre_query_block.%d" % (rp, gi), h, io["graph"], cfg["graph_slope"],
+                            out=Lnext.slice(qd[0], qd[0]) if (last and Lnext is not None) else None)
+        if ngs[i] == 0 and Lnext is not None:
+            raise RuntimeError("num_graph_module == 0 is not supported by the fused program")
+        q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope)
+        q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope)
+        # Linear(64 -> 2): channel 0 = new x bit -> row 4+i, channel 1 = new y bit -> row 10+i  (pipeline.py:375-378)
+        em.linear(q, rp + ".query_block.mlps.4", ACT_NONE, 0.0, out_f32=True,
+                  ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
+        p.decode(io["bits"], i, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
+        L = Lnext
+    # seg_block Conv2d(nf -> seg_dim, 1x1) on the last feature map, NCHW fp32 out (pipeline.py:349,383)
+    wseg = em.W("seg_block.weight")
+    sd_ = wseg.shape[0]
+    p.conv(f, "seg_block", wseg, em._unit(sd_), em.W("seg_block.bias"), 1, 1, 1, 0, sd_, out_f32=True,
+           ostr=(0, sd_ * f.H * f.W, f.W, 1, f.H * f.W), out_tbuf=io["seg_tb"])
+    return feats, f

@@ -1,0 +1,153 @@
+/*
+ * checkerpose_hip.h -- C ABI of libcheckerpose_hip.so (MI355X / gfx950).
+ *
+ * The reference (RuyiLian/CheckerPose) has NO native code and NO FFI: its hot path is the torch-op
+ * sequence inside InitNet_GNN.forward / PoseNet_GNNskip.forward.  Each entry point below therefore
+ * replaces a span of reference Python (cited per function, paths relative to
+ * /root/reference/checkerpose) rather than an existing foreign function.  The binding a maintainer
+ * adds on the reference side is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + ints, no torch / HIP types in signatures; `cp_stream_t` is a hipStream_t
+ *     passed as void* (NULL = default stream).
+ *   - every buffer (activations, packed weights, outputs) is caller-owned DEVICE memory; the
+ *     library allocates nothing, keeps no mutable global state, is re-entrant and stream-ordered.
+ *   - activations are channels-last: (B, H, W, Cphys) with Cphys a multiple of cp_chan_align(dtype);
+ *     padded channels are zero.  Graph features are (B, N, Cphys), i.e. the same layout with H=1.
+ *   - returns CP_OK (0) or a negative code; cp_strerror() names it.
+ */
+#ifndef CHECKERPOSE_HIP_H
+#define CHECKERPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cp_stream_t;
+
+enum { CP_F32 = 0, CP_BF16 = 1 };
+enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_LEAKY = 2 };
+enum {
+  CP_OK = 0,
+  CP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  CP_ERR_HIP = -2,       /* a HIP runtime call failed (launch error, bad pointer, ...) */
+  CP_ERR_ALIGN = -3,     /* pointer or stride not aligned as the kernel requires */
+  CP_ERR_RANGE = -4      /* buffer too large for 32-bit buffer addressing (>= 2 GiB) */
+};
+
+int cp_version(void);
+const char* cp_strerror(int code);
+
+/* elements per 16 bytes: 4 (f32) or 8 (bf16).  Physical channel counts are multiples of this. */
+int cp_chan_align(int dtype);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing (init / load_state_dict time, not the hot path).
+ * Packs a PyTorch-layout fp32 weight into MFMA-fragment order for cp_conv2d_igemm:
+ *   K index = (r, s, cin) with cin padded to cin_phys; blocks of 1 KiB = one (16-channel tile,
+ *   K-chunk) wave fragment, ordered [tile][chunk][lane][16 B].
+ * transposed = 0 : w is (Cout, Cin, R, S)      (nn.Conv2d / nn.Linear with R=S=1)
+ * transposed = 1 : w is (Cin, Cout, 3, 3) of ConvTranspose2d(k3,s2,p1,op1) (pipeline.py:187-197) and
+ *                  `phase` = 2*a+b selects the sub-pixel phase (output row parity a, column parity b);
+ *                  the packed kernel then has R=1+a, S=1+b taps.
+ * row_map (optional, length cout_rows): packed output row n takes source row row_map[n] (or zeros if
+ *   row_map[n] < 0); NULL = identity.  Used to interleave zero rows (init MLP, init.py:107).
+ * ------------------------------------------------------------------------------------------- */
+size_t cp_packed_weight_bytes(int dtype, int cout_rows, int cin_phys, int R, int S);
+int cp_pack_conv_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int R, int S,
+                        int cin_phys, int transposed, int phase, const int32_t* row_map, int cout_rows,
+                        void* packed);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (fp32: v_mfma_f32_16x16x4_f32, bf16: v_mfma_f32_16x16x32_bf16),
+ * fused per-channel affine (folded BatchNorm or bias), optional residual add, activation.
+ * Replaces every nn.Conv2d(+BatchNorm2d)(+ReLU/LeakyReLU) and nn.Linear on the path:
+ *   backbone convs (timm hrnet/resnet via backbone.py:48), init.py:85-95 (conv1x1), init.py:58-62 +
+ *   pipeline.py:49-53 (EdgeConv 1x1 conv, in its factored per-node form), init.py:107 (mlp),
+ *   pipeline.py:183-211 (decoder), pipeline.py:146-147 (patch_generator), pipeline.py:61-69,168-180
+ *   (MLPs), pipeline.py:349 (seg_block).
+ *
+ *   out[o_base + b*o_sb + oy*o_sy + ox*o_sx + c*o_sc] =
+ *       act( conv(in)[b,oy,ox,c] * scale[c] + shift[c] + residual[same index] )
+ * ------------------------------------------------------------------------------------------- */
+typedef struct CpConvDesc {
+  int32_t dtype;          /* CP_F32 | CP_BF16: type of in / packed weights / residual / out */
+  int32_t out_f32;        /* 1: out (and residual) are fp32 regardless of dtype (final logits, seg) */
+  int32_t B, H, W;        /* input spatial size */
+  int32_t Cin;            /* channels contracted (physical, multiple of cp_chan_align) */
+  int32_t in_cstride;     /* elements between consecutive input pixels (>= in_coff + Cin) */
+  int32_t in_coff;        /* first channel of the input slice */
+  int32_t R, S, stride, pad;
+  int32_t Ho, Wo;         /* output spatial size (iy = oy*stride - pad + r) */
+  int32_t Cout;           /* channels stored (physical) ; weights were packed with cout_rows >= Cout */
+  int32_t act;            /* CP_ACT_* */
+  float slope;            /* LeakyReLU negative slope */
+  int64_t o_base, o_sb, o_sy, o_sx, o_sc;   /* output (and residual) element strides */
+} CpConvDesc;
+
+int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                    const float* scale, const float* shift, const void* residual, void* out);
+
+/* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
+ * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
+int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,
+                              int C, int in_cstride, int in_coff, int out_cstride, int out_coff);
+
+/* HRNet fuse layer sum (timm HighResolutionModule.forward): out = relu?( sum_t nearest_up(src_t, 2^shift_t) ),
+ * all (B, H>>shift_t, W>>shift_t, C) contiguous.  nsrc <= 4. */
+int cp_fuse_sum_act(cp_stream_t stream, int dtype, int nsrc, const void* const* srcs, const int32_t* shifts,
+                    void* out, int B, int H, int W, int C, int relu);
+
+/* max_pool2d(3, 2, 1) for the resnet34 stem (timm resnet). (B,H,W,C) -> (B,H/2,W/2,C) */
+int cp_maxpool3x3s2(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W, int C);
+
+/* ---------------------------------------------------------------------------------------------
+ * EdgeConv aggregation, factored form of StaticGraph_module.forward (init.py:64-68 == pipeline.py:55-59,
+ * get_graph_feature init.py:36-49).  pq is the per-node GEMM output (B, N, 2*C): [P' | Q'] with the
+ * BatchNorm scale folded in (P' = s*W1 x, Q' = s*(W2-W1) x + t), so
+ *   out[b,i,c] = leaky( max_k P'[b, idx[g,i,k], c] + Q'[b,i,c] ),   g = graph_ids ? graph_ids[b] : 0
+ * idx is (G, N, K) int32 (LM: per-object tables, pipeline_lm.py:57).  Writes channels
+ * [out_coff, out_coff+C) of (B, N, out_cstride).
+ * ------------------------------------------------------------------------------------------- */
+int cp_edgeconv_gather_max(cp_stream_t stream, int dtype, const void* pq, const int32_t* idx,
+                           const int32_t* graph_ids, void* out, int B, int N, int K, int C, int G,
+                           int out_cstride, int out_coff, float slope);
+
+/* Index2Feat_module.forward gather (pipeline.py:156-163) fused with the RoI mask multiply (pipeline.py:280):
+ * patches (B, Hp, Wp, E); for keypoint (b,i) taps (2y,2x), (2y+k,2x), (2y,2x+k), (2y+k,2x+k) ->
+ * out[b,i, out_coff + t*E + e] = patches[b,ty,tx,e] * mask[b,i].  ids int32 (B,N), mask fp32 (B,N). */
+int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* patches, const int32_t* x_id,
+                         const int32_t* y_id, const float* mask, void* out, int B, int N, int Hp, int Wp,
+                         int E, int k, int out_cstride, int out_coff);
+
+/* Bit decode (pipeline.py:72-127, 367-369, 380-381) on the fp32 logit block `bits` (B, 13, N):
+ * row 0 = roi, rows 1..6 = x bits (MSB first), rows 7..12 = y bits.
+ *   stage < 0 : mask = bits[0] > 0 ; x_id = MSB-first int of rows 1..3 ; y_id of rows 7..9
+ *   stage = i : x_id = 2*x_id + (bits[4+i] > 0) ; y_id = 2*y_id + (bits[10+i] > 0)
+ * (sigmoid(z) > 0.5  <=>  z > 0).  Also mirrors the ids to int64 (the reference's return dtype). */
+int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, float* mask, int32_t* x_id,
+                   int32_t* y_id, int64_t* x_id64, int64_t* y_id64, int B, int N);
+
+/* layout plumbing at the boundary: NCHW fp32 image -> channels-last `dtype` (C padded with zeros to
+ * Cphys), and channels-last slice -> NCHW fp32 (for `return_img_feats`, init.py:123-124). */
+int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, void* out, int B, int C, int H, int W,
+                    int Cphys);
+int cp_nhwc_to_nchw_f32(cp_stream_t stream, int dtype, const void* in, float* out, int B, int C, int H, int W,
+                        int in_cstride, int in_coff);
+
+/* ---------------------------------------------------------------------------------------------
+ * hipGraph helpers: capture the launch sequence of one forward (everything above is capture-safe:
+ * no allocation, no synchronisation) and replay it with one call.
+ * ------------------------------------------------------------------------------------------- */
+int cp_graph_begin_capture(cp_stream_t stream);
+int cp_graph_end_capture(cp_stream_t stream, void** graph_exec_out);
+int cp_graph_launch(void* graph_exec, cp_stream_t stream);
+int cp_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHECKERPOSE_HIP_H */

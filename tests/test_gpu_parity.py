@@ -1,0 +1,378 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden vectors.  Tolerances (written here, per SURVEY.md §8c / BASELINE.json north_star):
+  fp32 path : |logit - oracle| <= 1e-4 absolute on logits of O(1..5); per-op 2e-5 * (1 + |ref|); ids bit-exact
+  bf16 path : not a 1e-4 path (bf16 has 8 mantissa bits): per-op 3e-2 * (1 + |ref|), end-to-end bit agreement >= 97 %
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from checkerpose_amd import _abi
+from checkerpose_amd._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
+from oracle import checkerpose_oracle as O
+from tests.common import (ape_p3d, build_net, det_image, det_tensor, golden, inject_feats, lm_p3d, oracle_kwargs)
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
+TOL = {CP_F32: 2e-5, CP_BF16: 3e-2}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def to_cl(x, dtype, cphys=None):
+    """NCHW fp32 CPU -> channels-last (B,H,W,Cphys) `dtype` on the GPU, zero padded."""
+    B, Cc, H, W = x.shape
+    E = 8 if dtype == CP_BF16 else 4
+    cp = cphys or rup(Cc, E)
+    out = torch.zeros(B, H, W, cp, dtype=DT[dtype])
+    out[..., :Cc] = x.permute(0, 2, 3, 1).to(DT[dtype])
+    return out.to(dev()).contiguous()
+
+
+def from_cl(t, Cc):
+    return t[..., :Cc].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dtype):
+    """round the reference INPUT the way the device sees it (bf16 inputs are rounded once)"""
+    return x.to(DT[dtype]).float()
+
+
+def close(a, b, tol):
+    a, b = a.double(), b.double()
+    err = ((a - b).abs() / (1 + b.abs())).max().item()
+    assert err <= tol, "max rel err %.3e > %.1e" % (err, tol)
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack(lib, dtype, w, cin_phys, R, S, rows=None, transposed=0, phase=0):
+    Cout, Cin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    rows = rows or Cout
+    buf = torch.empty(lib.cp_packed_weight_bytes(dtype, rows, cin_phys, R, S), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv_weight(st(), dtype, wd.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase, None, rows,
+                                       buf.data_ptr()))
+    torch.cuda.synchronize()
+    return buf
+
+
+def run_conv(lib, dtype, x, w, scale, shift, stride, pad, act=ACT_NONE, slope=0.0, residual=None):
+    """x NCHW fp32 (CPU), w (Cout,Cin,R,S).  Returns NCHW fp32 (CPU) from the channels-last HIP conv."""
+    B, Cin, H, W = x.shape
+    Cout, _, R, S = w.shape
+    E = 8 if dtype == CP_BF16 else 4
+    xin = to_cl(x, dtype)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    cop = rup(Cout, E)
+    out = torch.full((B, Ho, Wo, cop), float("nan"), dtype=DT[dtype], device=dev())
+    pw = pack(lib, dtype, w, xin.shape[-1], R, S)
+    n16 = rup(Cout, 16)
+    sc = torch.zeros(n16); sc[:Cout] = scale
+    sh = torch.zeros(n16); sh[:Cout] = shift
+    sc, sh = sc.to(dev()), sh.to(dev())
+    res = to_cl(residual, dtype) if residual is not None else None
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = R, S, stride, pad, Ho, Wo, cop, act, slope
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, Ho * Wo * cop, Wo * cop, cop, 1
+    _abi.check(lib.cp_conv2d_igemm(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                   res.data_ptr() if res is not None else None, out.data_ptr()), "conv")
+    torch.cuda.synchronize()
+    if cop > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+    return from_cl(out, Cout)
+
+
+CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, act, residual)
+    (2, 3, 32, 32, 64, 3, 2, 1, ACT_RELU, False),      # stem: 3 input channels padded to 4 / 8
+    (1, 64, 16, 16, 64, 3, 2, 1, ACT_RELU, False),
+    (2, 18, 16, 16, 18, 3, 1, 1, ACT_RELU, True),      # HRNet basic block, ragged channels + residual
+    (1, 36, 9, 11, 72, 3, 2, 1, ACT_NONE, False),      # odd spatial sizes
+    (1, 144, 8, 8, 18, 1, 1, 0, ACT_NONE, False),      # fuse 1x1
+    (1, 256, 8, 8, 256, 3, 1, 1, ACT_RELU, False),     # decoder 3x3
+    (2, 256, 16, 16, 64, 2, 1, 1, ACT_NONE, False),    # patch_generator k=2 pad=1 -> (H+1, W+1)
+    (3, 64, 1, 100, 128, 1, 1, 0, ACT_LEAKY, False),   # linear over keypoints, M not a tile multiple
+    (1, 16, 40, 40, 10, 7, 2, 3, ACT_RELU, False),     # 7x7 stride 2 (resnet stem shape class)
+]
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_vs_torch_cpu(lib, dtype, case):
+    B, Cin, H, W, Cout, k, stride, pad, act, has_res = case
+    x = det_tensor("cx%s" % (case,), (B, Cin, H, W))
+    w = det_tensor("cw%s" % (case,), (Cout, Cin, k, k), (2.0 / (Cin * k * k)) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("cs%s" % (case,), (Cout,))
+    shift = 0.2 * det_tensor("ct%s" % (case,), (Cout,))
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = det_tensor("cr%s" % (case,), tuple(ref.shape))
+        ref = ref + rnd(res, dtype)
+    ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.01) if act == ACT_LEAKY else ref)
+    got = run_conv(lib, dtype, x, w, scale, shift, stride, pad, act, 0.01, res)
+    close(got, ref, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_convtranspose_phases_vs_torch_cpu(lib, dtype):
+    """ConvTranspose2d(k3,s2,p1,op1) (pipeline.py:187-197) as 4 sub-pixel phase convs."""
+    B, Cin, H, W, Cout = 2, 32, 5, 6, 24
+    x = det_tensor("tx", (B, Cin, H, W))
+    w = det_tensor("tw", (Cin, Cout, 3, 3), 0.2)
+    ref = F.conv_transpose2d(rnd(x, dtype), rnd(w, dtype), None, stride=2, padding=1, output_padding=1)
+    xin = to_cl(x, dtype)
+    cop = rup(Cout, 8 if dtype == CP_BF16 else 4)
+    out = torch.full((B, 2 * H, 2 * W, cop), float("nan"), dtype=DT[dtype], device=dev())
+    one = torch.ones(rup(Cout, 16), device=dev()); zero = torch.zeros(rup(Cout, 16), device=dev())
+    for ph in range(4):
+        a, b = ph >> 1, ph & 1
+        pw = pack(lib, dtype, w, xin.shape[-1], 1 + a, 1 + b, transposed=1, phase=ph)
+        d = CpConvDesc()
+        d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+        d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 1 + a, 1 + b, 1, 0, H, W, cop, ACT_NONE, 0.0
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = (a * 2 * W + b) * cop, 4 * H * W * cop, 2 * 2 * W * cop, 2 * cop, 1
+        _abi.check(lib.cp_conv2d_igemm(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), one.data_ptr(), zero.data_ptr(), None,
+                                       out.data_ptr()), "convT phase")
+    torch.cuda.synchronize()
+    close(from_cl(out, Cout), ref, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_upsample_fuse_maxpool(lib, dtype):
+    tol = TOL[dtype]
+    # bilinear x2 align_corners into a channel slice of a wider buffer (how the decoder builds its concat)
+    x = det_tensor("ux", (2, 24, 5, 7))
+    xin = to_cl(x, dtype)
+    out = torch.zeros(2, 10, 14, 40, dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_upsample2x_bilinear_ac(st(), dtype, xin.data_ptr(), out.data_ptr(), 2, 5, 7, 24, 24, 0, 40, 16))
+    torch.cuda.synchronize()
+    ref = F.interpolate(rnd(x, dtype), scale_factor=2, mode="bilinear", align_corners=True)
+    close(out[..., 16:40].float().cpu().permute(0, 3, 1, 2), ref, max(tol, 1e-5) if dtype == CP_F32 else 1e-2)
+    assert float(out[..., :16].float().abs().max()) == 0.0
+    # HRNet fuse: identity + two nearest-upsampled terms, ReLU
+    a, b, c = det_tensor("fa", (2, 20, 8, 8)), det_tensor("fb", (2, 20, 4, 4)), det_tensor("fc", (2, 20, 2, 2))
+    srcs = [to_cl(t, dtype, 24 if dtype == CP_BF16 else 20) for t in (a, b, c)]
+    cp = srcs[0].shape[-1]
+    o = torch.empty(2, 8, 8, cp, dtype=DT[dtype], device=dev())
+    arr = (C.c_void_p * 4)(*[s.data_ptr() for s in srcs], None)
+    sh = (C.c_int32 * 4)(0, 1, 2, 0)
+    _abi.check(lib.cp_fuse_sum_act(st(), dtype, 3, arr, sh, o.data_ptr(), 2, 8, 8, cp, 1))
+    torch.cuda.synchronize()
+    ref = F.relu(rnd(a, dtype) + F.interpolate(rnd(b, dtype), scale_factor=2, mode="nearest")
+                 + F.interpolate(rnd(c, dtype), scale_factor=4, mode="nearest"))
+    close(from_cl(o, 20), ref, tol)
+    # max pool 3x3 s2 p1
+    x = det_tensor("mp", (2, 16, 12, 10))
+    xin = to_cl(x, dtype)
+    o = torch.empty(2, 6, 5, 16, dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_maxpool3x3s2(st(), dtype, xin.data_ptr(), o.data_ptr(), 2, 12, 10, 16))
+    torch.cuda.synchronize()
+    close(from_cl(o, 16), F.max_pool2d(rnd(x, dtype), 3, 2, 1), 1e-7)
+
+
+def _edge_ref(sd, pfx, x, idx, slope=0.2):
+    return O.static_graph_module(sd, pfx, x, idx, slope)
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("Cc,pfx", [(64, "init_net.pre_query_block.0"), (256, "refine_net.1.pre_query_block.2")])
+def test_edgeconv_factored_vs_reference_form(lib, dtype, Cc, pfx):
+    """Factored EdgeConv (per-node GEMM -> [P'|Q'], gather-max) == the reference's per-edge conv+BN+LeakyReLU+max
+    on the real LM-O `ape` kNN graph, with mixed-sign BatchNorm gammas."""
+    from checkerpose_amd.engine import Program, WeightStore
+    from checkerpose_amd.netbuilder import NetEmitter
+    net = build_net(seed=0)
+    sd_cpu = net.state_dict()
+    assert (sd_cpu[pfx + ".conv.1.weight"] < 0).any() and (sd_cpu[pfx + ".conv.1.weight"] > 0).any()
+    idx = net.init_net.knn_idx
+    B, N = 3, 512
+    x = det_tensor("ex%d" % Cc, (B, Cc, N))
+    ref = _edge_ref(sd_cpu, pfx, rnd(x, dtype), idx)
+    sd = {k: v.to(dev()) for k, v in sd_cpu.items() if k.startswith(pfx)}
+    ws = WeightStore(lib, sd, dtype, dev())
+    prog = Program(lib, ws, dtype, B, dev())
+    em = NetEmitter(prog, sd)
+    xin = prog.act(1, N, Cc)
+    idx_d = idx.to(torch.int32).contiguous().to(dev())
+    out = em.edgeconv(pfx, xin, dict(idx=idx_d, gids=None, K=20, G=1), 0.2)
+    prog._add(lambda *a: 0, lambda P: (), "keepalive", [xin.tbuf, out.tbuf], [])   # nothing is recycled before read-back
+    prog.finalize()
+    es = 2 if dtype == CP_BF16 else 4
+
+    def tview(a):
+        n = a.B * a.H * a.W * a.cstride
+        return prog.workspace[a.tbuf.offset: a.tbuf.offset + n * es].view(DT[dtype]).view(a.B, a.W, a.cstride)
+
+    tview(xin).copy_(x.permute(0, 2, 1).to(DT[dtype]))
+    prog.run(st())
+    torch.cuda.synchronize()
+    got = tview(out).float().cpu().permute(0, 2, 1)
+    close(got, ref, 1e-5 if dtype == CP_F32 else 4e-2)
+
+
+def test_edgeconv_per_sample_graphs_lm(lib):
+    """LM twin: each sample gathers along its own object's graph (pipeline_lm.py:55-57), 1-based obj_ids."""
+    B, N, K, Cc = 4, 512, 20, 64
+    idx = O.knn(lm_p3d(512), K)                                    # (15, N, K)
+    obj = torch.tensor([3, 15, 1, 9])
+    pq = det_tensor("lmpq", (B, N, 2 * Cc))
+    P, Q = pq[..., :Cc], pq[..., Cc:]
+    gi = idx[obj - 1]                                              # (B,N,K)
+    nb = torch.gather(P.unsqueeze(2).expand(B, N, K, Cc), 1, gi.unsqueeze(-1).expand(B, N, K, Cc))
+    ref = F.leaky_relu(nb.max(dim=2)[0] + Q, 0.2)
+    out = torch.empty(B, N, Cc, device=dev())
+    pq_d, idx_d = pq.to(dev()), idx.to(torch.int32).contiguous().to(dev())
+    gids = (obj - 1).to(torch.int32).to(dev())
+    _abi.check(lib.cp_edgeconv_gather_max(st(), CP_F32, pq_d.data_ptr(), idx_d.data_ptr(), gids.data_ptr(), out.data_ptr(),
+                                          B, N, K, Cc, 15, Cc, 0, 0.2))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)                              # pure gather/max/add: bit exact
+
+
+@pytest.mark.parametrize("H", [16, 32, 64])
+def test_index2feat_gather_vs_golden(lib, H):
+    """4-tap local feature gather incl. border ids, against the REFERENCE module's golden output."""
+    g = golden("blk_index2feat_h%d" % H)
+    i = {16: 0, 32: 1, 64: 2}[H]
+    net = build_net(seed=0)
+    sd = net.state_dict()
+    B, N = 2, 512
+    f = det_tensor("i2f%d" % H, (B, 256, H, H))
+    w = sd["refine_net.%d.local_feat_ext_block.patch_generator.weight" % i]
+    bias = sd["refine_net.%d.local_feat_ext_block.patch_generator.bias" % i]
+    patches = run_conv(lib, CP_F32, f, w, torch.ones(64), bias, 1, 1)          # (B,64,H+1,W+1)
+    p_cl = patches.permute(0, 2, 3, 1).contiguous().to(dev())
+    xid = torch.from_numpy(g["xid"].astype(np.int32)).to(dev()); yid = torch.from_numpy(g["yid"].astype(np.int32)).to(dev())
+    mask = torch.ones(B, N, device=dev())
+    out = torch.zeros(B, N, 320, device=dev())
+    _abi.check(lib.cp_index2feat_gather(st(), CP_F32, p_cl.data_ptr(), xid.data_ptr(), yid.data_ptr(), mask.data_ptr(),
+                                        out.data_ptr(), B, N, H + 1, H + 1, 64, 2, 320, 0))
+    torch.cuda.synchronize()
+    got = out[..., :256].cpu().permute(0, 2, 1)
+    close(got[:, :, ::4], torch.from_numpy(g["out"]), 2e-5)
+    assert float(out[..., 256:].abs().max()) == 0.0
+    mask0 = torch.zeros(B, N, device=dev())                       # RoI mask multiply (pipeline.py:280)
+    _abi.check(lib.cp_index2feat_gather(st(), CP_F32, p_cl.data_ptr(), xid.data_ptr(), yid.data_ptr(), mask0.data_ptr(),
+                                        out.data_ptr(), B, N, H + 1, H + 1, 64, 2, 320, 0))
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0
+
+
+def test_bits_decode_exact(lib):
+    B, N = 3, 700
+    bits = det_tensor("bits", (B, 13, N))
+    bits[0, 0, 0] = 0.0; bits[0, 1, 1] = 0.0; bits[0, 4, 2] = -0.0          # z == 0 -> bit 0 (pipeline.py:89-90)
+    bd = bits.to(dev())
+    mask = torch.empty(B, N, device=dev()); xid = torch.empty(B, N, dtype=torch.int32, device=dev()); yid = torch.empty_like(xid)
+    x64 = torch.empty(B, N, dtype=torch.int64, device=dev()); y64 = torch.empty_like(x64)
+    _abi.check(lib.cp_bits_decode(st(), bd.data_ptr(), -1, mask.data_ptr(), xid.data_ptr(), yid.data_ptr(), x64.data_ptr(), y64.data_ptr(), B, N))
+    rx, ry = O.id_from_code_prob(bits[:, 1:4]), O.id_from_code_prob(bits[:, 7:10])
+    assert torch.equal(mask.cpu(), O.mask_from_prob(bits[:, 0:1])[:, 0]) and torch.equal(x64.cpu(), rx) and torch.equal(y64.cpu(), ry)
+    for s in range(3):
+        _abi.check(lib.cp_bits_decode(st(), bd.data_ptr(), s, mask.data_ptr(), xid.data_ptr(), yid.data_ptr(), x64.data_ptr(), y64.data_ptr(), B, N))
+        rx = rx * 2 + O.id_from_bit_prob(bits[:, 4 + s:5 + s]); ry = ry * 2 + O.id_from_bit_prob(bits[:, 10 + s:11 + s])
+        assert torch.equal(x64.cpu(), rx) and torch.equal(y64.cpu(), ry) and torch.equal(xid.cpu().long(), rx)
+    assert torch.equal(x64.cpu(), O.id_from_code_prob(bits[:, 1:7]))         # == MSB-first decode of all 6 bits
+
+
+# ------------------------------------------------------------------------------------------- end to end
+def _cmp_e2e(out, ref, tol=1e-4, margin=None):
+    names = ("roi", "xb", "yb", "seg")
+    worst = 0.0
+    for a, b, n in zip(out[:4], ref[:4], names):
+        b = b if torch.is_tensor(b) else torch.from_numpy(np.asarray(b))
+        assert tuple(a.shape) == tuple(b.shape), n
+        worst = max(worst, float((a.float().cpu() - b).abs().max()))
+    assert worst <= tol, "max |logit - ref| = %.3e" % worst
+    for a, b in zip(out[4:], ref[4:]):
+        b = b if torch.is_tensor(b) else torch.from_numpy(np.asarray(b).astype(np.int64))
+        assert a.dtype == torch.int64 and torch.equal(a.cpu(), b)
+    return worst
+
+
+def test_e2e_fp32_vs_golden_hrnet_and_oracle(lib):
+    """Full PoseNet_GNNskip (HRNet-W18 + decoder + 3 refine stages), fp32 path, B=1, LM-O ape N=512: against the
+    golden 6-tuple (reference head on the oracle backbone) AND a live oracle run; also InitNet_GNN alone (config #1)."""
+    g = golden("e2e_hrnet")
+    net = build_net(seed=int(g["seed"]))
+    img = det_image(1)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
+    net = net.to(dev())
+    out = net(img.to(dev()), ape_p3d(512).to(dev()).expand(1, -1, -1))
+    _cmp_e2e(out, ref)
+    _cmp_e2e(out, (g["roi"], g["xb"], g["yb"], g["seg"], g["xid"], g["yid"]), tol=3e-4)   # ref-vs-oracle fp32 reorder noise included
+    o2 = net(img.to(dev()), None)                       # second call = hipGraph replay; must be identical
+    for a, b in zip(out, o2):
+        assert torch.equal(a, b)
+    init_out = net.init_net(img.to(dev()))
+    assert tuple(init_out.shape) == (1, 7, 512)
+    assert float((init_out.cpu() - torch.from_numpy(g["init_out"])).abs().max()) <= 1e-4
+    o3, feats, gf = net.init_net(img.to(dev()), return_graph_feats=True)
+    assert [tuple(f.shape[1:]) for f in feats] == [(128, 64, 64), (256, 32, 32), (512, 16, 16), (1024, 8, 8)]
+    assert tuple(gf.shape) == (1, 64, 512) and torch.equal(o3, init_out)
+
+
+def test_e2e_fp32_batch_ragged_and_stage_truncation(lib):
+    net = build_net(seed=1)
+    img = det_image(3, seed=5)
+    sd = net.state_dict()
+    ref, _ = O.posenet_forward(sd, img, net.init_net.knn_idx, 512, **oracle_kwargs())
+    ref1, _ = O.posenet_forward(sd, img, net.init_net.knn_idx, 512, stage=1, **oracle_kwargs())
+    net = net.to(dev())
+    _cmp_e2e(net(img.to(dev()), None), ref)
+    out1 = net(img.to(dev()), None, stage=1)
+    assert tuple(out1[1].shape) == (3, 4, 512) and tuple(out1[3].shape) == (3, 2, 16, 16)
+    _cmp_e2e(out1, ref1)
+
+
+def test_e2e_lm_per_object_graphs_vs_golden(lib):
+    g = golden("e2e_lm_injected")   # head only (features injected) -> compare the full net against the live oracle instead,
+    net = build_net(seed=int(g["seed"]), lm=True)               # and the golden pins the oracle (tests/test_oracle.py)
+    obj = torch.tensor([1, 9, 15, 9])
+    img = det_image(4, seed=2)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx[obj - 1], 512, **oracle_kwargs())
+    net = net.to(dev())
+    out = net(img.to(dev()), None, obj.to(dev()))
+    _cmp_e2e(out, ref)
+
+
+def test_e2e_n4096_dense_keypoints(lib):
+    """config #5 shape class: N=4096 keypoints (stress of the gather), B=1, fp32."""
+    net = build_net(npoint=4096, seed=3)
+    img = det_image(1, seed=7)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 4096, **oracle_kwargs())
+    net = net.to(dev())
+    _cmp_e2e(net(img.to(dev()), None), ref)
+
+
+def test_e2e_bf16_bit_agreement(lib):
+    """bf16 path (BASELINE config #2): not a 1e-4 path.  Judged on agreement of the thresholded outputs."""
+    net = build_net(seed=1)
+    img = det_image(4, seed=3)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
+    net = net.to(dev()).set_compute_dtype("bf16")
+    out = net(img.to(dev()), None)
+    roi_agree = float(((out[0].cpu() > 0) == (ref[0] > 0)).float().mean())
+    init_bits = float(((out[1].cpu()[:, :3] > 0) == (ref[1][:, :3] > 0)).float().mean())
+    seg_agree = float(((out[3].cpu() > 0) == (ref[3] > 0)).float().mean())
+    err = float((out[0].cpu() - ref[0]).abs().max())
+    print("bf16: roi agree %.4f init-x-bits agree %.4f seg agree %.4f max roi err %.3e" % (roi_agree, init_bits, seg_agree, err))
+    assert roi_agree >= 0.97 and init_bits >= 0.97 and seg_agree >= 0.97
+    assert torch.isfinite(out[1]).all() and torch.isfinite(out[3]).all()

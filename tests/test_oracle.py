@@ -1,0 +1,107 @@
+"""CPU: pin the oracle (oracle/checkerpose_oracle.py) against the golden vectors that the REFERENCE's own
+modules produced (tests/golden/make_golden.py).  Tolerances: fp32, |err| <= 2e-5 * (1 + |ref|) per block."""
+import numpy as np
+import torch
+
+from oracle import checkerpose_oracle as O
+from tests.common import ape_p3d, build_net, det_image, det_tensor, golden, inject_feats, lm_p3d, oracle_kwargs
+
+torch.set_grad_enabled(False)
+
+
+def close(a, b, tol=2e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    err = np.abs(a - b) / (1.0 + np.abs(b))
+    assert err.max() <= tol, "max rel err %.3e" % err.max()
+
+
+def test_knn_tables_match_reference():
+    for n in (512, 4096):
+        idx = O.knn(ape_p3d(n), 20)[0].numpy()
+        ref = golden("knn_ape%d" % n)["idx"][0].astype(np.int64)
+        assert (np.sort(idx, 1) == np.sort(ref, 1)).all()
+        assert (idx[:, 0] == np.arange(n)).all()           # self is neighbour 0
+    idx = O.knn(lm_p3d(512), 20).numpy()
+    assert (np.sort(idx, 2) == np.sort(golden("knn_lm512")["idx"].astype(np.int64), 2)).all()
+
+
+def test_product_knn_equals_oracle_knn():
+    from checkerpose_amd.model.init import knn
+    p = ape_p3d(512)
+    assert torch.equal(knn(p, 20), O.knn(p, 20))
+
+
+def test_blocks_match_reference():
+    net = build_net(seed=0)
+    sd = net.state_dict()
+    idx = net.init_net.knn_idx
+    B = 2
+    g = golden("blk_edgeconv")
+    close(O.static_graph_module(sd, "init_net.pre_query_block.0", det_tensor("x64", (B, 64, 512)), idx), g["y64"])
+    close(O.static_graph_module(sd, "refine_net.1.pre_query_block.2", det_tensor("x256", (B, 256, 512)), idx)[:, :, ::4], g["y256"])
+    for i, H in enumerate((16, 32, 64)):
+        g = golden("blk_index2feat_h%d" % H)
+        f = det_tensor("i2f%d" % H, (B, 256, H, H))
+        out = O.index2feat(sd, "refine_net.%d.local_feat_ext_block" % i, f, torch.from_numpy(g["xid"].astype(np.int64)),
+                           torch.from_numpy(g["yid"].astype(np.int64)), 2)
+        close(out[:, :, ::4], g["out"])
+    g = golden("blk_upsample")
+    close(O.upsample_module(sd, "up_net.0", det_tensor("up0", (1, 1024, 4, 4)).abs(), True), g["up0"])
+    close(O.upsample_module(sd, "up_net.1", det_tensor("up1", (1, 768, 6, 6)).abs(), False), g["up1"])
+    close(O.upsample_module(sd, "up_net.2", det_tensor("up2", (1, 512, 5, 7)).abs(), False), g["up2"])
+    g = golden("blk_refine0")
+    roi = torch.where(det_tensor("roi", (B, 1, 512)) > -0.3, 1.0, 0.0)
+    xid = torch.from_numpy((np.arange(B * 512).reshape(B, 512) * 3) % 8).long()
+    yid = torch.from_numpy((np.arange(B * 512).reshape(B, 512) * 11 + 2) % 8).long()
+    bits, gf = O.refine_module(sd, "refine_net.0", det_tensor("imf16", (B, 256, 16, 16)).abs(), det_tensor("gfeat", (B, 64, 512)),
+                               roi, xid, yid, idx, 3)
+    close(bits, g["bits"]); close(gf[:, :, ::4], g["feat"])
+    g = golden("blk_initnet_injected")
+    out, _, g0 = O.init_net_forward(sd, "init_net.", None, idx, 512, img_feats=inject_feats(B))
+    close(out, g["out"]); close(g0, g["graph"])
+
+
+def _check_e2e(o, g, tol=1e-4):
+    roi, xb, yb, seg, xid, yid = o
+    for a, k in ((roi, "roi"), (xb, "xb"), (yb, "yb"), (seg, "seg")):
+        assert np.abs(a.numpy() - g[k]).max() <= tol, k
+    assert (xid.numpy() == g["xid"]).all() and (yid.numpy() == g["yid"]).all()
+    assert xid.dtype == torch.int64 and roi.shape[1] == 1 and xb.shape[1] == 6
+
+
+def test_e2e_injected_matches_reference():
+    g = golden("e2e_injected")
+    net = build_net(seed=int(g["seed"]))
+    o, _ = O.posenet_forward(net.state_dict(), None, net.init_net.knn_idx, 512, img_feats=inject_feats(2), **oracle_kwargs())
+    _check_e2e(o, g)
+    assert float(g["margin"]) > 1e-4
+
+
+def test_e2e_hrnet_matches_reference_head_on_oracle_backbone():
+    g = golden("e2e_hrnet")
+    net = build_net(seed=int(g["seed"]))
+    o, inter = O.posenet_forward(net.state_dict(), det_image(1), net.init_net.knn_idx, 512, **oracle_kwargs())
+    _check_e2e(o, g)
+    assert [tuple(f.shape[1:]) for f in inter["img_feats"]] == [(128, 64, 64), (256, 32, 32), (512, 16, 16), (1024, 8, 8)]
+    sd_i = {k[len("init_net."):]: v for k, v in net.state_dict().items() if k.startswith("init_net.")}
+    out, _, _ = O.init_net_forward(sd_i, "", det_image(1), net.init_net.knn_idx, 512)
+    assert np.abs(out.numpy() - g["init_out"]).max() <= 1e-4
+
+
+def test_e2e_lm_matches_reference():
+    g = golden("e2e_lm_injected")
+    net = build_net(seed=int(g["seed"]), lm=True)
+    obj = torch.from_numpy(g["obj_ids"])
+    o, _ = O.posenet_forward(net.state_dict(), None, net.init_net.knn_idx[obj - 1], 512, img_feats=inject_feats(3, seed=1),
+                             **oracle_kwargs())
+    _check_e2e(o, g)
+
+
+def test_resnet34_contract():
+    from checkerpose_amd.model.backbone import ResNet34Features
+    from checkerpose_amd.detweights import fill_state_dict_
+    m = ResNet34Features()
+    sd = fill_state_dict_(m.state_dict())
+    f = O.resnet34_features(sd, "", det_image(1))
+    assert [tuple(t.shape[1:]) for t in f] == [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]   # pipeline.py:7
