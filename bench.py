@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- forward throughput of the CheckerPose hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32] [--npoint 512]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one forward of PoseNet_GNNskip (HRNet-W18 + decoder + 3 progressive GNN stages,
+hr18GNN2_res6_gnn3Skip_mlpQuery, LM-O `ape` keypoints, npt=512) over one batch of B synthetic 256x256 crops
+already resident in HBM; every rank runs its own replica on its own batch shard (pure data parallel: the
+forward has no collective), so scaling is weak and value = N*B*K / max-over-ranks(time).
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the
+MFMA implicit-GEMM conv) and `cpu_baseline` (oracle restatement timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def build(npoint, seed=1):
+    from tests.common import build_net
+    return build_net(npoint=npoint, seed=seed)
+
+
+def cpu_baseline(npoint, seconds=12.0):
+    """The oracle (validated CPU restatement incl. its HRNet-W18) on the host cores: B=1 forwards for ~`seconds`."""
+    from oracle import checkerpose_oracle as O
+    from tests.common import det_image, oracle_kwargs
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = build(npoint)
+    sd = net.state_dict()
+    img = det_image(1, seed=0)
+    with torch.no_grad():
+        O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds or n < 3:
+            O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
+
+
+def kernel_breakdown(net, B, steps):
+    """Per-kernel-family device time of one step, measured live with HIP events on the launch stream (eager
+    replay of the same launch program, one event pair per launch)."""
+    prog = net.program_for(B)
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    fam = {}
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in prog.calls]
+    for _ in range(steps):
+        for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+            e0.record(stream)
+            fn(sp, *args[1:])
+            e1.record(stream)
+        torch.cuda.synchronize()
+        for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+            k = name.split(":")[0]
+            t, c = fam.get(k, (0.0, 0))
+            fam[k] = (t + e0.elapsed_time(e1), c + 1)
+    return {k: {"ms_per_step": t / steps, "launches_per_step": c // steps} for k, (t, c) in fam.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--npoint", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.set_grad_enabled(False)
+
+    from tests.common import det_image
+    net = build(a.npoint).to(dev).set_compute_dtype(a.dtype)
+    net.clone_outputs = False            # outputs stay in the program's persistent buffers (no per-step clones)
+    B = a.batch
+    img = det_image(B, seed=100 + rank).to(dev)      # this rank's shard, resident in HBM before timing
+
+    def step():
+        return net(img, None)
+
+    for _ in range(max(a.warmup, 2)):    # >= 2: first call builds + runs eagerly, second captures the hipGraph
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms_per_step = el / a.steps * 1e3
+    value = world * B * a.steps / el
+
+    out = {"metric": "crops/sec forward (256x256, npt=%d)" % a.npoint, "value": round(value, 1), "unit": "crops/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d, PoseNet_GNNskip forward, "
+                                  "deterministic random-init weights" % a.npoint,
+                      "crops_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d (no forward collective)" % world,
+                      "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls)}}
+    if rank == 0:
+        prog = net.program_for(B)
+        if not a.no_breakdown:
+            fam = kernel_breakdown(net, B, min(a.steps, 5))
+            conv = fam["conv"]
+            conv_s = conv["ms_per_step"] * 1e-3
+            ach = prog.flops / conv_s / 1e12
+            launches = conv["launches_per_step"]
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d conv/linear launches of a step)" % launches,
+                               "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
+                               "algorithmic_gflop_per_launch_avg": round(prog.flops / launches / 1e9, 3),
+                               "avg_launch_us": round(conv_s / launches * 1e6, 2)}
+            # memory-bound neighbour-gather kernel: algorithmic bytes = N*K*C*e + 2*N*C*e + N*K*4 per layer
+            eg = fam.get("edge_gather")
+            if eg:
+                e = 2 if a.dtype == "bf16" else 4
+                N, K = a.npoint, 20
+                by = B * sum(N * K * c * e + 2 * N * c * e + N * K * 4 for c in (64, 64) + (256,) * 9)
+                gbs = by / (eg["ms_per_step"] * 1e-3) / 1e9
+                out["roofline_gather"] = {"bound": "hbm", "kernel": "edgeconv_gather_max_kernel (11 launches)",
+                                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                          "algorithmic_mb_per_step": round(by / 1e6, 1)}
+            out["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            out["dense_gflop_per_crop"] = round(prog.flops / B / 1e9, 2)
+            out["workspace_mb"] = round(prog.workspace_bytes / 2 ** 20, 1)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.npoint)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
