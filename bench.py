@@ -31,18 +31,33 @@ def build(npoint, seed=1):
     return build_net(npoint=npoint, seed=seed)
 
 
+def host_threads():
+    """Threads the CPU baseline may really use: affinity mask and cgroup CPU quota, not os.cpu_count() (the GPU box
+    reports 256 logical CPUs; oversubscribing torch's intra-op pool on them is pathologically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(npoint, seconds=12.0):
     """The oracle (validated CPU restatement incl. its HRNet-W18) on the host cores: B=1 forwards for ~`seconds`."""
     from oracle import checkerpose_oracle as O
     from tests.common import det_image, oracle_kwargs
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     net = build(npoint)
     sd = net.state_dict()
     img = det_image(1, seed=0)
     with torch.no_grad():
+        t0 = time.perf_counter()
         O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())      # warm-up
+        first = time.perf_counter() - t0
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds or n < 3:
+        while (time.perf_counter() - t0 < seconds and first < seconds) or n < 1:          # bounded: ~`seconds` of CPU work
             O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())
             n += 1
         dt = time.perf_counter() - t0
@@ -50,7 +65,7 @@ def cpu_baseline(npoint, seconds=12.0):
             "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
 
 
-def kernel_breakdown(net, B, steps):
+def kernel_breakdown(net, B, steps, dump=None):
     """Per-kernel-family device time of one step, measured live with HIP events on the launch stream (eager
     replay of the same launch program, one event pair per launch)."""
     prog = net.program_for(B)
@@ -68,6 +83,18 @@ def kernel_breakdown(net, B, steps):
             k = name.split(":")[0]
             t, c = fam.get(k, (0.0, 0))
             fam[k] = (t + e0.elapsed_time(e1), c + 1)
+    per_conv = []
+    ci = 0
+    for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+        if name.startswith("conv:"):
+            wk, M, Cout, K, fl = prog.conv_log[ci]
+            ci += 1
+            ms = e0.elapsed_time(e1)          # last step's duration of this launch
+            per_conv.append({"name": wk, "M": M, "Cout": Cout, "K": K, "gflop": round(fl / 1e9, 3), "us": round(ms * 1e3, 1),
+                             "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0})
+    if dump:
+        with open(dump, "w") as f:
+            json.dump(sorted(per_conv, key=lambda r: -r["us"]), f, indent=0)
     return {k: {"ms_per_step": t / steps, "launches_per_step": c // steps} for k, (t, c) in fam.items()}
 
 
@@ -81,6 +108,7 @@ def main():
     ap.add_argument("--npoint", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--dump-convs", default=None, help="write per-conv-launch timings (json) to this path")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,7 +163,7 @@ def main():
     if rank == 0:
         prog = net.program_for(B)
         if not a.no_breakdown:
-            fam = kernel_breakdown(net, B, min(a.steps, 5))
+            fam = kernel_breakdown(net, B, min(a.steps, 5), a.dump_convs)
             conv = fam["conv"]
             conv_s = conv["ms_per_step"] * 1e-3
             ach = prog.flops / conv_s / 1e12
