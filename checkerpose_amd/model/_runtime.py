@@ -120,7 +120,8 @@ class HipForwardMixin:
             self._programs[key] = pr
         io, prog = pr["io"], pr["prog"]
         with torch.cuda.device(device):
-            io["img"].copy_(img)                              # boundary: stage the caller's NCHW fp32 batch
+            if img.data_ptr() != io["img"].data_ptr():        # zero-copy when the caller filled input_buffer(B)
+                io["img"].copy_(img)                          # boundary: stage the caller's NCHW fp32 batch
             if self.LM:
                 if obj_ids is None:
                     raise ValueError("obj_ids is required for the LM networks")
@@ -146,6 +147,14 @@ class HipForwardMixin:
         if self.clone_outputs:
             out = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in out.items()}
         return out
+
+    def input_buffer(self, B, stage=None):
+        """The persistent (B,3,256,256) fp32 device tensor the launch program reads.  A producer (data loader, bench)
+        that writes crops into it and passes it to forward() skips the staging copy.  Needs one prior forward at B."""
+        for k, pr in self._programs.items():
+            if k[0] == B and k[2] == stage and k[3] == self.compute_dtype:
+                return pr["io"]["img"]
+        raise RuntimeError("no program for batch %d yet: run one forward first" % B)
 
     def program_for(self, B, stage=None):
         """Introspection for bench / tests: the cached Program of batch size B (after at least one forward)."""

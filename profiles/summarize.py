@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs (gpurun_out/prof_*) into the small per-round summaries committed here.
+  python profiles/summarize.py gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write profiles/r01_bf16_b128
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in
+separate passes, are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read -> doubled."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def main(stats_dir, fetch_dir, write_dir, out_prefix):
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0])))
+    ours = [r for r in rows if not r["Name"].startswith(("void at::", "__amd_rocclr"))]
+    tot = sum(float(r["TotalDurationNs"]) for r in ours)
+    pmc = {}
+    for key, d, mult in (("fetch", fetch_dir, 2.0), ("write", write_dir, 1.0)):
+        acc = defaultdict(lambda: [0.0, 0])
+        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+        if f:
+            for r in csv.DictReader(open(f[0])):
+                a = acc[r["Kernel_Name"]]
+                a[0] += float(r["Counter_Value"]) * 1024.0 * mult
+                a[1] += 1
+        pmc[key] = acc
+    with open(out_prefix + "_kernel_summary.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct_of_our_kernels", "avg_hbm_read_MB(FETCH_SIZE*2)", "avg_hbm_write_MB"])
+        for r in ours:
+            n = r["Name"]
+            fr, fw = pmc["fetch"].get(n), pmc["write"].get(n)
+            w.writerow([short(n), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
+                        "%.2f" % (100 * float(r["TotalDurationNs"]) / tot),
+                        "%.3f" % (fr[0] / fr[1] / 1e6) if fr and fr[1] else "", "%.3f" % (fw[0] / fw[1] / 1e6) if fw and fw[1] else ""])
+    print(open(out_prefix + "_kernel_summary.csv").read())
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
