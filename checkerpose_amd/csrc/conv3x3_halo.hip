@@ -1,0 +1,309 @@
+// 3x3 / stride 1 / pad 1 convolution with an LDS-staged input halo tile (the decoder + HRNet body convs:
+// > 85 % of the forward's dense FLOPs).
+//
+// Why a second conv kernel: in the generic implicit GEMM (conv_igemm.hip) every tap re-reads its activation
+// fragments from L2 in fragment shape (16 pixel rows x 64 B per wave instruction), so a 3x3 conv moves 9x its
+// input through the texture path and bf16 MFMA sits at ~17 % of peak.  Here a block stages the (8+2)x(16+2) pixel
+// halo of ONE 64-byte channel chunk in LDS once and all 9 taps read their fragments from it:
+//   * block = 8x16 output pixels x 128 output channels; 4 waves, wave w owns channels [32w, 32w+32) of ALL 128
+//     pixels -> 8 pixel fragments (one per tile row) x 2 channel tiles, 16 accumulators.
+//   * activations: LDS image [q = 16-byte piece 0..3][pixel 0..191][16 B]; lane (x = l&15, q = l>>4) of fragment
+//     (row mt, tap r,s) reads pixel (mt+r)*18 + s + x of plane q -> every 16-lane ds_read_b128 group covers 16
+//     distinct 16-byte slots mod 16 (plane pitch 192 pixels == 0 mod 16): conflict-free.
+//   * weights: NOT through LDS -- the 4 waves own disjoint channels, so each packed fragment (one coalesced
+//     1 KiB buffer load) is read by exactly one wave: no redundancy, and the LDS port is left to the activations.
+//   * epilogue: packed-weight rows are permuted so lane q ends with channels 8q..8q+7 of its 32-channel group
+//     (tile nt -> channels 8q+4nt..+3): one 16-byte (bf16) / two 16-byte (f32) stores per pixel, 64/128
+//     contiguous bytes per pixel across the four q lanes.
+// One barrier per channel chunk (two LDS buffers); the next chunk's halo is prefetched into registers under the
+// 9 x 16 MFMAs (bf16) / 9 x 64 MFMAs (f32) of the current one.
+#include "common.h"
+
+struct HaloParams {
+  const void* in; const void* w; const float* scale; const float* shift; const void* res; void* out;
+  int B, H, W, Cin, in_cs, in_coff, nchunk, Cout, ngroups, NB;
+  int tiles_x, tiles_y, total_tiles;
+  int act; float slope;
+  uint32_t in_bytes, w_bytes;
+  long long o_base, o_sb, o_sy, o_sx;
+};
+
+constexpr int HTH = 8, HTW = 16, HPW = HTW + 2, HPH = HTH + 2, HNPIX = 192;   // 180 halo pixels, plane padded to 192
+constexpr int HPLANE = HNPIX * 16, HBUF = 4 * HPLANE;                          // bytes
+
+template <typename Tag> struct MmaH;
+template <> struct MmaH<F32Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+  }
+};
+template <> struct MmaH<BF16Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+  }
+};
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
+  constexpr int E = Tag::E;
+  constexpr int KCH = 4 * E;
+  constexpr int ES = 16 / E;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * HBUF
+
+  // ---- block -> (spatial tile, channel block).  All channel blocks of a tile run on ONE XCD (same blockIdx % 8
+  // label, consecutive slots) so the halo they all stage is an L2 hit after the first.
+  const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nblk = slot % p.NB;
+  const int t = (slot / p.NB) * 8 + label;
+  if (t >= p.total_tiles) return;                      // whole block, before any barrier
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int b = t / tpi;
+  const int trem = t - b * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * HTH, x0 = tx * HTW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int g = nblk * 4 + wave;                       // 32-channel group of this wave
+  const bool wave_active = g < p.ngroups;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // ---- staging map: thread handles pieces i = tid + 256k (k = 0..2), piece = (halo pixel hp = i>>2, q = i&3)
+  uint32_t s_goff[3];      // element offset of (pixel, channel q*E) without the chunk offset; 0xFFFFFFFF = outside
+  uint32_t s_lds[3];       // LDS byte offset inside a buffer
+  int s_cq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + 256 * k;
+    const int hp = i >> 2, pq = i & 3;
+    const int py = hp / HPW, px = hp - py * HPW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = (hp < HPH * HPW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    s_goff[k] = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pq * E) : 0xFFFFFFFFu;
+    s_lds[k] = (uint32_t)(pq * HPLANE + (hp < HNPIX ? hp : 0) * 16);
+    s_cq[k] = pq * E;
+  }
+  const bool s_do[3] = {true, true, (tid + 512) < HNPIX * 4};   // pieces 720..767 pad the planes (never read)
+
+  auto stage_load = [&](u32x4* v, int c) {
+    const int c0 = c * KCH;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool ok = (s_goff[k] != 0xFFFFFFFFu) & (c0 + s_cq[k] < p.Cin);
+      const uint32_t off = ok ? (s_goff[k] + (uint32_t)c0) * ES : 0x80000000u;
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+  auto stage_write = [&](const u32x4* v, int buf) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (s_do[k]) *(u32x4*)(smem + buf * HBUF + s_lds[k]) = v[k];
+  };
+
+  f32x4 acc[HTH][2];
+#pragma unroll
+  for (int mt = 0; mt < HTH; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // weight fragments of (group g, chunk c, tap, nt): [g][c][tap][nt][lane][16 B]
+  const uint32_t wbase = ((uint32_t)(wave_active ? g : 0) * p.nchunk * 18u * 64u + lane) * 16u;
+  auto w_load = [&](u32x4* w, int c, int tap) {
+    const uint32_t off = wbase + ((uint32_t)c * 18u + (uint32_t)tap * 2u) * 1024u;
+    w[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+    w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u, 0, 0));
+  };
+  const uint32_t a_lane = (uint32_t)(q * HPLANE + x * 16);
+  auto taps = [&](int buf, int tap, const u32x4* w) {
+    const int r = tap / 3, s = tap - 3 * r;
+    const unsigned char* base = smem + buf * HBUF + a_lane + (r * HPW + s) * 16;
+    u32x4 a[HTH];
+#pragma unroll
+    for (int mt = 0; mt < HTH; ++mt) a[mt] = *(const u32x4*)(base + mt * HPW * 16);
+#pragma unroll
+    for (int mt = 0; mt < HTH; ++mt) {
+      MmaH<Tag>::run(w[0], a[mt], acc[mt][0]);
+      MmaH<Tag>::run(w[1], a[mt], acc[mt][1]);
+    }
+  };
+
+  // ---- prologue: chunk 0 into LDS buffer 0
+  u32x4 sv[3];
+  stage_load(sv, 0);
+  u32x4 wA[2], wB[2];
+  w_load(wA, 0, 0);
+  stage_write(sv, 0);
+  __syncthreads();
+
+  for (int c = 0; c < p.nchunk; ++c) {
+    const int buf = c & 1;
+    w_load(wB, c, 1);
+    stage_load(sv, c + 1);               // unconditional: past the last chunk every piece is out of range -> zeros
+    // 9 taps, weights ping-pong one tap ahead (static register names: fully unrolled)
+    taps(buf, 0, wA); w_load(wA, c, 2);
+    taps(buf, 1, wB); w_load(wB, c, 3);
+    taps(buf, 2, wA); w_load(wA, c, 4);
+    taps(buf, 3, wB); w_load(wB, c, 5);
+    taps(buf, 4, wA); w_load(wA, c, 6);
+    taps(buf, 5, wB); w_load(wB, c, 7);
+    taps(buf, 6, wA); w_load(wA, c, 8);
+    taps(buf, 7, wB); w_load(wB, c + 1, 0);   // first tap of the next chunk (out of range past the end -> zeros)
+    taps(buf, 8, wA);
+    wA[0] = wB[0]; wA[1] = wB[1];
+    stage_write(sv, buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!wave_active) return;
+  // ---- epilogue: lane (x, q) holds, per tile row mt, pixel (y0+mt, x0+x) x channels g*32 + 8q + {0..7}
+  const int ch = g * 32 + q * 8;
+  if (ch >= p.Cout) return;
+  const bool hi_ok = ch + 4 < p.Cout;                  // Cout is a multiple of 4: second half may be absent
+  const int ox = x0 + x;
+  float sc[8], sh[8];
+  {
+    const f32x4 s0 = *(const f32x4*)(p.scale + ch), t0 = *(const f32x4*)(p.shift + ch);
+    const f32x4 s1 = *(const f32x4*)(p.scale + ch + 4), t1 = *(const f32x4*)(p.shift + ch + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sh[j] = t0[j]; sc[4 + j] = s1[j]; sh[4 + j] = t1[j]; }
+  }
+  if (ox >= p.W) return;
+#pragma unroll
+  for (int mt = 0; mt < HTH; ++mt) {
+    const int oy = y0 + mt;
+    if (oy >= p.H) continue;
+    const long long o = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = acc[mt][0][j] * sc[j] + sh[j]; v[4 + j] = acc[mt][1][j] * sc[4 + j] + sh[4 + j]; }
+    if (p.res) {
+      if (E == 4) {
+        const f32x4 r0 = *(const f32x4*)((const float*)p.res + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r0[j];
+        if (hi_ok) {
+          const f32x4 r1 = *(const f32x4*)((const float*)p.res + o + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[4 + j] += r1[j];
+        }
+      } else {
+        const u32x2 r0 = *(const u32x2*)((const uint16_t*)p.res + o);
+        v[0] += __uint_as_float(r0.x << 16); v[1] += __uint_as_float(r0.x & 0xffff0000u);
+        v[2] += __uint_as_float(r0.y << 16); v[3] += __uint_as_float(r0.y & 0xffff0000u);
+        if (hi_ok) {
+          const u32x2 r1 = *(const u32x2*)((const uint16_t*)p.res + o + 4);
+          v[4] += __uint_as_float(r1.x << 16); v[5] += __uint_as_float(r1.x & 0xffff0000u);
+          v[6] += __uint_as_float(r1.y << 16); v[7] += __uint_as_float(r1.y & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+      else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+    }
+    if (E == 4) {
+      *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      if (hi_ok) *(f32x4*)((float*)p.out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      if (hi_ok) {
+        u32x4 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+        if ((((uintptr_t)((uint16_t*)p.out + o)) & 15u) == 0) *(u32x4*)((uint16_t*)p.out + o) = pk;
+        else { *(u32x2*)((uint16_t*)p.out + o) = u32x2{pk.x, pk.y}; *(u32x2*)((uint16_t*)p.out + o + 4) = u32x2{pk.z, pk.w}; }
+      } else {
+        u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)((uint16_t*)p.out + o) = pk;
+      }
+    }
+  }
+}
+
+// ---- packing: [group g (32 ch)][chunk c][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
+// channel g*32 + 8*qr + 4*nt + reg (the permutation that makes the epilogue stores 16 bytes wide).
+template <typename Tag>
+__global__ void pack_halo_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int nchunk,
+                                        size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % E);
+  const int lane = (int)((i / E) % 64);
+  size_t blk = i / (E * 64);
+  const int nt = (int)(blk % 2); blk /= 2;
+  const int tap = (int)(blk % 9); blk /= 9;
+  const int c = (int)(blk % nchunk);
+  const int g = (int)(blk / nchunk);
+  const int row = lane & 15, kq = lane >> 4;
+  const int n = g * 32 + (row >> 2) * 8 + nt * 4 + (row & 3);
+  const int cin = c * (4 * E) + kq * E + e;
+  float v = 0.f;
+  if (n < Cout && cin < Cin) v = w[((size_t)n * Cin + cin) * 9 + tap];
+  store_elem<Tag>(out, i, v);
+}
+
+extern "C" size_t cp_packed_halo_weight_bytes(int dtype, int Cout, int cin_phys) {
+  const int E = cp_chan_align(dtype), KCH = 4 * E;
+  const size_t nchunk = ((size_t)cin_phys + KCH - 1) / KCH;
+  const size_t ngroups = ((size_t)Cout + 31) / 32;
+  return ngroups * nchunk * 18 * 1024;
+}
+
+extern "C" int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys,
+                                           void* packed) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const int nchunk = (cin_phys + 4 * E - 1) / (4 * E);
+  const size_t total = cp_packed_halo_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(pack_halo_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+  else
+    hipLaunchKernelGGL(pack_halo_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+  return cp_check_launch();
+}
+
+extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                               const float* scale, const float* shift, const void* residual, void* out) {
+  if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
+  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
+    return CP_ERR_INVALID;
+  const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0) return CP_ERR_INVALID;
+  if (d->Cin <= 0 || d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
+  if (d->Cout <= 0 || d->Cout % 4) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift)) return CP_ERR_ALIGN;
+  if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4)) return CP_ERR_ALIGN;
+  if (((uintptr_t)out % (4 * es)) || (residual && ((uintptr_t)residual % (4 * es)))) return CP_ERR_ALIGN;
+  const long long in_bytes = (long long)d->B * d->H * d->W * d->in_cstride * es;
+  if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
+  HaloParams p;
+  p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.nchunk = (d->Cin + 4 * E - 1) / (4 * E);
+  p.Cout = d->Cout; p.ngroups = (d->Cout + 31) / 32; p.NB = (p.ngroups + 3) / 4;
+  p.tiles_x = (d->W + HTW - 1) / HTW; p.tiles_y = (d->H + HTH - 1) / HTH;
+  const long long tt = (long long)d->B * p.tiles_x * p.tiles_y;
+  if (tt >= (1LL << 28)) return CP_ERR_RANGE;
+  p.total_tiles = (int)tt;
+  p.act = d->act; p.slope = d->slope;
+  p.in_bytes = (uint32_t)in_bytes;
+  const size_t wb = cp_packed_halo_weight_bytes(d->dtype, d->Cout, d->Cin);
+  if (wb >= (1ull << 31)) return CP_ERR_RANGE;
+  p.w_bytes = (uint32_t)wb;
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  const unsigned grid = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
+  // scale/shift are read 8 at a time at ch = g*32 + 8q < Cout: vectors must be padded to a multiple of 8 (they are: 16)
+  if (d->dtype == CP_F32)
+    hipLaunchKernelGGL(conv3x3_halo_kernel<F32Tag>, dim3(grid), dim3(256), 2 * HBUF, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(conv3x3_halo_kernel<BF16Tag>, dim3(grid), dim3(256), 2 * HBUF, (hipStream_t)stream, p);
+  return cp_check_launch();
+}

@@ -28,7 +28,7 @@ struct ConvParams {
   int R, S, stride, pad;
   int KC, Cout, n_tiles;
   int act; float slope; int out_f32;
-  uint32_t in_bytes;
+  uint32_t in_bytes, w_bytes;
   long long o_base, o_sb, o_sy, o_sx, o_sc;
 };
 
@@ -82,13 +82,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  // weight fragment pointers (tile index clamped: a partial last channel block recomputes a valid tile)
-  const u32x4* wp[NT];
+  // weights through the SAME load kind (buffer loads): hipcc then counts vmcnt across both operand streams
+  // instead of draining to 0 (mixed global/buffer loads made it wait for the prefetched chunk too).
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  // weight fragment byte offsets (tile index clamped: a partial last channel block recomputes a valid tile)
+  uint32_t woff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     int t = nt0 + nt;
     t = t < p.n_tiles ? t : p.n_tiles - 1;
-    wp[nt] = (const u32x4*)p.w + (size_t)t * p.KC * 64 + lane;
+    woff[nt] = ((uint32_t)t * p.KC * 64 + lane) * 16u;
   }
 
   f32x4 acc[MT][NT];
@@ -97,22 +101,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const bool wide_c = p.Cin >= KCH;   // wave-uniform: at most one tap step per chunk
   auto load_chunk = [&](u32x4* a, u32x4* w, int kc) {
     const int tapoff = (r * p.W + s) * p.in_cs + c;
     const bool tap_ok = r < p.R;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const bool ok = tap_ok && (unsigned)(iy0[mt] + r) < (unsigned)p.H && (unsigned)(ix0[mt] + s) < (unsigned)p.W;
+      const bool ok = tap_ok & ((unsigned)(iy0[mt] + r) < (unsigned)p.H) & ((unsigned)(ix0[mt] + s) < (unsigned)p.W);
       const uint32_t off = ok ? (uint32_t)(rowbase[mt] + tapoff) * ES : 0x80000000u;
       a[mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) w[nt] = wp[nt][(size_t)kc * 64];
-    // advance the lane's K state by one chunk
+    for (int nt = 0; nt < NT; ++nt)
+      w[nt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[nt] + (uint32_t)kc * 1024u, 0, 0));
+    // advance the lane's K state by one chunk (branch-free when Cin >= KCH)
     c += KCH;
-    while (c >= p.Cin) {
-      c -= p.Cin;
-      if (++s == p.S) { s = 0; ++r; }
+    if (wide_c) {
+      const bool wrap = c >= p.Cin;
+      c = wrap ? c - p.Cin : c;
+      s += wrap ? 1 : 0;
+      const bool swrap = s == p.S;
+      s = swrap ? 0 : s;
+      r += swrap ? 1 : 0;
+    } else {
+      while (c >= p.Cin) {
+        c -= p.Cin;
+        if (++s == p.S) { s = 0; ++r; }
+      }
     }
   };
   auto compute = [&](const u32x4* a, const u32x4* w) {
@@ -122,17 +137,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       for (int nt = 0; nt < NT; ++nt) Mma<Tag>::run(w[nt], a[mt], acc[mt][nt]);
   };
 
-  // ---- main loop, register double-buffered (chunk kc+1 in flight while chunk kc feeds the MFMAs)
+  // ---- main loop, register double-buffered and STRAIGHT-LINE: two chunks are always in flight.  Loads past the
+  // last chunk are issued unconditionally (their offsets are out of range -> the buffer unit returns zeros, and
+  // the tap index is past R -> invalid), so there is no control-flow join between a load and its use and hipcc
+  // emits counted `s_waitcnt vmcnt(8)` instead of draining the prefetch (a conditional prefetch made it wait to 0).
   u32x4 a0[MT], w0[NT], a1[MT], w1[NT];
   load_chunk(a0, w0, 0);
-  int kc = 0;
-  for (; kc + 2 <= p.KC; kc += 2) {
-    load_chunk(a1, w1, kc + 1);
+  load_chunk(a1, w1, 1);
+  for (int kc = 0; kc < p.KC; kc += 2) {
     compute(a0, w0);
-    if (kc + 2 < p.KC) load_chunk(a0, w0, kc + 2);
-    compute(a1, w1);
+    load_chunk(a0, w0, kc + 2);
+    if (kc + 1 < p.KC) compute(a1, w1);     // wave-uniform; no loads inside the branch
+    load_chunk(a1, w1, kc + 3);
   }
-  if (kc < p.KC) compute(a0, w0);
 
   // ---- epilogue: lane holds pixel (lane&15) x channels 4q..4q+3 of every (mt, nt) tile
   const bool vec = (p.o_sc == 1);
@@ -244,6 +261,7 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   p.Cout = d->Cout; p.n_tiles = (d->Cout + 15) / 16;
   p.act = d->act; p.slope = d->slope; p.out_f32 = d->out_f32;
   p.in_bytes = (uint32_t)in_bytes;
+  p.w_bytes = (uint32_t)((size_t)p.n_tiles * p.KC * 1024);
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx; p.o_sc = d->o_sc;
 
   // tile choice: NT minimises padded channel tiles (ties -> wider), MT=4 (256 pixels/block) unless the

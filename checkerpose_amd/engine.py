@@ -7,6 +7,7 @@ Nothing here computes: torch is used for device memory, parameter access and the
 arithmetic step is a HIP kernel behind include/checkerpose_hip.h.  No fallback path exists.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -14,6 +15,7 @@ from . import _abi
 from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
+USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
 
@@ -71,6 +73,20 @@ class WeightStore:
         _abi.check(self.lib.cp_pack_conv_weight(st, self.dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
                                                 rm.data_ptr() if rm is not None else None, cout_rows, out.data_ptr()),
                    "cp_pack_conv_weight(%s)" % name)
+        self.cache[ck] = out
+        return out
+
+    def pack_halo(self, name, w, Cout, Cin, cin_phys):
+        """3x3/s1/p1 weights in the halo kernel's image (cp_pack_conv3x3_halo_weight)."""
+        ck = ("halo", name, cin_phys)
+        if ck in self.cache:
+            return self.cache[ck]
+        out = torch.empty(self.lib.cp_packed_halo_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
+        w = w.contiguous()
+        self.keep.append(w)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _abi.check(self.lib.cp_pack_conv3x3_halo_weight(st, self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
+                   "cp_pack_conv3x3_halo_weight(%s)" % name)
         self.cache[ck] = out
         return out
 
@@ -144,7 +160,12 @@ class Program:
         rows = cout_rows if cout_rows is not None else wCout
         if wCin != x.C:
             raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
-        packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map)
+        halo = (USE_HALO and R == 3 and S == 3 and stride == 1 and pad == 1 and ostr is None and not out_f32
+                and not transposed and row_map is None and x.W >= 16 and x.H >= 8 and wCout >= 96)
+        if halo:
+            packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
+        else:
+            packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map)
         sc, sh = self.ws.affine(wkey + "#" + str(phase), scale, shift, rows)
         Ho, Wo = out_hw if out_hw is not None else ((x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1)
         d = CpConvDesc()
@@ -168,7 +189,7 @@ class Program:
         if residual is not None and ostr is None:
             assert (residual.cstride, residual.coff, residual.H, residual.W) == (out.cstride, out.coff, out.H, out.W), \
                 "residual must share the output layout"
-        fn = self.lib.cp_conv2d_igemm
+        fn = self.lib.cp_conv3x3_halo if halo else self.lib.cp_conv2d_igemm
         dref = C.byref(d)
         pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
         xtb = x.tbuf

@@ -91,6 +91,18 @@ typedef struct CpConvDesc {
 int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                     const float* scale, const float* shift, const void* residual, void* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 specialisation with an LDS-staged input halo tile (decoder convs pipeline.py:183-211,
+ * HRNet/ResNet body convs): same arithmetic and descriptor as cp_conv2d_igemm (requires R=S=3, stride=1, pad=1,
+ * o_sc=1, out_f32=0) but its own packed-weight image ([32-ch group][chunk][tap][tile][lane][16 B], rows permuted
+ * for 16-byte epilogue stores).  scale/shift must be readable 8 floats at a time (pad to a multiple of 8).
+ * ------------------------------------------------------------------------------------------- */
+size_t cp_packed_halo_weight_bytes(int dtype, int Cout, int cin_phys);
+int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys,
+                                void* packed);
+int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                    const float* scale, const float* shift, const void* residual, void* out);
+
 /* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
  * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
 int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,

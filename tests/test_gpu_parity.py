@@ -129,6 +129,58 @@ def test_conv_igemm_vs_torch_cpu(lib, dtype, case):
     close(got, ref, TOL[dtype])
 
 
+HALO_CASES = [  # (B, Cin, H, W, Cout, act, residual)
+    (2, 64, 16, 32, 64, ACT_RELU, False),      # exact tiles, Cin = 2..4 chunks, Cout = 2 groups
+    (1, 256, 16, 16, 256, ACT_RELU, False),    # decoder shape class: 2 channel blocks of 128
+    (2, 18, 24, 40, 18, ACT_RELU, True),       # HRNet branch 0: ragged Cin/Cout (18 -> 20/24), partial chunk, residual
+    (1, 36, 13, 21, 72, ACT_NONE, False),      # H, W not tile multiples (masked stores, zero halo)
+    (3, 144, 8, 16, 40, ACT_LEAKY, True),      # single tile row, Cout = 40 (second half of a lane's 8 channels absent)
+    (1, 512, 8, 16, 32, ACT_RELU, False),      # deep K (16/32 chunks), odd/even chunk counts
+]
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
+    """LDS-halo 3x3/s1/p1 kernel (cp_conv3x3_halo) == torch CPU conv + affine + residual + act."""
+    B, Cin, H, W, Cout, act, has_res = case
+    x = det_tensor("hx%s" % (case,), (B, Cin, H, W))
+    w = det_tensor("hw%s" % (case,), (Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("hs%s" % (case,), (Cout,))
+    shift = 0.2 * det_tensor("ht%s" % (case,), (Cout,))
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = det_tensor("hr%s" % (case,), tuple(ref.shape))
+        ref = ref + rnd(res, dtype)
+    ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.01) if act == ACT_LEAKY else ref)
+    E = 8 if dtype == CP_BF16 else 4
+    xin = to_cl(x, dtype)
+    cop = rup(Cout, E)
+    out = torch.full((B, H, W, cop), float("nan"), dtype=DT[dtype], device=dev())
+    pw = torch.empty(lib.cp_packed_halo_weight_bytes(dtype, Cout, xin.shape[-1]), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv3x3_halo_weight(st(), dtype, wd.data_ptr(), Cout, Cin, xin.shape[-1], pw.data_ptr()))
+    n16 = rup(Cout, 16)
+    sc = torch.zeros(n16); sc[:Cout] = scale
+    sh = torch.zeros(n16); sh[:Cout] = shift
+    sc, sh = sc.to(dev()), sh.to(dev())
+    rs = to_cl(res, dtype) if res is not None else None
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 1, 1, H, W, cop, act, 0.01
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * cop, W * cop, cop, 1
+    _abi.check(lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                   rs.data_ptr() if rs is not None else None, out.data_ptr()), "halo conv")
+    torch.cuda.synchronize()
+    if cop > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+    close(from_cl(out, Cout), ref, TOL[dtype])
+    d.stride = 2                                        # unsupported shape -> loud error, no silent fallback
+    assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
+
+
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 def test_convtranspose_phases_vs_torch_cpu(lib, dtype):
     """ConvTranspose2d(k3,s2,p1,op1) (pipeline.py:187-197) as 4 sub-pixel phase convs."""
