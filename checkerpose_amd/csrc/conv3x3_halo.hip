@@ -46,7 +46,7 @@ template <> struct MmaH<BF16Tag> {
   }
 };
 
-template <typename Tag>
+template <typename Tag, bool HAS_RES>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
@@ -173,6 +173,37 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sh[j] = t0[j]; sc[4 + j] = s1[j]; sh[4 + j] = t1[j]; }
   }
   if (ox >= p.W) return;
+  // all residual loads first (res may alias out: a load after a store would serialise behind it)
+  float rvv[HAS_RES ? HTH : 1][8];   // only the residual instantiation pays the 64 registers
+  if constexpr (HAS_RES) {
+#pragma unroll
+    for (int mt = 0; mt < HTH; ++mt) {
+      const int oy = y0 + mt;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rvv[mt][j] = 0.f;
+      if (oy >= p.H) continue;
+      const long long o = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+      if (E == 4) {
+        const f32x4 r0 = *(const f32x4*)((const float*)p.res + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rvv[mt][j] = r0[j];
+        if (hi_ok) {
+          const f32x4 r1 = *(const f32x4*)((const float*)p.res + o + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rvv[mt][4 + j] = r1[j];
+        }
+      } else {
+        const u32x2 r0 = *(const u32x2*)((const uint16_t*)p.res + o);
+        rvv[mt][0] = __uint_as_float(r0.x << 16); rvv[mt][1] = __uint_as_float(r0.x & 0xffff0000u);
+        rvv[mt][2] = __uint_as_float(r0.y << 16); rvv[mt][3] = __uint_as_float(r0.y & 0xffff0000u);
+        if (hi_ok) {
+          const u32x2 r1 = *(const u32x2*)((const uint16_t*)p.res + o + 4);
+          rvv[mt][4] = __uint_as_float(r1.x << 16); rvv[mt][5] = __uint_as_float(r1.x & 0xffff0000u);
+          rvv[mt][6] = __uint_as_float(r1.y << 16); rvv[mt][7] = __uint_as_float(r1.y & 0xffff0000u);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < HTH; ++mt) {
     const int oy = y0 + mt;
@@ -181,26 +212,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = acc[mt][0][j] * sc[j] + sh[j]; v[4 + j] = acc[mt][1][j] * sc[4 + j] + sh[4 + j]; }
-    if (p.res) {
-      if (E == 4) {
-        const f32x4 r0 = *(const f32x4*)((const float*)p.res + o);
+    if constexpr (HAS_RES) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += r0[j];
-        if (hi_ok) {
-          const f32x4 r1 = *(const f32x4*)((const float*)p.res + o + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[4 + j] += r1[j];
-        }
-      } else {
-        const u32x2 r0 = *(const u32x2*)((const uint16_t*)p.res + o);
-        v[0] += __uint_as_float(r0.x << 16); v[1] += __uint_as_float(r0.x & 0xffff0000u);
-        v[2] += __uint_as_float(r0.y << 16); v[3] += __uint_as_float(r0.y & 0xffff0000u);
-        if (hi_ok) {
-          const u32x2 r1 = *(const u32x2*)((const uint16_t*)p.res + o + 4);
-          v[4] += __uint_as_float(r1.x << 16); v[5] += __uint_as_float(r1.x & 0xffff0000u);
-          v[6] += __uint_as_float(r1.y << 16); v[7] += __uint_as_float(r1.y & 0xffff0000u);
-        }
-      }
+      for (int j = 0; j < 8; ++j) v[j] += rvv[HAS_RES ? mt : 0][j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -222,6 +236,181 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small-Cout variant (Cout <= 80: the HRNet 18/36/72-channel body convs, 64-channel layer1/stem convs).  These
+// layers are HBM/texture-path bound, not MFMA bound, and a 32-channel-per-wave split would idle most waves, so:
+//   * the 4 waves split the PIXELS (wave w owns tile rows 2w, 2w+1) and every wave computes all NT = ceil(Cout/16)
+//     channel tiles;
+//   * both operands go through LDS: the activation halo as above and the chunk's 9*NT weight fragments (linear copy
+//     of the packed image), so the texture path only sees each byte once per block;
+//   * packed rows are permuted so lane q ends with channels [4*NT*q, 4*NT*(q+1)): the four q lanes of a pixel write
+//     its whole channel vector contiguously and the 16 pixels of a fragment are adjacent in memory.
+template <typename Tag, int NT>
+__global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p) {
+  constexpr int E = Tag::E;
+  constexpr int KCH = 4 * E;
+  constexpr int ES = 16 / E;
+  constexpr int WPIECES = 9 * NT * 64;                 // 16-byte pieces of one chunk's weights
+  constexpr int WITER = (WPIECES + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [A: HBUF][W: 9*NT KiB]
+  unsigned char* const sA = smem;
+  unsigned char* const sW = smem + HBUF;
+
+  const int t = blockIdx.x;                            // one block per spatial tile (no channel blocks)
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int b = t / tpi;
+  const int trem = t - b * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * HTH, x0 = tx * HTW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  uint32_t s_goff[3], s_lds[3];
+  int s_cq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + 256 * k;
+    const int hp = i >> 2, pq = i & 3;
+    const int py = hp / HPW, px = hp - py * HPW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = (hp < HPH * HPW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    s_goff[k] = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pq * E) : 0xFFFFFFFFu;
+    s_lds[k] = (uint32_t)(pq * HPLANE + hp * 16);
+    s_cq[k] = pq * E;
+  }
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t a_lane = (uint32_t)(q * HPLANE + (2 * wave * HPW + x) * 16);
+  for (int c = 0; c < p.nchunk; ++c) {
+    // ---- global -> registers (activation halo pieces + this chunk's weight image)
+    const int c0 = c * KCH;
+    u32x4 sv[3], wv[WITER];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool ok = (s_goff[k] != 0xFFFFFFFFu) & (c0 + s_cq[k] < p.Cin);
+      const uint32_t off = ok ? (s_goff[k] + (uint32_t)c0) * ES : 0x80000000u;
+      sv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < WITER; ++k) {
+      const int i = tid + 256 * k;
+      const uint32_t off = i < WPIECES ? ((uint32_t)c * WPIECES + (uint32_t)i) * 16u : 0x80000000u;
+      wv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+    }
+    if (c > 0) __syncthreads();                        // everyone is done reading the previous chunk's LDS image
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *(u32x4*)(sA + s_lds[k]) = sv[k];
+#pragma unroll
+    for (int k = 0; k < WITER; ++k) {
+      const int i = tid + 256 * k;
+      if (i < WPIECES) *(u32x4*)(sW + i * 16) = wv[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s2 = tap - 3 * r;
+      const unsigned char* ab = sA + a_lane + (r * HPW + s2) * 16;
+      const u32x4 a0 = *(const u32x4*)(ab);
+      const u32x4 a1 = *(const u32x4*)(ab + HPW * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 w = *(const u32x4*)(sW + (tap * NT + nt) * 1024 + lane * 16);
+        MmaH<Tag>::run(w, a0, acc[0][nt]);
+        MmaH<Tag>::run(w, a1, acc[1][nt]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (x, q): pixel (y0 + 2*wave + mt, x0 + x), channels 4*NT*q + 4*nt + {0..3}
+  const int ox = x0 + x;
+  if (ox >= p.W) return;
+  const int chq = q * 4 * NT;
+  long long obase[2];
+  bool rok[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int oy = y0 + 2 * wave + mt;
+    rok[mt] = oy < p.H;
+    obase[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + chq;
+  }
+  f32x4 rv[2][NT];     // all residual loads before the first store (res may alias out)
+  if (p.res) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        rv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rok[mt] && chq + nt * 4 < p.Cout) {
+          if (E == 4) rv[mt][nt] = *(const f32x4*)((const float*)p.res + obase[mt] + nt * 4);
+          else {
+            const u32x2 r2 = *(const u32x2*)((const uint16_t*)p.res + obase[mt] + nt * 4);
+            rv[mt][nt] = f32x4{__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xffff0000u),
+                               __uint_as_float(r2.y << 16), __uint_as_float(r2.y & 0xffff0000u)};
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (!rok[mt]) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = chq + nt * 4;
+      if (ch >= p.Cout) continue;
+      const f32x4 sc = *(const f32x4*)(p.scale + ch), sh = *(const f32x4*)(p.shift + ch);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * sc[j] + sh[j];
+      if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rv[mt][nt][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      }
+      if (E == 4) *(f32x4*)((float*)p.out + obase[mt] + nt * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + obase[mt] + nt * 4) = pk; }
+    }
+  }
+}
+
+// packing for the small-Cout variant: [chunk][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
+// channel 4*NT*qr + 4*nt + reg.
+template <typename Tag>
+__global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int NT,
+                                          size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % E);
+  const int lane = (int)((i / E) % 64);
+  size_t blk = i / (E * 64);
+  const int nt = (int)(blk % NT); blk /= NT;
+  const int tap = (int)(blk % 9);
+  const int c = (int)(blk / 9);
+  const int row = lane & 15, kq = lane >> 4;
+  const int n = (row >> 2) * 4 * NT + nt * 4 + (row & 3);
+  const int cin = c * (4 * E) + kq * E + e;
+  float v = 0.f;
+  if (n < Cout && cin < Cin) v = w[((size_t)n * Cin + cin) * 9 + tap];
+  store_elem<Tag>(out, i, v);
+}
+
+static inline bool halo_small(int Cout) { return Cout <= 80; }
 
 // ---- packing: [group g (32 ch)][chunk c][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
 // channel g*32 + 8*qr + 4*nt + reg (the permutation that makes the epilogue stores 16 bytes wide).
@@ -249,6 +438,7 @@ __global__ void pack_halo_weight_kernel(const float* __restrict__ w, void* __res
 extern "C" size_t cp_packed_halo_weight_bytes(int dtype, int Cout, int cin_phys) {
   const int E = cp_chan_align(dtype), KCH = 4 * E;
   const size_t nchunk = ((size_t)cin_phys + KCH - 1) / KCH;
+  if (halo_small(Cout)) return nchunk * 9 * (((size_t)Cout + 15) / 16) * 1024;   // [chunk][tap][nt][lane][16 B]
   const size_t ngroups = ((size_t)Cout + 31) / 32;
   return ngroups * nchunk * 18 * 1024;
 }
@@ -262,6 +452,14 @@ extern "C" int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const 
   const int nchunk = (cin_phys + 4 * E - 1) / (4 * E);
   const size_t total = cp_packed_halo_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
   const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (halo_small(Cout)) {
+    const int NT = (Cout + 15) / 16;
+    if (dtype == CP_F32)
+      hipLaunchKernelGGL(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, total);
+    else
+      hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, total);
+    return cp_check_launch();
+  }
   if (dtype == CP_F32)
     hipLaunchKernelGGL(pack_halo_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
   else
@@ -299,11 +497,30 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   if (wb >= (1ull << 31)) return CP_ERR_RANGE;
   p.w_bytes = (uint32_t)wb;
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  if (halo_small(d->Cout)) {   // d->Cout is the PHYSICAL count; the pack call used the logical one -> same tile count
+    const int NT = (d->Cout + 15) / 16;
+    const size_t lds = HBUF + (size_t)9 * NT * 1024;
+    hipStream_t st = (hipStream_t)stream;
+#define CP_HS(TAG, N) hipLaunchKernelGGL((conv3x3_halo_s_kernel<TAG, N>), dim3((unsigned)tt), dim3(256), lds, st, p)
+    if (d->dtype == CP_F32) {
+      switch (NT) { case 1: CP_HS(F32Tag, 1); break; case 2: CP_HS(F32Tag, 2); break; case 3: CP_HS(F32Tag, 3); break;
+                    case 4: CP_HS(F32Tag, 4); break; default: CP_HS(F32Tag, 5); break; }
+    } else {
+      switch (NT) { case 1: CP_HS(BF16Tag, 1); break; case 2: CP_HS(BF16Tag, 2); break; case 3: CP_HS(BF16Tag, 3); break;
+                    case 4: CP_HS(BF16Tag, 4); break; default: CP_HS(BF16Tag, 5); break; }
+    }
+#undef CP_HS
+    return cp_check_launch();
+  }
   const unsigned grid = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
   // scale/shift are read 8 at a time at ch = g*32 + 8q < Cout: vectors must be padded to a multiple of 8 (they are: 16)
-  if (d->dtype == CP_F32)
-    hipLaunchKernelGGL(conv3x3_halo_kernel<F32Tag>, dim3(grid), dim3(256), 2 * HBUF, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(conv3x3_halo_kernel<BF16Tag>, dim3(grid), dim3(256), 2 * HBUF, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CP_F32) {
+    if (residual) hipLaunchKernelGGL((conv3x3_halo_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+  } else {
+    if (residual) hipLaunchKernelGGL((conv3x3_halo_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+  }
   return cp_check_launch();
 }

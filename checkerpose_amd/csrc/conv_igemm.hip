@@ -19,6 +19,8 @@
 //
 // Replaces (reference, relative to /root/reference/checkerpose): every nn.Conv2d/BatchNorm2d/ReLU,
 // nn.Linear/LeakyReLU on the path -- see include/checkerpose_hip.h for the file:line list.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ConvParams {
@@ -151,17 +153,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     load_chunk(a1, w1, kc + 3);
   }
 
-  // ---- epilogue: lane holds pixel (lane&15) x channels 4q..4q+3 of every (mt, nt) tile
+  // ---- epilogue: lane holds pixel (lane&15) x channels 4q..4q+3 of every (mt, nt) tile.
+  // Residuals are ALL loaded before the first store: `res` may alias `out` (no __restrict__), so a load issued
+  // after a store would be ordered behind it and the epilogue would degrade into MT*NT serial memory round trips.
   const bool vec = (p.o_sc == 1);
+  const bool f32io = p.out_f32 || E == 4;
+  long long pix[MT];
+  bool pok[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_wave + mt * 16 + x;
-    if (m >= p.M) continue;
-    const int b = m / p.HoWo;
-    const int rem = m - b * p.HoWo;
+    pok[mt] = m < p.M;
+    const int mm = pok[mt] ? m : 0;
+    const int b = mm / p.HoWo;
+    const int rem = mm - b * p.HoWo;
     const int oy = rem / p.Wo;
     const int ox = rem - oy * p.Wo;
-    const long long pix = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx;
+    pix[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx;
+  }
+  f32x4 rv[MT][NT];
+  if (vec && p.res) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nt0 + nt) * 16 + q * 4;
+        rv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pok[mt] && nt0 + nt < p.n_tiles && n < p.Cout) {
+          const long long o = pix[mt] + n;
+          if (f32io) rv[mt][nt] = *(const f32x4*)((const float*)p.res + o);
+          else {
+            const u32x2 r2 = *(const u32x2*)((const uint16_t*)p.res + o);
+            rv[mt][nt] = f32x4{__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xffff0000u),
+                               __uint_as_float(r2.y << 16), __uint_as_float(r2.y & 0xffff0000u)};
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!pok[mt]) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 16 + q * 4;
@@ -172,24 +203,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * sc[j] + sh[j];
       if (vec) {
-        const long long o = pix + n;
+        const long long o = pix[mt] + n;
         if (p.res) {
-          if (p.out_f32 || E == 4) {
-            const f32x4 rv = *(const f32x4*)((const float*)p.res + o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += rv[j];
-          } else {
-            const u32x2 rv = *(const u32x2*)((const uint16_t*)p.res + o);
-            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-          }
+          for (int j = 0; j < 4; ++j) v[j] += rv[mt][nt][j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
           else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
         }
-        if (p.out_f32 || E == 4) {
+        if (f32io) {
           *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
           u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
@@ -199,12 +223,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (n + j >= p.Cout) continue;
-          const long long o = pix + (long long)(n + j) * p.o_sc;
+          const long long o = pix[mt] + (long long)(n + j) * p.o_sc;
           float y = v[j];
-          if (p.res) y += (p.out_f32 || E == 4) ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
+          if (p.res) y += f32io ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
           if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
           else if (p.act == CP_ACT_LEAKY) y = y > 0.f ? y : y * p.slope;
-          if (p.out_f32 || E == 4) ((float*)p.out)[o] = y;
+          if (f32io) ((float*)p.out)[o] = y;
           else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
         }
       }
@@ -272,7 +296,10 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
     if (padded < best) { best = padded; NT = nt; }
   }
   const long long blocks4 = ((M + 255) / 256) * ((p.n_tiles + NT - 1) / NT);
-  const int MT = blocks4 >= 512 ? 4 : 2;
+  // MT=4 (256 pixels/block) for MFMA-heavy shapes; MT=2 when the grid would be small OR the layer is memory-bound
+  // (few K-chunks: more, lighter waves keep more bytes in flight -- measured +20..30 % on the 1x1 convs).
+  int MT = (blocks4 >= 512 && p.KC > 4) ? 4 : 2;
+  if (const char* e = getenv("CP_CONV_MT")) MT = atoi(e) == 2 ? 2 : 4;   // kernel-work A/B switch
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_F32) { if (MT == 4) dispatch_nt<F32Tag, 4>(p, NT, st); else dispatch_nt<F32Tag, 2>(p, NT, st); }
   else                    { if (MT == 4) dispatch_nt<BF16Tag, 4>(p, NT, st); else dispatch_nt<BF16Tag, 2>(p, NT, st); }

@@ -161,7 +161,11 @@ class Program:
         if wCin != x.C:
             raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
         halo = (USE_HALO and R == 3 and S == 3 and stride == 1 and pad == 1 and ostr is None and not out_f32
-                and not transposed and row_map is None and x.W >= 16 and x.H >= 8 and wCout >= 96)
+                and not transposed and row_map is None and x.W >= 16 and x.H >= 8)
+        if halo and wCout <= 80 and self.dtype == CP_F32:
+            # small-Cout variant pads Cin to 64-byte chunks PER TAP: in fp32 (MFMA-bound) that only pays when the
+            # padding waste is small (measured: 18/36-channel convs are faster on the generic kernel in fp32)
+            halo = _rup(x.Cphys, 16) <= 1.15 * x.Cphys
         if halo:
             packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
         else:
