@@ -120,6 +120,10 @@ class Program:
         self.keep = []
         self.workspace = None
         self.calls = None
+        self.lane = 0          # current launch lane (stream) -- see par_begin()
+        self.nlanes = 1
+        self.regions = []      # [start_op, end_op] of fork/join regions (buffer lifetimes are extended over them)
+        self._open = None
         self.flops = 0         # dense MACs*2 issued through cp_conv2d_igemm (algorithmic, unpadded)
         self.conv_log = []     # (name, M, Cout, K, flops) per conv launch -- bench roofline uses it
 
@@ -148,7 +152,34 @@ class Program:
             if t.first is None:
                 t.first = i
             t.last = i
-        self.ops.append((fn, argb, name))
+        self.ops.append((fn, argb, name, self.lane))
+
+    # ---- structured concurrency: independent sub-chains (HRNet branches, decoder vs GNN refinement) are launched on
+    # separate lanes; under hipGraph capture each lane is its own stream joined by events, so the graph gets parallel
+    # branches and the latency-bound small kernels overlap the big ones.  Eager replay ignores lanes (one stream,
+    # program order) and is therefore the sequential reference the captured graph must reproduce bit for bit.
+    def par_begin(self, nlanes):
+        assert self._open is None, "regions do not nest"
+        self.ops.append(("__fork__", nlanes))
+        self._open = len(self.ops)
+        self.nlanes = max(self.nlanes, nlanes)
+        self.lane = 0
+
+    def set_lane(self, k):
+        assert self._open is not None
+        self.lane = k
+
+    def sync(self, src, dst):
+        """lane `dst` waits for everything launched on lane `src` so far"""
+        assert self._open is not None and src != dst
+        self.ops.append(("__sync__", src, dst))
+
+    def par_end(self):
+        assert self._open is not None
+        self.ops.append(("__join__",))
+        self.regions.append((self._open - 1, len(self.ops) - 1))
+        self._open = None
+        self.lane = 0
 
     # ---- ops
     def conv(self, x: Act, wkey, w, scale, shift, R, S, stride, pad, Cout, act=ACT_NONE, slope=0.0, residual: Act = None,
@@ -280,6 +311,12 @@ class Program:
     def finalize(self):
         """Linear-scan placement of every workspace tensor by liveness (outputs are placed before the op's dead
         inputs are released, so an op never aliases its own operands)."""
+        assert self._open is None
+        for t in self.tbufs:                      # inside a fork/join region nothing may be recycled: another lane
+            if t.fixed is None and t.first is not None:   # can still be reading (or not yet have written) it
+                for rs, re in self.regions:
+                    if t.first <= re and t.last >= rs:
+                        t.last = max(t.last, re)
         births, deaths = {}, {}
         for t in self.tbufs:
             if t.fixed is None and t.first is not None:
@@ -319,11 +356,53 @@ class Program:
                 return t.fixed.data_ptr()
             return base + t.offset
 
-        self.calls = [(fn, (None,) + tuple(argb(P)), name) for fn, argb, name in self.ops]
+        self.calls = []       # kernel launches only: (fn, (None, args...), name)
+        self.sched = []       # launches + fork/sync/join markers: ("op", call_index, lane) | ("fork", n) | ...
+        for op in self.ops:
+            if op[0] == "__fork__":
+                self.sched.append(("fork", op[1]))
+            elif op[0] == "__sync__":
+                self.sched.append(("sync", op[1], op[2]))
+            elif op[0] == "__join__":
+                self.sched.append(("join",))
+            else:
+                fn, argb, name, lane = op
+                self.sched.append(("op", len(self.calls), lane))
+                self.calls.append((fn, (None,) + tuple(argb(P)), name))
         return self
 
     def run(self, stream_ptr):
+        """Sequential replay on one stream (program order)."""
         for fn, args, name in self.calls:
             rc = fn(stream_ptr, *args[1:])
             if rc != 0:
                 _abi.check(rc, name)
+
+    def run_lanes(self, streams):
+        """Replay with fork/join across `streams` (torch.cuda.Stream list, streams[0] = main).  Meant to be called
+        while streams[0] is being captured into a hipGraph: the event edges become graph dependencies."""
+        ptr = [s.cuda_stream for s in streams]
+        active = 1
+        for item in self.sched:
+            kind = item[0]
+            if kind == "op":
+                fn, args, name = self.calls[item[1]]
+                rc = fn(ptr[item[2]], *args[1:])
+                if rc != 0:
+                    _abi.check(rc, name)
+            elif kind == "fork":
+                active = item[1]
+                ev = torch.cuda.Event()
+                ev.record(streams[0])
+                for k in range(1, active):
+                    streams[k].wait_event(ev)
+            elif kind == "sync":
+                ev = torch.cuda.Event()
+                ev.record(streams[item[1]])
+                streams[item[2]].wait_event(ev)
+            else:   # join
+                for k in range(1, active):
+                    ev = torch.cuda.Event()
+                    ev.record(streams[k])
+                    streams[0].wait_event(ev)
+                active = 1

@@ -18,6 +18,7 @@ class HipForwardMixin:
         self._idx_dev = None
         self.compute_dtype = os.environ.get("CHECKERPOSE_AMD_DTYPE", "fp32")
         self.use_graph = os.environ.get("CHECKERPOSE_AMD_GRAPH", "1") != "0"
+        self.use_lanes = os.environ.get("CHECKERPOSE_AMD_LANES", "1") != "0"   # parallel graph branches
         self.clone_outputs = True
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -129,16 +130,20 @@ class HipForwardMixin:
             cur = torch.cuda.current_stream(device)
             if self.use_graph and pr["warm"]:
                 if pr["graph"] is None:
-                    side = torch.cuda.Stream(device)
+                    lanes = [torch.cuda.Stream(device) for _ in range(prog.nlanes if self.use_lanes else 1)]
+                    side = lanes[0]
                     side.wait_stream(cur)
                     _abi.check(lib.cp_graph_begin_capture(side.cuda_stream), "graph capture begin")
                     try:
-                        prog.run(side.cuda_stream)
+                        if len(lanes) > 1:
+                            prog.run_lanes(lanes)
+                        else:
+                            prog.run(side.cuda_stream)
                     finally:
                         gx = C.c_void_p()
                         rc = lib.cp_graph_end_capture(side.cuda_stream, C.byref(gx))
                     _abi.check(rc, "graph capture end")
-                    pr["graph"], pr["side"] = gx, side
+                    pr["graph"], pr["side"] = gx, lanes
                 _abi.check(lib.cp_graph_launch(pr["graph"], cur.cuda_stream), "graph launch")
             else:
                 prog.run(cur.cuda_stream)

@@ -59,13 +59,15 @@ class NetEmitter:
     def hr_module(self, pfx, xs):
         nb = len(xs)
         xs = list(xs)
-        for b in range(nb):
+        p = self.p
+        # lane j: branch j's four BasicBlocks, then every fuse-layer conv chain that is fed by branch j
+        terms = [[None] * nb for _ in range(nb)]
+        p.par_begin(nb)
+        for j in range(nb):
+            p.set_lane(j)
             for k in range(4):
-                xs[b] = self.basic_block("%s.branches.%d.%d" % (pfx, b, k), xs[b])
-        outs = []
-        for i in range(nb):
-            terms, shifts = [], []
-            for j in range(nb):
+                xs[j] = self.basic_block("%s.branches.%d.%d" % (pfx, j, k), xs[j])
+            for i in range(nb):
                 q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
                 if j == i:
                     t = xs[j]
@@ -75,10 +77,15 @@ class NetEmitter:
                     t = xs[j]
                     for k in range(i - j):
                         t = self.conv_bn(t, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), 3, 2, 1, relu=(k != i - j - 1))
-                terms.append(t)
-                shifts.append(max(j - i, 0))
-            out = self.p.act(xs[i].H, xs[i].W, xs[i].C)
-            outs.append(self.p.fuse_sum(terms, shifts, out, relu=True))
+                terms[i][j] = t
+        p.par_end()
+        outs = []
+        p.par_begin(nb)                      # the nb fuse sums are independent of each other
+        for i in range(nb):
+            p.set_lane(i)
+            out = p.act(xs[i].H, xs[i].W, xs[i].C)
+            outs.append(p.fuse_sum(terms[i], [max(j - i, 0) for j in range(nb)], out, relu=True))
+        p.par_end()
         return outs
 
     def hrnet(self, pfx, x, feat_outs=None):
@@ -94,8 +101,13 @@ class NetEmitter:
                 xs = xs + [self.conv_bn(xs[-1], t + ".0", t + ".1", 3, 2, 1)]
             for m in range(nmod):
                 xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs)
-        return [self.bottleneck("%sincre_modules.%d.0" % (pfx, i), f, out=(feat_outs[i] if feat_outs else None))
-                for i, f in enumerate(xs)]
+        feats = []
+        self.p.par_begin(len(xs))            # the four incre bottlenecks are independent
+        for i, f in enumerate(xs):
+            self.p.set_lane(i)
+            feats.append(self.bottleneck("%sincre_modules.%d.0" % (pfx, i), f, out=(feat_outs[i] if feat_outs else None)))
+        self.p.par_end()
+        return feats
 
     def resnet34(self, pfx, x, feat_outs=None):
         x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 7, 2, 3)
@@ -178,7 +190,12 @@ def emit_posenet(em: NetEmitter, cfg, io):
     feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None)
     p.decode(io["bits"], -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
     f = feats[-1]
+    # lane 0: decoder chain up_net[0..2] -> seg (MFMA-bound) ; lane 1: refine stages (latency-bound graph kernels).
+    # refine[i] needs up_net[i]'s output (sync 0 -> 1) and refine[i-1]; up_net[i+1] needs only up_net[i].
+    if active > 0:
+        p.par_begin(2)
     for i in range(active):
+        p.set_lane(0)
         up = "up_net.%d" % i
         if i == 0:   # ConvTranspose2d(k3,s2,p1,op1)+BN+ReLU as 4 sub-pixel phase convs, then 2x conv3x3+BN+ReLU
             wt = em.W(up + ".0.weight")                     # (Cin, Cout, 3, 3)
@@ -199,6 +216,8 @@ def emit_posenet(em: NetEmitter, cfg, io):
             f = em.conv_bn(cat, up + ".1", up + ".2", 3, 1, 1)
             f = em.conv_bn(f, up + ".4", up + ".5", 3, 1, 1)
         # ---- Refine_moduleGNN.forward pipeline.py:262-298
+        p.sync(0, 1)
+        p.set_lane(1)
         rp = "refine_net.%d" % i
         wpg = em.W(rp + ".local_feat_ext_block.patch_generator.weight")     # (E, nf, k, k)
         Ech = wpg.shape[0]
@@ -222,8 +241,12 @@ def emit_posenet(em: NetEmitter, cfg, io):
         p.decode(io["bits"], i, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
         L = Lnext
     # seg_block Conv2d(nf -> seg_dim, 1x1) on the last feature map, NCHW fp32 out (pipeline.py:349,383)
+    if active > 0:
+        p.set_lane(0)
     wseg = em.W("seg_block.weight")
     sd_ = wseg.shape[0]
     p.conv(f, "seg_block", wseg, em._unit(sd_), em.W("seg_block.bias"), 1, 1, 1, 0, sd_, out_f32=True,
            ostr=(0, sd_ * f.H * f.W, f.W, 1, f.H * f.W), out_tbuf=io["seg_tb"])
+    if active > 0:
+        p.par_end()
     return feats, f

@@ -388,7 +388,12 @@ def test_e2e_fp32_batch_ragged_and_stage_truncation(lib):
     ref, _ = O.posenet_forward(sd, img, net.init_net.knn_idx, 512, **oracle_kwargs())
     ref1, _ = O.posenet_forward(sd, img, net.init_net.knn_idx, 512, stage=1, **oracle_kwargs())
     net = net.to(dev())
-    _cmp_e2e(net(img.to(dev()), None), ref)
+    eager = net(img.to(dev()), None)                     # 1st call: sequential eager replay (program order)
+    _cmp_e2e(eager, ref)
+    for _ in range(4):                                   # 2nd..: hipGraph with parallel lanes (HRNet branches,
+        again = net(img.to(dev()), None)                 # decoder || refinement) must reproduce it bit for bit
+        for a, b in zip(eager, again):
+            assert torch.equal(a, b)
     out1 = net(img.to(dev()), None, stage=1)
     assert tuple(out1[1].shape) == (3, 4, 512) and tuple(out1[3].shape) == (3, 2, 16, 16)
     _cmp_e2e(out1, ref1)
