@@ -45,7 +45,7 @@ class HipForwardMixin:
         return self
 
     # ---- program construction
-    def _build(self, lib, B, size, stage, want_feats, want_graph, device):
+    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False):
         dtype = DTYPES[self.compute_dtype]
         cfg = self._net_cfg()
         cfg["img_size"] = size
@@ -70,6 +70,8 @@ class HipForwardMixin:
             y64=torch.zeros(B, N, dtype=torch.int64, device=device),
             gids=torch.zeros(B, dtype=torch.int32, device=device) if self.LM else None,
         )
+        if teacher:   # teacher forcing (tests): the discrete feedback is decoded from THESE logits, not the computed ones
+            io["decode_bits"] = torch.zeros(B, 13, N, dtype=torch.float32, device=device)
         prog = Program(lib, ws, dtype, B, device)
         io["graph"] = dict(idx=idx, gids=io["gids"], K=idx.shape[2], G=G)
         io["bits_tb"] = prog.fixed(io["bits"])
@@ -98,7 +100,7 @@ class HipForwardMixin:
         return dict(prog=prog, io=io, graph=None, warm=False, side=None)
 
     # ---- one forward
-    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False):
+    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False, teacher_bits=None):
         if self.training:
             raise RuntimeError("checkerpose_amd: train-mode forward (batch-statistics BatchNorm + autograd) is not "
                                "implemented; call .eval().  There is no PyTorch fallback.")
@@ -113,16 +115,18 @@ class HipForwardMixin:
         if p0.device != device:
             raise RuntimeError("module parameters are on %s but the input is on %s" % (p0.device, device))
         B, size = img.shape[0], img.shape[2]
-        key = (B, size, stage, self.compute_dtype, want_feats, want_graph)
+        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None)
         pr = self._programs.get(key)
         if pr is None:
             with torch.cuda.device(device):
-                pr = self._build(lib, B, size, stage, want_feats, want_graph, device)
+                pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None)
             self._programs[key] = pr
         io, prog = pr["io"], pr["prog"]
         with torch.cuda.device(device):
             if img.data_ptr() != io["img"].data_ptr():        # zero-copy when the caller filled input_buffer(B)
                 io["img"].copy_(img)                          # boundary: stage the caller's NCHW fp32 batch
+            if teacher_bits is not None:
+                io["decode_bits"].copy_(teacher_bits)
             if self.LM:
                 if obj_ids is None:
                     raise ValueError("obj_ids is required for the LM networks")

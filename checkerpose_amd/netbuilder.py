@@ -188,7 +188,8 @@ def emit_posenet(em: NetEmitter, cfg, io):
 
     L = local_buf(0) if active > 0 else None
     feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None)
-    p.decode(io["bits"], -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
+    dbits = io.get("decode_bits", io["bits"])      # teacher forcing (tests only): decode from supplied logits
+    p.decode(dbits, -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
     f = feats[-1]
     # lane 0: decoder chain up_net[0..2] -> seg (MFMA-bound) ; lane 1: refine stages (latency-bound graph kernels).
     # refine[i] needs up_net[i]'s output (sync 0 -> 1) and refine[i-1]; up_net[i+1] needs only up_net[i].
@@ -238,7 +239,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
         # Linear(64 -> 2): channel 0 = new x bit -> row 4+i, channel 1 = new y bit -> row 10+i  (pipeline.py:375-378)
         em.linear(q, rp + ".query_block.mlps.4", ACT_NONE, 0.0, out_f32=True,
                   ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
-        p.decode(io["bits"], i, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
+        p.decode(dbits, i, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
         L = Lnext
     # seg_block Conv2d(nf -> seg_dim, 1x1) on the last feature map, NCHW fp32 out (pipeline.py:349,383)
     if active > 0:

@@ -433,3 +433,41 @@ def test_e2e_bf16_bit_agreement(lib):
     print("bf16: roi agree %.4f init-x-bits agree %.4f seg agree %.4f max roi err %.3e" % (roi_agree, init_bits, seg_agree, err))
     assert roi_agree >= 0.97 and init_bits >= 0.97 and seg_agree >= 0.97
     assert torch.isfinite(out[1]).all() and torch.isfinite(out[3]).all()
+
+
+def test_e2e_teacher_forced_per_stage(lib):
+    """Per-stage parity with the discrete feedback forced to the oracle's decisions: every stage's logits must match
+    even if an earlier near-zero logit would have flipped a bit."""
+    net = build_net(seed=2)
+    img = det_image(2, seed=11)
+    ref, inter = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
+    tbits = torch.zeros(2, 13, 512)
+    tbits[:, 0:1], tbits[:, 1:7], tbits[:, 7:13] = ref[0], ref[1], ref[2]
+    # adversarial teacher: flip the sign of the 64 smallest-margin decision logits -> a different gather pattern
+    flipped = tbits.clone()
+    flat = flipped[:, [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]].reshape(-1)
+    idx = flat.abs().argsort()[:64]
+    sel = flipped[:, [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]].reshape(-1)
+    sel[idx] = -sel[idx]
+    flipped[:, [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]] = sel.reshape(2, 11, 512)
+    forced = {"roi": O.mask_from_prob(flipped[:, 0:1]),
+              "x": [O.id_from_code_prob(flipped[:, 1:4 + i]) for i in range(3)],
+              "y": [O.id_from_code_prob(flipped[:, 7:10 + i]) for i in range(3)]}
+    ref_f, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, forced=forced, **oracle_kwargs())
+    net = net.to(dev())
+    out = net.forward_teacher_forced(img.to(dev()), tbits.to(dev()))
+    _cmp_e2e(out, ref)
+    out_f = net.forward_teacher_forced(img.to(dev()), flipped.to(dev()))
+    worst = max(float((a.cpu() - b).abs().max()) for a, b in zip(out_f[:4], ref_f[:4]))
+    assert worst <= 1e-4, worst
+    assert float((ref_f[1] - ref[1]).abs().max()) > 1e-3       # the flipped teacher really changed later stages
+
+
+def test_e2e_resnet34_backbone(lib):
+    """resnet34 backbone (config/lm/res34GNN2_res6_gnn3Skip_mlpQuery_lm.txt): 7x7 stem, max-pool, strided BasicBlocks."""
+    net = build_net(seed=8, backbone="resnet34")   # seed with a mixed RoI bit (49 %) and margin 9e-4
+    img = det_image(2, seed=9)
+    kw = dict(oracle_kwargs(), backbone="resnet34")
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **kw)
+    net = net.to(dev())
+    _cmp_e2e(net(img.to(dev()), None), ref)
