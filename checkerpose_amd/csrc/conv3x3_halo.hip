@@ -119,12 +119,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u, 0, 0));
   };
   const uint32_t a_lane = (uint32_t)(q * HPLANE + x * 16);
-  auto taps = [&](int buf, int tap, const u32x4* w) {
+  auto a_load = [&](u32x4* a, int buf, int tap) {          // 8 pixel-row fragments of one tap from the LDS halo
     const int r = tap / 3, s = tap - 3 * r;
     const unsigned char* base = smem + buf * HBUF + a_lane + (r * HPW + s) * 16;
-    u32x4 a[HTH];
 #pragma unroll
     for (int mt = 0; mt < HTH; ++mt) a[mt] = *(const u32x4*)(base + mt * HPW * 16);
+  };
+  auto mma = [&](const u32x4* a, const u32x4* w) {
 #pragma unroll
     for (int mt = 0; mt < HTH; ++mt) {
       MmaH<Tag>::run(w[0], a[mt], acc[mt][0]);
@@ -132,32 +133,42 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     }
   };
 
-  // ---- prologue: chunk 0 into LDS buffer 0
+  // ---- prologue: chunk 0 into LDS buffer 0.  Software pipeline per tap (pinned with sched_barrier, hipcc
+  // otherwise sinks every prefetch to just before its use):
+  //   weights  : TWO taps ahead in three rotating register sets (9 taps = 3 x 3 -> seamless across chunks);
+  //              a fragment load has ~2 x 16 MFMAs to come back from L2
+  //   halo rows: ONE tap ahead in two register sets (ds_read latency hides under the current tap's MFMAs)
   u32x4 sv[3];
   stage_load(sv, 0);
-  u32x4 wA[2], wB[2];
-  w_load(wA, 0, 0);
+  u32x4 w0[2], w1[2], w2[2], aA[HTH], aB[HTH];
+  w_load(w0, 0, 0);
+  w_load(w1, 0, 1);
   stage_write(sv, 0);
   __syncthreads();
 
+#define CP_TAP(T, ACUR, ANEXT, WCUR, WNEXT, CN, TN)                      \
+  w_load(WNEXT, CN, TN);                                                 \
+  if (T < 8) a_load(ANEXT, buf, T + 1);                                  \
+  __builtin_amdgcn_sched_barrier(0);                                     \
+  mma(ACUR, WCUR);                                                       \
+  __builtin_amdgcn_sched_barrier(0);
   for (int c = 0; c < p.nchunk; ++c) {
     const int buf = c & 1;
-    w_load(wB, c, 1);
     stage_load(sv, c + 1);               // unconditional: past the last chunk every piece is out of range -> zeros
-    // 9 taps, weights ping-pong one tap ahead (static register names: fully unrolled)
-    taps(buf, 0, wA); w_load(wA, c, 2);
-    taps(buf, 1, wB); w_load(wB, c, 3);
-    taps(buf, 2, wA); w_load(wA, c, 4);
-    taps(buf, 3, wB); w_load(wB, c, 5);
-    taps(buf, 4, wA); w_load(wA, c, 6);
-    taps(buf, 5, wB); w_load(wB, c, 7);
-    taps(buf, 6, wA); w_load(wA, c, 8);
-    taps(buf, 7, wB); w_load(wB, c + 1, 0);   // first tap of the next chunk (out of range past the end -> zeros)
-    taps(buf, 8, wA);
-    wA[0] = wB[0]; wA[1] = wB[1];
+    a_load(aA, buf, 0);
+    CP_TAP(0, aA, aB, w0, w2, c, 2)
+    CP_TAP(1, aB, aA, w1, w0, c, 3)
+    CP_TAP(2, aA, aB, w2, w1, c, 4)
+    CP_TAP(3, aB, aA, w0, w2, c, 5)
+    CP_TAP(4, aA, aB, w1, w0, c, 6)
+    CP_TAP(5, aB, aA, w2, w1, c, 7)
+    CP_TAP(6, aA, aB, w0, w2, c, 8)
+    CP_TAP(7, aB, aA, w1, w0, c + 1, 0)  // next chunk's taps 0, 1 (out of range past the end -> zeros)
+    CP_TAP(8, aA, aB, w2, w1, c + 1, 1)
     stage_write(sv, buf ^ 1);
     __syncthreads();
   }
+#undef CP_TAP
 
   if (!wave_active) return;
   // ---- epilogue: lane (x, q) holds, per tile row mt, pixel (y0+mt, x0+x) x channels g*32 + 8q + {0..7}
