@@ -383,6 +383,12 @@ class Program:
         while streams[0] is being captured into a hipGraph: the event edges become graph dependencies."""
         ptr = [s.cuda_stream for s in streams]
         active = 1
+        events = []          # returned: the caller keeps them alive until the capture has ended
+
+        def new_event():
+            events.append(torch.cuda.Event())
+            return events[-1]
+
         for item in self.sched:
             kind = item[0]
             if kind == "op":
@@ -392,17 +398,50 @@ class Program:
                     _abi.check(rc, name)
             elif kind == "fork":
                 active = item[1]
-                ev = torch.cuda.Event()
+                ev = new_event()
                 ev.record(streams[0])
                 for k in range(1, active):
                     streams[k].wait_event(ev)
             elif kind == "sync":
-                ev = torch.cuda.Event()
+                ev = new_event()
                 ev.record(streams[item[1]])
                 streams[item[2]].wait_event(ev)
             else:   # join
                 for k in range(1, active):
-                    ev = torch.cuda.Event()
+                    ev = new_event()
                     ev.record(streams[k])
                     streams[0].wait_event(ev)
                 active = 1
+        return events
+
+
+class ProgramGroup:
+    """Several independent Programs (batch slices of one forward) replayed together.  Sequential replay runs them one
+    after the other; under hipGraph capture each gets its own set of lane streams forked from / joined to the main
+    stream, so the memory-bound phases of one slice (stem, HRNet body) overlap the MFMA-bound phases of another
+    (decoder convs).  Each Program owns its workspace, so slices never alias."""
+
+    def __init__(self, progs):
+        self.progs = progs
+        self.nlanes = max(p.nlanes for p in progs)
+
+    @property
+    def calls(self):
+        return [c for p in self.progs for c in p.calls]
+
+    @property
+    def conv_log(self):
+        return [c for p in self.progs for c in p.conv_log]
+
+    @property
+    def flops(self):
+        return sum(p.flops for p in self.progs)
+
+    @property
+    def workspace_bytes(self):
+        return sum(p.workspace_bytes for p in self.progs)
+
+    def run(self, stream_ptr):
+        for p in self.progs:
+            p.run(stream_ptr)
+

@@ -7,7 +7,7 @@ import os
 import torch
 
 from .. import _abi
-from ..engine import DTYPES, Program, WeightStore
+from ..engine import DTYPES, Program, ProgramGroup, WeightStore
 from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
 
 
@@ -19,6 +19,7 @@ class HipForwardMixin:
         self.compute_dtype = os.environ.get("CHECKERPOSE_AMD_DTYPE", "fp32")
         self.use_graph = os.environ.get("CHECKERPOSE_AMD_GRAPH", "1") != "0"
         self.use_lanes = os.environ.get("CHECKERPOSE_AMD_LANES", "1") != "0"   # parallel graph branches
+        self.batch_splits = int(os.environ.get("CHECKERPOSE_AMD_SPLITS", "1"))   # concurrent batch slices per forward (measured: 1 is fastest; 2 and 4 lose 8 % / 30 % at B=128)
         self.clone_outputs = True
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -28,7 +29,8 @@ class HipForwardMixin:
         lib = _abi._lib
         for pr in getattr(self, "_programs", {}).values():
             if pr.get("graph") and lib is not None:
-                lib.cp_graph_destroy(pr["graph"])
+                for g in pr["graph"]:
+                    lib.cp_graph_destroy(g)
         self._programs, self._stores, self._idx_dev = {}, {}, None
 
     def _apply(self, fn, *a, **k):
@@ -72,29 +74,42 @@ class HipForwardMixin:
         )
         if teacher:   # teacher forcing (tests): the discrete feedback is decoded from THESE logits, not the computed ones
             io["decode_bits"] = torch.zeros(B, 13, N, dtype=torch.float32, device=device)
-        prog = Program(lib, ws, dtype, B, device)
-        io["graph"] = dict(idx=idx, gids=io["gids"], K=idx.shape[2], G=G)
-        io["bits_tb"] = prog.fixed(io["bits"])
-        em = NetEmitter(prog, sd)
-        if cfg["kind"] == "init":
-            feats, g = emit_init_net(em, cfg, io, "")
-        else:
+        # batch slices: independent sub-programs that the captured graph runs concurrently (see ProgramGroup)
+        nsplit = self.batch_splits if (B >= 8 * self.batch_splits and B % self.batch_splits == 0) else 1
+        Bs = B // nsplit
+        fs = None
+        if cfg["kind"] != "init":
             nref = cfg["res_log2"] - 3
             fs = (size // 32) << (stage if stage is not None else nref)
             io["seg"] = torch.zeros(B, cfg["seg_output_dim"], fs, fs, dtype=torch.float32, device=device)
-            io["seg_tb"] = prog.fixed(io["seg"])
-            feats, _ = emit_posenet(em, cfg, io)
-            g = None
         if want_feats:
-            io["img_feats"] = []
-            for f in feats:
-                t = torch.empty(B, f.C, f.H, f.W, dtype=torch.float32, device=device)
-                prog.to_nchw_f32(f, t)
-                io["img_feats"].append(t)
-        if want_graph and g is not None:
-            io["graph_feats"] = torch.empty(B, g.C, N, dtype=torch.float32, device=device)
-            prog.to_nchw_f32(g, io["graph_feats"])
-        prog.finalize()
+            io["img_feats"] = None
+        progs = []
+        for si in range(nsplit):
+            sl = slice(si * Bs, (si + 1) * Bs)
+            sio = {k: (v[sl] if torch.is_tensor(v) else v) for k, v in io.items()}
+            prog = Program(lib, ws, dtype, Bs, device)
+            sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
+            sio["bits_tb"] = prog.fixed(sio["bits"])
+            em = NetEmitter(prog, sd)
+            if cfg["kind"] == "init":
+                feats, g = emit_init_net(em, cfg, sio, "")
+            else:
+                sio["seg_tb"] = prog.fixed(sio["seg"])
+                feats, _ = emit_posenet(em, cfg, sio)
+                g = None
+            if want_feats:
+                if io["img_feats"] is None:
+                    io["img_feats"] = [torch.empty(B, f.C, f.H, f.W, dtype=torch.float32, device=device) for f in feats]
+                for f, t in zip(feats, io["img_feats"]):
+                    prog.to_nchw_f32(f, t[sl])
+            if want_graph and g is not None:
+                if "graph_feats" not in io:
+                    io["graph_feats"] = torch.empty(B, g.C, N, dtype=torch.float32, device=device)
+                prog.to_nchw_f32(g, io["graph_feats"][sl])
+            prog.finalize()
+            progs.append(prog)
+        prog = ProgramGroup(progs)
         torch.cuda.current_stream(device).synchronize()      # weight packing done before temporaries die
         ws.keep.clear()
         return dict(prog=prog, io=io, graph=None, warm=False, side=None)
@@ -134,21 +149,37 @@ class HipForwardMixin:
             cur = torch.cuda.current_stream(device)
             if self.use_graph and pr["warm"]:
                 if pr["graph"] is None:
-                    lanes = [torch.cuda.Stream(device) for _ in range(prog.nlanes if self.use_lanes else 1)]
-                    side = lanes[0]
-                    side.wait_stream(cur)
-                    _abi.check(lib.cp_graph_begin_capture(side.cuda_stream), "graph capture begin")
-                    try:
-                        if len(lanes) > 1:
-                            prog.run_lanes(lanes)
-                        else:
-                            prog.run(side.cuda_stream)
-                    finally:
-                        gx = C.c_void_p()
-                        rc = lib.cp_graph_end_capture(side.cuda_stream, C.byref(gx))
-                    _abi.check(rc, "graph capture end")
-                    pr["graph"], pr["side"] = gx, lanes
-                _abi.check(lib.cp_graph_launch(pr["graph"], cur.cuda_stream), "graph launch")
+                    # one hipGraph per batch slice (each with its own parallel lanes); the slices' graphs are then
+                    # launched concurrently on separate streams, forked from / joined to the caller's stream
+                    graphs, keep = [], []
+                    for sub in prog.progs:
+                        lanes = [torch.cuda.Stream(device) for _ in range(sub.nlanes if self.use_lanes else 1)]
+                        lanes[0].wait_stream(cur)
+                        _abi.check(lib.cp_graph_begin_capture(lanes[0].cuda_stream), "graph capture begin")
+                        try:
+                            if len(lanes) > 1:
+                                keep.append(sub.run_lanes(lanes))
+                            else:
+                                sub.run(lanes[0].cuda_stream)
+                        finally:
+                            gx = C.c_void_p()
+                            rc = lib.cp_graph_end_capture(lanes[0].cuda_stream, C.byref(gx))
+                        _abi.check(rc, "graph capture end")
+                        graphs.append(gx)
+                        keep.append(lanes)
+                    pr["graph"] = graphs
+                    pr["side"] = dict(keep=keep, streams=[torch.cuda.Stream(device) for _ in graphs[1:]],
+                                      fork=torch.cuda.Event(), joins=[torch.cuda.Event() for _ in graphs[1:]])
+                graphs, sd_ = pr["graph"], pr["side"]
+                if len(graphs) > 1:
+                    sd_["fork"].record(cur)
+                    for g, st_, ej in zip(graphs[1:], sd_["streams"], sd_["joins"]):
+                        st_.wait_event(sd_["fork"])
+                        _abi.check(lib.cp_graph_launch(g, st_.cuda_stream), "graph launch")
+                        ej.record(st_)
+                _abi.check(lib.cp_graph_launch(graphs[0], cur.cuda_stream), "graph launch")
+                for ej in (sd_["joins"] if len(graphs) > 1 else []):
+                    cur.wait_event(ej)
             else:
                 prog.run(cur.cuda_stream)
                 pr["warm"] = True

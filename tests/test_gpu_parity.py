@@ -471,3 +471,20 @@ def test_e2e_resnet34_backbone(lib):
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **kw)
     net = net.to(dev())
     _cmp_e2e(net(img.to(dev()), None), ref)
+
+
+def test_batch_slices_concurrent_graphs_bitwise(lib):
+    """B=16 is run as two concurrent 8-crop slice graphs (CHECKERPOSE_AMD_SPLITS=2): identical, bit for bit, to the
+    unsplit sequential replay; bf16 so the test is cheap on the CPU side (no oracle needed: pure scheduling check)."""
+    img = det_image(16, seed=3).to(dev())
+    net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    net.batch_splits = 2
+    o1 = net(img, None)            # eager (sequential)
+    o2 = net(img, None)            # two graphs launched concurrently
+    o3 = net(img, None)
+    ref = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    ref.batch_splits, ref.use_graph = 1, False
+    o4 = ref(img, None)
+    for a, b, c, d in zip(o1, o2, o3, o4):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    assert len(net.program_for(16).progs) == 2 and len(ref.program_for(16).progs) == 1
