@@ -1,0 +1,304 @@
+// 1x1 convolution / Linear layer as an LDS-staged GEMM (the EdgeConv node GEMMs 256->512, the 256-wide MLPs,
+// conv1x1 1024->N, incre conv3): M = pixels or keypoints (rows, K contiguous), N = Cout >= 96, K = Cin >= 64.
+//
+// Same operand split as the 3x3 halo kernel (conv3x3_halo.hip): the block's 128 rows are staged in LDS in full
+// 256-byte row segments (16 consecutive lanes read one row's 256 contiguous bytes: coalesced, each byte crosses
+// the texture path once per block instead of once per wave and per fragment), the 4 waves own disjoint 32-channel
+// groups so each packed weight fragment (1 KiB coalesced buffer load) is read by exactly one wave.
+//   LDS image per K super-chunk (4 chunks of 64 B): [chunk][q = 16-B piece][row 0..127][16 B]  (32 KiB, x2 buffers)
+//   ds_read_b128 of fragment (row block mt, chunk, q): rows consecutive -> conflict-free (plane pitch 2 KiB).
+// Weights: four rotating register sets, three chunks ahead; row fragments: one chunk ahead (sched_barrier pinned).
+// Packed-weight image = the halo kernel's with one tap: [32-ch group][chunk][tile][lane][16 B], rows permuted so a
+// lane ends with 8 consecutive channels (16-byte bf16 / 2 x 16-byte f32 stores).
+#include "common.h"
+
+struct GemmParams {
+  const void* in; const void* w; const float* scale; const float* shift; const void* res; void* out;
+  int M, HoWo, Wo, Cin, in_cs, in_coff, nchunk, nsuper, Cout, ngroups, NB, m_blocks;
+  int act; float slope;
+  uint32_t in_bytes, w_bytes;
+  long long o_base, o_sb, o_sy, o_sx;
+};
+
+constexpr int GROWS = 128, GSUP = 4;                       // rows per block, chunks per super-chunk
+constexpr int GPLANE = GROWS * 16, GCHUNK = 4 * GPLANE, GBUF = GSUP * GCHUNK;   // 2 KiB, 8 KiB, 32 KiB
+
+template <typename Tag> struct MmaG;
+template <> struct MmaG<F32Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+  }
+};
+template <> struct MmaG<BF16Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+  }
+};
+
+template <typename Tag, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmParams p) {
+  constexpr int E = Tag::E;
+  constexpr int KCH = 4 * E;
+  constexpr int ES = 16 / E;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * GBUF
+
+  // block -> (row block, channel block); channel blocks of one row block share a blockIdx % 8 label (one XCD's L2)
+  const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nblk = slot % p.NB;
+  const int mb = (slot / p.NB) * 8 + label;
+  if (mb >= p.m_blocks) return;
+  const int m0 = mb * GROWS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int g = nblk * 4 + wave;
+  const bool wave_active = g < p.ngroups;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // staging map: piece i = tid + 256k (k = 0..7): row = i >> 4, piece-in-row pr = i & 15 (chunk = pr >> 2, q = pr & 3)
+  const int s_pr = tid & 15;
+  uint32_t s_goff[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = (tid >> 4) + 16 * k;
+    const int m = m0 + row;
+    s_goff[k] = m < p.M ? (uint32_t)(m * p.in_cs + p.in_coff + s_pr * E) : 0xFFFFFFFFu;
+  }
+  const uint32_t s_lds0 = (uint32_t)((s_pr >> 2) * GCHUNK + (s_pr & 3) * GPLANE + (tid >> 4) * 16);   // + k*16 rows
+
+  auto stage_load = [&](u32x4* v, int sc) {
+    const int c0 = sc * GSUP * KCH;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = (s_goff[k] != 0xFFFFFFFFu) & (c0 + s_pr * E < p.Cin);
+      const uint32_t off = ok ? (s_goff[k] + (uint32_t)c0) * ES : 0x80000000u;
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+  auto stage_write = [&](const u32x4* v, int buf) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(u32x4*)(smem + buf * GBUF + s_lds0 + k * 16 * 16) = v[k];
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const uint32_t wbase = ((uint32_t)(wave_active ? g : 0) * p.nchunk * 2u * 64u + lane) * 16u;   // [g][chunk][nt][lane]
+  auto w_load = [&](u32x4* w, int chunk) {
+    const uint32_t off = wbase + (uint32_t)chunk * 2048u;      // chunks past the end are out of range -> zeros
+    w[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+    w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u, 0, 0));
+  };
+  const uint32_t a_lane = (uint32_t)(q * GPLANE + x * 16);
+  auto a_load = [&](u32x4* a, int buf, int cc) {
+    const unsigned char* base = smem + buf * GBUF + cc * GCHUNK + a_lane;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) a[mt] = *(const u32x4*)(base + mt * 256);
+  };
+  auto mma = [&](const u32x4* a, const u32x4* w) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      MmaG<Tag>::run(w[0], a[mt], acc[mt][0]);
+      MmaG<Tag>::run(w[1], a[mt], acc[mt][1]);
+    }
+  };
+
+  u32x4 sv[8];
+  stage_load(sv, 0);
+  u32x4 w0[2], w1[2], w2[2], w3[2], aA[8], aB[8];
+  w_load(w0, 0); w_load(w1, 1); w_load(w2, 2);
+  stage_write(sv, 0);
+  __syncthreads();
+
+#define CP_STEP(CC, ACUR, ANEXT, WCUR, WNEXT)                            \
+  w_load(WNEXT, sc * GSUP + CC + 3);                                     \
+  if (CC < GSUP - 1) a_load(ANEXT, buf, CC + 1);                         \
+  __builtin_amdgcn_sched_barrier(0);                                     \
+  mma(ACUR, WCUR);                                                       \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int sc = 0; sc < p.nsuper; ++sc) {
+    const int buf = sc & 1;
+    stage_load(sv, sc + 1);              // past the end: every piece out of range -> zeros (never consumed)
+    a_load(aA, buf, 0);
+    CP_STEP(0, aA, aB, w0, w3)
+    CP_STEP(1, aB, aA, w1, w0)
+    CP_STEP(2, aA, aB, w2, w1)
+    CP_STEP(3, aB, aA, w3, w2)
+    stage_write(sv, buf ^ 1);
+    __syncthreads();
+  }
+#undef CP_STEP
+
+  if (!wave_active) return;
+  // ---- epilogue: lane (x, q): rows m0 + 16*mt + x, channels g*32 + 8q + {0..7}
+  const int ch = g * 32 + q * 8;
+  if (ch >= p.Cout) return;
+  const bool hi_ok = ch + 4 < p.Cout;
+  float sc8[8], sh8[8];
+  {
+    const f32x4 s0 = *(const f32x4*)(p.scale + ch), t0 = *(const f32x4*)(p.shift + ch);
+    const f32x4 s1 = *(const f32x4*)(p.scale + ch + 4), t1 = *(const f32x4*)(p.shift + ch + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc8[j] = s0[j]; sh8[j] = t0[j]; sc8[4 + j] = s1[j]; sh8[4 + j] = t1[j]; }
+  }
+  long long o[8];
+  bool ok[8];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + mt * 16 + x;
+    ok[mt] = m < p.M;
+    const int mm = ok[mt] ? m : 0;
+    const int b = mm / p.HoWo;
+    const int rem = mm - b * p.HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    o[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+  }
+  float rvv[HAS_RES ? 8 : 1][8];
+  if constexpr (HAS_RES) {                // all residual loads before the first store (res may alias out)
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rvv[mt][j] = 0.f;
+      if (!ok[mt]) continue;
+      if (E == 4) {
+        const f32x4 r0 = *(const f32x4*)((const float*)p.res + o[mt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rvv[mt][j] = r0[j];
+        if (hi_ok) {
+          const f32x4 r1 = *(const f32x4*)((const float*)p.res + o[mt] + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rvv[mt][4 + j] = r1[j];
+        }
+      } else {
+        const u32x2 r0 = *(const u32x2*)((const uint16_t*)p.res + o[mt]);
+        rvv[mt][0] = __uint_as_float(r0.x << 16); rvv[mt][1] = __uint_as_float(r0.x & 0xffff0000u);
+        rvv[mt][2] = __uint_as_float(r0.y << 16); rvv[mt][3] = __uint_as_float(r0.y & 0xffff0000u);
+        if (hi_ok) {
+          const u32x2 r1 = *(const u32x2*)((const uint16_t*)p.res + o[mt] + 4);
+          rvv[mt][4] = __uint_as_float(r1.x << 16); rvv[mt][5] = __uint_as_float(r1.x & 0xffff0000u);
+          rvv[mt][6] = __uint_as_float(r1.y << 16); rvv[mt][7] = __uint_as_float(r1.y & 0xffff0000u);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    if (!ok[mt]) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = acc[mt][0][j] * sc8[j] + sh8[j]; v[4 + j] = acc[mt][1][j] * sc8[4 + j] + sh8[4 + j]; }
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rvv[mt][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+      else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+    }
+    if (E == 4) {
+      *(f32x4*)((float*)p.out + o[mt]) = f32x4{v[0], v[1], v[2], v[3]};
+      if (hi_ok) *(f32x4*)((float*)p.out + o[mt] + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else if (hi_ok) {
+      u32x4 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+      if ((((uintptr_t)((uint16_t*)p.out + o[mt])) & 15u) == 0) *(u32x4*)((uint16_t*)p.out + o[mt]) = pk;
+      else { *(u32x2*)((uint16_t*)p.out + o[mt]) = u32x2{pk.x, pk.y}; *(u32x2*)((uint16_t*)p.out + o[mt] + 4) = u32x2{pk.z, pk.w}; }
+    } else {
+      u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+      *(u32x2*)((uint16_t*)p.out + o[mt]) = pk;
+    }
+  }
+}
+
+// ---- packing: [group g (32 ch)][chunk][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt -> channel g*32 + 8*qr + 4*nt + reg
+template <typename Tag>
+__global__ void pack_gemm_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int nchunk,
+                                        const int32_t* __restrict__ row_map, size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % E);
+  const int lane = (int)((i / E) % 64);
+  size_t blk = i / (E * 64);
+  const int nt = (int)(blk % 2); blk /= 2;
+  const int c = (int)(blk % nchunk);
+  const int g = (int)(blk / nchunk);
+  const int row = lane & 15, kq = lane >> 4;
+  const int n = g * 32 + (row >> 2) * 8 + nt * 4 + (row & 3);
+  const int cin = c * (4 * E) + kq * E + e;
+  float v = 0.f;
+  if (n < Cout && cin < Cin) v = w[(size_t)n * Cin + cin];
+  store_elem<Tag>(out, i, v);
+}
+
+extern "C" size_t cp_packed_gemm_weight_bytes(int dtype, int Cout, int cin_phys) {
+  const int E = cp_chan_align(dtype), KCH = 4 * E;
+  const size_t nchunk = ((size_t)cin_phys + KCH - 1) / KCH;
+  return (((size_t)Cout + 31) / 32) * nchunk * 2 * 1024;
+}
+
+extern "C" int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const int nchunk = (cin_phys + 4 * E - 1) / (4 * E);
+  const size_t total = cp_packed_gemm_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(pack_gemm_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
+  else
+    hipLaunchKernelGGL(pack_gemm_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
+  return cp_check_launch();
+}
+
+extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                            const float* scale, const float* shift, const void* residual, void* out) {
+  if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
+  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
+    return CP_ERR_INVALID;
+  const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0) return CP_ERR_INVALID;
+  if (d->Cin <= 0 || d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
+  if (d->Cout <= 0 || d->Cout % 4) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift)) return CP_ERR_ALIGN;
+  if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4)) return CP_ERR_ALIGN;
+  if (((uintptr_t)out % (4 * es)) || (residual && ((uintptr_t)residual % (4 * es)))) return CP_ERR_ALIGN;
+  const long long M = (long long)d->B * d->H * d->W;
+  const long long in_bytes = M * d->in_cstride * es;
+  if (in_bytes >= (1LL << 31) || M >= (1LL << 31)) return CP_ERR_RANGE;
+  GemmParams p;
+  p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
+  p.M = (int)M; p.HoWo = d->H * d->W; p.Wo = d->W;
+  p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.nchunk = (d->Cin + 4 * E - 1) / (4 * E);
+  p.nsuper = (p.nchunk + GSUP - 1) / GSUP;
+  p.Cout = d->Cout; p.ngroups = (d->Cout + 31) / 32; p.NB = (p.ngroups + 3) / 4;
+  p.m_blocks = (int)((M + GROWS - 1) / GROWS);
+  p.act = d->act; p.slope = d->slope;
+  p.in_bytes = (uint32_t)in_bytes;
+  const size_t wb = cp_packed_gemm_weight_bytes(d->dtype, d->Cout, d->Cin);
+  if (wb >= (1ull << 31)) return CP_ERR_RANGE;
+  p.w_bytes = (uint32_t)wb;
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CP_F32) {
+    if (residual) hipLaunchKernelGGL((gemm_rows_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+    else hipLaunchKernelGGL((gemm_rows_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+  } else {
+    if (residual) hipLaunchKernelGGL((gemm_rows_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+    else hipLaunchKernelGGL((gemm_rows_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+  }
+  return cp_check_launch();
+}

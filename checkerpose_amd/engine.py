@@ -16,6 +16,7 @@ from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
+USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
 
@@ -87,6 +88,20 @@ class WeightStore:
         st = torch.cuda.current_stream(self.device).cuda_stream
         _abi.check(self.lib.cp_pack_conv3x3_halo_weight(st, self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
                    "cp_pack_conv3x3_halo_weight(%s)" % name)
+        self.cache[ck] = out
+        return out
+
+    def pack_gemm(self, name, w, Cout, Cin, cin_phys):
+        """1x1 / Linear weights in the LDS-GEMM kernel's image (cp_pack_gemm_weight)."""
+        ck = ("gemm", name, cin_phys)
+        if ck in self.cache:
+            return self.cache[ck]
+        out = torch.empty(self.lib.cp_packed_gemm_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
+        w = w.contiguous()
+        self.keep.append(w)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _abi.check(self.lib.cp_pack_gemm_weight(st, self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
+                   "cp_pack_gemm_weight(%s)" % name)
         self.cache[ck] = out
         return out
 
@@ -197,8 +212,12 @@ class Program:
             # small-Cout variant pads Cin to 64-byte chunks PER TAP: in fp32 (MFMA-bound) that only pays when the
             # padding waste is small (measured: 18/36-channel convs are faster on the generic kernel in fp32)
             halo = _rup(x.Cphys, 16) <= 1.15 * x.Cphys
+        gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
+                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= 16 * self.E)
         if halo:
             packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
+        elif gemm:
+            packed = self.ws.pack_gemm(wkey, w, wCout, wCin, x.Cphys)
         else:
             packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map)
         sc, sh = self.ws.affine(wkey + "#" + str(phase), scale, shift, rows)
@@ -224,7 +243,7 @@ class Program:
         if residual is not None and ostr is None:
             assert (residual.cstride, residual.coff, residual.H, residual.W) == (out.cstride, out.coff, out.H, out.W), \
                 "residual must share the output layout"
-        fn = self.lib.cp_conv3x3_halo if halo else self.lib.cp_conv2d_igemm
+        fn = self.lib.cp_conv3x3_halo if halo else (self.lib.cp_gemm_rows if gemm else self.lib.cp_conv2d_igemm)
         dref = C.byref(d)
         pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
         xtb = x.tbuf

@@ -103,6 +103,16 @@ int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const float* w, i
 int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                     const float* scale, const float* shift, const void* residual, void* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * 1x1 conv / Linear specialisation with LDS-staged rows (EdgeConv node GEMMs, 256-wide MLPs pipeline.py:61-69,
+ * 168-180, conv1x1 init.py:85-95, incre conv3): same arithmetic and descriptor as cp_conv2d_igemm (requires
+ * R=S=1, stride=1, pad=0, o_sc=1, out_f32=0), own packed image ([32-ch group][chunk][tile][lane][16 B]).
+ * ------------------------------------------------------------------------------------------- */
+size_t cp_packed_gemm_weight_bytes(int dtype, int Cout, int cin_phys);
+int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed);
+int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                 const float* scale, const float* shift, const void* residual, void* out);
+
 /* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
  * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
 int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,

@@ -181,6 +181,57 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
     assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
 
 
+GEMM_CASES = [  # (B, H, W, Cin, Cout, act, residual)
+    (2, 1, 200, 256, 512, ACT_NONE, False),     # EdgeConv node GEMM shape class, M = 400 not a multiple of 128
+    (1, 16, 16, 64, 256, ACT_RELU, True),       # bottleneck conv3 + residual, K = 1 (f32: 1) super-chunk
+    (3, 1, 100, 320, 256, ACT_LEAKY, False),    # pre_graph MLP: K = 320 (ragged super-chunk)
+    (1, 8, 8, 1024, 136, ACT_RELU, True),       # deep K, Cout = 136 (partial last channel group), residual
+    (1, 5, 7, 144, 100, ACT_NONE, False),       # odd everything
+]
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_rows_vs_torch_cpu(lib, dtype, case):
+    """LDS-staged 1x1 conv / Linear kernel (cp_gemm_rows) == torch CPU conv1x1 + affine + residual + act."""
+    B, H, W, Cin, Cout, act, has_res = case
+    x = det_tensor("gx%s" % (case,), (B, Cin, H, W))
+    w = det_tensor("gw%s" % (case,), (Cout, Cin, 1, 1), (2.0 / Cin) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("gs%s" % (case,), (Cout,))
+    shift = 0.2 * det_tensor("gt%s" % (case,), (Cout,))
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype)) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = det_tensor("gr%s" % (case,), tuple(ref.shape))
+        ref = ref + rnd(res, dtype)
+    ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.01) if act == ACT_LEAKY else ref)
+    E = 8 if dtype == CP_BF16 else 4
+    xin = to_cl(x, dtype)
+    cop = rup(Cout, E)
+    out = torch.full((B, H, W, cop), float("nan"), dtype=DT[dtype], device=dev())
+    pw = torch.empty(lib.cp_packed_gemm_weight_bytes(dtype, Cout, xin.shape[-1]), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_gemm_weight(st(), dtype, wd.data_ptr(), Cout, Cin, xin.shape[-1], pw.data_ptr()))
+    n16 = rup(Cout, 16)
+    sc = torch.zeros(n16); sc[:Cout] = scale
+    sh = torch.zeros(n16); sh[:Cout] = shift
+    sc, sh = sc.to(dev()), sh.to(dev())
+    rs = to_cl(res, dtype) if res is not None else None
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 1, 1, 1, 0, H, W, cop, act, 0.01
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * cop, W * cop, cop, 1
+    _abi.check(lib.cp_gemm_rows(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                rs.data_ptr() if rs is not None else None, out.data_ptr()), "gemm rows")
+    torch.cuda.synchronize()
+    if cop > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0
+    close(from_cl(out, Cout), ref, TOL[dtype])
+    d.R = 3
+    assert lib.cp_gemm_rows(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
+
+
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 def test_convtranspose_phases_vs_torch_cpu(lib, dtype):
     """ConvTranspose2d(k3,s2,p1,op1) (pipeline.py:187-197) as 4 sub-pixel phase convs."""

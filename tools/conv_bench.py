@@ -25,6 +25,9 @@ SHAPES = [  # name, H, Cin, Cout, k, stride, pad, residual
     ("l1 64->64 3x3 @64", 64, 64, 64, 3, 1, 1, False),
     ("stem 3->64 3x3 s2 @256", 256, 3, 64, 3, 2, 1, False),
     ("edge gemm 256->512 (N=512)", None, 256, 512, 1, 1, 0, False),
+    ("mlp 256->256 (N=512)", None, 256, 256, 1, 1, 0, False),
+    ("mlp 512->256 (N=512)", None, 512, 256, 1, 1, 0, False),
+    ("incre 128->512 1x1 @16 +res", 16, 128, 512, 1, 1, 0, True),
     ("patch 256->64 k2 p1 @64", 64, 256, 64, 2, 1, 1, False),
     ("trans 256->18 3x3 @64", 64, 256, 18, 3, 1, 1, False),
 ]
@@ -40,6 +43,7 @@ def main():
     ap.add_argument("--dtype", default="both")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--halo", type=int, default=1)
+    ap.add_argument("--gemm", type=int, default=1)
     a = ap.parse_args()
     lib = _abi.load()
     dev = torch.device("cuda:0")
@@ -73,7 +77,11 @@ def main():
             if use_halo:
                 pw = torch.empty(lib.cp_packed_halo_weight_bytes(dt, Cout, cin_p), dtype=torch.uint8, device=dev)
                 _abi.check(lib.cp_pack_conv3x3_halo_weight(st, dt, w.data_ptr(), Cout, Cin, cin_p, pw.data_ptr()))
-            fnc = lib.cp_conv3x3_halo if use_halo else lib.cp_conv2d_igemm
+            use_gemm = a.gemm and k == 1 and stride == 1 and pad == 0 and Cout >= 96 and cin_p >= 16 * E
+            if use_gemm:
+                pw = torch.empty(lib.cp_packed_gemm_weight_bytes(dt, Cout, cin_p), dtype=torch.uint8, device=dev)
+                _abi.check(lib.cp_pack_gemm_weight(st, dt, w.data_ptr(), Cout, Cin, cin_p, pw.data_ptr()))
+            fnc = lib.cp_conv3x3_halo if use_halo else (lib.cp_gemm_rows if use_gemm else lib.cp_conv2d_igemm)
 
             def run():
                 _abi.check(fnc(st, C.byref(d), x.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
@@ -89,7 +97,7 @@ def main():
             us = e0.elapsed_time(e1) / a.reps * 1e3
             fl = 2.0 * B * Ho * Wo * k * k * Cin * Cout
             by = (x.numel() + out.numel() * (2 if has_res else 1)) * es
-            print("%-37s %8s %10.1f %10.1f %9.0f" % (name + (" [halo]" if use_halo else ""), "bf16" if dt == CP_BF16 else "fp32", us, fl / us / 1e6, by / us / 1e3))
+            print("%-37s %8s %10.1f %10.1f %9.0f" % (name + (" [halo]" if use_halo else (" [gemm]" if use_gemm else "")), "bf16" if dt == CP_BF16 else "fp32", us, fl / us / 1e6, by / us / 1e3))
 
 
 if __name__ == "__main__":
