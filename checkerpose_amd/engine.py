@@ -247,11 +247,18 @@ class Program:
         dref = C.byref(d)
         pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
         xtb = x.tbuf
+        if halo:
+            fam = "conv3x3_halo_s" if wCout <= 80 else "conv3x3_halo"
+        else:
+            fam = "gemm_rows" if gemm else "conv_igemm"
         self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(rtb) if rtb is not None else None, P(otb)),
-                  "conv:" + wkey, [xtb, rtb], [otb])
+                  fam + ":" + wkey, [xtb, rtb], [otb])
         fl = 2 * x.B * Ho * Wo * R * S * wCin * wCout
         self.flops += fl
-        self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl))
+        oes = 4 if out_f32 else self.es
+        nbytes = (x.B * x.H * x.W * wCin * self.es + x.B * Ho * Wo * wCout * oes * (2 if residual is not None else 1)
+                  + R * S * wCin * wCout * self.es)          # algorithmic: input + output (+ residual) + weights, unpadded
+        self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl, fam, nbytes))
         return out
 
     def upsample2x(self, x: Act, out: Act):
