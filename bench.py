@@ -67,6 +67,24 @@ def cpu_baseline(npoint, seconds=12.0):
             "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
 
 
+def pmc_traffic_mb(kernel_prefix, dtype):
+    """HBM bytes per launch (MB) of a kernel family from the committed rocprofv3 PMC summary of this same bench command
+    (profiles/r*_<dtype>_b128_kernel_summary.csv: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied
+    by profiles/summarize.py).  None when no summary for this dtype is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_b128_kernel_summary.csv" % dtype)))
+    if not files:
+        return None
+    tot, calls = 0.0, 0
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith(kernel_prefix + "<") and r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
+            n = int(r["calls"])
+            tot += n * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"]))
+            calls += n
+    return round(tot / calls, 2) if calls else None
+
+
 def kernel_breakdown(net, B, steps, dump=None):
     """Per-kernel-family device time of one step, measured live with HIP events on the launch stream (eager
     replay of the same launch program, one event pair per launch)."""
@@ -198,6 +216,11 @@ def main():
                                    "frac": pd["frac_mfma"], "traffic": None,
                                    "algorithmic_gflop_per_launch_avg": round(fl_by[dom] / n / 1e9, 3),
                                    "avg_launch_us": round(d["ms_per_step"] * 1e3 / n, 2)}
+            if B == 128:     # the committed PMC summary is for this exact command (B=128)
+                tr = pmc_traffic_mb(MFMA_KERNELS[dom], a.dtype)
+                if tr is not None:
+                    out["roofline"]["traffic"] = tr
+                    out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch (rocprofv3 PMC, profiles/)"
             tot_s = sum(v["ms_per_step"] for v in mf.values()) * 1e-3
             out["mfma_kernels"] = per
             out["mfma_all"] = {"achieved": round(prog.flops / tot_s / 1e12, 2), "unit": "TFLOP/s",
