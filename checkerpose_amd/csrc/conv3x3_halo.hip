@@ -304,6 +304,36 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const uint32_t a_lane = (uint32_t)(q * HPLANE + (2 * wave * HPW + x) * 16);
+  // residual prefetch: issued BEFORE the main loop so its HBM latency overlaps the staging + MFMA work instead of
+  // adding a second serial memory round trip in the epilogue (these layers are latency-bound).  Also satisfies the
+  // "all residual loads before the first store" rule (res may alias out).
+  const int ox = x0 + x;
+  const int chq = q * 4 * NT;
+  long long obase[2];
+  bool rok[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int oy = y0 + 2 * wave + mt;
+    rok[mt] = (oy < p.H) & (ox < p.W);
+    obase[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + chq;
+  }
+  f32x4 rv[2][NT];
+  if (p.res) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        rv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rok[mt] && chq + nt * 4 < p.Cout) {
+          if (E == 4) rv[mt][nt] = *(const f32x4*)((const float*)p.res + obase[mt] + nt * 4);
+          else {
+            const u32x2 r2 = *(const u32x2*)((const uint16_t*)p.res + obase[mt] + nt * 4);
+            rv[mt][nt] = f32x4{__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xffff0000u),
+                               __uint_as_float(r2.y << 16), __uint_as_float(r2.y & 0xffff0000u)};
+          }
+        }
+      }
+  }
   for (int c = 0; c < p.nchunk; ++c) {
     // ---- global -> registers (activation halo pieces + this chunk's weight image)
     const int c0 = c * KCH;
@@ -345,34 +375,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
   }
 
   // ---- epilogue: lane (x, q): pixel (y0 + 2*wave + mt, x0 + x), channels 4*NT*q + 4*nt + {0..3}
-  const int ox = x0 + x;
   if (ox >= p.W) return;
-  const int chq = q * 4 * NT;
-  long long obase[2];
-  bool rok[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int oy = y0 + 2 * wave + mt;
-    rok[mt] = oy < p.H;
-    obase[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + chq;
-  }
-  f32x4 rv[2][NT];     // all residual loads before the first store (res may alias out)
-  if (p.res) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        rv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rok[mt] && chq + nt * 4 < p.Cout) {
-          if (E == 4) rv[mt][nt] = *(const f32x4*)((const float*)p.res + obase[mt] + nt * 4);
-          else {
-            const u32x2 r2 = *(const u32x2*)((const uint16_t*)p.res + obase[mt] + nt * 4);
-            rv[mt][nt] = f32x4{__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xffff0000u),
-                               __uint_as_float(r2.y << 16), __uint_as_float(r2.y & 0xffff0000u)};
-          }
-        }
-      }
-  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     if (!rok[mt]) continue;
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
     }
   }
 }
+
 
 // packing for the small-Cout variant: [chunk][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
 // channel 4*NT*qr + 4*nt + reg.
@@ -510,8 +514,8 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
   if (halo_small(d->Cout)) {   // d->Cout is the PHYSICAL count; the pack call used the logical one -> same tile count
     const int NT = (d->Cout + 15) / 16;
-    const size_t lds = HBUF + (size_t)9 * NT * 1024;
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = HBUF + (size_t)9 * NT * 1024;
 #define CP_HS(TAG, N) hipLaunchKernelGGL((conv3x3_halo_s_kernel<TAG, N>), dim3((unsigned)tt), dim3(256), lds, st, p)
     if (d->dtype == CP_F32) {
       switch (NT) { case 1: CP_HS(F32Tag, 1); break; case 2: CP_HS(F32Tag, 2); break; case 3: CP_HS(F32Tag, 3); break;
