@@ -403,11 +403,201 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
 }
 
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused BasicBlock (timm resnet.BasicBlock inside the HRNet branches):
+//     out = relu( bn2(conv3x3( relu(bn1(conv3x3(x))) )) + x )          C -> C channels, C <= 32, one 64-byte chunk
+// The 18-channel branch at 64x64 is the critical path of every HRNet module (8 convs in series, each HBM-bound);
+// unfused, one block moves x, y1 (write + read), the residual x again and out = 5 tensors; fused it is x (with a
+// 2-pixel halo) + out.  Per 8x16 output tile:
+//   phase 1: stage the (8+4)x(16+4) halo of x in LDS; conv1 is evaluated on the (8+2)x(16+2) ring conv2 needs
+//            (12 fragments of 16 flattened pixels, 3 per wave), BN1+ReLU, pixels outside the image forced to 0
+//            (they are conv2's zero padding), written to LDS in conv2's operand layout;
+//   phase 2: conv2 exactly as conv3x3_halo_s_kernel reads its halo, residual taken from the x halo already in
+//            LDS (no second global read), BN2 + add + ReLU, contiguous per-pixel stores.
+// Weights of both convs travel through one LDS buffer (conv2's are prefetched into registers during phase 1).
+constexpr int FXW = HTW + 4, FXH = HTH + 4, FXPLANE = 256 * 16;      // 12 x 20 = 240 halo pixels, plane padded to 256
+
+template <typename Tag, int NT>
+__global__ __launch_bounds__(256) void basicblock_fused_kernel(const HaloParams p, const void* __restrict__ w2,
+                                                               const float* __restrict__ scale2, const float* __restrict__ shift2) {
+  constexpr int E = Tag::E;
+  constexpr int ES = 16 / E;
+  constexpr int WPIECES = 9 * NT * 64;
+  constexpr int WITER = (WPIECES + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x halo 16 KiB][y1 12 KiB][W 9*NT KiB]
+  unsigned char* const sX = smem;
+  unsigned char* const sY = smem + 4 * FXPLANE;
+  unsigned char* const sW = sY + HBUF;
+
+  const int t = blockIdx.x;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int b = t / tpi;
+  const int trem = t - b * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * HTH, x0 = tx * HTW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w2), 0, p.w_bytes, 0x00020000);
+
+  // ---- stage x halo (240 px x 4 pieces = 960 pieces -> 4 per thread, 1024 slots) and conv1 weights
+  u32x4 xv[4], wv[WITER];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + 256 * k;
+    const int hp = i >> 2, pq = i & 3;
+    const int py = hp / FXW, px = hp - py * FXW;
+    const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+    const bool ok = (hp < FXH * FXW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) & (pq * E < p.Cin);
+    const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pq * E) * ES : 0x80000000u;
+    xv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+  }
+#pragma unroll
+  for (int k = 0; k < WITER; ++k) {
+    const int i = tid + 256 * k;
+    wv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, i < WPIECES ? (uint32_t)i * 16u : 0x80000000u, 0, 0));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + 256 * k;
+    *(u32x4*)(sX + (i & 3) * FXPLANE + (i >> 2) * 16) = xv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < WITER; ++k) {
+    const int i = tid + 256 * k;
+    if (i < WPIECES) *(u32x4*)(sW + i * 16) = wv[k];
+  }
+  // conv2 weights: in flight during phase 1
+#pragma unroll
+  for (int k = 0; k < WITER; ++k) {
+    const int i = tid + 256 * k;
+    wv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, i < WPIECES ? (uint32_t)i * 16u : 0x80000000u, 0, 0));
+  }
+  __syncthreads();
+
+  // ---- phase 1: y1 = relu(bn1(conv1(x))) on the 10x18 ring, fragments f = 3*wave + i, pixel p1 = 16 f + x
+  {
+    f32x4 acc1[3][NT];
+    uint32_t xb[3];
+    bool inimg[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc1[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int p1 = (3 * wave + i) * 16 + x;
+      const int pc = p1 < HPH * HPW ? p1 : 0;
+      const int yy = pc / HPW, xx = pc - yy * HPW;
+      xb[i] = (uint32_t)(q * FXPLANE + (yy * FXW + xx) * 16);
+      const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+      inimg[i] = (p1 < HPH * HPW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s2 = tap - 3 * r;
+      u32x4 a[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = *(const u32x4*)(sX + xb[i] + (r * FXW + s2) * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 w = *(const u32x4*)(sW + (tap * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) MmaH<Tag>::run(w, a[i], acc1[i][nt]);
+      }
+    }
+    // BN1 + ReLU -> LDS in conv2's operand layout [piece][pixel][16 B]; conv1 rows are NOT permuted:
+    // lane (x, q) of tile nt holds channels 16 nt + 4 q + {0..3}
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p1 = (3 * wave + i) * 16 + x;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c0 = nt * 16 + q * 4;
+        const f32x4 sc = *(const f32x4*)(p.scale + c0), sh = *(const f32x4*)(p.shift + c0);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = inimg[i] ? fmaxf(acc1[i][nt][j] * sc[j] + sh[j], 0.f) : 0.f;
+        if (p1 < HNPIX) {
+          unsigned char* dst = sY + (c0 / E) * HPLANE + p1 * 16 + (c0 % E) * ES;
+          if (E == 4) *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+          else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)dst = pk; }
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // y1 complete, everyone done with conv1's weights
+#pragma unroll
+  for (int k = 0; k < WITER; ++k) {
+    const int i = tid + 256 * k;
+    if (i < WPIECES) *(u32x4*)(sW + i * 16) = wv[k];
+  }
+  // y1 pieces beyond 16*NT channels were never written: zero them (conv2 weights there are zero, but 0 * NaN = NaN)
+  if (16 * NT < 4 * E)
+    for (int i = tid; i < (4 * E - 16 * NT) / E * HNPIX; i += 256)
+      *(u32x4*)(sY + ((16 * NT) / E) * HPLANE + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // ---- phase 2: conv2 on the 8x16 tile (wave w: rows 2w, 2w+1), residual from the x halo in LDS
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t a_lane = (uint32_t)(q * HPLANE + (2 * wave * HPW + x) * 16);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int r = tap / 3, s2 = tap - 3 * r;
+    const unsigned char* ab = sY + a_lane + (r * HPW + s2) * 16;
+    const u32x4 a0 = *(const u32x4*)(ab);
+    const u32x4 a1 = *(const u32x4*)(ab + HPW * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const u32x4 w = *(const u32x4*)(sW + (tap * NT + nt) * 1024 + lane * 16);
+      MmaH<Tag>::run(w, a0, acc[0][nt]);
+      MmaH<Tag>::run(w, a1, acc[1][nt]);
+    }
+  }
+  const int ox = x0 + x;
+  if (ox >= p.W) return;
+  const int chq = q * 4 * NT;                          // conv2 rows ARE permuted: lane q holds channels 4 NT q + 4 nt + {0..3}
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int oy = y0 + 2 * wave + mt;
+    if (oy >= p.H) continue;
+    const long long o = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + chq;
+    const int xp = (2 * wave + mt + 2) * FXW + x + 2;  // this output pixel inside the x halo
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = chq + nt * 4;
+      if (ch >= p.Cout) continue;
+      const f32x4 sc = *(const f32x4*)(scale2 + ch), sh = *(const f32x4*)(shift2 + ch);
+      const unsigned char* rp = sX + (ch / E) * FXPLANE + xp * 16 + (ch % E) * ES;
+      float rr[4];
+      if (E == 4) { const f32x4 r4 = *(const f32x4*)rp; rr[0] = r4[0]; rr[1] = r4[1]; rr[2] = r4[2]; rr[3] = r4[3]; }
+      else {
+        const u32x2 r2 = *(const u32x2*)rp;
+        rr[0] = __uint_as_float(r2.x << 16); rr[1] = __uint_as_float(r2.x & 0xffff0000u);
+        rr[2] = __uint_as_float(r2.y << 16); rr[3] = __uint_as_float(r2.y & 0xffff0000u);
+      }
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][j] * sc[j] + sh[j] + rr[j], 0.f);
+      if (E == 4) *(f32x4*)((float*)p.out + o + nt * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + o + nt * 4) = pk; }
+    }
+  }
+}
+
 // packing for the small-Cout variant: [chunk][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
 // channel 4*NT*qr + 4*nt + reg.
 template <typename Tag>
 __global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int NT,
-                                          size_t total) {
+                                          int perm, size_t total) {
   constexpr int E = Tag::E;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -418,7 +608,7 @@ __global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __r
   const int tap = (int)(blk % 9);
   const int c = (int)(blk / 9);
   const int row = lane & 15, kq = lane >> 4;
-  const int n = (row >> 2) * 4 * NT + nt * 4 + (row & 3);
+  const int n = perm ? (row >> 2) * 4 * NT + nt * 4 + (row & 3) : nt * 16 + row;
   const int cin = c * (4 * E) + kq * E + e;
   float v = 0.f;
   if (n < Cout && cin < Cin) v = w[((size_t)n * Cin + cin) * 9 + tap];
@@ -470,9 +660,9 @@ extern "C" int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const 
   if (halo_small(Cout)) {
     const int NT = (Cout + 15) / 16;
     if (dtype == CP_F32)
-      hipLaunchKernelGGL(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, total);
+      hipLaunchKernelGGL(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
     else
-      hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, total);
+      hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
     return cp_check_launch();
   }
   if (dtype == CP_F32)
@@ -536,6 +726,66 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   } else {
     if (residual) hipLaunchKernelGGL((conv3x3_halo_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+  }
+  return cp_check_launch();
+}
+
+// ---- fused BasicBlock API --------------------------------------------------------------------------------------
+extern "C" int cp_pack_conv3x3_rows_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys,
+                                           void* packed) {
+  // conv1 of the fused BasicBlock: small-Cout halo image WITHOUT the row permutation (tile row i = channel 16 nt + i)
+  if (!w || !packed || Cout <= 0 || Cout > 80 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const int NT = (Cout + 15) / 16;
+  const size_t total = cp_packed_halo_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 0, total);
+  else
+    hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 0, total);
+  return cp_check_launch();
+}
+
+extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
+                                   const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
+                                   const float* shift2, void* out) {
+  if (!d || !in || !packed_w1 || !packed_w2 || !scale1 || !shift1 || !scale2 || !shift2 || !out) return CP_ERR_INVALID;
+  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
+    return CP_ERR_INVALID;
+  const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0) return CP_ERR_INVALID;
+  if (d->Cin != d->Cout || d->Cin > 4 * E || d->Cin > 32) return CP_ERR_INVALID;     // one 64-byte chunk, NT <= 2
+  if (d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(scale1) ||
+      !cp_aligned16(shift1) || !cp_aligned16(scale2) || !cp_aligned16(shift2)) return CP_ERR_ALIGN;
+  if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4) || ((uintptr_t)out % (4 * es))) return CP_ERR_ALIGN;
+  if (in == out) return CP_ERR_INVALID;               // the halo of a neighbouring tile would read half-written data
+  const long long in_bytes = (long long)d->B * d->H * d->W * d->in_cstride * es;
+  if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
+  HaloParams p;
+  p.in = in; p.w = packed_w1; p.scale = scale1; p.shift = shift1; p.res = nullptr; p.out = out;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.nchunk = 1; p.Cout = d->Cout; p.ngroups = 1; p.NB = 1;
+  p.tiles_x = (d->W + HTW - 1) / HTW; p.tiles_y = (d->H + HTH - 1) / HTH;
+  const long long tt = (long long)d->B * p.tiles_x * p.tiles_y;
+  if (tt >= (1LL << 28)) return CP_ERR_RANGE;
+  p.total_tiles = (int)tt;
+  p.act = CP_ACT_RELU; p.slope = 0.f;
+  p.in_bytes = (uint32_t)in_bytes;
+  const int NT = (d->Cout + 15) / 16;
+  p.w_bytes = (uint32_t)((size_t)9 * NT * 1024);
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  const size_t lds = 4 * FXPLANE + HBUF + (size_t)9 * NT * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CP_F32) {
+    if (NT == 1) hipLaunchKernelGGL((basicblock_fused_kernel<F32Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+    else hipLaunchKernelGGL((basicblock_fused_kernel<F32Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+  } else {
+    if (NT == 1) hipLaunchKernelGGL((basicblock_fused_kernel<BF16Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+    else hipLaunchKernelGGL((basicblock_fused_kernel<BF16Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
   }
   return cp_check_launch();
 }

@@ -16,6 +16,7 @@ from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
+USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
@@ -88,6 +89,20 @@ class WeightStore:
         st = torch.cuda.current_stream(self.device).cuda_stream
         _abi.check(self.lib.cp_pack_conv3x3_halo_weight(st, self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
                    "cp_pack_conv3x3_halo_weight(%s)" % name)
+        self.cache[ck] = out
+        return out
+
+    def pack_rows3x3(self, name, w, Cout, Cin, cin_phys):
+        """conv1 of the fused BasicBlock (cp_pack_conv3x3_rows_weight: small-Cout halo image, rows unpermuted)."""
+        ck = ("rows3x3", name, cin_phys)
+        if ck in self.cache:
+            return self.cache[ck]
+        out = torch.empty(self.lib.cp_packed_halo_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
+        w = w.contiguous()
+        self.keep.append(w)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _abi.check(self.lib.cp_pack_conv3x3_rows_weight(st, self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
+                   "cp_pack_conv3x3_rows_weight(%s)" % name)
         self.cache[ck] = out
         return out
 
@@ -259,6 +274,35 @@ class Program:
         nbytes = (x.B * x.H * x.W * wCin * self.es + x.B * Ho * Wo * wCout * oes * (2 if residual is not None else 1)
                   + R * S * wCin * wCout * self.es)          # algorithmic: input + output (+ residual) + weights, unpadded
         self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl, fam, nbytes))
+        return out
+
+    def can_fuse_basicblock(self, x: Act, C_):
+        return (USE_FUSED_BB and C_ <= 32 and x.Cphys <= 4 * self.E and x.W >= 16 and x.H >= 8 and x.C == C_)
+
+    def basicblock_fused(self, x: Act, k1, w1, s1, t1, k2, w2, s2, t2):
+        """relu(bn2(conv2(relu(bn1(conv1(x))))) + x) in one launch (cp_basicblock_fused)."""
+        C_ = w1.shape[0]
+        pw1 = self.ws.pack_rows3x3(k1, w1, C_, C_, x.Cphys)
+        pw2 = self.ws.pack_halo(k2, w2, C_, C_, x.Cphys)
+        a1 = self.ws.affine(k1 + "#0", s1, t1, C_)
+        a2 = self.ws.affine(k2 + "#0", s2, t2, C_)
+        out = self.act(x.H, x.W, C_)
+        d = CpConvDesc()
+        d.dtype, d.out_f32, d.B, d.H, d.W = self.dtype, 0, x.B, x.H, x.W
+        d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 3, 3, 1, 1, x.H, x.W
+        d.Cout, d.act, d.slope = out.Cphys, ACT_RELU, 0.0
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
+        self.keep += [d, pw1, pw2, a1, a2]
+        fn = self.lib.cp_basicblock_fused
+        dref = C.byref(d)
+        ptrs = (pw1.data_ptr(), a1[0].data_ptr(), a1[1].data_ptr(), pw2.data_ptr(), a2[0].data_ptr(), a2[1].data_ptr())
+        xtb, otb = x.tbuf, out.tbuf
+        self._add(fn, lambda P: (dref, P(xtb)) + ptrs + (P(otb),), "basicblock_fused:" + k1, [xtb], [otb])
+        fl = 2 * x.B * x.H * x.W * 9 * C_ * C_
+        nb = x.B * x.H * x.W * C_ * self.es
+        self.flops += 2 * fl
+        self.conv_log.append((k1, x.B * x.H * x.W, C_, 9 * C_, 2 * fl, "basicblock_fused", 2 * nb + 2 * 9 * C_ * C_ * self.es))
         return out
 
     def upsample2x(self, x: Act, out: Act):

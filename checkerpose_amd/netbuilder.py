@@ -41,6 +41,12 @@ class NetEmitter:
 
     # ---- timm resnet blocks
     def basic_block(self, pfx, x, stride=1):
+        w1 = self.W(pfx + ".conv1.weight")
+        if (stride == 1 and (pfx + ".downsample.0.weight") not in self.sd and w1.shape[0] == w1.shape[1]
+                and self.p.can_fuse_basicblock(x, w1.shape[0])):
+            s1, t1 = self.ws.bn_fold(pfx + ".bn1")
+            s2, t2 = self.ws.bn_fold(pfx + ".bn2")
+            return self.p.basicblock_fused(x, pfx + ".conv1", w1, s1, t1, pfx + ".conv2", self.W(pfx + ".conv2.weight"), s2, t2)
         y = self.conv_bn(x, pfx + ".conv1", pfx + ".bn1", 3, stride, 1)
         sc = x
         if (pfx + ".downsample.0.weight") in self.sd:

@@ -103,6 +103,16 @@ int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const float* w, i
 int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                     const float* scale, const float* shift, const void* residual, void* out);
 
+/* Fused timm BasicBlock of the HRNet branches (C -> C channels, C <= 32 and one 64-byte chunk, stride 1):
+ *   out = relu( conv3x3(relu(conv3x3(x)*s1+t1))*s2+t2 + x )     -- intermediate and residual never leave LDS.
+ * packed_w1: cp_pack_conv3x3_rows_weight (unpermuted rows); packed_w2: cp_pack_conv3x3_halo_weight.
+ * Descriptor as cp_conv3x3_halo with Cin == Cout; `out` must not alias `in`. */
+int cp_pack_conv3x3_rows_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys,
+                                void* packed);
+int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
+                        const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
+                        const float* shift2, void* out);
+
 /* ---------------------------------------------------------------------------------------------
  * 1x1 conv / Linear specialisation with LDS-staged rows (EdgeConv node GEMMs, 256-wide MLPs pipeline.py:61-69,
  * 168-180, conv1x1 init.py:85-95, incre conv3): same arithmetic and descriptor as cp_conv2d_igemm (requires

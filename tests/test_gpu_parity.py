@@ -181,6 +181,51 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
     assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
 
 
+@pytest.mark.parametrize("dtype,Cc", [(CP_BF16, 18), (CP_BF16, 32), (CP_BF16, 8), (CP_F32, 16), (CP_F32, 10)])
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 13, 21), (3, 8, 16)])
+def test_basicblock_fused_vs_torch_cpu(lib, dtype, Cc, shape):
+    """Fused BasicBlock (cp_basicblock_fused) == relu(bn2(conv2(relu(bn1(conv1(x))))) + x), incl. image borders
+    (the intermediate's out-of-image ring must be zero padding, not conv1 of padded x) and ragged tiles."""
+    B, H, W = shape
+    x = det_tensor("bx%s%d" % (shape, Cc), (B, Cc, H, W))
+    w1 = det_tensor("bw1%d" % Cc, (Cc, Cc, 3, 3), (2.0 / (Cc * 9)) ** 0.5 * 1.7)
+    w2 = det_tensor("bw2%d" % Cc, (Cc, Cc, 3, 3), (2.0 / (Cc * 9)) ** 0.5 * 1.7)
+    s1, t1 = 1.0 + 0.3 * det_tensor("bs1%d" % Cc, (Cc,)), 0.3 * det_tensor("bt1%d" % Cc, (Cc,))
+    s2, t2 = 1.0 + 0.3 * det_tensor("bs2%d" % Cc, (Cc,)), 0.3 * det_tensor("bt2%d" % Cc, (Cc,))
+    xr = rnd(x, dtype)
+    y1 = F.relu(F.conv2d(xr, rnd(w1, dtype), None, 1, 1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1))
+    if dtype == CP_BF16:
+        y1 = rnd(y1, dtype)                    # the intermediate is stored as bf16 in LDS
+    ref = F.relu(F.conv2d(y1, rnd(w2, dtype), None, 1, 1) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1) + xr)
+    E = 8 if dtype == CP_BF16 else 4
+    xin = to_cl(x, dtype)
+    cp = xin.shape[-1]
+    out = torch.full((B, H, W, cp), float("nan"), dtype=DT[dtype], device=dev())
+    nb = lib.cp_packed_halo_weight_bytes(dtype, Cc, cp)
+    pw1 = torch.empty(nb, dtype=torch.uint8, device=dev()); pw2 = torch.empty(nb, dtype=torch.uint8, device=dev())
+    w1d, w2d = w1.contiguous().to(dev()), w2.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv3x3_rows_weight(st(), dtype, w1d.data_ptr(), Cc, Cc, cp, pw1.data_ptr()))
+    _abi.check(lib.cp_pack_conv3x3_halo_weight(st(), dtype, w2d.data_ptr(), Cc, Cc, cp, pw2.data_ptr()))
+
+    def pad(v):
+        o = torch.zeros(rup(Cc, 16)); o[:Cc] = v
+        return o.to(dev())
+    a = [pad(v) for v in (s1, t1, s2, t2)]
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = cp, cp, 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 1, 1, H, W, cp, ACT_RELU, 0.0
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * cp, W * cp, cp, 1
+    _abi.check(lib.cp_basicblock_fused(st(), C.byref(d), xin.data_ptr(), pw1.data_ptr(), a[0].data_ptr(), a[1].data_ptr(),
+                                       pw2.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), out.data_ptr()), "fused basic block")
+    torch.cuda.synchronize()
+    if cp > Cc:
+        assert float(out[..., Cc:].float().abs().max()) == 0.0
+    close(from_cl(out, Cc), ref, 2e-5 if dtype == CP_F32 else 3e-2)
+    assert lib.cp_basicblock_fused(st(), C.byref(d), xin.data_ptr(), pw1.data_ptr(), a[0].data_ptr(), a[1].data_ptr(),
+                                   pw2.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), xin.data_ptr()) == -1   # in-place refused
+
+
 GEMM_CASES = [  # (B, H, W, Cin, Cout, act, residual)
     (2, 1, 200, 256, 512, ACT_NONE, False),     # EdgeConv node GEMM shape class, M = 400 not a multiple of 128
     (1, 16, 16, 64, 256, ACT_RELU, True),       # bottleneck conv3 + residual, K = 1 (f32: 1) super-chunk
