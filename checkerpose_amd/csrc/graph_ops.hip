@@ -194,3 +194,47 @@ extern "C" int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, 
                      mask, x_id, y_id, x_id64, y_id64, N, total);
   return cp_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Post-forward decode on the device: what reference test.py:294-329 +
+// test_network_with_test_data.py:from_id_to_pose :50-66 do on the host with six .cpu().numpy() round trips per image:
+//   p2d[b,n]      = roi_xy_ori[b, :, y_id, x_id]                       (2-D coordinate of the predicted pixel)
+//   valid[b,n,0]  = sigmoid(roi) > 0.5                                   ("all" correspondences, check_seg=False)
+//   valid[b,n,1]  = valid0 && sigmoid(seg[b,1,y,x]) > 0.5                (kept by the FULL mask,  check_seg=True)
+//   valid[b,n,2]  = valid0 && sigmoid(seg[b,0,y,x]) > 0.5                (kept by the VISIBLE mask)
+//   count[b,k]    = number of valid correspondences per variant          (PnP needs >= 4 / 6, :69-99)
+// Only B*N*(2 floats + 3 bytes) leave the GPU instead of logits, ids and two 64x64 masks.
+__global__ void correspondences_kernel(const float* __restrict__ bits, const float* __restrict__ seg,
+                                       const int64_t* __restrict__ x_id, const int64_t* __restrict__ y_id,
+                                       const float* __restrict__ roi_xy, float* __restrict__ p2d, uint8_t* __restrict__ valid,
+                                       int32_t* __restrict__ count, int N, int HW, int Ww, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*N
+  if (i >= total) return;
+  const size_t b = i / N;
+  const int n = (int)(i - b * N);
+  const int x = (int)x_id[i], y = (int)y_id[i];
+  const size_t pix = (size_t)y * Ww + x;
+  p2d[2 * i + 0] = roi_xy[(b * 2 + 0) * HW + pix];
+  p2d[2 * i + 1] = roi_xy[(b * 2 + 1) * HW + pix];
+  const bool v0 = bits[b * 13 * (size_t)N + n] > 0.f;               // sigmoid(z) > 0.5  <=>  z > 0
+  const bool v1 = v0 && seg[(b * 2 + 1) * HW + pix] > 0.f;
+  const bool v2 = v0 && seg[(b * 2 + 0) * HW + pix] > 0.f;
+  valid[3 * i + 0] = v0; valid[3 * i + 1] = v1; valid[3 * i + 2] = v2;
+  // per-image counts: integer atomics (hipcc folds a wave's adds to one address into a single atomic)
+  if (v0) atomicAdd(&count[b * 3 + 0], 1);
+  if (v1) atomicAdd(&count[b * 3 + 1], 1);
+  if (v2) atomicAdd(&count[b * 3 + 2], 1);
+}
+
+extern "C" int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id,
+                                  const int64_t* y_id, const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count,
+                                  int B, int N, int H, int W) {
+  if (!bits || !seg || !x_id || !y_id || !roi_xy_ori || !p2d || !valid || !count || B <= 0 || N <= 0 || H <= 0 || W <= 0)
+    return CP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(count, 0, (size_t)B * 3 * sizeof(int32_t), st) != hipSuccess) return CP_ERR_HIP;
+  const size_t total = (size_t)B * N;
+  hipLaunchKernelGGL(correspondences_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bits, seg, x_id, y_id,
+                     roi_xy_ori, p2d, valid, count, N, H * W, W, total);
+  return cp_check_launch();
+}

@@ -163,6 +163,12 @@ int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* patches, con
 int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, float* mask, int32_t* x_id,
                    int32_t* y_id, int64_t* x_id64, int64_t* y_id64, int B, int N);
 
+/* Post-forward decode on the device (next-row N2; reference test.py:294-329 + test_network_with_test_data.py:50-66):
+ * bits (B,13,N) fp32 logits, seg (B,2,H,W) fp32 logits (0 = visible, 1 = full), ids int64 (B,N), roi_xy_ori (B,2,H,W)
+ * fp32 -> p2d (B,N,2) fp32, valid (B,N,3) uint8 [all | full-mask | visible-mask], count (B,3) int32. */
+int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id, const int64_t* y_id,
+                       const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W);
+
 /* layout plumbing at the boundary: NCHW fp32 image -> channels-last `dtype` (C padded with zeros to
  * Cphys), and channels-last slice -> NCHW fp32 (for `return_img_feats`, init.py:123-124). */
 int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, void* out, int B, int C, int H, int W,

@@ -282,3 +282,22 @@ def posenet_forward(sd, img, knn_idx, npoint, backbone="hrnet_w18", res_log2=6, 
             x_id, y_id = forced["x"][i + 1], forced["y"][i + 1]
     seg = _conv(sd, "seg_block", f)
     return (roi, xb, yb, seg, x_id, y_id), inter
+
+
+# --------------------------------------------------------------------------- post-forward decode (next-row N2)
+def correspondences(roi, seg, x_id, y_id, roi_xy_ori):
+    """Host-side correspondence extraction of the reference, per image: test.py:294-329 (sigmoid > 0.5 thresholds,
+    seg channel 0 = visible, 1 = full) + test_network_with_test_data.py:50-59 (`disc_p2d = roi_xy_ori[y_id, x_id]`,
+    `valid = roi_bit > 0.5 [and seg_mask[y_id, x_id] > 0.5]`).  Tensors: roi (B,1,N), seg (B,2,H,W), ids (B,N),
+    roi_xy_ori (B,2,H,W).  Returns p2d (B,N,2), valid (B,N,3) uint8 [all, full, visible], count (B,3)."""
+    B, _, N = roi.shape
+    roi_bit = torch.where(torch.sigmoid(roi) > 0.5, 1.0, 0.0)[:, 0]                 # (B,N)
+    segb = torch.where(torch.sigmoid(seg) > 0.5, 1.0, 0.0)
+    grid = roi_xy_ori.permute(0, 2, 3, 1)                                            # (B,H,W,2)  test.py:327
+    bi = torch.arange(B).view(B, 1).expand(B, N)
+    p2d = grid[bi, y_id, x_id]                                                       # (B,N,2)
+    v0 = roi_bit > 0.5
+    v1 = v0 & (segb[:, 1][bi, y_id, x_id] > 0.5)
+    v2 = v0 & (segb[:, 0][bi, y_id, x_id] > 0.5)
+    valid = torch.stack([v0, v1, v2], dim=2).to(torch.uint8)
+    return p2d, valid, valid.sum(dim=1).to(torch.int32)

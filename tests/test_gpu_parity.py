@@ -584,3 +584,20 @@ def test_batch_slices_concurrent_graphs_bitwise(lib):
     for a, b, c, d in zip(o1, o2, o3, o4):
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     assert len(net.program_for(16).progs) == 2 and len(ref.program_for(16).progs) == 1
+
+
+def test_postprocess_correspondences_on_device(lib):
+    """Next-row N2: device-side correspondence list == the reference's host-side extraction (oracle restatement of
+    test.py:294-329 + from_id_to_pose :50-59), bit exact, on real forward outputs."""
+    from checkerpose_amd.postprocess import correspondences
+    net = build_net(seed=1)
+    img = det_image(3, seed=5)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
+    grid = det_tensor("roi_xy", (3, 2, 64, 64), 300.0) + 320.0
+    rp2d, rvalid, rcount = O.correspondences(ref[0], ref[3], ref[4], ref[5], grid)
+    net = net.to(dev())
+    out = net(img.to(dev()), None)
+    p2d, valid, count = correspondences(out, grid.to(dev()))
+    torch.cuda.synchronize()
+    assert torch.equal(p2d.cpu(), rp2d) and torch.equal(valid.cpu(), rvalid) and torch.equal(count.cpu(), rcount)
+    assert 0 < int(rcount[:, 0].min()) and int(rcount[:, 2].sum()) <= int(rcount[:, 0].sum())

@@ -105,3 +105,17 @@ def test_resnet34_contract():
     sd = fill_state_dict_(m.state_dict())
     f = O.resnet34_features(sd, "", det_image(1))
     assert [tuple(t.shape[1:]) for t in f] == [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]   # pipeline.py:7
+
+
+def test_oracle_correspondences_known_answer():
+    """from_id_to_pose's index/validity logic on a hand-built case (no solver involved)."""
+    roi = torch.tensor([[[2.0, -1.0, 0.0, 3.0]]])                 # sigmoid>0.5 -> [1,0,0,1]   (z == 0 -> 0)
+    x_id = torch.tensor([[1, 0, 2, 3]]); y_id = torch.tensor([[0, 1, 2, 3]])
+    seg = torch.full((1, 2, 4, 4), -1.0)
+    seg[0, 1, 0, 1] = 1.0                                         # full mask contains (y=0,x=1)
+    seg[0, 0, 3, 3] = 1.0; seg[0, 1, 3, 3] = 1.0                  # both masks contain (3,3)
+    grid = torch.stack([torch.arange(16.).view(4, 4), 100 + torch.arange(16.).view(4, 4)])[None]
+    p2d, valid, count = O.correspondences(roi, seg, x_id, y_id, grid)
+    assert p2d[0].tolist() == [[1.0, 101.0], [4.0, 104.0], [10.0, 110.0], [15.0, 115.0]]
+    assert valid[0].tolist() == [[1, 1, 0], [0, 0, 0], [0, 0, 0], [1, 1, 1]]
+    assert count.tolist() == [[2, 2, 1]]
