@@ -138,14 +138,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("CHECKERPOSE_BENCH_BACKEND", "nccl")    # "gloo": exercise the N>1 path on a 1-GPU box
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", (local % ndev) if world > 1 else 0)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+        if backend == "nccl":                                          # nccl == RCCL over xGMI on ROCm
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     torch.set_grad_enabled(False)
 
     from tests.common import det_image
@@ -175,7 +178,7 @@ def main():
     if dist is not None:
         dist.barrier()
         from checkerpose_amd.parallel import max_over_ranks
-        el = max_over_ranks(el, dev)                      # slowest rank defines the whole-job step time
+        el = max_over_ranks(el, dev if backend == "nccl" else None)   # slowest rank defines the whole-job step time
     ms_per_step = el / a.steps * 1e3
     value = world * B * a.steps / el
 
