@@ -120,3 +120,37 @@ extern "C" int cp_nhwc_to_nchw_f32(cp_stream_t stream, int dtype, const void* in
   else return CP_ERR_INVALID;
   return cp_check_launch();
 }
+
+// ---- input side on the device: uint8 HWC crop -> ToTensor (/255) -> Normalize(mean, std)
+// (reference bop_dataset_pytorch.py:385-391: transforms.ToTensor() + transforms.Normalize((0.485,0.456,0.406),
+// (0.229,0.224,0.225))) -> channels-last `dtype`, zero-padded channels.  IEEE divisions, same op order as
+// torchvision (x/255, then (x-mean)/std), so the fp32 result is bit-identical to the host pipeline.
+template <typename Tag>
+__global__ void u8_to_nhwc_norm_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, int Cphys, float m0, float m1,
+                                       float m2, float s0, float s1, float s2, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W*Cphys
+  if (i >= total) return;
+  const int c = (int)(i % Cphys);
+  const size_t pix = i / Cphys;
+  float v = 0.f;
+  if (c < 3) {
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)in[pix * 3 + c], 255.0f), mean), sd);
+  }
+  store_elem<Tag>(out, i, v);
+}
+
+extern "C" int cp_u8hwc_to_nhwc_norm(cp_stream_t stream, int dtype, const uint8_t* in, void* out, int B, int H, int W,
+                                     int Cphys, const float* mean3, const float* std3) {
+  if (!in || !out || !mean3 || !std3 || B <= 0 || H <= 0 || W <= 0 || Cphys < 3) return CP_ERR_INVALID;
+  const size_t total = (size_t)B * H * W * Cphys;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    hipLaunchKernelGGL(u8_to_nhwc_norm_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Cphys, mean3[0],
+                       mean3[1], mean3[2], std3[0], std3[1], std3[2], total);
+  else if (dtype == CP_BF16)
+    hipLaunchKernelGGL(u8_to_nhwc_norm_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Cphys, mean3[0],
+                       mean3[1], mean3[2], std3[0], std3[1], std3[2], total);
+  else return CP_ERR_INVALID;
+  return cp_check_launch();
+}

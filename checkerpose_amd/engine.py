@@ -371,6 +371,17 @@ class Program:
         self._add(fn, lambda P: (self.dtype, ip, P(ot), self.B, Cc, H, W, out.Cphys), "nchw_to_nhwc", [], [ot])
         return out
 
+    def u8_to_nhwc_norm(self, img_u8_t, H, W, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """uint8 (B,H,W,3) crop -> ToTensor + Normalize -> channels-last activation (cp_u8hwc_to_nhwc_norm)."""
+        out = self.act(H, W, 3)
+        fn = self.lib.cp_u8hwc_to_nhwc_norm
+        ot = out.tbuf
+        ip = img_u8_t.data_ptr()
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        self.keep += [m3, s3]
+        self._add(fn, lambda P: (self.dtype, ip, P(ot), self.B, H, W, out.Cphys, m3, s3), "u8_to_nhwc_norm", [], [ot])
+        return out
+
     def to_nchw_f32(self, x: Act, out_t):
         fn = self.lib.cp_nhwc_to_nchw_f32
         xt = x.tbuf

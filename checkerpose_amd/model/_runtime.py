@@ -47,11 +47,12 @@ class HipForwardMixin:
         return self
 
     # ---- program construction
-    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False):
+    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False, u8=False):
         dtype = DTYPES[self.compute_dtype]
         cfg = self._net_cfg()
         cfg["img_size"] = size
         cfg["stage"] = stage
+        cfg["uint8_input"] = u8
         N = cfg["npoint"]
         sd = self.state_dict()
         if dtype not in self._stores:
@@ -63,7 +64,8 @@ class HipForwardMixin:
         idx = self._idx_dev
         G = idx.shape[0]
         io = dict(
-            img=torch.empty(B, 3, size, size, dtype=torch.float32, device=device),
+            img=(torch.empty(B, size, size, 3, dtype=torch.uint8, device=device) if u8
+                 else torch.empty(B, 3, size, size, dtype=torch.float32, device=device)),
             bits=torch.zeros(B, 13, N, dtype=torch.float32, device=device),
             mask=torch.zeros(B, N, dtype=torch.float32, device=device),
             xid=torch.zeros(B, N, dtype=torch.int32, device=device),
@@ -122,7 +124,11 @@ class HipForwardMixin:
         if not (torch.is_tensor(img) and img.is_cuda):
             raise RuntimeError("checkerpose_amd: input must be a CUDA/HIP tensor on an MI355X; there is no CPU fallback "
                                "(the CPU restatement lives in oracle/ and is test infrastructure only).")
-        if img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.shape[2] != 256:
+        u8 = img.dtype == torch.uint8       # extension: raw (B,256,256,3) uint8 crops, normalised on the device
+        if u8:
+            if img.dim() != 4 or img.shape[3] != 3 or img.shape[1] != img.shape[2] or img.shape[1] != 256:
+                raise ValueError("expected uint8 img of shape (B, 256, 256, 3), got %s" % (tuple(img.shape),))
+        elif img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.shape[2] != 256:
             raise ValueError("expected img of shape (B, 3, 256, 256), got %s" % (tuple(img.shape),))
         lib = _abi.load()
         device = img.device
@@ -130,11 +136,11 @@ class HipForwardMixin:
         if p0.device != device:
             raise RuntimeError("module parameters are on %s but the input is on %s" % (p0.device, device))
         B, size = img.shape[0], img.shape[2]
-        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None)
+        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None, u8)
         pr = self._programs.get(key)
         if pr is None:
             with torch.cuda.device(device):
-                pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None)
+                pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None, u8)
             self._programs[key] = pr
         io, prog = pr["io"], pr["prog"]
         with torch.cuda.device(device):

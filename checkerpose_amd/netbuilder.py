@@ -147,7 +147,10 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
     """InitNet_GNN.forward init.py:109-128.  Returns (feats [Act], graph_feats Act)."""
     p = em.p
     N = cfg["npoint"]
-    x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
+    if cfg.get("uint8_input"):     # raw uint8 HWC crops: ToTensor + Normalize on the device (row N3)
+        x = p.u8_to_nhwc_norm(io["img"], cfg["img_size"], cfg["img_size"])
+    else:
+        x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
     bb = pfx + "img_backbone."
     feats = em.hrnet(bb, x) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
     f = feats[-1]                                           # (B, 8, 8, Cb)

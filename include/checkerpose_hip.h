@@ -176,6 +176,12 @@ int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, void* out, i
 int cp_nhwc_to_nchw_f32(cp_stream_t stream, int dtype, const void* in, float* out, int B, int C, int H, int W,
                         int in_cstride, int in_coff);
 
+/* Input side on the device (next-row N3; reference bop_dataset_pytorch.py:385-391 ToTensor + Normalize): uint8
+ * (B,H,W,3) crop -> (x/255 - mean)/std -> channels-last `dtype` with Cphys channels (zero padded).  mean3/std3 are
+ * HOST pointers to 3 floats. */
+int cp_u8hwc_to_nhwc_norm(cp_stream_t stream, int dtype, const uint8_t* in, void* out, int B, int H, int W, int Cphys,
+                          const float* mean3, const float* std3);
+
 /* ---------------------------------------------------------------------------------------------
  * hipGraph helpers: capture the launch sequence of one forward (everything above is capture-safe:
  * no allocation, no synchronisation) and replay it with one call.

@@ -301,3 +301,13 @@ def correspondences(roi, seg, x_id, y_id, roi_xy_ori):
     v2 = v0 & (segb[:, 0][bi, y_id, x_id] > 0.5)
     valid = torch.stack([v0, v1, v2], dim=2).to(torch.uint8)
     return p2d, valid, valid.sum(dim=1).to(torch.int32)
+
+
+# --------------------------------------------------------------------------- input side (next-row N3)
+def preprocess_uint8(img_u8):
+    """bop_dataset_pytorch.py:385-391: transforms.ToTensor() (uint8 HWC -> float CHW / 255) then
+    transforms.Normalize((0.485,0.456,0.406),(0.229,0.224,0.225)) (sub mean, div std).  (B,H,W,3) u8 -> (B,3,H,W) f32."""
+    x = img_u8.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return x.sub(mean).div(std)

@@ -601,3 +601,18 @@ def test_postprocess_correspondences_on_device(lib):
     torch.cuda.synchronize()
     assert torch.equal(p2d.cpu(), rp2d) and torch.equal(valid.cpu(), rvalid) and torch.equal(count.cpu(), rcount)
     assert 0 < int(rcount[:, 0].min()) and int(rcount[:, 2].sum()) <= int(rcount[:, 0].sum())
+
+
+def test_uint8_input_path_on_device(lib):
+    """Next-row N3: raw uint8 HWC crops normalised on the device == ToTensor+Normalize on the host (oracle
+    restatement of bop_dataset_pytorch.py:385-391): bit-identical network outputs in fp32, and within 1e-4 of the oracle."""
+    net = build_net(seed=1)
+    u8 = (det_tensor("u8img", (2, 256, 256, 3)).abs() * 255.999).to(torch.uint8)
+    x = O.preprocess_uint8(u8)
+    ref, _ = O.posenet_forward(net.state_dict(), x, net.init_net.knn_idx, 512, **oracle_kwargs())
+    net = net.to(dev())
+    o_float = net(x.to(dev()), None)
+    o_u8 = net(u8.to(dev()), None)
+    for a, b in zip(o_float, o_u8):
+        assert torch.equal(a, b)
+    _cmp_e2e(o_u8, ref)
