@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from checkerpose_amd.parallel import aggregate_crops_per_sec, gather_outputs, max_over_ranks, shard_bounds
+from checkerpose_amd.parallel import (aggregate_crops_per_sec, allreduce_gradients_, gather_outputs, max_over_ranks,
+                                      shard_bounds)
 
 
 def test_shard_bounds_cover_batch_exactly():
@@ -37,7 +38,10 @@ def _worker(rank, world, port, q):
     mx = max_over_ranks(el)
     thr = aggregate_crops_per_sec(hi - lo, el)
     full = gather_outputs(local)
-    q.put((rank, lo, hi, el, mx, thr, full.numpy().tolist()))
+    # gradient all-reduce: three tensors, tiny bucket size -> 2 buckets; mean over ranks
+    grads = [torch.full((5,), float(rank + 1)), torch.full((3, 2), 10.0 * (rank + 1)), torch.full((4,), -1.0 * rank)]
+    nb = allreduce_gradients_(grads, bucket_bytes=40)
+    q.put((rank, lo, hi, el, mx, thr, full.numpy().tolist(), nb, [g.flatten().tolist() for g in grads]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,8 +55,9 @@ def test_two_rank_gloo_aggregation():
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
-    (r0, lo0, hi0, el0, mx0, thr0, full0), (r1, lo1, hi1, el1, mx1, thr1, full1) = res
+    (r0, lo0, hi0, el0, mx0, thr0, full0, nb0, g0), (r1, lo1, hi1, el1, mx1, thr1, full1, nb1, g1) = res
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)
     assert mx0 == mx1 and abs(mx0 - max(el0, el1)) < 1e-9          # slowest rank defines the step time
     assert abs(thr0 - 7 / mx0) < 1e-6 and thr0 == thr1             # whole-job crops / max time
     assert full0 == full1 == [[float(i)] * 3 for i in range(7)]    # rank-ordered ragged gather
+    assert nb0 == nb1 == 2 and g0 == g1 == [[1.5] * 5, [15.0] * 6, [-0.5] * 4]     # bucketed mean all-reduce

@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--halo", type=int, default=1)
     ap.add_argument("--gemm", type=int, default=1)
+    ap.add_argument("--gemm-min-k", type=int, default=16)
+    ap.add_argument("--gemm-min-cout", type=int, default=96)
     a = ap.parse_args()
     lib = _abi.load()
     dev = torch.device("cuda:0")
@@ -77,7 +79,7 @@ def main():
             if use_halo:
                 pw = torch.empty(lib.cp_packed_halo_weight_bytes(dt, Cout, cin_p), dtype=torch.uint8, device=dev)
                 _abi.check(lib.cp_pack_conv3x3_halo_weight(st, dt, w.data_ptr(), Cout, Cin, cin_p, pw.data_ptr()))
-            use_gemm = a.gemm and k == 1 and stride == 1 and pad == 0 and Cout >= 96 and cin_p >= 16 * E
+            use_gemm = a.gemm and k == 1 and stride == 1 and pad == 0 and Cout >= a.gemm_min_cout and cin_p >= a.gemm_min_k * E
             if use_gemm:
                 pw = torch.empty(lib.cp_packed_gemm_weight_bytes(dt, Cout, cin_p), dtype=torch.uint8, device=dev)
                 _abi.check(lib.cp_pack_gemm_weight(st, dt, w.data_ptr(), Cout, Cin, cin_p, pw.data_ptr()))
