@@ -29,7 +29,7 @@ struct ConvParams {
   int Cin, in_cs, in_coff;
   int R, S, stride, pad;
   int KC, Cout, n_tiles;
-  int act; float slope; int out_f32;
+  int act; float slope; int out_f32; int epi_lds;
   uint32_t in_bytes, w_bytes;
   long long o_base, o_sb, o_sy, o_sx, o_sc;
 };
@@ -153,6 +153,89 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     load_chunk(a1, w1, kc + 3);
   }
 
+  // ---- coalesced epilogue through wave-private LDS (channels-last output with NT in {1,2,4}).
+  // Measured (rocprofv3 PMC, 64->256 1x1 conv + residual): the texture-address unit was 72 % busy and its cost is
+  // ~4 cycles per distinct 128-byte line an instruction touches; the MFMA-layout epilogue below touches 16 lines
+  // per 512-byte store / residual load (32-byte pieces of 16 pixel rows) and capped the kernel at ~2.4 TB/s.
+  // Here the scaled accumulators are transposed through LDS so that every lane moves 16 contiguous bytes and
+  // consecutive lanes walk one pixel's channels: full-line accesses, 4x fewer line touches for residual + store.
+  if constexpr (MT == 2 && (NT == 1 || NT == 2 || NT == 4)) if (p.epi_lds) {
+    extern __shared__ __attribute__((aligned(16))) float epi_smem[];
+    constexpr int ROWF = NT * 16 + 4;                       // floats per pixel row (+4: spreads the banks)
+    float* my = epi_smem + wave * (MT * 16 * ROWF);
+    constexpr bool f32o = (E == 4);                          // host enables this path only when out dtype == T
+    constexpr int CPL = f32o ? 4 : 8;                        // channels per 16-byte lane access
+    constexpr int LPP = NT * 16 / CPL;                       // lanes per pixel
+    constexpr int PPP = 64 / LPP;                            // pixels per pass
+    constexpr int NPASS = MT * 16 / PPP;
+    const int pl0 = lane / LPP, cg = lane - pl0 * LPP;
+    const int cch = nt0 * 16 + cg * CPL;                     // first channel of this lane
+    const bool cok = cch < p.Cout;
+    // residual loads first (may alias out), in the coalesced mapping
+    u32x4 rres[NPASS];
+    long long ofs[NPASS];
+    bool okp[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int m = m_wave + ps * PPP + pl0;
+      okp[ps] = (m < p.M) & cok;
+      const int mm = m < p.M ? m : 0;
+      const int b = mm / p.HoWo;
+      const int rem = mm - b * p.HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      ofs[ps] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + cch;
+      rres[ps] = u32x4{0u, 0u, 0u, 0u};
+      if (p.res && okp[ps])
+        rres[ps] = f32o ? *(const u32x4*)((const float*)p.res + ofs[ps]) : *(const u32x4*)((const uint16_t*)p.res + ofs[ps]);
+    }
+    // scaled accumulators -> LDS [pixel][channel] (fp32)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nt0 + nt) * 16 + q * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nt0 + nt < p.n_tiles && n < p.Cout) {
+          const f32x4 sc = *(const f32x4*)(p.scale + n);
+          const f32x4 sh = *(const f32x4*)(p.shift + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * sc[j] + sh[j];
+        }
+        *(f32x4*)(my + (mt * 16 + x) * ROWF + nt * 16 + q * 4) = v;
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const float* src = my + (ps * PPP + pl0) * ROWF + cg * CPL;
+      float v[8];
+      const f32x4 v0 = *(const f32x4*)src;
+      v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+      if (!f32o) { const f32x4 v1 = *(const f32x4*)(src + 4); v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3]; }
+      if (!okp[ps]) continue;
+      if (p.res) {
+        if (f32o) {
+          v[0] += __uint_as_float(rres[ps].x); v[1] += __uint_as_float(rres[ps].y);
+          v[2] += __uint_as_float(rres[ps].z); v[3] += __uint_as_float(rres[ps].w);
+        } else {
+          float r8[8];
+          Vec16<BF16Tag>::unpack(rres[ps], r8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += r8[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      }
+      if (f32o) *(f32x4*)((float*)p.out + ofs[ps]) = f32x4{v[0], v[1], v[2], v[3]};
+      else *(u32x4*)((uint16_t*)p.out + ofs[ps]) = Vec16<BF16Tag>::pack(v);
+    }
+    return;
+  }
+
   // ---- epilogue: lane holds pixel (lane&15) x channels 4q..4q+3 of every (mt, nt) tile.
   // Residuals are ALL loaded before the first store: `res` may alias `out` (no __restrict__), so a load issued
   // after a store would be ordered behind it and the epilogue would degrade into MT*NT serial memory round trips.
@@ -240,7 +323,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 template <typename Tag, int MT, int NT>
 static void launch(const ConvParams& p, hipStream_t st) {
   dim3 grid((p.M + 4 * MT * 16 - 1) / (4 * MT * 16), (p.n_tiles + NT - 1) / NT);
-  hipLaunchKernelGGL((conv_igemm_kernel<Tag, MT, NT>), grid, dim3(256), 0, st, p);
+  const size_t lds = p.epi_lds ? (size_t)4 * MT * 16 * (NT * 16 + 4) * sizeof(float) : 0;
+  hipLaunchKernelGGL((conv_igemm_kernel<Tag, MT, NT>), grid, dim3(256), lds, st, p);
 }
 
 template <typename Tag, int MT>
@@ -300,6 +384,12 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   // (few K-chunks: more, lighter waves keep more bytes in flight -- measured +20..30 % on the 1x1 convs).
   int MT = (blocks4 >= 512 && p.KC > 4) ? 4 : 2;
   if (const char* e = getenv("CP_CONV_MT")) MT = atoi(e) == 2 ? 2 : 4;   // kernel-work A/B switch
+  // coalesced LDS epilogue: channels-last vector output, NT in {1,2,4}, 16-byte alignment of every row piece
+  const int oes_ = d->out_f32 ? 4 : es;
+  const int cpl = 16 / oes_;
+  p.epi_lds = (MT == 2 && d->o_sc == 1 && !d->out_f32 && (NT == 1 || NT == 2 || NT == 4) && d->Cout % cpl == 0 && d->o_base % cpl == 0 &&
+               d->o_sb % cpl == 0 && d->o_sy % cpl == 0 && d->o_sx % cpl == 0 && ((uintptr_t)out % 16) == 0 &&
+               (!residual || ((uintptr_t)residual % 16) == 0) && !getenv("CP_NO_EPI_LDS")) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_F32) { if (MT == 4) dispatch_nt<F32Tag, 4>(p, NT, st); else dispatch_nt<F32Tag, 2>(p, NT, st); }
   else                    { if (MT == 4) dispatch_nt<BF16Tag, 4>(p, NT, st); else dispatch_nt<BF16Tag, 2>(p, NT, st); }

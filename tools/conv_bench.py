@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dtype", default="both")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default=None, help="substring filter on the shape name")
     ap.add_argument("--halo", type=int, default=1)
     ap.add_argument("--gemm", type=int, default=1)
     ap.add_argument("--gemm-min-k", type=int, default=16)
@@ -53,6 +54,8 @@ def main():
     dts = {"bf16": [CP_BF16], "fp32": [CP_F32], "both": [CP_BF16, CP_F32]}[a.dtype]
     print("%-37s %8s %10s %10s %9s" % ("shape (B=%d)" % a.batch, "dtype", "us", "TFLOP/s", "GB/s(alg)"))
     for name, H, Cin, Cout, k, stride, pad, has_res in SHAPES:
+        if a.only and a.only not in name:
+            continue
         for dt in dts:
             E, es, tdt = (8, 2, torch.bfloat16) if dt == CP_BF16 else (4, 4, torch.float32)
             B = a.batch
