@@ -97,6 +97,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     woff[nt] = ((uint32_t)t * p.KC * 64 + lane) * 16u;
   }
 
+  // ---- coalesced-epilogue bookkeeping + residual prefetch (see the epilogue): issued BEFORE the main loop so the
+  // residual's HBM round trip overlaps the operand loads instead of following the MFMAs (these launches are
+  // latency-bound: PMC showed waves parked on memory 57 % of their life with ~11 waves resident per CU).
+  constexpr bool EPI = (MT == 2 && (NT == 1 || NT == 2 || NT == 4));
+  constexpr bool f32o = (E == 4);                            // host enables this path only when out dtype == T
+  constexpr int CPL = f32o ? 4 : 8;                          // channels per 16-byte lane access
+  constexpr int LPP = EPI ? NT * 16 / CPL : 1;               // lanes per pixel
+  constexpr int PPP = 64 / LPP;                              // pixels per pass
+  constexpr int NPASS = EPI ? MT * 16 / PPP : 1;
+  const int pl0 = lane / LPP, cg = lane - pl0 * LPP;
+  const int cch = nt0 * 16 + cg * CPL;                       // first channel of this lane
+  u32x4 rres[NPASS];
+  long long ofs[NPASS];
+  bool okp[NPASS];
+  if constexpr (EPI) if (p.epi_lds) {
+    const bool cok = cch < p.Cout;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int m = m_wave + ps * PPP + pl0;
+      okp[ps] = (m < p.M) & cok;
+      const int mm = m < p.M ? m : 0;
+      const int b = mm / p.HoWo;
+      const int rem = mm - b * p.HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      ofs[ps] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + cch;
+      rres[ps] = u32x4{0u, 0u, 0u, 0u};
+      if (p.res && okp[ps])
+        rres[ps] = f32o ? *(const u32x4*)((const float*)p.res + ofs[ps]) : *(const u32x4*)((const uint16_t*)p.res + ofs[ps]);
+    }
+  }
+
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -159,36 +191,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // per 512-byte store / residual load (32-byte pieces of 16 pixel rows) and capped the kernel at ~2.4 TB/s.
   // Here the scaled accumulators are transposed through LDS so that every lane moves 16 contiguous bytes and
   // consecutive lanes walk one pixel's channels: full-line accesses, 4x fewer line touches for residual + store.
-  if constexpr (MT == 2 && (NT == 1 || NT == 2 || NT == 4)) if (p.epi_lds) {
+  if constexpr (EPI) if (p.epi_lds) {
     extern __shared__ __attribute__((aligned(16))) float epi_smem[];
     constexpr int ROWF = NT * 16 + 4;                       // floats per pixel row (+4: spreads the banks)
     float* my = epi_smem + wave * (MT * 16 * ROWF);
-    constexpr bool f32o = (E == 4);                          // host enables this path only when out dtype == T
-    constexpr int CPL = f32o ? 4 : 8;                        // channels per 16-byte lane access
-    constexpr int LPP = NT * 16 / CPL;                       // lanes per pixel
-    constexpr int PPP = 64 / LPP;                            // pixels per pass
-    constexpr int NPASS = MT * 16 / PPP;
-    const int pl0 = lane / LPP, cg = lane - pl0 * LPP;
-    const int cch = nt0 * 16 + cg * CPL;                     // first channel of this lane
-    const bool cok = cch < p.Cout;
-    // residual loads first (may alias out), in the coalesced mapping
-    u32x4 rres[NPASS];
-    long long ofs[NPASS];
-    bool okp[NPASS];
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int m = m_wave + ps * PPP + pl0;
-      okp[ps] = (m < p.M) & cok;
-      const int mm = m < p.M ? m : 0;
-      const int b = mm / p.HoWo;
-      const int rem = mm - b * p.HoWo;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
-      ofs[ps] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + cch;
-      rres[ps] = u32x4{0u, 0u, 0u, 0u};
-      if (p.res && okp[ps])
-        rres[ps] = f32o ? *(const u32x4*)((const float*)p.res + ofs[ps]) : *(const u32x4*)((const uint16_t*)p.res + ofs[ps]);
-    }
     // scaled accumulators -> LDS [pixel][channel] (fp32)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
