@@ -68,13 +68,13 @@ def cpu_baseline(npoint, seconds=12.0):
             "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
 
 
-def pmc_traffic_mb(kernel_prefix, dtype):
+def pmc_traffic_mb(kernel_prefix, dtype, B):
     """HBM bytes per launch (MB) of a kernel family from the committed rocprofv3 PMC summary of this same bench command
-    (profiles/r*_<dtype>_b128_kernel_summary.csv: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied
+    (profiles/r*_<dtype>_b<B>_kernel_summary.csv: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied
     by profiles/summarize.py).  None when no summary for this dtype is committed."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_b128_kernel_summary.csv" % dtype)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_b%d_kernel_summary.csv" % (dtype, B))))
     if not files:
         return None
     tot, calls = 0.0, 0
@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="crops per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--npoint", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,8 +220,8 @@ def main():
                                    "frac": pd["frac_mfma"], "traffic": None,
                                    "algorithmic_gflop_per_launch_avg": round(fl_by[dom] / n / 1e9, 3),
                                    "avg_launch_us": round(d["ms_per_step"] * 1e3 / n, 2)}
-            if B == 128:     # the committed PMC summary is for this exact command (B=128)
-                tr = pmc_traffic_mb(MFMA_KERNELS[dom], a.dtype)
+            if True:         # a committed PMC summary of this exact command (same dtype and batch), if any
+                tr = pmc_traffic_mb(MFMA_KERNELS[dom], a.dtype, B)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr
                     out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch (rocprofv3 PMC, profiles/)"

@@ -66,23 +66,29 @@ extern "C" int cp_pack_conv_weight(cp_stream_t stream, int dtype, const float* w
   return cp_check_launch();
 }
 
-// ---- NCHW fp32 -> channels-last (zero-padded channels).  One thread per output pixel-channel-group.
+// ---- NCHW fp32 -> channels-last (zero-padded channels).  One thread per PIXEL: the C plane reads are coalesced
+// across lanes (consecutive pixels of one plane) and each lane writes its pixel's Cphys channels as 16-byte vectors.
 template <typename Tag>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, void* __restrict__ out, int C, int HW, int Cphys,
                                     size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*Cphys
-  if (i >= total) return;
-  const int c = (int)(i % Cphys);
-  const size_t pix = i / Cphys;
+  constexpr int E = Tag::E;
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW
+  if (pix >= total) return;
   const size_t b = pix / HW, hw = pix - b * HW;
-  const float v = c < C ? in[(b * C + c) * HW + hw] : 0.f;
-  store_elem<Tag>(out, i, v);
+  for (int c0 = 0; c0 < Cphys; c0 += E) {
+    float v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = (c0 + e) < C ? in[(b * C + c0 + e) * HW + hw] : 0.f;
+    ((u32x4*)out)[(pix * Cphys + c0) / E] = Vec16<Tag>::pack(v);
+  }
 }
 
 extern "C" int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, void* out, int B, int C, int H, int W,
                                int Cphys) {
   if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cphys < C) return CP_ERR_INVALID;
-  const size_t total = (size_t)B * H * W * Cphys;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (Cphys % cp_chan_align(dtype) || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  const size_t total = (size_t)B * H * W;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, Cphys, total);
