@@ -17,6 +17,8 @@
 //     contiguous bytes per pixel across the four q lanes.
 // One barrier per channel chunk (two LDS buffers); the next chunk's halo is prefetched into registers under the
 // 9 x 16 MFMAs (bf16) / 9 x 64 MFMAs (f32) of the current one.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct HaloParams {
@@ -247,6 +249,223 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     }
   }
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wide variant of the N-split halo kernel for Cout % 64 == 0, Cout >= 256 (the decoder convs = 80 % of all FLOPs):
+// each wave owns 64 channels (4 tiles) of all 128 pixels, the block covers 256 channels.  Compared with the
+// 32-channel-per-wave kernel every halo row fragment read from LDS now feeds 4 MFMAs instead of 2 (half the LDS
+// traffic per MFMA) and the halo is staged once per 256 instead of per 128 output channels.  The 128 accumulator
+// registers leave room for only half-tap operand sets, so the halo rows are pipelined in two halves (rows 0-3 /
+// 4-7): each half's ds_reads are issued under the other half's 16 MFMAs.  Rows are permuted so lane q ends with
+// channels 16q..16q+15 of its 64-channel group: two 16-byte stores per pixel, 128 contiguous bytes across q.
+template <typename Tag, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams p) {
+  constexpr int E = Tag::E;
+  constexpr int KCH = 4 * E;
+  constexpr int ES = 16 / E;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * HBUF
+
+  const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nblk = slot % p.NB;                       // 256-channel block
+  const int t = (slot / p.NB) * 8 + label;
+  if (t >= p.total_tiles) return;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int b = t / tpi;
+  const int trem = t - b * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * HTH, x0 = tx * HTW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int g = nblk * 4 + wave;                      // 64-channel group of this wave (always < Cout / 64)
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  uint32_t s_goff[3], s_lds[3];
+  int s_cq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + 256 * k;
+    const int hp = i >> 2, pq = i & 3;
+    const int py = hp / HPW, px = hp - py * HPW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = (hp < HPH * HPW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    s_goff[k] = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pq * E) : 0xFFFFFFFFu;
+    s_lds[k] = (uint32_t)(pq * HPLANE + hp * 16);
+    s_cq[k] = pq * E;
+  }
+  auto stage_load = [&](u32x4* v, int c) {
+    const int c0 = c * KCH;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool ok = (s_goff[k] != 0xFFFFFFFFu) & (c0 + s_cq[k] < p.Cin);
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (s_goff[k] + (uint32_t)c0) * ES : 0x80000000u, 0, 0));
+    }
+  };
+  auto stage_write = [&](const u32x4* v, int buf) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *(u32x4*)(smem + buf * HBUF + s_lds[k]) = v[k];
+  };
+
+  f32x4 acc[HTH][4];
+#pragma unroll
+  for (int mt = 0; mt < HTH; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weights: [g64][chunk][tap][nt 0..3][lane][16 B]
+  const uint32_t wbase = ((uint32_t)g * p.nchunk * 36u * 64u + lane) * 16u;
+  auto w_load = [&](u32x4* w, int c, int tap) {
+    const uint32_t off = wbase + ((uint32_t)c * 36u + (uint32_t)tap * 4u) * 1024u;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) w[nt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + nt * 1024u, 0, 0));
+  };
+  const uint32_t a_lane = (uint32_t)(q * HPLANE + x * 16);
+  auto a_load = [&](u32x4* a, int buf, int tap, int half) {      // rows 4*half .. 4*half+3 of one tap
+    const int r = tap / 3, s2 = tap - 3 * r;
+    const unsigned char* base = smem + buf * HBUF + a_lane + ((r + 4 * half) * HPW + s2) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *(const u32x4*)(base + i * HPW * 16);
+  };
+  auto mma = [&](const u32x4* a, const u32x4* w, int half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) MmaH<Tag>::run(w[nt], a[i], acc[4 * half + i][nt]);
+  };
+
+  u32x4 sv[3];
+  stage_load(sv, 0);
+  u32x4 wA[4], wB[4], a0[4], a1[4];
+  w_load(wA, 0, 0);
+  stage_write(sv, 0);
+  __syncthreads();
+
+  // weights one tap (32 MFMAs, ~512 cycles) ahead in two sets; a third set (two taps ahead) measured no faster
+#define CP_TAP4(T, WCUR, WNEXT, CN, TN)                                                 \
+  a_load(a1, buf, T, 1); w_load(WNEXT, CN, TN); __builtin_amdgcn_sched_barrier(0);       \
+  mma(a0, WCUR, 0); __builtin_amdgcn_sched_barrier(0);                                   \
+  if (T < 8) a_load(a0, buf, T + 1, 0);                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  mma(a1, WCUR, 1); __builtin_amdgcn_sched_barrier(0);
+  for (int c = 0; c < p.nchunk; ++c) {
+    const int buf = c & 1;
+    stage_load(sv, c + 1);
+    a_load(a0, buf, 0, 0);
+    CP_TAP4(0, wA, wB, c, 1)
+    CP_TAP4(1, wB, wA, c, 2)
+    CP_TAP4(2, wA, wB, c, 3)
+    CP_TAP4(3, wB, wA, c, 4)
+    CP_TAP4(4, wA, wB, c, 5)
+    CP_TAP4(5, wB, wA, c, 6)
+    CP_TAP4(6, wA, wB, c, 7)
+    CP_TAP4(7, wB, wA, c, 8)
+    CP_TAP4(8, wA, wB, c + 1, 0)          // next chunk's tap 0 (out of range past the end -> zeros)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wA[nt] = wB[nt];
+    stage_write(sv, buf ^ 1);
+    __syncthreads();
+  }
+#undef CP_TAP4
+
+  // ---- epilogue: lane (x, q): pixel (y0+mt, x0+x), channels g*64 + 16q + 4nt + {0..3}
+  const int ch = g * 64 + q * 16;
+  const int ox = x0 + x;
+  if (ox >= p.W) return;
+  float sc[16], sh[16];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const f32x4 s4 = *(const f32x4*)(p.scale + ch + 4 * nt), t4 = *(const f32x4*)(p.shift + ch + 4 * nt);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[4 * nt + j] = s4[j]; sh[4 * nt + j] = t4[j]; }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {              // residual handled 4 rows at a time (register budget)
+    u32x4 rr[HAS_RES ? 4 : 1][E == 4 ? 4 : 2];
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = y0 + 4 * half + i;
+        const long long o = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+#pragma unroll
+        for (int k = 0; k < (E == 4 ? 4 : 2); ++k) {
+          rr[i][k] = u32x4{0u, 0u, 0u, 0u};
+          if (oy < p.H) rr[i][k] = E == 4 ? *(const u32x4*)((const float*)p.res + o + 4 * k) : *(const u32x4*)((const uint16_t*)p.res + o + 8 * k);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mt = 4 * half + i;
+      const int oy = y0 + mt;
+      if (oy >= p.H) continue;
+      const long long o = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+      float v[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mt][nt][j] * sc[4 * nt + j] + sh[4 * nt + j];
+      if constexpr (HAS_RES) {
+        if (E == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[4 * k + 0] += __uint_as_float(rr[i][k].x); v[4 * k + 1] += __uint_as_float(rr[i][k].y);
+            v[4 * k + 2] += __uint_as_float(rr[i][k].z); v[4 * k + 3] += __uint_as_float(rr[i][k].w);
+          }
+        } else {
+          float r8[8];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            Vec16<BF16Tag>::unpack(rr[i][k], r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[8 * k + j] += r8[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      }
+      if (E == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)((float*)p.out + o + 4 * k) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+      } else {
+        *(u32x4*)((uint16_t*)p.out + o) = Vec16<BF16Tag>::pack(v);
+        *(u32x4*)((uint16_t*)p.out + o + 8) = Vec16<BF16Tag>::pack(v + 8);
+      }
+    }
+  }
+}
+
+// packing for the wide variant: [g64][chunk][tap][nt 0..3][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
+// channel g*64 + 16*qr + 4*nt + reg.
+template <typename Tag>
+__global__ void pack_halo4_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int nchunk,
+                                         size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % E);
+  const int lane = (int)((i / E) % 64);
+  size_t blk = i / (E * 64);
+  const int nt = (int)(blk % 4); blk /= 4;
+  const int tap = (int)(blk % 9); blk /= 9;
+  const int c = (int)(blk % nchunk);
+  const int g = (int)(blk / nchunk);
+  const int row = lane & 15, kq = lane >> 4;
+  const int n = g * 64 + (row >> 2) * 16 + nt * 4 + (row & 3);
+  const int cin = c * (4 * E) + kq * E + e;
+  float v = 0.f;
+  if (n < Cout && cin < Cin) v = w[((size_t)n * Cin + cin) * 9 + tap];
+  store_elem<Tag>(out, i, v);
+}
+
+static inline bool halo_wide(int Cout) { return Cout >= 256 && Cout % 256 == 0 && !getenv("CP_NO_HALO4"); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Small-Cout variant (Cout <= 80: the HRNet 18/36/72-channel body convs, 64-channel layer1/stem convs).  These
@@ -665,6 +884,13 @@ extern "C" int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const 
       hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
     return cp_check_launch();
   }
+  if (halo_wide(Cout)) {
+    if (dtype == CP_F32)
+      hipLaunchKernelGGL(pack_halo4_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+    else
+      hipLaunchKernelGGL(pack_halo4_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+    return cp_check_launch();
+  }
   if (dtype == CP_F32)
     hipLaunchKernelGGL(pack_halo_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
   else
@@ -715,6 +941,20 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
                     case 4: CP_HS(BF16Tag, 4); break; default: CP_HS(BF16Tag, 5); break; }
     }
 #undef CP_HS
+    return cp_check_launch();
+  }
+  if (halo_wide(d->Cout)) {
+    p.NB = d->Cout / 256 + ((d->Cout % 256) ? 1 : 0);
+    if (d->Cout % 256) return CP_ERR_INVALID;          // wide variant: whole 256-channel blocks only
+    const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
+    hipStream_t st4 = (hipStream_t)stream;
+    if (d->dtype == CP_F32) {
+      if (residual) hipLaunchKernelGGL((conv3x3_halo4_kernel<F32Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      else hipLaunchKernelGGL((conv3x3_halo4_kernel<F32Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+    } else {
+      if (residual) hipLaunchKernelGGL((conv3x3_halo4_kernel<BF16Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      else hipLaunchKernelGGL((conv3x3_halo4_kernel<BF16Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+    }
     return cp_check_launch();
   }
   const unsigned grid = (unsigned)(((tt + 7) / 8) * 8 * p.NB);

@@ -263,7 +263,7 @@ class Program:
         pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
         xtb = x.tbuf
         if halo:
-            fam = "conv3x3_halo_s" if wCout <= 80 else "conv3x3_halo"
+            fam = "conv3x3_halo_s" if wCout <= 80 else ("conv3x3_halo4" if wCout % 256 == 0 else "conv3x3_halo")
         else:
             fam = "gemm_rows" if gemm else "conv_igemm"
         self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(rtb) if rtb is not None else None, P(otb)),
