@@ -236,13 +236,15 @@ def main():
                 N, K = a.npoint, 20
                 by = B * sum(N * K * c * e + 2 * N * c * e + N * K * 4 for c in (64, 64) + (256,) * 9)
                 gbs = by / (eg["ms_per_step"] * 1e-3) / 1e9
-                out["roofline_gather"] = {"bound": "hbm", "kernel": "edgeconv_gather_max_kernel (11 launches)",
-                                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                hbm_by = B * sum(2 * N * c * e for c in (64, 64) + (256,) * 9)       # compulsory: read P'|Q' once, write out
+                out["roofline_gather"] = {"bound": "l2", "kernel": "edgeconv_gather_max_kernel (11 launches)",
+                                          "achieved": round(gbs, 1), "peak": 34500.0, "unit": "GB/s",
+                                          "frac": round(gbs / 34500.0, 4), "traffic": None,
                                           "algorithmic_mb_per_step": round(by / 1e6, 1),
-                                          "note": "algorithmic bytes include the K=20 neighbour rows, which are served by "
-                                                  "the XCD L2 (a crop's P' table is 256-512 KiB); compulsory HBM bytes are "
-                                                  "2*N*C*e per layer (SURVEY.md 8d), i.e. ~1/11 of this figure"}
+                                          "compulsory_hbm_gbs": round(hbm_by / (eg["ms_per_step"] * 1e-3) / 1e9, 1),
+                                          "note": "algorithmic bytes = K=20 neighbour rows + centre + write + idx (SURVEY.md 8d); the "
+                                                  "neighbour rows are served by the XCD L2 (a crop's P' table is 256-512 KiB, all its "
+                                                  "blocks share one XCD), so the roof is the ~34.5 TB/s aggregate L2, not HBM"}
             out["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             out["dense_gflop_per_crop"] = round(prog.flops / B / 1e9, 2)
             out["workspace_mb"] = round(prog.workspace_bytes / 2 ** 20, 1)

@@ -92,3 +92,89 @@ def test_common_ops_helpers():
     from checkerpose_amd.common_ops import from_dim_str_to_tuple, get_batch_size
     assert get_batch_size(0.75, 32) == (8, 24)
     assert from_dim_str_to_tuple("1024_256_32") == (1024, 256, 32) and from_dim_str_to_tuple(None) is None
+
+
+def _desc(**kw):
+    d = _abi.CpConvDesc()
+    base = dict(dtype=_abi.CP_F32, out_f32=0, B=1, H=8, W=16, Cin=16, in_cstride=16, in_coff=0, R=3, S=3, stride=1, pad=1,
+                Ho=8, Wo=16, Cout=16, act=0, slope=0.0, o_base=0, o_sb=8 * 16 * 16, o_sy=16 * 16, o_sx=16, o_sc=1)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_descriptor_validation_without_gpu(lib):
+    """Every conv entry point rejects bad descriptors BEFORE touching the device (fake, never-dereferenced pointers)."""
+    A = 0x10000                        # 16-byte aligned fake device address
+    ok = _desc()
+    f = lib.cp_conv2d_igemm
+    assert f(None, C.byref(_desc(dtype=7)), A, A, A, A, None, A) == -1                  # unknown dtype
+    assert f(None, C.byref(_desc(Cin=18, in_cstride=18)), A, A, A, A, None, A) == -3    # channels not 16-byte multiples
+    assert f(None, C.byref(_desc(Cout=18)), A, A, A, A, None, A) == -3                  # vector epilogue needs Cout % 4
+    assert f(None, C.byref(_desc(in_coff=8, Cin=16, in_cstride=16)), A, A, A, A, None, A) == -3   # slice outside stride
+    assert f(None, C.byref(ok), A + 4, A, A, A, None, A) == -3                          # misaligned input pointer
+    assert f(None, C.byref(_desc(B=1 << 20, H=64, W=64, in_cstride=256, Cin=256)), A, A, A, A, None, A) == -4   # >= 2 GiB
+    assert f(None, C.byref(_desc(stride=0)), A, A, A, A, None, A) == -1
+    h = lib.cp_conv3x3_halo
+    assert h(None, C.byref(_desc(stride=2)), A, A, A, A, None, A) == -1                 # halo kernel: 3x3/s1/p1 only
+    assert h(None, C.byref(_desc(o_sc=2)), A, A, A, A, None, A) == -1
+    assert h(None, C.byref(_desc(out_f32=1)), A, A, A, A, None, A) == -1
+    g = lib.cp_gemm_rows
+    assert g(None, C.byref(_desc(R=3, S=3)), A, A, A, A, None, A) == -1                 # gemm kernel: 1x1 only
+    assert g(None, C.byref(_desc(R=1, S=1, pad=0, Cin=18, in_cstride=18)), A, A, A, A, None, A) == -3
+    bb = lib.cp_basicblock_fused
+    assert bb(None, C.byref(_desc(Cin=64, in_cstride=64, Cout=64)), A, A, A, A, A, A, A, A + 0x100000) == -1   # C > 32
+    assert bb(None, C.byref(_desc()), A, A, A, A, A, A, A, A) == -1                     # in-place refused
+    assert lib.cp_edgeconv_gather_max(None, 0, A, A, None, A, 1, 512, 20, 30, 1, 32, 0, 0.2) == -3      # C not a 16-B multiple
+    assert lib.cp_edgeconv_gather_max(None, 0, A, A, None, A, 1, 512, 100, 64, 1, 64, 0, 0.2) == -1     # K > 64
+    assert lib.cp_index2feat_gather(None, 0, A, A, A, A, A, 1, 512, 17, 17, 64, 2, 200, 0) == -3        # 4*E > out stride
+    assert lib.cp_fuse_sum_act(None, 0, 5, None, None, A, 1, 8, 8, 16, 1) == -1                          # nsrc > 4
+    assert lib.cp_upsample2x_bilinear_ac(None, 0, A, A, 1, 4, 4, 18, 20, 0, 20, 0) == -3
+    assert lib.cp_maxpool3x3s2(None, 0, A, A, 1, 7, 8, 16) == -1                                          # odd height
+    assert lib.cp_packed_halo_weight_bytes(_abi.CP_BF16, 256, 512) == 8 * 16 * 18 * 1024               # 8 groups x 16 chunks
+    assert lib.cp_packed_halo_weight_bytes(_abi.CP_BF16, 18, 24) == 1 * 9 * 2 * 1024                    # small-Cout image
+    assert lib.cp_packed_gemm_weight_bytes(_abi.CP_F32, 512, 256) == 16 * 16 * 2 * 1024
+
+
+def test_workspace_planner_never_aliases_live_tensors():
+    """engine.Program.finalize(): linear-scan placement -- tensors whose live ranges overlap never overlap in memory,
+    and fork/join regions pin every tensor they touch until the join (host logic only: no device needed)."""
+    from checkerpose_amd.engine import Program, TBuf
+
+    class _Lib:
+        def cp_chan_align(self, dt):
+            return 4
+
+    class _WS:
+        pass
+
+    prog = Program.__new__(Program)
+    prog.lib, prog.ws, prog.dtype, prog.B, prog.device = _Lib(), _WS(), 0, 2, "cpu"
+    prog.E, prog.es, prog.ops, prog.tbufs, prog.keep = 4, 4, [], [], []
+    prog.lane, prog.nlanes, prog.regions, prog._open, prog.flops, prog.conv_log = 0, 1, [], None, 0, []
+    import random
+    rnd = random.Random(0)
+    live = []
+    for i in range(60):
+        if i == 20:
+            prog.par_begin(3)
+        if i == 40:
+            prog.par_end()
+        t = prog.tensor(rnd.randint(1, 50) * 64)
+        reads = rnd.sample(live, min(len(live), rnd.randint(0, 3)))
+        prog._add(lambda *a: 0, lambda P: (), "op%d" % i, reads, [t])
+        live.append(t)
+        if len(live) > 6:
+            live.pop(rnd.randrange(len(live)))
+    import torch
+    orig_empty = torch.empty
+    prog.finalize()
+    placed = [t for t in prog.tbufs if t.first is not None]
+    for a in placed:
+        for b in placed:
+            if a is not b and a.first <= b.last and b.first <= a.last:          # live ranges overlap
+                assert a.offset + a.nbytes <= b.offset or b.offset + b.nbytes <= a.offset
+    rs, re = prog.regions[0]
+    assert all(t.last >= re for t in placed if t.first <= re and t.last >= rs)   # pinned until the join
+    assert prog.workspace_bytes <= sum(t.nbytes for t in placed)
