@@ -616,3 +616,33 @@ def test_uint8_input_path_on_device(lib):
     for a, b in zip(o_float, o_u8):
         assert torch.equal(a, b)
     _cmp_e2e(o_u8, ref)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_full_batch_size_property_batch_independence(lib, dt):
+    """Size-independent property at the BENCH batch size: a crop's outputs must not depend on its batch mates or on
+    the batch size (different grids, tiles, workspace placement, graph lanes).  128 crops = 4 distinct crops x 32
+    copies: every copy must equal, bit for bit, the B=4 forward -- which test_e2e_* pins to the oracle (fp32)."""
+    net = build_net(seed=1).to(dev()).set_compute_dtype(dt)
+    img4 = det_image(4, seed=21).to(dev())
+    ref4 = net(img4, None)
+    big = img4.repeat(32, 1, 1, 1)                        # crop i of the big batch == crop i % 4
+    net(big, None)                                        # eager
+    out = net(big, None)                                  # hipGraph with lanes
+    for a, r in zip(out, ref4):
+        assert a.shape[0] == 128
+        assert torch.equal(a, r.repeat(32, *([1] * (r.dim() - 1))))
+
+
+def test_e2e_ycbv_object_graph(lib):
+    """BASELINE config #4 shape class: a YCB-V object (its own FPS keypoints -> its own kNN graph and weights; the
+    reference trains one network per object, train.py:384,396)."""
+    import os
+    from tests.common import GOLDEN, p3d_from
+    p3d = p3d_from(np.load(os.path.join(GOLDEN, "fps_ycbv_obj01.npy")).astype(np.float64), 512)
+    net = build_net(p3d=p3d, seed=6)
+    img = det_image(2, seed=13)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
+    assert not torch.equal(net.init_net.knn_idx, O.knn(ape_p3d(512), 20))       # really a different graph
+    net = net.to(dev())
+    _cmp_e2e(net(img.to(dev()), None), ref)
