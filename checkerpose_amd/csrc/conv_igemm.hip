@@ -28,7 +28,7 @@ struct ConvParams {
   int M, H, W, HoWo, Wo;
   int Cin, in_cs, in_coff;
   int R, S, stride, pad;
-  int KC, Cout, n_tiles;
+  int KC, Cout, n_tiles, m_blocks, n_blocks, old_map;
   int act; float slope; int out_f32; int epi_lds;
   uint32_t in_bytes, w_bytes;
   long long o_base, o_sb, o_sy, o_sx, o_sc;
@@ -57,8 +57,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x = lane & 15, q = lane >> 4;
-  const int m_wave = blockIdx.x * (4 * MT * 16) + wave * (MT * 16);
-  const int nt0 = blockIdx.y * NT;
+  // block -> (pixel block, channel block): channel blocks are the FAST index and all channel blocks of one pixel
+  // block share a blockIdx % 8 label (one XCD): they run back to back on one L2, so the activation tile they all
+  // read is fetched from HBM once and the 128-byte channel slices they each write/read of the same pixel rows are
+  // touched together (full DRAM rows instead of four strided sweeps over the output / residual tensors).
+  const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int nblk = slot % p.n_blocks;
+  int mblk = (slot / p.n_blocks) * 8 + label;
+  if (p.old_map) { const int m8 = (p.m_blocks + 7) / 8 * 8; mblk = blockIdx.x % m8; nblk = blockIdx.x / m8; }   // A/B only
+  if (mblk >= p.m_blocks) return;
+  const int m_wave = mblk * (4 * MT * 16) + wave * (MT * 16);
+  const int nt0 = nblk * NT;
 
   // ---- per-(lane, mt) pixel decode: input window origin and element offset of (iy0, ix0)
   int iy0[MT], ix0[MT], rowbase[MT];
@@ -327,8 +336,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
 // ------------------------------------------------------------------------------------------------ host
 template <typename Tag, int MT, int NT>
-static void launch(const ConvParams& p, hipStream_t st) {
-  dim3 grid((p.M + 4 * MT * 16 - 1) / (4 * MT * 16), (p.n_tiles + NT - 1) / NT);
+static void launch(ConvParams p, hipStream_t st) {
+  p.m_blocks = (p.M + 4 * MT * 16 - 1) / (4 * MT * 16);
+  p.n_blocks = (p.n_tiles + NT - 1) / NT;
+  p.old_map = getenv("CP_OLD_MAP") ? 1 : 0;
+  dim3 grid((unsigned)((p.m_blocks + 7) / 8 * 8) * p.n_blocks);
   const size_t lds = p.epi_lds ? (size_t)4 * MT * 16 * (NT * 16 + 4) * sizeof(float) : 0;
   hipLaunchKernelGGL((conv_igemm_kernel<Tag, MT, NT>), grid, dim3(256), lds, st, p);
 }
