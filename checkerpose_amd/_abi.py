@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libcheckerpose_hip.so")
 
 CP_F32, CP_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+LOSS_BCE, LOSS_L1 = 0, 1
 
 
 class CpConvDesc(C.Structure):
@@ -21,7 +22,7 @@ class CpConvDesc(C.Structure):
                 ("o_sc", C.c_int64)]
 
 
-_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 # name -> (restype, argtypes); exactly the symbols declared in include/checkerpose_hip.h
 SIGNATURES = {
@@ -46,6 +47,12 @@ SIGNATURES = {
     "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_bits_decode": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
     "cp_correspondences": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "cp_edgeconv_bwd_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "cp_edgeconv_gather_max_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_index2feat_gather_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_loss_workspace_bytes": (C.c_size_t, []),
+    "cp_code_loss": (_I, [_P, _I, _P, _L, _P, _L, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "cp_mask_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
     "cp_nchw_to_nhwc": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I]),
     "cp_u8hwc_to_nhwc_norm": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cp_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),

@@ -30,6 +30,7 @@ typedef void* cp_stream_t;
 
 enum { CP_F32 = 0, CP_BF16 = 1 };
 enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_LEAKY = 2 };
+enum { CP_LOSS_BCE = 0, CP_LOSS_L1 = 1 };   /* loss_type of losses/code_loss.py ("CE" is not used by train.py:87-88) */
 enum {
   CP_OK = 0,
   CP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
@@ -168,6 +169,45 @@ int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, float* mask
  * fp32 -> p2d (B,N,2) fp32, valid (B,N,3) uint8 [all | full-mask | visible-mask], count (B,3) int32. */
 int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id, const int64_t* y_id,
                        const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training side: backward of the fused graph ops + the loss head of train.py:307-320.
+ * Gradients are fp32; `pq` is the forward's saved GEMM output in `dtype`.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Backward of cp_edgeconv_gather_max == autograd of `x.max(dim=-1)` over get_graph_feature + LeakyReLU
+ * (init.py:36-49,64-68): gq = gout * leaky'(max_k P' + Q');  dQ'[b,i] = gq;  dP'[b,j] = sum of gq over the edges
+ * (i,k) with idx[i,k] == j that won the max (first arg-max).  gout (B,N,gout_cstride) fp32 (channels
+ * [gout_coff, +C)), dpq (B,N,2C) fp32 fully overwritten.  rev_ptr (G,N+1) / rev_edge (G,N*K): the static graph's
+ * reverse adjacency -- flat edge ids i*K+k stably sorted by idx[i,k] -- so the scatter is a deterministic gather.
+ * workspace: cp_edgeconv_bwd_workspace_bytes(B,N,C) bytes. */
+size_t cp_edgeconv_bwd_workspace_bytes(int B, int N, int C);
+int cp_edgeconv_gather_max_bwd(cp_stream_t stream, int dtype, const void* pq, const int32_t* idx,
+                               const int32_t* rev_ptr, const int32_t* rev_edge, const int32_t* graph_ids,
+                               const float* gout, float* dpq, void* workspace, int B, int N, int K, int C,
+                               int G, int gout_cstride, int gout_coff, float slope);
+
+/* Backward of cp_index2feat_gather == autograd of the four advanced-index gathers + mask multiply
+ * (pipeline.py:156-163,280): dpatches (B,Hp,Wp,E) fp32, zeroed then scatter-added (fp32 hardware atomics). */
+int cp_index2feat_gather_bwd(cp_stream_t stream, const float* gout, const int32_t* x_id, const int32_t* y_id,
+                             const float* mask, float* dpatches, int B, int N, int Hp, int Wp, int E, int k,
+                             int gout_cstride, int gout_coff);
+
+/* UnmaskedCodeLoss (mask == NULL; losses/code_loss.py:6-27) / MaskedCodeLoss (mask (B,N); code_loss.py:30-62):
+ * pred (B,nbits,N) fp32 logits with batch stride pred_bstride (elements), gt likewise (train.py:312-313 passes the
+ * slice pixel_x_codes[:, :num_proj_bits]).  loss_type CP_LOSS_BCE (BCEWithLogits) | CP_LOSS_L1 (L1 on sigmoid).
+ * Writes loss[0] and, if dpred != NULL, d loss / d pred (same indexing, stride dpred_bstride).
+ * workspace: cp_loss_workspace_bytes() bytes, 16-byte aligned. */
+size_t cp_loss_workspace_bytes(void);
+int cp_code_loss(cp_stream_t stream, int loss_type, const float* pred, long long pred_bstride, const float* gt,
+                 long long gt_bstride, const float* mask, int B, int nbits, int N, float* loss, float* dpred,
+                 long long dpred_bstride, void* workspace);
+
+/* MaskLoss_interpolate (losses/mask_loss.py:6-17): mean | sigmoid(pred[b,0]) - nearest_resize(gt[b]) |.
+ * pred points at channel 0 of the slice the caller passes (train.py:315-316: pred_seg[:, 0:1] / [:, 1:2]), (h,w)
+ * contiguous with batch stride pred_bstride; gt (B,Hm,Wm) fp32 contiguous. */
+int cp_mask_loss(cp_stream_t stream, const float* pred, long long pred_bstride, const float* gt, int B, int h,
+                 int w, int Hm, int Wm, float* loss, float* dpred, long long dpred_bstride, void* workspace);
 
 /* layout plumbing at the boundary: NCHW fp32 image -> channels-last `dtype` (C padded with zeros to
  * Cphys), and channels-last slice -> NCHW fp32 (for `return_img_feats`, init.py:123-124). */
