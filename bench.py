@@ -26,7 +26,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skill
 PEAK_HBM_GBS = 8000.0
 MFMA_KERNELS = {"conv_igemm": "conv_igemm_kernel", "conv3x3_halo": "conv3x3_halo_kernel", "conv3x3_halo4": "conv3x3_halo4_kernel",
                 "conv3x3_halo_s": "conv3x3_halo_s_kernel", "gemm_rows": "gemm_rows_kernel",
-                "basicblock_fused": "basicblock_fused_kernel"}
+                "basicblock_fused": "basicblock_fused_kernel", "bottleneck_fused": "bottleneck_fused_kernel"}
 
 
 def build(npoint, seed=1):

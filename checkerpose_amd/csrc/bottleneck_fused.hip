@@ -1,0 +1,281 @@
+// Fused Bottleneck (timm resnet.Bottleneck inside HRNet layer1, blocks 1..3):
+//     out = relu( bn3(conv1x1( relu(bn2(conv3x3( relu(bn1(conv1x1(x))) ))) )) + x )      256 -> 64 -> 64 -> 256, bf16
+// Unfused, one block moves x (2 MB/crop), t1 (write+read), t2 (write+read), the residual x again and out: 8 MB per
+// crop at 64x64; the three launches are bandwidth/latency-bound (~2.7 TB/s effective).  Fused it is x (with a 1-pixel
+// halo, 1.4x) + out = 4.8 MB.  One persistent 8-wave block per CU, per 8x16 output tile:
+//   stage : the 10x18 halo of x (180 px x 512 B = 92 KB) -> LDS as [8-channel piece][pixel][16 B] planes, loads in
+//           full-line order (consecutive lanes walk one pixel's 512 bytes).  The next tile's loads are issued into
+//           registers before the current tile's store phase, so their latency hides behind it.
+//   conv1 : 1x1, K=256 on all 180 halo pixels (12 fragments): wave w owns channel tile w&3 and 6 fragments;
+//           BN1+ReLU, pixels outside the image forced to 0 (they are conv2's zero padding) -> t1 in LDS.
+//   conv2 : 3x3 on t1 -> 8x16 pixels, wave w owns channel tile w&3 and 4 rows; BN2+ReLU -> t2 in LDS.
+//   conv3 : 1x1 64->256, wave w owns channel tiles 2w, 2w+1 for all 8 rows; BN3 + residual read from the x halo in
+//           LDS (no second global read) + ReLU, written back IN PLACE over the x tile;
+//   store : the finished 128 px x 512 B tile leaves LDS in full-line order.
+// conv2's and conv3's weight fragments stay in REGISTERS for the life of the block (18 + 4 fragments = 88 VGPRs),
+// conv1's 8 are re-read from L2 per tile: per tile the HBM traffic is the x halo in and the output tile out.
+// Tile order: crops b == xcd (mod 8) run on XCD `xcd` (blockIdx % 8), neighbouring tiles of a crop at the same time,
+// so the halo rows two tiles share are L2 hits.
+#include "common.h"
+
+namespace {
+
+constexpr int BTH = 8, BTW = 16, BPW = BTW + 2, BPH = BTH + 2;   // 10 x 18 halo
+constexpr int BNPIX = BPH * BPW;                                 // 180 halo pixels, planes padded to 192
+constexpr int PITCH_X = 192 * 16 + 16;                           // +16: consecutive planes shift by one 16-byte slot
+constexpr int PITCH_T = 128 * 16 + 16;
+constexpr int XPLANES = 32, MPLANES = 8;                         // 256 / 8, 64 / 8 channel pieces
+constexpr int SX_BYTES = XPLANES * PITCH_X, ST1_BYTES = MPLANES * PITCH_X, ST2_BYTES = MPLANES * PITCH_T;
+constexpr int LDS_BYTES = SX_BYTES + ST1_BYTES + ST2_BYTES;      // 140 032
+constexpr int XITER = 12;                                        // 10 halo rows + 2 loads for the two extra columns
+
+struct BottleneckParams {
+  const void* in; void* out;
+  const void *w1, *w2, *w3;
+  const float *s1, *t1, *s2, *t2, *s3, *t3;
+  int B, H, W, in_cs, in_coff, tiles_x, tiles_y;
+  uint32_t in_bytes;
+  long long o_base, o_sb, o_sy, o_sx;
+};
+
+__device__ __forceinline__ void mma_bf16(const u32x4& w, const u32x4& a, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sX = smem;
+  unsigned char* const sT1 = smem + SX_BYTES;
+  unsigned char* const sT2 = sT1 + ST1_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int x = lane & 15, q = lane >> 4;
+  const int nt = wave & 3, half = wave >> 2;
+
+  // ---- block-resident weights (generic packing [tile][chunk][lane][16 B], see cp_pack_conv_weight)
+  u32x4 W2[18], W3[2][2];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) W2[k] = ((const u32x4*)p.w2)[(nt * 18 + k) * 64 + lane];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) W3[t][c] = ((const u32x4*)p.w3)[((2 * wave + t) * 2 + c) * 64 + lane];
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+
+  // halo loads of local tile index li (crop (li / tpi) * 8 + xcd); a tile past the end loads zeros.
+  // Thread -> (column tid>>5, piece tid&31) walks halo rows 0..9 of columns 0..15 (offsets affine in the row: no
+  // per-iteration lane constants for the compiler to hoist and spill); the two right-hand columns take 2 more loads.
+  const int scol = tid >> 5, spc = tid & 31;
+  const int erow = tid >> 6, ecol = BTW + ((tid >> 5) & 1);     // extras: rows 0..7 (it 10), rows 8..9 (it 11, tid < 128)
+  auto issue_loads = [&](int li, u32x4* xv) {
+    const int b = (li / tpi) * 8 + xcd;
+    const int trem = li % tpi;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * BTH - 1, x0 = tx * BTW - 1;
+    const bool tok = b < p.B;
+    {
+      const int gx = x0 + scol;
+      const bool cok = tok & ((unsigned)gx < (unsigned)p.W);
+      const int base = ((b * p.H + y0) * p.W + gx) * p.in_cs + p.in_coff + spc * 8;
+#pragma unroll
+      for (int it = 0; it < BPH; ++it) {
+        const bool ok = cok & ((unsigned)(y0 + it) < (unsigned)p.H);
+        const uint32_t off = ok ? (uint32_t)(base + it * p.W * p.in_cs) * 2u : 0x80000000u;
+        xv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int gy = y0 + erow + 8 * e, gx = x0 + ecol;
+      const bool ok = tok & (e == 0 || tid < 128) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+      const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + spc * 8) * 2u : 0x80000000u;
+      xv[BPH + e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+
+  // pad pixels 180..191 of the x planes are read by conv1's last fragment (results discarded): zero them once
+  for (int i = tid; i < XPLANES * 12; i += 512) *(u32x4*)(sX + (i / 12) * PITCH_X + (BNPIX + i % 12) * 16) = u32x4{0u, 0u, 0u, 0u};
+
+  u32x4 xv[XITER];
+  int li = j0;
+  issue_loads(li, xv);
+  for (; (li / tpi) * 8 + xcd < p.B; li += nbx) {
+    const int b = (li / tpi) * 8 + xcd;
+    const int trem = li % tpi;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * BTH, x0 = tx * BTW;
+
+    // conv1's weight fragments are re-fetched per tile (8 KB per wave from L2, in flight during the staging):
+    // keeping them resident too does not fit 256 VGPRs next to conv2's 18 and conv3's 4 fragments
+    u32x4 W1[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) W1[kc] = ((const u32x4*)p.w1)[(nt * 8 + kc) * 64 + lane];
+    // ---- stage: registers -> LDS planes
+    {
+      unsigned char* dst = sX + spc * PITCH_X + scol * 16;
+#pragma unroll
+      for (int it = 0; it < BPH; ++it) *(u32x4*)(dst + it * BPW * 16) = xv[it];
+      unsigned char* de = sX + spc * PITCH_X + (erow * BPW + ecol) * 16;
+      *(u32x4*)de = xv[BPH];
+      if (tid < 128) *(u32x4*)(de + 8 * BPW * 16) = xv[BPH + 1];
+    }
+    __syncthreads();
+
+    // ---- conv1 (1x1, K = 256): channel tile nt, fragments 6*half .. 6*half+5 of the halo
+    {
+      f32x4 acc[6];
+#pragma unroll
+      for (int f = 0; f < 6; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const unsigned char* base = sX + (kc * 4 + q) * PITCH_X + ((half * 6) * 16 + x) * 16;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) mma_bf16(W1[kc], *(const u32x4*)(base + f * 256), acc[f]);
+      }
+      const int c0 = nt * 16 + q * 4;
+      const f32x4 sc = *(const f32x4*)(p.s1 + c0), sh = *(const f32x4*)(p.t1 + c0);
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
+        const int p1 = (half * 6 + f) * 16 + x;
+        const int py = p1 / BPW, px = p1 - py * BPW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool inimg = (p1 < BNPIX) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[f][e] * sc[e] + sh[e], 0.f) : 0.f;
+        u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)(sT1 + (c0 >> 3) * PITCH_X + p1 * 16 + (c0 & 7) * 2) = pk;
+      }
+    }
+    __syncthreads();
+
+    // ---- conv2 (3x3 on t1): channel tile nt, rows 4*half .. 4*half+3
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int r3 = tap / 3, s3 = tap - 3 * r3;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const unsigned char* base = sT1 + (c2 * 4 + q) * PITCH_X + ((half * 4 + r3) * BPW + x + s3) * 16;
+#pragma unroll
+          for (int f = 0; f < 4; ++f) mma_bf16(W2[tap * 2 + c2], *(const u32x4*)(base + f * BPW * 16), acc[f]);
+        }
+      }
+      const int c0 = nt * 16 + q * 4;
+      const f32x4 sc = *(const f32x4*)(p.s2 + c0), sh = *(const f32x4*)(p.t2 + c0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[f][e] * sc[e] + sh[e], 0.f);
+        u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)(sT2 + (c0 >> 3) * PITCH_T + ((half * 4 + f) * 16 + x) * 16 + (c0 & 7) * 2) = pk;
+      }
+    }
+    __syncthreads();
+
+    // ---- conv3 (1x1, K = 64): channel tiles 2*wave, 2*wave+1, all 8 rows (two passes of 4: bounds the live
+    // accumulators + operands); + residual (x tile in LDS), written back in place
+#pragma unroll 1
+    for (int fh = 0; fh < 2; ++fh) {
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const unsigned char* base = sT2 + (c2 * 4 + q) * PITCH_T + (fh * 64 + x) * 16;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const u32x4 a = *(const u32x4*)(base + f * 256);
+          mma_bf16(W3[0][c2], a, acc[f][0]);
+          mma_bf16(W3[1][c2], a, acc[f][1]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c0 = (2 * wave + t) * 16 + q * 4;
+        const f32x4 sc = *(const f32x4*)(p.s3 + c0), sh = *(const f32x4*)(p.t3 + c0);
+        unsigned char* col = sX + (c0 >> 3) * PITCH_X + ((fh * 4 + 1) * BPW + 1 + x) * 16 + (c0 & 7) * 2;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          u32x2* rp = (u32x2*)(col + f * BPW * 16);
+          const u32x2 r2 = *rp;
+          float v[4];
+          v[0] = fmaxf(acc[f][t][0] * sc[0] + sh[0] + __uint_as_float(r2.x << 16), 0.f);
+          v[1] = fmaxf(acc[f][t][1] * sc[1] + sh[1] + __uint_as_float(r2.x & 0xffff0000u), 0.f);
+          v[2] = fmaxf(acc[f][t][2] * sc[2] + sh[2] + __uint_as_float(r2.y << 16), 0.f);
+          v[3] = fmaxf(acc[f][t][3] * sc[3] + sh[3] + __uint_as_float(r2.y & 0xffff0000u), 0.f);
+          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          *rp = pk;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- next tile's halo loads take off now; this tile's output leaves LDS meanwhile
+    issue_loads(li + nbx, xv);
+    {
+      const int ox = x0 + scol;
+      const unsigned char* src = sX + spc * PITCH_X + (BPW + 1 + scol) * 16;
+      uint16_t* gp = (uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)y0 * p.o_sy + (long long)ox * p.o_sx + spc * 8;
+#pragma unroll
+      for (int row = 0; row < BTH; ++row) {
+        const u32x4 v = *(const u32x4*)(src + row * BPW * 16);
+        if (ox < p.W && y0 + row < p.H) *(u32x4*)(gp + (long long)row * p.o_sy) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
+                                   const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
+                                   const float* shift2, const void* packed_w3, const float* scale3, const float* shift3,
+                                   void* out) {
+  if (!d || !in || !out || !packed_w1 || !packed_w2 || !packed_w3 || !scale1 || !shift1 || !scale2 || !shift2 || !scale3 || !shift3)
+    return CP_ERR_INVALID;
+  if (d->dtype != CP_BF16 || d->out_f32 || d->o_sc != 1) return CP_ERR_INVALID;          // bf16 storage only (LDS budget)
+  if (d->Cin != 256 || d->Cout != 256 || d->stride != 1 || d->Ho != d->H || d->Wo != d->W) return CP_ERR_INVALID;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || in == out) return CP_ERR_INVALID;
+  if (d->in_coff % 8 || d->in_cstride % 8 || d->in_coff + 256 > d->in_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(out) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(packed_w3) ||
+      !cp_aligned16(scale1) || !cp_aligned16(shift1) || !cp_aligned16(scale2) || !cp_aligned16(shift2) || !cp_aligned16(scale3) ||
+      !cp_aligned16(shift3))
+    return CP_ERR_ALIGN;
+  if ((d->o_base % 8) || (d->o_sb % 8) || (d->o_sy % 8) || (d->o_sx % 8)) return CP_ERR_ALIGN;
+  const long long in_bytes = (long long)d->B * d->H * d->W * d->in_cstride * 2;
+  if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
+  BottleneckParams p;
+  p.in = in; p.out = out; p.w1 = packed_w1; p.w2 = packed_w2; p.w3 = packed_w3;
+  p.s1 = scale1; p.t1 = shift1; p.s2 = scale2; p.t2 = shift2; p.s3 = scale3; p.t3 = shift3;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.tiles_x = (d->W + BTW - 1) / BTW; p.tiles_y = (d->H + BTH - 1) / BTH;
+  p.in_bytes = (uint32_t)in_bytes;
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return CP_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)bottleneck_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return CP_ERR_HIP;
+    attr_set = true;
+  }
+  // one persistent block per CU, a multiple of 8 (XCD labels); never more blocks than tiles of the crops one XCD owns
+  const long long per_xcd = (long long)((d->B + 7) / 8) * p.tiles_x * p.tiles_y;
+  long long nbx = n_cu / 8 > 0 ? n_cu / 8 : 1;
+  if (nbx > per_xcd) nbx = per_xcd;
+  hipLaunchKernelGGL(bottleneck_fused_kernel, dim3((unsigned)(8 * nbx)), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  return cp_check_launch();
+}

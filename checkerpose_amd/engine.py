@@ -16,6 +16,7 @@ from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
+USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 256-64-64-256 Bottleneck kernel (bf16)
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
@@ -303,6 +304,39 @@ class Program:
         nb = x.B * x.H * x.W * C_ * self.es
         self.flops += 2 * fl
         self.conv_log.append((k1, x.B * x.H * x.W, C_, 9 * C_, 2 * fl, "basicblock_fused", 2 * nb + 2 * 9 * C_ * C_ * self.es))
+        return out
+
+    def can_fuse_bottleneck(self, x: Act, planes, cout):
+        return (USE_FUSED_BN and self.dtype == CP_BF16 and x.C == 256 and x.Cphys == 256 and planes == 64 and cout == 256
+                and x.B * x.H * x.W * x.cstride * 2 < (1 << 31))
+
+    def bottleneck_fused(self, x: Act, keys, ws, affs, out: Act = None):
+        """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) in one launch (cp_bottleneck_fused).
+        keys/ws/affs: (conv1, conv2, conv3) cache keys, fp32 weights and folded (scale, shift) pairs."""
+        pw = [self.ws.pack(keys[0], ws[0], 64, 256, 1, 1, 256, 64), self.ws.pack(keys[1], ws[1], 64, 64, 3, 3, 64, 64),
+              self.ws.pack(keys[2], ws[2], 256, 64, 1, 1, 64, 256)]
+        af = [self.ws.affine(keys[i] + "#0", affs[i][0], affs[i][1], (64, 64, 256)[i]) for i in range(3)]
+        if out is None:
+            out = self.act(x.H, x.W, 256)
+        d = CpConvDesc()
+        d.dtype, d.out_f32, d.B, d.H, d.W = self.dtype, 0, x.B, x.H, x.W
+        d.Cin, d.in_cstride, d.in_coff = 256, x.cstride, x.coff
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 3, 3, 1, 1, x.H, x.W
+        d.Cout, d.act, d.slope = 256, ACT_RELU, 0.0
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
+        self.keep += [d] + pw + af
+        fn = self.lib.cp_bottleneck_fused
+        dref = C.byref(d)
+        ptrs = ()
+        for i in range(3):
+            ptrs += (pw[i].data_ptr(), af[i][0].data_ptr(), af[i][1].data_ptr())
+        xtb, otb = x.tbuf, out.tbuf
+        self._add(fn, lambda P: (dref, P(xtb)) + ptrs + (P(otb),), "bottleneck_fused:" + keys[0], [xtb], [otb])
+        npx = x.B * x.H * x.W
+        fl = 2 * npx * (256 * 64 + 9 * 64 * 64 + 64 * 256)
+        self.flops += fl
+        wbytes = (256 * 64 + 9 * 64 * 64 + 64 * 256) * self.es
+        self.conv_log.append((keys[0], npx, 256, 256, fl, "bottleneck_fused", 2 * npx * 256 * self.es + wbytes))
         return out
 
     def upsample2x(self, x: Act, out: Act):

@@ -54,6 +54,12 @@ class NetEmitter:
         return self.conv_bn(y, pfx + ".conv2", pfx + ".bn2", 3, 1, 1, relu=True, residual=sc)
 
     def bottleneck(self, pfx, x, out=None):
+        w1, w3 = self.W(pfx + ".conv1.weight"), self.W(pfx + ".conv3.weight")
+        if ((pfx + ".downsample.0.weight") not in self.sd and w1.shape[1] == w3.shape[0]
+                and self.p.can_fuse_bottleneck(x, w1.shape[0], w3.shape[0])):
+            keys = [pfx + ".conv%d" % i for i in (1, 2, 3)]
+            affs = [self.ws.bn_fold(pfx + ".bn%d" % i) for i in (1, 2, 3)]
+            return self.p.bottleneck_fused(x, keys, [w1, self.W(pfx + ".conv2.weight"), w3], affs, out=out)
         y = self.conv_bn(x, pfx + ".conv1", pfx + ".bn1", 1, 1, 0)
         y = self.conv_bn(y, pfx + ".conv2", pfx + ".bn2", 3, 1, 1)
         sc = x

@@ -114,6 +114,17 @@ int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, const void* in,
                         const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
                         const float* shift2, void* out);
 
+/* timm resnet.Bottleneck (HRNet layer1 blocks 1..3, inside timm.create_model, backbone.py:35) in ONE launch:
+ *   out = relu( bn3(conv1x1( relu(bn2(conv3x3( relu(bn1(conv1x1(x))) ))) )) + x ),  256 -> 64 -> 64 -> 256 channels.
+ * bf16 storage only (the x halo tile + both intermediates live in 140 KB of LDS).  d: dtype CP_BF16, Cin = Cout =
+ * 256, stride 1, H/W/B, input slice and output strides as for cp_conv2d_igemm; in != out.  All three weights in the
+ * generic image of cp_pack_conv_weight: w1 (64,256,1,1) cin_phys 256; w2 (64,64,3,3) cin_phys 64; w3 (256,64,1,1)
+ * cin_phys 64.  scale/shift: folded BatchNorm of each conv (64, 64, 256 floats, 16-byte aligned). */
+int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
+                        const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
+                        const float* shift2, const void* packed_w3, const float* scale3, const float* shift3,
+                        void* out);
+
 /* ---------------------------------------------------------------------------------------------
  * 1x1 conv / Linear specialisation with LDS-staged rows (EdgeConv node GEMMs, 256-wide MLPs pipeline.py:61-69,
  * 168-180, conv1x1 init.py:85-95, incre conv3): same arithmetic and descriptor as cp_conv2d_igemm (requires

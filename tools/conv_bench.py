@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--gemm-min-k", type=int, default=16)
     ap.add_argument("--gemm-min-cout", type=int, default=96)
     a = ap.parse_args()
+    if os.environ.get("CP_BENCH_LIB"):
+        _abi.LIB_PATH = os.environ["CP_BENCH_LIB"]
     lib = _abi.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
