@@ -37,7 +37,7 @@ SIGNATURES = {
     "cp_conv3x3_halo": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
     "cp_pack_conv3x3_rows_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_basicblock_fused": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
-    "cp_bottleneck_fused": (_I, [_P, C.POINTER(CpConvDesc)] + [_P] * 11),
+    "cp_bottleneck_fused": (_I, [_P, C.POINTER(CpConvDesc)] + [_P] * 14),
     "cp_packed_gemm_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "cp_pack_gemm_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_gemm_rows": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),

@@ -24,15 +24,16 @@ constexpr int BTH = 8, BTW = 16, BPW = BTW + 2, BPH = BTH + 2;   // 10 x 18 halo
 constexpr int BNPIX = BPH * BPW;                                 // 180 halo pixels, planes padded to 192
 constexpr int PITCH_X = 192 * 16 + 16;                           // +16: consecutive planes shift by one 16-byte slot
 constexpr int PITCH_T = 128 * 16 + 16;
-constexpr int XPLANES = 32, MPLANES = 8;                         // 256 / 8, 64 / 8 channel pieces
-constexpr int SX_BYTES = XPLANES * PITCH_X, ST1_BYTES = MPLANES * PITCH_X, ST2_BYTES = MPLANES * PITCH_T;
-constexpr int LDS_BYTES = SX_BYTES + ST1_BYTES + ST2_BYTES;      // 140 032
-constexpr int XITER = 12;                                        // 10 halo rows + 2 loads for the two extra columns
+constexpr int MPLANES = 8, OPLANES = 32;                         // 64 / 8, 256 / 8 channel pieces
+constexpr int ST1_BYTES = MPLANES * PITCH_X, ST2_BYTES = MPLANES * PITCH_T, SO_BYTES = OPLANES * PITCH_T;
+// XCH = 64-byte chunks of the input row: 8 (256 channels, identity shortcut, output written in place over the x tile)
+// or 2 (64 channels, projection shortcut `downsample`, output tile in its own LDS region).
+constexpr int lds_bytes(int XCH, bool HAS_DS) { return XCH * 4 * PITCH_X + ST1_BYTES + ST2_BYTES + (HAS_DS ? SO_BYTES : 0); }   // 140 032 / 131 968
 
 struct BottleneckParams {
   const void* in; void* out;
-  const void *w1, *w2, *w3;
-  const float *s1, *t1, *s2, *t2, *s3, *t3;
+  const void *w1, *w2, *w3, *wd;
+  const float *s1, *t1, *s2, *t2, *s3, *t3, *sd, *td;
   int B, H, W, in_cs, in_coff, tiles_x, tiles_y;
   uint32_t in_bytes;
   long long o_base, o_sb, o_sy, o_sx;
@@ -42,11 +43,16 @@ __device__ __forceinline__ void mma_bf16(const u32x4& w, const u32x4& a, f32x4& 
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
 }
 
+template <int XCH, bool HAS_DS>
 __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckParams p) {
+  constexpr int XPLANES = XCH * 4;
+  constexpr int SX_BYTES = XPLANES * PITCH_X;
+  constexpr int XITER = XCH == 8 ? 12 : (192 * XPLANES + 511) / 512;   // 10 halo rows + 2 extra-column loads | generic
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sX = smem;
   unsigned char* const sT1 = smem + SX_BYTES;
   unsigned char* const sT2 = sT1 + ST1_BYTES;
+  unsigned char* const sO = sT2 + ST2_BYTES;                     // HAS_DS only
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,28 +84,41 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     const int y0 = ty * BTH - 1, x0 = tx * BTW - 1;
     const bool tok = b < p.B;
-    {
-      const int gx = x0 + scol;
-      const bool cok = tok & ((unsigned)gx < (unsigned)p.W);
-      const int base = ((b * p.H + y0) * p.W + gx) * p.in_cs + p.in_coff + spc * 8;
+    if constexpr (XCH == 8) {
+      {
+        const int gx = x0 + scol;
+        const bool cok = tok & ((unsigned)gx < (unsigned)p.W);
+        const int base = ((b * p.H + y0) * p.W + gx) * p.in_cs + p.in_coff + spc * 8;
 #pragma unroll
-      for (int it = 0; it < BPH; ++it) {
-        const bool ok = cok & ((unsigned)(y0 + it) < (unsigned)p.H);
-        const uint32_t off = ok ? (uint32_t)(base + it * p.W * p.in_cs) * 2u : 0x80000000u;
+        for (int it = 0; it < BPH; ++it) {
+          const bool ok = cok & ((unsigned)(y0 + it) < (unsigned)p.H);
+          const uint32_t off = ok ? (uint32_t)(base + it * p.W * p.in_cs) * 2u : 0x80000000u;
+          xv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int gy = y0 + erow + 8 * e, gx = x0 + ecol;
+        const bool ok = tok & (e == 0 || tid < 128) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+        const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + spc * 8) * 2u : 0x80000000u;
+        xv[BPH + e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+      }
+    } else {                                                     // narrow input: piece i = tid + 512 it -> (pixel, piece)
+#pragma unroll
+      for (int it = 0; it < XITER; ++it) {
+        const int i = tid + 512 * it;
+        const int hp = i / XPLANES, pc = i % XPLANES;
+        const int py = hp / BPW, px = hp - py * BPW;
+        const int gy = y0 + py, gx = x0 + px;
+        const bool ok = tok & (hp < BNPIX) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+        const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pc * 8) * 2u : 0x80000000u;
         xv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
       }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int gy = y0 + erow + 8 * e, gx = x0 + ecol;
-      const bool ok = tok & (e == 0 || tid < 128) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-      const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + spc * 8) * 2u : 0x80000000u;
-      xv[BPH + e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
     }
   };
 
   // pad pixels 180..191 of the x planes are read by conv1's last fragment (results discarded): zero them once
-  for (int i = tid; i < XPLANES * 12; i += 512) *(u32x4*)(sX + (i / 12) * PITCH_X + (BNPIX + i % 12) * 16) = u32x4{0u, 0u, 0u, 0u};
+  if constexpr (XCH == 8) for (int i = tid; i < XPLANES * 12; i += 512) *(u32x4*)(sX + (i / 12) * PITCH_X + (BNPIX + i % 12) * 16) = u32x4{0u, 0u, 0u, 0u};
 
   u32x4 xv[XITER];
   int li = j0;
@@ -112,17 +131,23 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
 
     // conv1's weight fragments are re-fetched per tile (8 KB per wave from L2, in flight during the staging):
     // keeping them resident too does not fit 256 VGPRs next to conv2's 18 and conv3's 4 fragments
-    u32x4 W1[8];
+    u32x4 W1[XCH];
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) W1[kc] = ((const u32x4*)p.w1)[(nt * 8 + kc) * 64 + lane];
+    for (int kc = 0; kc < XCH; ++kc) W1[kc] = ((const u32x4*)p.w1)[(nt * XCH + kc) * 64 + lane];
     // ---- stage: registers -> LDS planes
-    {
+    if constexpr (XCH == 8) {
       unsigned char* dst = sX + spc * PITCH_X + scol * 16;
 #pragma unroll
       for (int it = 0; it < BPH; ++it) *(u32x4*)(dst + it * BPW * 16) = xv[it];
       unsigned char* de = sX + spc * PITCH_X + (erow * BPW + ecol) * 16;
       *(u32x4*)de = xv[BPH];
       if (tid < 128) *(u32x4*)(de + 8 * BPW * 16) = xv[BPH + 1];
+    } else {
+#pragma unroll
+      for (int it = 0; it < XITER; ++it) {
+        const int i = tid + 512 * it;                            // pad pixels receive the zeros of their invalid loads
+        *(u32x4*)(sX + (i % XPLANES) * PITCH_X + (i / XPLANES) * 16) = xv[it];
+      }
     }
     __syncthreads();
 
@@ -132,7 +157,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
 #pragma unroll
       for (int f = 0; f < 6; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) {
+      for (int kc = 0; kc < XCH; ++kc) {
         const unsigned char* base = sX + (kc * 4 + q) * PITCH_X + ((half * 6) * 16 + x) * 16;
 #pragma unroll
         for (int f = 0; f < 6; ++f) mma_bf16(W1[kc], *(const u32x4*)(base + f * 256), acc[f]);
@@ -184,37 +209,70 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
 
     // ---- conv3 (1x1, K = 64): channel tiles 2*wave, 2*wave+1, all 8 rows (two passes of 4: bounds the live
     // accumulators + operands); + residual (x tile in LDS), written back in place
+    constexpr int RP = HAS_DS ? 2 : 4;                           // rows per pass (two accumulator sets with the shortcut)
 #pragma unroll 1
-    for (int fh = 0; fh < 2; ++fh) {
-      f32x4 acc[4][2];
+    for (int fh = 0; fh < 8 / RP; ++fh) {
+      f32x4 acc[RP][2], accd[HAS_DS ? RP : 1][2];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int f = 0; f < RP; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
-        const unsigned char* base = sT2 + (c2 * 4 + q) * PITCH_T + (fh * 64 + x) * 16;
+        const unsigned char* base = sT2 + (c2 * 4 + q) * PITCH_T + (fh * RP * 16 + x) * 16;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < RP; ++f) {
           const u32x4 a = *(const u32x4*)(base + f * 256);
           mma_bf16(W3[0][c2], a, acc[f][0]);
           mma_bf16(W3[1][c2], a, acc[f][1]);
+        }
+      }
+      if constexpr (HAS_DS) {                                    // projection shortcut: 1x1 conv of the tile's own x pixels
+        u32x4 Wd[2][2];                                          // re-read per pass (L2): resident they would spill
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) Wd[t][c] = ((const u32x4*)p.wd)[((2 * wave + t) * 2 + c) * 64 + lane];
+#pragma unroll
+        for (int f = 0; f < RP; ++f) { accd[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accd[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c2 = 0; c2 < XCH; ++c2) {
+          const unsigned char* base = sX + (c2 * 4 + q) * PITCH_X + ((fh * RP + 1) * BPW + 1 + x) * 16;
+#pragma unroll
+          for (int f = 0; f < RP; ++f) {
+            const u32x4 a = *(const u32x4*)(base + f * BPW * 16);
+            mma_bf16(Wd[0][c2], a, accd[f][0]);
+            mma_bf16(Wd[1][c2], a, accd[f][1]);
+          }
         }
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int c0 = (2 * wave + t) * 16 + q * 4;
         const f32x4 sc = *(const f32x4*)(p.s3 + c0), sh = *(const f32x4*)(p.t3 + c0);
-        unsigned char* col = sX + (c0 >> 3) * PITCH_X + ((fh * 4 + 1) * BPW + 1 + x) * 16 + (c0 & 7) * 2;
+        if constexpr (HAS_DS) {
+          const f32x4 scd = *(const f32x4*)(p.sd + c0), shd = *(const f32x4*)(p.td + c0);
+          unsigned char* col = sO + (c0 >> 3) * PITCH_T + (fh * RP * 16 + x) * 16 + (c0 & 7) * 2;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          u32x2* rp = (u32x2*)(col + f * BPW * 16);
-          const u32x2 r2 = *rp;
-          float v[4];
-          v[0] = fmaxf(acc[f][t][0] * sc[0] + sh[0] + __uint_as_float(r2.x << 16), 0.f);
-          v[1] = fmaxf(acc[f][t][1] * sc[1] + sh[1] + __uint_as_float(r2.x & 0xffff0000u), 0.f);
-          v[2] = fmaxf(acc[f][t][2] * sc[2] + sh[2] + __uint_as_float(r2.y << 16), 0.f);
-          v[3] = fmaxf(acc[f][t][3] * sc[3] + sh[3] + __uint_as_float(r2.y & 0xffff0000u), 0.f);
-          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-          *rp = pk;
+          for (int f = 0; f < RP; ++f) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[f][t][e] * sc[e] + sh[e] + (accd[f][t][e] * scd[e] + shd[e]), 0.f);
+            u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)(col + f * 256) = pk;
+          }
+        } else {
+          unsigned char* col = sX + (c0 >> 3) * PITCH_X + ((fh * RP + 1) * BPW + 1 + x) * 16 + (c0 & 7) * 2;
+#pragma unroll
+          for (int f = 0; f < RP; ++f) {
+            u32x2* rp = (u32x2*)(col + f * BPW * 16);
+            const u32x2 r2 = *rp;
+            float v[4];
+            v[0] = fmaxf(acc[f][t][0] * sc[0] + sh[0] + __uint_as_float(r2.x << 16), 0.f);
+            v[1] = fmaxf(acc[f][t][1] * sc[1] + sh[1] + __uint_as_float(r2.x & 0xffff0000u), 0.f);
+            v[2] = fmaxf(acc[f][t][2] * sc[2] + sh[2] + __uint_as_float(r2.y << 16), 0.f);
+            v[3] = fmaxf(acc[f][t][3] * sc[3] + sh[3] + __uint_as_float(r2.y & 0xffff0000u), 0.f);
+            u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            *rp = pk;
+          }
         }
       }
     }
@@ -224,11 +282,12 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     issue_loads(li + nbx, xv);
     {
       const int ox = x0 + scol;
-      const unsigned char* src = sX + spc * PITCH_X + (BPW + 1 + scol) * 16;
+      const unsigned char* src = HAS_DS ? sO + spc * PITCH_T + scol * 16 : sX + spc * PITCH_X + (BPW + 1 + scol) * 16;
+      constexpr int RSTEP = HAS_DS ? 256 : BPW * 16;
       uint16_t* gp = (uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)y0 * p.o_sy + (long long)ox * p.o_sx + spc * 8;
 #pragma unroll
       for (int row = 0; row < BTH; ++row) {
-        const u32x4 v = *(const u32x4*)(src + row * BPW * 16);
+        const u32x4 v = *(const u32x4*)(src + row * RSTEP);
         if (ox < p.W && y0 + row < p.H) *(u32x4*)(gp + (long long)row * p.o_sy) = v;
       }
     }
@@ -241,23 +300,25 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
 extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
                                    const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
                                    const float* shift2, const void* packed_w3, const float* scale3, const float* shift3,
-                                   void* out) {
+                                   const void* packed_wd, const float* scaled, const float* shiftd, void* out) {
   if (!d || !in || !out || !packed_w1 || !packed_w2 || !packed_w3 || !scale1 || !shift1 || !scale2 || !shift2 || !scale3 || !shift3)
     return CP_ERR_INVALID;
+  const bool ds = packed_wd != nullptr;
+  if (ds != (scaled != nullptr) || ds != (shiftd != nullptr)) return CP_ERR_INVALID;
   if (d->dtype != CP_BF16 || d->out_f32 || d->o_sc != 1) return CP_ERR_INVALID;          // bf16 storage only (LDS budget)
-  if (d->Cin != 256 || d->Cout != 256 || d->stride != 1 || d->Ho != d->H || d->Wo != d->W) return CP_ERR_INVALID;
+  if (d->Cin != (ds ? 64 : 256) || d->Cout != 256 || d->stride != 1 || d->Ho != d->H || d->Wo != d->W) return CP_ERR_INVALID;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || in == out) return CP_ERR_INVALID;
-  if (d->in_coff % 8 || d->in_cstride % 8 || d->in_coff + 256 > d->in_cstride) return CP_ERR_ALIGN;
+  if (d->in_coff % 8 || d->in_cstride % 8 || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(in) || !cp_aligned16(out) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(packed_w3) ||
       !cp_aligned16(scale1) || !cp_aligned16(shift1) || !cp_aligned16(scale2) || !cp_aligned16(shift2) || !cp_aligned16(scale3) ||
-      !cp_aligned16(shift3))
+      !cp_aligned16(shift3) || !cp_aligned16(packed_wd) || !cp_aligned16(scaled) || !cp_aligned16(shiftd))
     return CP_ERR_ALIGN;
   if ((d->o_base % 8) || (d->o_sb % 8) || (d->o_sy % 8) || (d->o_sx % 8)) return CP_ERR_ALIGN;
   const long long in_bytes = (long long)d->B * d->H * d->W * d->in_cstride * 2;
   if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
   BottleneckParams p;
-  p.in = in; p.out = out; p.w1 = packed_w1; p.w2 = packed_w2; p.w3 = packed_w3;
-  p.s1 = scale1; p.t1 = shift1; p.s2 = scale2; p.t2 = shift2; p.s3 = scale3; p.t3 = shift3;
+  p.in = in; p.out = out; p.w1 = packed_w1; p.w2 = packed_w2; p.w3 = packed_w3; p.wd = packed_wd;
+  p.s1 = scale1; p.t1 = shift1; p.s2 = scale2; p.t2 = shift2; p.s3 = scale3; p.t3 = shift3; p.sd = scaled; p.td = shiftd;
   p.B = d->B; p.H = d->H; p.W = d->W; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
   p.tiles_x = (d->W + BTW - 1) / BTW; p.tiles_y = (d->H + BTH - 1) / BTH;
   p.in_bytes = (uint32_t)in_bytes;
@@ -268,7 +329,8 @@ extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, cons
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return CP_ERR_HIP;
-    if (hipFuncSetAttribute((const void*)bottleneck_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)bottleneck_fused_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(8, false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bottleneck_fused_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, true)) != hipSuccess)
       return CP_ERR_HIP;
     attr_set = true;
   }
@@ -276,6 +338,8 @@ extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, cons
   const long long per_xcd = (long long)((d->B + 7) / 8) * p.tiles_x * p.tiles_y;
   long long nbx = n_cu / 8 > 0 ? n_cu / 8 : 1;
   if (nbx > per_xcd) nbx = per_xcd;
-  hipLaunchKernelGGL(bottleneck_fused_kernel, dim3((unsigned)(8 * nbx)), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)(8 * nbx));
+  if (ds) hipLaunchKernelGGL((bottleneck_fused_kernel<2, true>), grid, dim3(512), lds_bytes(2, true), (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((bottleneck_fused_kernel<8, false>), grid, dim3(512), lds_bytes(8, false), (hipStream_t)stream, p);
   return cp_check_launch();
 }

@@ -306,21 +306,26 @@ class Program:
         self.conv_log.append((k1, x.B * x.H * x.W, C_, 9 * C_, 2 * fl, "basicblock_fused", 2 * nb + 2 * 9 * C_ * C_ * self.es))
         return out
 
-    def can_fuse_bottleneck(self, x: Act, planes, cout):
-        return (USE_FUSED_BN and self.dtype == CP_BF16 and x.C == 256 and x.Cphys == 256 and planes == 64 and cout == 256
+    def can_fuse_bottleneck(self, x: Act, planes, cout, has_ds):
+        cin = 64 if has_ds else 256
+        return (USE_FUSED_BN and self.dtype == CP_BF16 and x.C == cin and x.Cphys == cin and planes == 64 and cout == 256
                 and x.B * x.H * x.W * x.cstride * 2 < (1 << 31))
 
     def bottleneck_fused(self, x: Act, keys, ws, affs, out: Act = None):
-        """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) in one launch (cp_bottleneck_fused).
-        keys/ws/affs: (conv1, conv2, conv3) cache keys, fp32 weights and folded (scale, shift) pairs."""
-        pw = [self.ws.pack(keys[0], ws[0], 64, 256, 1, 1, 256, 64), self.ws.pack(keys[1], ws[1], 64, 64, 3, 3, 64, 64),
+        """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)) in one launch (cp_bottleneck_fused).
+        keys/ws/affs: (conv1, conv2, conv3[, downsample]) cache keys, fp32 weights and folded (scale, shift) pairs."""
+        has_ds = len(keys) == 4
+        cin = x.C
+        pw = [self.ws.pack(keys[0], ws[0], 64, cin, 1, 1, cin, 64), self.ws.pack(keys[1], ws[1], 64, 64, 3, 3, 64, 64),
               self.ws.pack(keys[2], ws[2], 256, 64, 1, 1, 64, 256)]
-        af = [self.ws.affine(keys[i] + "#0", affs[i][0], affs[i][1], (64, 64, 256)[i]) for i in range(3)]
+        if has_ds:
+            pw.append(self.ws.pack(keys[3], ws[3], 256, 64, 1, 1, 64, 256))
+        af = [self.ws.affine(keys[i] + "#0", affs[i][0], affs[i][1], (64, 64, 256, 256)[i]) for i in range(len(keys))]
         if out is None:
             out = self.act(x.H, x.W, 256)
         d = CpConvDesc()
         d.dtype, d.out_f32, d.B, d.H, d.W = self.dtype, 0, x.B, x.H, x.W
-        d.Cin, d.in_cstride, d.in_coff = 256, x.cstride, x.coff
+        d.Cin, d.in_cstride, d.in_coff = cin, x.cstride, x.coff
         d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 3, 3, 1, 1, x.H, x.W
         d.Cout, d.act, d.slope = 256, ACT_RELU, 0.0
         d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
@@ -328,15 +333,17 @@ class Program:
         fn = self.lib.cp_bottleneck_fused
         dref = C.byref(d)
         ptrs = ()
-        for i in range(3):
+        for i in range(len(keys)):
             ptrs += (pw[i].data_ptr(), af[i][0].data_ptr(), af[i][1].data_ptr())
+        if not has_ds:
+            ptrs += (None, None, None)
         xtb, otb = x.tbuf, out.tbuf
         self._add(fn, lambda P: (dref, P(xtb)) + ptrs + (P(otb),), "bottleneck_fused:" + keys[0], [xtb], [otb])
         npx = x.B * x.H * x.W
-        fl = 2 * npx * (256 * 64 + 9 * 64 * 64 + 64 * 256)
+        macs = cin * 64 + 9 * 64 * 64 + 64 * 256 + (64 * 256 if has_ds else 0)
+        fl = 2 * npx * macs
         self.flops += fl
-        wbytes = (256 * 64 + 9 * 64 * 64 + 64 * 256) * self.es
-        self.conv_log.append((keys[0], npx, 256, 256, fl, "bottleneck_fused", 2 * npx * 256 * self.es + wbytes))
+        self.conv_log.append((keys[0], npx, 256, cin, fl, "bottleneck_fused", npx * (cin + 256) * self.es + macs * self.es))
         return out
 
     def upsample2x(self, x: Act, out: Act):

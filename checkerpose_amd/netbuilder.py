@@ -55,11 +55,22 @@ class NetEmitter:
 
     def bottleneck(self, pfx, x, out=None):
         w1, w3 = self.W(pfx + ".conv1.weight"), self.W(pfx + ".conv3.weight")
-        if ((pfx + ".downsample.0.weight") not in self.sd and w1.shape[1] == w3.shape[0]
-                and self.p.can_fuse_bottleneck(x, w1.shape[0], w3.shape[0])):
+        has_ds = (pfx + ".downsample.0.weight") in self.sd
+        if (self.p.can_fuse_bottleneck(x, w1.shape[0], w3.shape[0], has_ds) and w1.shape[1] == x.C
+                and (has_ds or w1.shape[1] == w3.shape[0])):
             keys = [pfx + ".conv%d" % i for i in (1, 2, 3)]
             affs = [self.ws.bn_fold(pfx + ".bn%d" % i) for i in (1, 2, 3)]
-            return self.p.bottleneck_fused(x, keys, [w1, self.W(pfx + ".conv2.weight"), w3], affs, out=out)
+            ws = [w1, self.W(pfx + ".conv2.weight"), w3]
+            if has_ds:
+                wd = self.W(pfx + ".downsample.0.weight")
+                if tuple(wd.shape[2:]) != (1, 1) or wd.shape[0] != 256:
+                    has_ds = None
+                else:
+                    keys.append(pfx + ".downsample.0")
+                    affs.append(self.ws.bn_fold(pfx + ".downsample.1"))
+                    ws.append(wd)
+            if has_ds is not None:
+                return self.p.bottleneck_fused(x, keys, ws, affs, out=out)
         y = self.conv_bn(x, pfx + ".conv1", pfx + ".bn1", 1, 1, 0)
         y = self.conv_bn(y, pfx + ".conv2", pfx + ".bn2", 3, 1, 1)
         sc = x

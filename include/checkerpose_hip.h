@@ -114,16 +114,19 @@ int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, const void* in,
                         const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
                         const float* shift2, void* out);
 
-/* timm resnet.Bottleneck (HRNet layer1 blocks 1..3, inside timm.create_model, backbone.py:35) in ONE launch:
- *   out = relu( bn3(conv1x1( relu(bn2(conv3x3( relu(bn1(conv1x1(x))) ))) )) + x ),  256 -> 64 -> 64 -> 256 channels.
- * bf16 storage only (the x halo tile + both intermediates live in 140 KB of LDS).  d: dtype CP_BF16, Cin = Cout =
- * 256, stride 1, H/W/B, input slice and output strides as for cp_conv2d_igemm; in != out.  All three weights in the
- * generic image of cp_pack_conv_weight: w1 (64,256,1,1) cin_phys 256; w2 (64,64,3,3) cin_phys 64; w3 (256,64,1,1)
- * cin_phys 64.  scale/shift: folded BatchNorm of each conv (64, 64, 256 floats, 16-byte aligned). */
+/* timm resnet.Bottleneck of HRNet layer1 (inside timm.create_model, backbone.py:35) in ONE launch:
+ *   out = relu( bn3(conv1x1( relu(bn2(conv3x3( relu(bn1(conv1x1(x))) ))) )) + shortcut(x) ),  Cin -> 64 -> 64 -> 256
+ *   blocks 1..3: Cin = 256, shortcut = identity (packed_wd = scaled = shiftd = NULL);
+ *   block 0    : Cin = 64,  shortcut = bn_d(conv1x1_d(x)) (`downsample`), packed_wd (256,64,1,1) + its folded BN.
+ * bf16 storage only (the x halo tile, both intermediates and the output tile live in <= 140 KB of LDS).  d: dtype
+ * CP_BF16, Cin as above, Cout = 256, stride 1, H/W/B, input slice and output strides as for cp_conv2d_igemm;
+ * in != out.  All weights in the generic image of cp_pack_conv_weight: w1 (64,Cin,1,1) cin_phys Cin; w2 (64,64,3,3)
+ * cin_phys 64; w3 / wd (256,64,1,1) cin_phys 64.  scale/shift: folded BatchNorm (64, 64, 256, 256 floats, 16-byte
+ * aligned). */
 int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
                         const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
                         const float* shift2, const void* packed_w3, const float* scale3, const float* shift3,
-                        void* out);
+                        const void* packed_wd, const float* scaled, const float* shiftd, void* out);
 
 /* ---------------------------------------------------------------------------------------------
  * 1x1 conv / Linear specialisation with LDS-staged rows (EdgeConv node GEMMs, 256-wide MLPs pipeline.py:61-69,

@@ -226,48 +226,57 @@ def test_basicblock_fused_vs_torch_cpu(lib, dtype, Cc, shape):
                                    pw2.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), xin.data_ptr()) == -1   # in-place refused
 
 
+@pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 13, 21), (9, 8, 16), (3, 64, 64)])
-def test_bottleneck_fused_vs_torch_cpu(lib, shape):
-    """Fused Bottleneck (cp_bottleneck_fused, bf16) == relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) with
-    both intermediates rounded to bf16 (they live in LDS as bf16), incl. image borders (t1's out-of-image ring must be
-    zero padding), ragged tiles, more crops than XCDs, and a channel-sliced input / strided output."""
+def test_bottleneck_fused_vs_torch_cpu(lib, shape, ds):
+    """Fused Bottleneck (cp_bottleneck_fused, bf16) == relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) +
+    shortcut(x)) with both intermediates rounded to bf16 (they live in LDS as bf16): identity shortcut (256 in) and the
+    projection shortcut of layer1.0 (64 in); image borders (t1's out-of-image ring must be zero padding), ragged tiles,
+    more crops than XCDs, a channel-sliced input and a strided output."""
     dtype = CP_BF16
     B, H, W = shape
-    x = det_tensor("btx%s" % (shape,), (B, 256, H, W))
-    w1 = det_tensor("btw1", (64, 256, 1, 1), (2.0 / 256) ** 0.5 * 1.7)
+    Cin = 64 if ds else 256
+    x = det_tensor("btx%s%d" % (shape, Cin), (B, Cin, H, W))
+    w1 = det_tensor("btw1%d" % Cin, (64, Cin, 1, 1), (2.0 / Cin) ** 0.5 * 1.7)
     w2 = det_tensor("btw2", (64, 64, 3, 3), (2.0 / (64 * 9)) ** 0.5 * 1.7)
     w3 = det_tensor("btw3", (256, 64, 1, 1), (2.0 / 64) ** 0.5 * 0.7)
-    aff = [(1.0 + 0.3 * det_tensor("bts%d" % i, (n,)), 0.3 * det_tensor("btt%d" % i, (n,))) for i, n in enumerate((64, 64, 256))]
+    wd = det_tensor("btwd", (256, 64, 1, 1), (2.0 / 64) ** 0.5)
+    aff = [(1.0 + 0.3 * det_tensor("bts%d" % i, (n,)), 0.3 * det_tensor("btt%d" % i, (n,))) for i, n in enumerate((64, 64, 256, 256))]
     v4 = lambda v: v.view(1, -1, 1, 1)
     xr = rnd(x, dtype)
     y1 = rnd(F.relu(F.conv2d(xr, rnd(w1, dtype)) * v4(aff[0][0]) + v4(aff[0][1])), dtype)
     y2 = rnd(F.relu(F.conv2d(y1, rnd(w2, dtype), None, 1, 1) * v4(aff[1][0]) + v4(aff[1][1])), dtype)
-    ref = F.relu(F.conv2d(y2, rnd(w3, dtype)) * v4(aff[2][0]) + v4(aff[2][1]) + xr)
-    cs, coff = 256 + 16, 8                                         # input = channel slice [8, 264) of a wider tensor
+    short = F.conv2d(xr, rnd(wd, dtype)) * v4(aff[3][0]) + v4(aff[3][1]) if ds else xr
+    ref = F.relu(F.conv2d(y2, rnd(w3, dtype)) * v4(aff[2][0]) + v4(aff[2][1]) + short)
+    cs, coff = Cin + 16, 8                                         # input = channel slice [8, 8+Cin) of a wider tensor
     xin = torch.zeros(B, H, W, cs, dtype=DT[dtype], device=dev())
-    xin[..., coff:coff + 256] = x.permute(0, 2, 3, 1).to(dev()).to(DT[dtype])
+    xin[..., coff:coff + Cin] = x.permute(0, 2, 3, 1).to(dev()).to(DT[dtype])
     ocs = 256 + 8
     out = torch.full((B, H, W, ocs), float("nan"), dtype=DT[dtype], device=dev())
     pws = []
-    for w, (co, ci, r) in zip((w1, w2, w3), ((64, 256, 1), (64, 64, 3), (256, 64, 1))):
+    for w, (co, ci, r) in zip((w1, w2, w3, wd), ((64, Cin, 1), (64, 64, 3), (256, 64, 1), (256, 64, 1))):
         pw = torch.empty(lib.cp_packed_weight_bytes(dtype, co, ci, r, r), dtype=torch.uint8, device=dev())
-        wd = w.contiguous().to(dev())
-        _abi.check(lib.cp_pack_conv_weight(st(), dtype, wd.data_ptr(), co, ci, r, r, ci, 0, 0, None, co, pw.data_ptr()))
+        wdev = w.contiguous().to(dev())
+        _abi.check(lib.cp_pack_conv_weight(st(), dtype, wdev.data_ptr(), co, ci, r, r, ci, 0, 0, None, co, pw.data_ptr()))
         pws.append(pw)
     a = [v.contiguous().to(dev()) for pair in aff for v in pair]
     d = CpConvDesc()
     d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
-    d.Cin, d.in_cstride, d.in_coff = 256, cs, coff
+    d.Cin, d.in_cstride, d.in_coff = Cin, cs, coff
     d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 1, 1, H, W, 256, ACT_RELU, 0.0
     d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * ocs, W * ocs, ocs, 1
     args = (pws[0].data_ptr(), a[0].data_ptr(), a[1].data_ptr(), pws[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(),
             pws[2].data_ptr(), a[4].data_ptr(), a[5].data_ptr())
+    args += (pws[3].data_ptr(), a[6].data_ptr(), a[7].data_ptr()) if ds else (None, None, None)
     _abi.check(lib.cp_bottleneck_fused(st(), C.byref(d), xin.data_ptr(), *args, out.data_ptr()), "fused bottleneck")
     torch.cuda.synchronize()
     assert bool(torch.isnan(out[..., 256:].float()).all())          # channels past 256 of the output rows untouched
     close(from_cl(out[..., :256].contiguous(), 256), ref, 4e-2)
     assert lib.cp_bottleneck_fused(st(), C.byref(d), xin.data_ptr(), *args, xin.data_ptr()) == -1      # in-place refused
-    d.dtype = CP_F32
+    assert lib.cp_bottleneck_fused(st(), C.byref(d), xin.data_ptr(), *(args[:9] + (args[9], None, None)), out.data_ptr()) == -1 or not ds
+    d.Cin = 256 if ds else 64
+    assert lib.cp_bottleneck_fused(st(), C.byref(d), xin.data_ptr(), *args, out.data_ptr()) == -1      # Cin must match the shortcut kind
+    d.Cin, d.dtype = Cin, CP_F32
     assert lib.cp_bottleneck_fused(st(), C.byref(d), xin.data_ptr(), *args, out.data_ptr()) == -1      # bf16 only
 
 
