@@ -812,6 +812,182 @@ __global__ __launch_bounds__(256) void basicblock_fused_kernel(const HaloParams 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent bf16 variant of the fused BasicBlock for 16 < C <= 32 (the 18-channel HRNet branch, 32 launches per
+// forward).  Knock-out timing of the one-tile-per-block kernel above (B=256: 75 us) showed neither global memory
+// (no loads + no stores: 62 us) nor the MFMAs (removing them made it slower) on the critical path: it is bound by
+// LDS traffic -- per tile 36 KB of weights written to and 144 KB read back from LDS next to 180 KB of activation
+// fragment reads, one ds_read per two MFMAs.  Here
+//   * blocks stay resident (2 x 4 waves per CU) and BOTH weight sets live in registers (36 fragments per wave),
+//   * conv2 re-uses activation fragments across output rows: input row R at shift s feeds output rows R, R-1, R-2, so
+//     a wave's two rows need 12 fragment reads for 36 MFMAs instead of 18,
+//   * the next tile's halo loads are issued before the current tile's epilogue,
+//   * the finished tile is written back over the x tile in LDS and leaves in full-line order.
+// LDS reads per tile drop from 324 KB to 156 KB.  Tile order as in the fused Bottleneck (crops b == xcd (mod 8) on
+// XCD blockIdx % 8).
+constexpr int PBX_PITCH = 256 * 16 + 16, PBT_PITCH = 192 * 16 + 16;      // x halo planes (240 px) / t1 planes (180 px)
+constexpr int PB_LDS = 4 * PBX_PITCH + 4 * PBT_PITCH;                    // 28 800 B
+
+__global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloParams p, const void* __restrict__ w2,
+                                                                    const float* __restrict__ scale2,
+                                                                    const float* __restrict__ shift2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sX = smem;
+  unsigned char* const sT = smem + 4 * PBX_PITCH;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+  const int x = lane & 15, q = lane >> 4;
+
+  u32x4 W1[9][2], W2[9][2];                                    // [chunk 0][tap][nt][lane][16 B] images, NT = 2
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      W1[tap][nt] = ((const u32x4*)p.w)[(tap * 2 + nt) * 64 + lane];
+      W2[tap][nt] = ((const u32x4*)w2)[(tap * 2 + nt) * 64 + lane];
+    }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int npc = p.Cin >> 3;                                  // 16-byte pieces per input pixel (Cphys / 8 <= 4)
+
+  // x halo: 240 px x 4 pieces = 960 pieces, 4 per thread (piece index tid + 256 it; >= 960 idle)
+  auto issue_loads = [&](int li, u32x4* xv) {
+    const int b = (li / tpi) * 8 + xcd;
+    const int trem = li % tpi;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * HTH - 2, x0 = tx * HTW - 2;
+    const bool tok = b < p.B;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + 256 * it;
+      const int hp = i >> 2, pq = i & 3;
+      const int py = hp / FXW, px = hp - py * FXW;
+      const int gy = y0 + py, gx = x0 + px;
+      const bool ok = tok & (hp < FXH * FXW) & (pq < npc) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+      const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pq * 8) * 2u : 0x80000000u;
+      xv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+
+  // per-lane geometry of conv1's three fragments (tile-independent): t1 pixel p1 = (3 wave + i) * 16 + x on the ring
+  uint32_t xb[3];
+  int p1y[3], p1x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p1 = (3 * wave + i) * 16 + x;
+    const int pc = p1 < HPH * HPW ? p1 : 0;
+    p1y[i] = p1 < HPH * HPW ? pc / HPW : -64;                  // pad pixels: never inside the image
+    p1x[i] = pc - (pc / HPW) * HPW;
+    xb[i] = (uint32_t)(q * PBX_PITCH + ((pc / HPW) * FXW + p1x[i]) * 16);
+  }
+
+  u32x4 xv[4];
+  int li = j0;
+  issue_loads(li, xv);
+  for (; (li / tpi) * 8 + xcd < p.B; li += nbx) {
+    const int b = (li / tpi) * 8 + xcd;
+    const int trem = li % tpi;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * HTH, x0 = tx * HTW;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + 256 * it;
+      *(u32x4*)(sX + (i & 3) * PBX_PITCH + (i >> 2) * 16) = xv[it];     // i >> 2 <= 255: inside the padded plane
+    }
+    __syncthreads();
+
+    // ---- conv1 on the 10x18 ring -> t1 (BN1 + ReLU, zero outside the image); rows of conv1 are not permuted
+    {
+      f32x4 acc[3][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int r = tap / 3, s2 = tap - 3 * r;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const u32x4 a = *(const u32x4*)(sX + xb[i] + (r * FXW + s2) * 16);
+          MmaH<BF16Tag>::run(W1[tap][0], a, acc[i][0]);
+          MmaH<BF16Tag>::run(W1[tap][1], a, acc[i][1]);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c1 = nt * 16 + q * 4;
+        const f32x4 sc = *(const f32x4*)(p.scale + c1), sh = *(const f32x4*)(p.shift + c1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int p1 = (3 * wave + i) * 16 + x;
+          const bool inimg = ((unsigned)(y0 - 1 + p1y[i]) < (unsigned)p.H) & ((unsigned)(x0 - 1 + p1x[i]) < (unsigned)p.W);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[i][nt][e] * sc[e] + sh[e], 0.f) : 0.f;
+          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(sT + (c1 >> 3) * PBT_PITCH + p1 * 16 + (c1 & 7) * 2) = pk;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- conv2 on rows 2 wave, 2 wave + 1: ring rows 2 wave .. 2 wave + 3, each fragment feeds both output rows
+    {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const unsigned char* ab = sT + q * PBT_PITCH + (2 * wave * HPW + x) * 16;
+#pragma unroll
+      for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+          const u32x4 a = *(const u32x4*)(ab + (R * HPW + s2) * 16);
+          if (R < 3) {                                          // output row 0, tap row R
+            MmaH<BF16Tag>::run(W2[R * 3 + s2][0], a, acc[0][0]);
+            MmaH<BF16Tag>::run(W2[R * 3 + s2][1], a, acc[0][1]);
+          }
+          if (R > 0) {                                          // output row 1, tap row R - 1
+            MmaH<BF16Tag>::run(W2[(R - 1) * 3 + s2][0], a, acc[1][0]);
+            MmaH<BF16Tag>::run(W2[(R - 1) * 3 + s2][1], a, acc[1][1]);
+          }
+        }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c2 = q * 8 + nt * 4;                          // conv2 rows are permuted: lane q holds channels 8 q + 4 nt + {0..3}
+        const f32x4 sc = *(const f32x4*)(scale2 + c2), sh = *(const f32x4*)(shift2 + c2);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          u32x2* rp = (u32x2*)(sX + (c2 >> 3) * PBX_PITCH + ((2 * wave + mt + 2) * FXW + x + 2) * 16 + (c2 & 7) * 2);
+          const u32x2 r2 = *rp;
+          float v[4];
+          v[0] = fmaxf(acc[mt][nt][0] * sc[0] + sh[0] + __uint_as_float(r2.x << 16), 0.f);
+          v[1] = fmaxf(acc[mt][nt][1] * sc[1] + sh[1] + __uint_as_float(r2.x & 0xffff0000u), 0.f);
+          v[2] = fmaxf(acc[mt][nt][2] * sc[2] + sh[2] + __uint_as_float(r2.y << 16), 0.f);
+          v[3] = fmaxf(acc[mt][nt][3] * sc[3] + sh[3] + __uint_as_float(r2.y & 0xffff0000u), 0.f);
+          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          *rp = pk;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- next tile's loads take off; this tile leaves LDS: piece i -> (pixel i / opc, piece i % opc) over 128 px
+    issue_loads(li + nbx, xv);
+    {
+      const int opc = (p.Cout + 7) >> 3;                       // output pieces per pixel (Cphys / 8)
+      for (int i = tid; i < 128 * opc; i += 256) {
+        const int pxl = i / opc, pc = i - pxl * opc;
+        const int row = pxl >> 4, col = pxl & 15;
+        const int oy = y0 + row, ox = x0 + col;
+        const u32x4 v = *(const u32x4*)(sX + pc * PBX_PITCH + ((row + 2) * FXW + col + 2) * 16);
+        if (oy < p.H && ox < p.W)
+          *(u32x4*)((uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + pc * 8) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // packing for the small-Cout variant: [chunk][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
 // channel 4*NT*qr + 4*nt + reg.
 template <typename Tag>
@@ -1020,6 +1196,20 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
   const size_t lds = 4 * FXPLANE + HBUF + (size_t)9 * NT * 1024;
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CP_BF16 && NT == 2 && !getenv("CP_NO_BB_PERSIST")) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return CP_ERR_HIP;
+    }
+    // two resident 4-wave blocks per CU, a multiple of 8 (XCD labels), never more than the tiles one XCD owns
+    const long long per_xcd = (long long)((d->B + 7) / 8) * p.tiles_x * p.tiles_y;
+    long long nbx = 2 * n_cu / 8 > 0 ? 2 * n_cu / 8 : 1;
+    if (nbx > per_xcd) nbx = per_xcd;
+    hipLaunchKernelGGL(basicblock_persist_kernel, dim3((unsigned)(8 * nbx)), dim3(256), PB_LDS, st, p, packed_w2, scale2, shift2);
+    return cp_check_launch();
+  }
   if (d->dtype == CP_F32) {
     if (NT == 1) hipLaunchKernelGGL((basicblock_fused_kernel<F32Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
     else hipLaunchKernelGGL((basicblock_fused_kernel<F32Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);

@@ -14,6 +14,13 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_ops.npz"))
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _grad_on():
+    """other test modules switch autograd off globally (inference parity); these tests need it"""
+    with torch.enable_grad():
+        yield
+
+
 @pytest.mark.parametrize("name", list(TC.CODE_CASES))
 def test_code_loss(name):
     from checkerpose_amd.losses import MaskedCodeLoss, UnmaskedCodeLoss
