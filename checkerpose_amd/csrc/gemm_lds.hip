@@ -10,6 +10,8 @@
 // Weights: four rotating register sets, three chunks ahead; row fragments: one chunk ahead (sched_barrier pinned).
 // Packed-weight image = the halo kernel's with one tap: [32-ch group][chunk][tile][lane][16 B], rows permuted so a
 // lane ends with 8 consecutive channels (16-byte bf16 / 2 x 16-byte f32 stores).
+#include <stdlib.h>
+
 #include "common.h"
 
 struct GemmParams {
@@ -219,6 +221,132 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-stationary persistent variant (bf16, K <= 256, no residual): the EdgeConv node GEMMs 256 -> 512 and the
+// 256-wide MLP layers (M = B*N rows).  The kernel above re-streams a block's 64 KB weight slice from L2 for every
+// 128-row block -- at M = 131072 that is as many bytes through the texture path as the activations themselves, and
+// the 128x128 tile caps the arithmetic intensity at ~65 flop/B (measured 0.28 PFLOP/s, 1.7 TB/s algorithmic).  Here a
+// wave owns 64 output channels and keeps ALL of their weight fragments in registers (8 chunks x 4 tiles = 128 VGPRs)
+// while its block walks row tiles of 64: per tile only the 32 KB of activation rows are loaded (double-buffered LDS,
+// next tile's loads in flight during the MFMAs, one barrier per tile) and every fragment read feeds 4 MFMAs.
+// Column-group blocks of one row stream share a blockIdx % 8 label: the rows they both read are an L2 hit.
+constexpr int WS_ROWS = 64, WS_NCH = 8;
+constexpr int WS_PITCH = WS_ROWS * 16 + 16;                 // plane [row][16 B]; +16: consecutive planes shift one slot
+constexpr int WS_BUF = WS_NCH * 4 * WS_PITCH;               // 33 280 B
+
+__global__ __launch_bounds__(256, 2) void gemm_rows_ws_kernel(const GemmParams p, const int ncg, const int n_rt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * WS_BUF
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cg = slot % ncg, stream = slot / ncg;
+  const int nstreams = (gridDim.x >> 3) / ncg;               // row streams per XCD
+  const int g0 = (cg * 4 + wave) * 2;                        // first of this wave's two 32-channel groups
+  const bool act0 = g0 < p.ngroups, act1 = g0 + 1 < p.ngroups;
+
+  // ---- resident weights: [group][chunk][nt][lane][16 B]; chunks >= nchunk and groups past the end stay zero
+  u32x4 W[WS_NCH][4];
+#pragma unroll
+  for (int kc = 0; kc < WS_NCH; ++kc)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int g = g0 + (t >> 1);
+      W[kc][t] = u32x4{0u, 0u, 0u, 0u};
+      if (kc < p.nchunk && g < p.ngroups) W[kc][t] = ((const u32x4*)p.w)[((size_t)(g * p.nchunk + kc) * 2 + (t & 1)) * 64 + lane];
+    }
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  // staging: piece i = tid + 256 k (k = 0..7): row = i >> 5, piece-in-row pr = i & 31 (= chunk * 4 + q)
+  const int s_pr = tid & 31, s_row = tid >> 5;               // rows s_row + 8 k
+  auto stage_load = [&](u32x4* v, int rt) {
+    const int m0 = rt * WS_ROWS;
+    const bool pok = (rt < n_rt) & (s_pr * 8 < p.Cin);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int m = m0 + s_row + 8 * k;
+      const uint32_t off = (pok & (m < p.M)) ? (uint32_t)(m * p.in_cs + p.in_coff + s_pr * 8) * 2u : 0x80000000u;
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+  auto stage_write = [&](const u32x4* v, int buf) {
+    unsigned char* dst = smem + buf * WS_BUF + s_pr * WS_PITCH + s_row * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(u32x4*)(dst + k * 8 * 16) = v[k];
+  };
+
+  const int rt_step = nstreams * 8;
+  int rt = stream * 8 + xcd;
+  u32x4 sv[8];
+  stage_load(sv, rt);
+  stage_write(sv, 0);
+  __syncthreads();
+  int buf = 0;
+  for (; rt < n_rt; rt += rt_step, buf ^= 1) {
+    stage_load(sv, rt + rt_step);                            // past the end: zeros, never consumed
+    const int m0 = rt * WS_ROWS;
+#pragma unroll 1
+    for (int mh = 0; mh < 2; ++mh) {                         // two passes of 32 rows: bounds the live accumulators
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* ab = smem + buf * WS_BUF + q * WS_PITCH + (mh * 32 + x) * 16;
+#pragma unroll
+    for (int kc = 0; kc < WS_NCH; ++kc) {
+      if (kc < p.nchunk) {                                   // block-uniform
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const u32x4 a = *(const u32x4*)(ab + kc * 4 * WS_PITCH + mt * 256);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) MmaG<BF16Tag>::run(W[kc][t], a, acc[mt][t]);
+        }
+      }
+    }
+    // ---- epilogue: lane (x, q): row m0 + 16 mt + x, channels (g0 + h) * 32 + 8 q + {0..7}  (h = 0, 1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!(h ? act1 : act0)) continue;
+      const int ch = (g0 + h) * 32 + q * 8;
+      if (ch >= p.Cout) continue;
+      const bool hi_ok = ch + 4 < p.Cout;
+      const f32x4 s0 = *(const f32x4*)(p.scale + ch), t0 = *(const f32x4*)(p.shift + ch);
+      const f32x4 s1 = *(const f32x4*)(p.scale + ch + 4), t1 = *(const f32x4*)(p.shift + ch + 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + mh * 32 + mt * 16 + x;
+        if (m >= p.M) continue;
+        const int b = m / p.HoWo;
+        const int rem = m - b * p.HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        uint16_t* op = (uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = acc[mt][2 * h][j] * s0[j] + t0[j]; v[4 + j] = acc[mt][2 * h + 1][j] * s1[j] + t1[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+          else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        }
+        if (hi_ok) {
+          u32x4 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+          if ((((uintptr_t)op) & 15u) == 0) *(u32x4*)op = pk;
+          else { *(u32x2*)op = u32x2{pk.x, pk.y}; *(u32x2*)(op + 4) = u32x2{pk.z, pk.w}; }
+        } else {
+          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)op = pk;
+        }
+      }
+    }
+    }
+    stage_write(sv, buf ^ 1);
+    __syncthreads();
+  }
+}
+
 // ---- packing: [group g (32 ch)][chunk][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt -> channel g*32 + 8*qr + 4*nt + reg
 template <typename Tag>
 __global__ void pack_gemm_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int nchunk,
@@ -293,6 +421,24 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
   const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CP_BF16 && !residual && p.nchunk <= WS_NCH && M >= 16384 && !getenv("CP_NO_GEMM_WS")) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return CP_ERR_HIP;
+      if (hipFuncSetAttribute((const void*)gemm_rows_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_BUF) != hipSuccess)
+        return CP_ERR_HIP;
+    }
+    const int ncg = (p.ngroups + 7) / 8;                      // column groups of 256 channels
+    const int n_rt = (int)((M + WS_ROWS - 1) / WS_ROWS);
+    int per_xcd = 2 * n_cu / 8;                               // resident blocks per XCD (2 per CU)
+    int nstreams = per_xcd / ncg > 0 ? per_xcd / ncg : 1;
+    const int need = (n_rt + 7) / 8;                          // row tiles one XCD label owns
+    if (nstreams > need) nstreams = need;
+    hipLaunchKernelGGL(gemm_rows_ws_kernel, dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * WS_BUF, st, p, ncg, n_rt);
+    return cp_check_launch();
+  }
   if (d->dtype == CP_F32) {
     if (residual) hipLaunchKernelGGL((gemm_rows_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
     else hipLaunchKernelGGL((gemm_rows_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);

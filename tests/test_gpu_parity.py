@@ -286,6 +286,10 @@ GEMM_CASES = [  # (B, H, W, Cin, Cout, act, residual)
     (3, 1, 100, 320, 256, ACT_LEAKY, False),    # pre_graph MLP: K = 320 (ragged super-chunk)
     (1, 8, 8, 1024, 136, ACT_RELU, True),       # deep K, Cout = 136 (partial last channel group), residual
     (1, 5, 7, 144, 100, ACT_NONE, False),       # odd everything
+    # M >= 16384 without residual, K <= 256: the bf16 weight-stationary persistent kernel (gemm_rows_ws_kernel)
+    (33, 1, 512, 256, 512, ACT_NONE, False),    # EdgeConv node GEMM at full N: two column groups, M = 16896 (264 row tiles)
+    (4, 1, 4133, 160, 136, ACT_LEAKY, False),   # ragged M (16532 = 258.3 tiles), K = 160 (5 chunks), partial last group
+    (2, 96, 96, 72, 256, ACT_RELU, False),      # image-shaped rows (H, W strides), K = 72 (ragged chunk)
 ]
 
 
