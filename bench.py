@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 MFMA_KERNELS = {"conv_igemm": "conv_igemm_kernel", "conv3x3_halo": "conv3x3_halo_kernel", "conv3x3_halo4": "conv3x3_halo4_kernel",
-                "conv3x3_halo_s": "conv3x3_halo_s_kernel", "gemm_rows": "gemm_rows_kernel",
-                "basicblock_fused": "basicblock_fused_kernel", "bottleneck_fused": "bottleneck_fused_kernel"}
+                "conv3x3_halo_s": "conv3x3_halo_s_kernel", "gemm_rows": "gemm_rows_kernel|gemm_rows_ws_kernel",
+                "basicblock_fused": "basicblock_fused_kernel|basicblock_persist_kernel", "bottleneck_fused": "bottleneck_fused_kernel"}
 
 
 def build(npoint, seed=1):
@@ -79,7 +79,8 @@ def pmc_traffic_mb(kernel_prefix, dtype, B):
         return None
     tot, calls = 0.0, 0
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith(kernel_prefix + "<") and r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
+        hit = r["kernel"] == kernel_prefix
+        if hit and r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
             n = int(r["calls"])
             tot += n * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"]))
             calls += n
@@ -87,38 +88,53 @@ def pmc_traffic_mb(kernel_prefix, dtype, B):
 
 
 def kernel_breakdown(net, B, steps, dump=None):
-    """Per-kernel-family device time of one step, measured live with HIP events on the launch stream (eager
-    replay of the same launch program, one event pair per launch)."""
+    """Per-kernel device time of one step, measured live with HIP events on the launch stream (eager replay of the
+    same launch program, one event pair per launch).  Returns (per family, per kernel symbol): the symbol of every
+    launch is what the library reports through cp_last_kernel(), i.e. the row name in rocprofv3's kernel stats."""
+    from checkerpose_amd import _abi
+    lib = _abi.load()
     prog = net.program_for(B)
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
-    fam = {}
+    fam, sym = {}, {}
+    syms = []
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in prog.calls]
-    for _ in range(steps):
+    for it in range(steps):
         for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
             e0.record(stream)
             fn(sp, *args[1:])
             e1.record(stream)
+            if it == 0:
+                syms.append(lib.cp_last_kernel().decode())
         torch.cuda.synchronize()
-        for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+        for (fn, args, name), (e0, e1), sy in zip(prog.calls, evs, syms):
             k = name.split(":")[0]
+            ms = e0.elapsed_time(e1)
             t, c = fam.get(k, (0.0, 0))
-            fam[k] = (t + e0.elapsed_time(e1), c + 1)
+            fam[k] = (t + ms, c + 1)
+            r = sym.setdefault(sy, {"ms": 0.0, "n": 0, "flops": 0, "bytes": 0, "family": k})
+            r["ms"] += ms
+            r["n"] += 1
     per_conv = []
     ci = 0
     conv_log = prog.conv_log
-    for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+    for (fn, args, name), (e0, e1), sy in zip(prog.calls, evs, syms):
         if name.split(":")[0] in MFMA_KERNELS:
             wk, M, Cout, K, fl, kfam, nby = conv_log[ci]
             ci += 1
+            sym[sy]["flops"] += fl
+            sym[sy]["bytes"] += nby
             ms = e0.elapsed_time(e1)          # last step's duration of this launch
-            per_conv.append({"name": wk, "kernel": kfam, "M": M, "Cout": Cout, "K": K, "gflop": round(fl / 1e9, 3), "us": round(ms * 1e3, 1),
+            per_conv.append({"name": wk, "kernel": sy, "M": M, "Cout": Cout, "K": K, "gflop": round(fl / 1e9, 3), "us": round(ms * 1e3, 1),
                              "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0,
                              "alg_gbs": round(nby / (ms * 1e-3) / 1e9, 0) if ms > 0 else 0})
     if dump:
         with open(dump, "w") as f:
             json.dump(sorted(per_conv, key=lambda r: -r["us"]), f, indent=0)
-    return {k: {"ms_per_step": t / steps, "launches_per_step": c // steps} for k, (t, c) in fam.items()}
+    fams = {k: {"ms_per_step": t / steps, "launches_per_step": c // steps} for k, (t, c) in fam.items()}
+    symbols = {k: {"ms_per_step": r["ms"] / steps, "launches_per_step": r["n"] // steps, "flops": r["flops"], "bytes": r["bytes"],
+                   "family": r["family"]} for k, r in sym.items()}
+    return fams, symbols
 
 
 def main():
@@ -192,8 +208,8 @@ def main():
     if rank == 0:
         prog = net.program_for(B)
         if not a.no_breakdown:
-            fam = kernel_breakdown(net, B, min(a.steps, 5), a.dump_convs)
-            # the four MFMA kernel families; `roofline` = the one with the most device time
+            fam, symbols = kernel_breakdown(net, B, min(a.steps, 5), a.dump_convs)
+            # MFMA kernel families (host-side grouping) ...
             fl_by, by_by = {}, {}
             for wk, M, Cout, K, fl, kf, nby in prog.conv_log:
                 fl_by[kf] = fl_by.get(kf, 0) + fl
@@ -206,22 +222,34 @@ def main():
                 per[k] = {"kernel": MFMA_KERNELS[k], "ms_per_step": round(v["ms_per_step"], 3), "launches": v["launches_per_step"],
                           "tflops": round(tf, 1), "frac_mfma": round(tf / PEAK_TFLOPS[a.dtype], 4),
                           "alg_gbs": round(gb, 0), "frac_hbm": round(gb / PEAK_HBM_GBS, 4)}
-            dom = max(mf, key=lambda k: mf[k]["ms_per_step"])     # most device time
-            d, pd = mf[dom], per[dom]
-            n = d["launches_per_step"]
-            if pd["frac_hbm"] > pd["frac_mfma"]:                  # this family's launches sit closer to the HBM roof
-                out["roofline"] = {"bound": "hbm", "kernel": "%s (%d launches per step)" % (MFMA_KERNELS[dom], n),
+            # ... and per kernel SYMBOL (the granularity of rocprofv3's kernel stats): `roofline` = the symbol with the
+            # most device time per step, priced against the roof it sits closer to
+            ksym = {}
+            for k, v in symbols.items():
+                if not v["flops"]:
+                    continue
+                t = v["ms_per_step"] * 1e-3
+                tf, gb = v["flops"] / t / 1e12, v["bytes"] / t / 1e9
+                ksym[k] = {"ms_per_step": round(v["ms_per_step"], 3), "launches": v["launches_per_step"], "tflops": round(tf, 1),
+                           "frac_mfma": round(tf / PEAK_TFLOPS[a.dtype], 4), "alg_gbs": round(gb, 0),
+                           "frac_hbm": round(gb / PEAK_HBM_GBS, 4)}
+            dom = max(ksym, key=lambda k: ksym[k]["ms_per_step"])
+            pd, sv = ksym[dom], symbols[dom]
+            n = pd["launches"]
+            if pd["frac_hbm"] > pd["frac_mfma"]:
+                out["roofline"] = {"bound": "hbm", "kernel": "%s (%d launches per step)" % (dom, n),
                                    "achieved": pd["alg_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pd["frac_hbm"],
-                                   "traffic": None, "algorithmic_mb_per_launch_avg": round(by_by[dom] / n / 1e6, 2),
-                                   "avg_launch_us": round(d["ms_per_step"] * 1e3 / n, 2)}
+                                   "traffic": None, "algorithmic_mb_per_launch_avg": round(sv["bytes"] / n / 1e6, 2),
+                                   "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
             else:
-                out["roofline"] = {"bound": "mfma", "kernel": "%s (%d launches per step)" % (MFMA_KERNELS[dom], n),
+                out["roofline"] = {"bound": "mfma", "kernel": "%s (%d launches per step)" % (dom, n),
                                    "achieved": pd["tflops"], "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                                    "frac": pd["frac_mfma"], "traffic": None,
-                                   "algorithmic_gflop_per_launch_avg": round(fl_by[dom] / n / 1e9, 3),
-                                   "avg_launch_us": round(d["ms_per_step"] * 1e3 / n, 2)}
+                                   "algorithmic_gflop_per_launch_avg": round(sv["flops"] / n / 1e9, 3),
+                                   "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
+            out["kernel_symbols"] = dict(sorted(ksym.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8])
             if True:         # a committed PMC summary of this exact command (same dtype and batch), if any
-                tr = pmc_traffic_mb(MFMA_KERNELS[dom], a.dtype, B)
+                tr = pmc_traffic_mb(dom, a.dtype, B)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr
                     out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch (rocprofv3 PMC, profiles/)"

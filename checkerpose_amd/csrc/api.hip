@@ -1,7 +1,27 @@
 // Version / error strings and hipGraph capture helpers of the C ABI.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
 #include "common.h"
 
 extern "C" int cp_version(void) { return 100; }   // 0.1.0
+
+static thread_local char g_last_kernel[128] = "";
+void cp_mark_kernel(const char* fmt, ...) {
+  char tmp[128];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tmp, sizeof(tmp), fmt, ap);
+  va_end(ap);
+  // "(name<args>)" from a stringified launch expression -> "name<args>"
+  const char* b = tmp;
+  size_t n = strlen(tmp);
+  if (n >= 2 && tmp[0] == '(' && tmp[n - 1] == ')') { b = tmp + 1; n -= 2; }
+  memcpy(g_last_kernel, b, n);
+  g_last_kernel[n] = 0;
+}
+extern "C" const char* cp_last_kernel(void) { return g_last_kernel; }
 
 extern "C" const char* cp_strerror(int code) {
   switch (code) {

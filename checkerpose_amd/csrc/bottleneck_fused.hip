@@ -339,7 +339,7 @@ extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, cons
   long long nbx = n_cu / 8 > 0 ? n_cu / 8 : 1;
   if (nbx > per_xcd) nbx = per_xcd;
   const dim3 grid((unsigned)(8 * nbx));
-  if (ds) hipLaunchKernelGGL((bottleneck_fused_kernel<2, true>), grid, dim3(512), lds_bytes(2, true), (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((bottleneck_fused_kernel<8, false>), grid, dim3(512), lds_bytes(8, false), (hipStream_t)stream, p);
+  if (ds) CP_LAUNCH((bottleneck_fused_kernel<2, true>), grid, dim3(512), lds_bytes(2, true), (hipStream_t)stream, p);
+  else CP_LAUNCH((bottleneck_fused_kernel<8, false>), grid, dim3(512), lds_bytes(8, false), (hipStream_t)stream, p);
   return cp_check_launch();
 }

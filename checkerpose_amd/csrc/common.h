@@ -61,6 +61,9 @@ template <> __device__ __forceinline__ void store_elem<BF16Tag>(void* p, size_t 
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// profiling aid (cp_last_kernel): every launch site records the symbol it launches, spelled as rocprofv3 prints it
+void cp_mark_kernel(const char* fmt, ...);
+#define CP_LAUNCH(kernel, ...) do { cp_mark_kernel("%s", #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
 static inline int cp_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CP_OK : CP_ERR_HIP;

@@ -1055,22 +1055,22 @@ extern "C" int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const 
   if (halo_small(Cout)) {
     const int NT = (Cout + 15) / 16;
     if (dtype == CP_F32)
-      hipLaunchKernelGGL(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
+      CP_LAUNCH(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
     else
-      hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
+      CP_LAUNCH(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total);
     return cp_check_launch();
   }
   if (halo_wide(Cout)) {
     if (dtype == CP_F32)
-      hipLaunchKernelGGL(pack_halo4_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+      CP_LAUNCH(pack_halo4_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
     else
-      hipLaunchKernelGGL(pack_halo4_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+      CP_LAUNCH(pack_halo4_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
     return cp_check_launch();
   }
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(pack_halo_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+    CP_LAUNCH(pack_halo_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
   else
-    hipLaunchKernelGGL(pack_halo_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
+    CP_LAUNCH(pack_halo_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, total);
   return cp_check_launch();
 }
 
@@ -1108,7 +1108,7 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
     const int NT = (d->Cout + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = HBUF + (size_t)9 * NT * 1024;
-#define CP_HS(TAG, N) hipLaunchKernelGGL((conv3x3_halo_s_kernel<TAG, N>), dim3((unsigned)tt), dim3(256), lds, st, p)
+#define CP_HS(TAG, N) CP_LAUNCH((conv3x3_halo_s_kernel<TAG, N>), dim3((unsigned)tt), dim3(256), lds, st, p)
     if (d->dtype == CP_F32) {
       switch (NT) { case 1: CP_HS(F32Tag, 1); break; case 2: CP_HS(F32Tag, 2); break; case 3: CP_HS(F32Tag, 3); break;
                     case 4: CP_HS(F32Tag, 4); break; default: CP_HS(F32Tag, 5); break; }
@@ -1125,11 +1125,11 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
     const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
     hipStream_t st4 = (hipStream_t)stream;
     if (d->dtype == CP_F32) {
-      if (residual) hipLaunchKernelGGL((conv3x3_halo4_kernel<F32Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
-      else hipLaunchKernelGGL((conv3x3_halo4_kernel<F32Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      if (residual) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      else CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
     } else {
-      if (residual) hipLaunchKernelGGL((conv3x3_halo4_kernel<BF16Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
-      else hipLaunchKernelGGL((conv3x3_halo4_kernel<BF16Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      if (residual) CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
     }
     return cp_check_launch();
   }
@@ -1137,11 +1137,11 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   // scale/shift are read 8 at a time at ch = g*32 + 8q < Cout: vectors must be padded to a multiple of 8 (they are: 16)
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_F32) {
-    if (residual) hipLaunchKernelGGL((conv3x3_halo_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+    if (residual) CP_LAUNCH((conv3x3_halo_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+    else CP_LAUNCH((conv3x3_halo_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
   } else {
-    if (residual) hipLaunchKernelGGL((conv3x3_halo_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+    if (residual) CP_LAUNCH((conv3x3_halo_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
+    else CP_LAUNCH((conv3x3_halo_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
   }
   return cp_check_launch();
 }
@@ -1158,9 +1158,9 @@ extern "C" int cp_pack_conv3x3_rows_weight(cp_stream_t stream, int dtype, const 
   const size_t total = cp_packed_halo_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 0, total);
+    CP_LAUNCH(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 0, total);
   else
-    hipLaunchKernelGGL(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 0, total);
+    CP_LAUNCH(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 0, total);
   return cp_check_launch();
 }
 
@@ -1207,15 +1207,15 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
     const long long per_xcd = (long long)((d->B + 7) / 8) * p.tiles_x * p.tiles_y;
     long long nbx = 2 * n_cu / 8 > 0 ? 2 * n_cu / 8 : 1;
     if (nbx > per_xcd) nbx = per_xcd;
-    hipLaunchKernelGGL(basicblock_persist_kernel, dim3((unsigned)(8 * nbx)), dim3(256), PB_LDS, st, p, packed_w2, scale2, shift2);
+    CP_LAUNCH(basicblock_persist_kernel, dim3((unsigned)(8 * nbx)), dim3(256), PB_LDS, st, p, packed_w2, scale2, shift2);
     return cp_check_launch();
   }
   if (d->dtype == CP_F32) {
-    if (NT == 1) hipLaunchKernelGGL((basicblock_fused_kernel<F32Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
-    else hipLaunchKernelGGL((basicblock_fused_kernel<F32Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+    if (NT == 1) CP_LAUNCH((basicblock_fused_kernel<F32Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+    else CP_LAUNCH((basicblock_fused_kernel<F32Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
   } else {
-    if (NT == 1) hipLaunchKernelGGL((basicblock_fused_kernel<BF16Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
-    else hipLaunchKernelGGL((basicblock_fused_kernel<BF16Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+    if (NT == 1) CP_LAUNCH((basicblock_fused_kernel<BF16Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+    else CP_LAUNCH((basicblock_fused_kernel<BF16Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
   }
   return cp_check_launch();
 }

@@ -342,6 +342,7 @@ static void launch(ConvParams p, hipStream_t st) {
   p.old_map = getenv("CP_OLD_MAP") ? 1 : 0;
   dim3 grid((unsigned)((p.m_blocks + 7) / 8 * 8) * p.n_blocks);
   const size_t lds = p.epi_lds ? (size_t)4 * MT * 16 * (NT * 16 + 4) * sizeof(float) : 0;
+  cp_mark_kernel("conv_igemm_kernel<%s, %d, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : "F32Tag", MT, NT);
   hipLaunchKernelGGL((conv_igemm_kernel<Tag, MT, NT>), grid, dim3(256), lds, st, p);
 }
 

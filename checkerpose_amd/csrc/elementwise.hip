@@ -48,10 +48,10 @@ extern "C" int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const vo
   const size_t total = (size_t)B * 2 * H * 2 * W * CG;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(upsample2x_bilinear_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+    CP_LAUNCH(upsample2x_bilinear_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
                        CG, in_cstride, in_coff, out_cstride, out_coff, sy, sx, total);
   else
-    hipLaunchKernelGGL(upsample2x_bilinear_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+    CP_LAUNCH(upsample2x_bilinear_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
                        CG, in_cstride, in_coff, out_cstride, out_coff, sy, sx, total);
   return cp_check_launch();
 }
@@ -105,9 +105,9 @@ extern "C" int cp_fuse_sum_act(cp_stream_t stream, int dtype, int nsrc, const vo
   const size_t total = (size_t)B * H * W * CG;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(fuse_sum_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
+    CP_LAUNCH(fuse_sum_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
   else
-    hipLaunchKernelGGL(fuse_sum_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
+    CP_LAUNCH(fuse_sum_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
   return cp_check_launch();
 }
 
@@ -149,8 +149,8 @@ extern "C" int cp_maxpool3x3s2(cp_stream_t stream, int dtype, const void* in, vo
   const size_t total = (size_t)B * (H / 2) * (W / 2) * CG;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W, CG, total);
+    CP_LAUNCH(maxpool3x3s2_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W, CG, total);
   else
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W, CG, total);
+    CP_LAUNCH(maxpool3x3s2_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W, CG, total);
   return cp_check_launch();
 }

@@ -383,9 +383,9 @@ extern "C" int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w
   const size_t total = cp_packed_gemm_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(pack_gemm_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
+    CP_LAUNCH(pack_gemm_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
   else
-    hipLaunchKernelGGL(pack_gemm_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
+    CP_LAUNCH(pack_gemm_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
   return cp_check_launch();
 }
 
@@ -436,15 +436,15 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
     int nstreams = per_xcd / ncg > 0 ? per_xcd / ncg : 1;
     const int need = (n_rt + 7) / 8;                          // row tiles one XCD label owns
     if (nstreams > need) nstreams = need;
-    hipLaunchKernelGGL(gemm_rows_ws_kernel, dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * WS_BUF, st, p, ncg, n_rt);
+    CP_LAUNCH(gemm_rows_ws_kernel, dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * WS_BUF, st, p, ncg, n_rt);
     return cp_check_launch();
   }
   if (d->dtype == CP_F32) {
-    if (residual) hipLaunchKernelGGL((gemm_rows_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
-    else hipLaunchKernelGGL((gemm_rows_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+    if (residual) CP_LAUNCH((gemm_rows_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+    else CP_LAUNCH((gemm_rows_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
   } else {
-    if (residual) hipLaunchKernelGGL((gemm_rows_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
-    else hipLaunchKernelGGL((gemm_rows_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+    if (residual) CP_LAUNCH((gemm_rows_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+    else CP_LAUNCH((gemm_rows_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
   }
   return cp_check_launch();
 }

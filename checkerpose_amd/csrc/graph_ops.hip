@@ -87,6 +87,7 @@ static int launch_edge(hipStream_t st, const void* pq, const int32_t* idx, const
   constexpr int KPB = 256 / TPK;
   const int chunks = (N + KPB - 1) / KPB;
   const int grid = 8 * ((B + 7) / 8) * chunks;
+  cp_mark_kernel("edgeconv_gather_max_kernel<%s, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : "F32Tag", TPK);
   hipLaunchKernelGGL((edgeconv_gather_max_kernel<Tag, TPK>), dim3(grid), dim3(256), KPB * K * sizeof(int32_t), st, pq, idx,
                      gids, out, B, N, K, chunks, out_cs, out_coff, slope);
   return cp_check_launch();
@@ -152,10 +153,10 @@ extern "C" int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* p
   const size_t total = (size_t)B * N * 4 * EG;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(index2feat_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,
+    CP_LAUNCH(index2feat_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,
                        out, N, Hp, Wp, EG, k, out_cstride, out_coff, total);
   else
-    hipLaunchKernelGGL(index2feat_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,
+    CP_LAUNCH(index2feat_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,
                        out, N, Hp, Wp, EG, k, out_cstride, out_coff, total);
   return cp_check_launch();
 }
@@ -190,7 +191,7 @@ extern "C" int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, 
   if (!bits || !x_id || !y_id || B <= 0 || N <= 0 || stage > 2) return CP_ERR_INVALID;
   if (stage < 0 && !mask) return CP_ERR_INVALID;
   const size_t total = (size_t)B * N;
-  hipLaunchKernelGGL(bits_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits, stage,
+  CP_LAUNCH(bits_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits, stage,
                      mask, x_id, y_id, x_id64, y_id64, N, total);
   return cp_check_launch();
 }
@@ -234,7 +235,7 @@ extern "C" int cp_correspondences(cp_stream_t stream, const float* bits, const f
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(count, 0, (size_t)B * 3 * sizeof(int32_t), st) != hipSuccess) return CP_ERR_HIP;
   const size_t total = (size_t)B * N;
-  hipLaunchKernelGGL(correspondences_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bits, seg, x_id, y_id,
+  CP_LAUNCH(correspondences_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bits, seg, x_id, y_id,
                      roi_xy_ori, p2d, valid, count, N, H * W, W, total);
   return cp_check_launch();
 }

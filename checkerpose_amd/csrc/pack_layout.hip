@@ -58,10 +58,10 @@ extern "C" int cp_pack_conv_weight(cp_stream_t stream, int dtype, const float* w
   const size_t total = cp_packed_weight_bytes(dtype, cout_rows, cin_phys, R, S) / cp_elem_size(dtype);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(pack_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
+    CP_LAUNCH(pack_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
                        R, S, cin_phys, transposed, phase, row_map, cout_rows, KC, total);
   else
-    hipLaunchKernelGGL(pack_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
+    CP_LAUNCH(pack_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
                        R, S, cin_phys, transposed, phase, row_map, cout_rows, KC, total);
   return cp_check_launch();
 }
@@ -91,9 +91,9 @@ extern "C" int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, v
   const size_t total = (size_t)B * H * W;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, Cphys, total);
+    CP_LAUNCH(nchw_to_nhwc_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, Cphys, total);
   else if (dtype == CP_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, Cphys, total);
+    CP_LAUNCH(nchw_to_nhwc_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, Cphys, total);
   else return CP_ERR_INVALID;
   return cp_check_launch();
 }
@@ -120,9 +120,9 @@ extern "C" int cp_nhwc_to_nchw_f32(cp_stream_t stream, int dtype, const void* in
   if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || in_coff + C > in_cstride) return CP_ERR_INVALID;
   dim3 grid((H * W + 31) / 32, (C + 31) / 32, B), block(32, 8);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<F32Tag>, grid, block, 0, (hipStream_t)stream, in, out, C, H * W, in_cstride, in_coff);
+    CP_LAUNCH(nhwc_to_nchw_kernel<F32Tag>, grid, block, 0, (hipStream_t)stream, in, out, C, H * W, in_cstride, in_coff);
   else if (dtype == CP_BF16)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16Tag>, grid, block, 0, (hipStream_t)stream, in, out, C, H * W, in_cstride, in_coff);
+    CP_LAUNCH(nhwc_to_nchw_kernel<BF16Tag>, grid, block, 0, (hipStream_t)stream, in, out, C, H * W, in_cstride, in_coff);
   else return CP_ERR_INVALID;
   return cp_check_launch();
 }
@@ -152,10 +152,10 @@ extern "C" int cp_u8hwc_to_nhwc_norm(cp_stream_t stream, int dtype, const uint8_
   const size_t total = (size_t)B * H * W * Cphys;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    hipLaunchKernelGGL(u8_to_nhwc_norm_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Cphys, mean3[0],
+    CP_LAUNCH(u8_to_nhwc_norm_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Cphys, mean3[0],
                        mean3[1], mean3[2], std3[0], std3[1], std3[2], total);
   else if (dtype == CP_BF16)
-    hipLaunchKernelGGL(u8_to_nhwc_norm_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Cphys, mean3[0],
+    CP_LAUNCH(u8_to_nhwc_norm_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Cphys, mean3[0],
                        mean3[1], mean3[2], std3[0], std3[1], std3[2], total);
   else return CP_ERR_INVALID;
   return cp_check_launch();

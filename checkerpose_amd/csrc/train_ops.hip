@@ -116,6 +116,7 @@ static int launch_edge_bwd_a(hipStream_t st, const void* pq, const int32_t* idx,
   constexpr int KPB = 256 / TPK;
   const int chunks = (N + KPB - 1) / KPB;
   const int grid = 8 * ((B + 7) / 8) * chunks;
+  cp_mark_kernel("edgeconv_bwd_a_kernel<%s, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : "F32Tag", TPK);
   hipLaunchKernelGGL((edgeconv_bwd_a_kernel<Tag, TPK>), dim3(grid), dim3(256), KPB * K * sizeof(int32_t), st, pq, idx, gids,
                      gout, dpq, kstar, B, N, K, chunks, g_cs, g_coff, slope);
   return cp_check_launch();
@@ -145,7 +146,7 @@ extern "C" int cp_edgeconv_gather_max_bwd(cp_stream_t stream, int dtype, const v
   if (rc != CP_OK) return rc;
   const int npb = 256 / (C / 4);
   const int chunks = (N + npb - 1) / npb;
-  hipLaunchKernelGGL(edgeconv_bwd_b_kernel, dim3(8 * ((B + 7) / 8) * chunks), dim3(256), 0, st, rev_ptr, rev_edge, graph_ids, dpq,
+  CP_LAUNCH(edgeconv_bwd_b_kernel, dim3(8 * ((B + 7) / 8) * chunks), dim3(256), 0, st, rev_ptr, rev_edge, graph_ids, dpq,
                      kstar, B, N, K, C, chunks);
   return cp_check_launch();
 }
@@ -187,7 +188,7 @@ extern "C" int cp_index2feat_gather_bwd(cp_stream_t stream, const float* gout, c
   if (hipMemsetAsync(dpatches, 0, (size_t)B * Hp * Wp * E_ch * sizeof(float), st) != hipSuccess) return CP_ERR_HIP;
   const int EG4 = E_ch / 4;
   const size_t total = (size_t)B * N * 4 * EG4;
-  hipLaunchKernelGGL(index2feat_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, x_id, y_id, mask,
+  CP_LAUNCH(index2feat_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, x_id, y_id, mask,
                      dpatches, N, Hp, Wp, EG4, k, gout_cstride, gout_coff, total);
   return cp_check_launch();
 }
@@ -292,8 +293,8 @@ extern "C" int cp_code_loss(cp_stream_t stream, int loss_type, const float* pred
   CodeLossArgs a{pred, gt, mask, dpred, pred_bstride, gt_bstride, dpred_bstride, B, nbits, N, loss_type, mask ? 1 : 0};
   const long long total = per * B;
   const int blocks = (int)((total + 255) / 256 < LOSS_BLOCKS ? (total + 255) / 256 : LOSS_BLOCKS);
-  hipLaunchKernelGGL(code_loss_kernel, dim3(blocks), dim3(256), 0, st, a, ws, loss);
-  if (dpred) hipLaunchKernelGGL(code_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, ws);
+  CP_LAUNCH(code_loss_kernel, dim3(blocks), dim3(256), 0, st, a, ws, loss);
+  if (dpred) CP_LAUNCH(code_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, ws);
   return cp_check_launch();
 }
 
@@ -341,7 +342,7 @@ extern "C" int cp_mask_loss(cp_stream_t stream, const float* pred, long long pre
   MaskLossArgs a{pred, gt, dpred, pred_bstride, dpred_bstride, B, h, w, Hm, Wm};
   const long long total = per * B;
   const int blocks = (int)((total + 255) / 256 < LOSS_BLOCKS ? (total + 255) / 256 : LOSS_BLOCKS);
-  hipLaunchKernelGGL(mask_loss_kernel, dim3(blocks), dim3(256), 0, st, a, ws, loss);
-  if (dpred) hipLaunchKernelGGL(mask_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, ws);
+  CP_LAUNCH(mask_loss_kernel, dim3(blocks), dim3(256), 0, st, a, ws, loss);
+  if (dpred) CP_LAUNCH(mask_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, ws);
   return cp_check_launch();
 }

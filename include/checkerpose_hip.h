@@ -11,7 +11,8 @@
  *   - plain pointers + ints, no torch / HIP types in signatures; `cp_stream_t` is a hipStream_t
  *     passed as void* (NULL = default stream).
  *   - every buffer (activations, packed weights, outputs) is caller-owned DEVICE memory; the
- *     library allocates nothing, keeps no mutable global state, is re-entrant and stream-ordered.
+ *     library allocates nothing, keeps no mutable global state (beyond the thread-local cp_last_kernel note),
+ *     is re-entrant and stream-ordered.
  *   - activations are channels-last: (B, H, W, Cphys) with Cphys a multiple of cp_chan_align(dtype);
  *     padded channels are zero.  Graph features are (B, N, Cphys), i.e. the same layout with H=1.
  *   - returns CP_OK (0) or a negative code; cp_strerror() names it.
@@ -41,6 +42,9 @@ enum {
 
 int cp_version(void);
 const char* cp_strerror(int code);
+/* profiling aid: symbol of the HIP kernel the calling thread's most recent entry point launched, spelled as
+ * rocprofv3 --kernel-trace prints it (e.g. "conv_igemm_kernel<BF16Tag, 2, 4>"); "" before the first launch. */
+const char* cp_last_kernel(void);
 
 /* elements per 16 bytes: 4 (f32) or 8 (bf16).  Physical channel counts are multiples of this. */
 int cp_chan_align(int dtype);

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:70]
 
 
