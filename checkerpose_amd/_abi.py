@@ -24,6 +24,16 @@ class CpConvDesc(C.Structure):
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
+
+class CpWgradDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
+                ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
+                ("Cin", C.c_int32), ("x_cstride", C.c_int32), ("x_coff", C.c_int32),
+                ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("dw_base", C.c_int64), ("dw_sco", C.c_int64), ("dw_sci", C.c_int64), ("dw_sr", C.c_int64),
+                ("dw_ss", C.c_int64)]
+
+
 # name -> (restype, argtypes); exactly the symbols declared in include/checkerpose_hip.h
 SIGNATURES = {
     "cp_version": (_I, []),
@@ -55,6 +65,24 @@ SIGNATURES = {
     "cp_loss_workspace_bytes": (C.c_size_t, []),
     "cp_code_loss": (_I, [_P, _I, _P, _L, _P, _L, _P, _I, _I, _I, _P, _P, _L, _P]),
     "cp_mask_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
+    "cp_conv2d_wgrad": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P]),
+    "cp_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cp_bn_workspace_bytes": (C.c_size_t, [_I]),
+    "cp_bn_train_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "cp_affine_act": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F]),
+    "cp_bn_bwd_workspace_bytes": (C.c_size_t, [_I]),
+    "cp_bn_train_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
+                             _I, _P, _P, _P]),
+    "cp_edge_train_workspace_bytes": (C.c_size_t, [_I, _I]),
+    "cp_edgeconv_train_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P, _P, _P,
+                                   _I, _I, _I, _I, _I, _F]),
+    "cp_edgeconv_train_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                                   _I, _I, _I, _I, _I, _F]),
+    "cp_edge_weight_view": (_I, [_P, _P, _I, _I, _I, _P]),
+    "cp_upsample2x_bilinear_ac_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_fuse_sum_act_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_memset_zero": (_I, [_P, _P, C.c_size_t]),
+    "cp_strided_to_nhwc": (_I, [_P, _I, _P, _L, _L, _L, _L, _P, _I, _I, _I, _I]),
     "cp_nchw_to_nhwc": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I]),
     "cp_u8hwc_to_nhwc_norm": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cp_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),

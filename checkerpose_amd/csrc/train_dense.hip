@@ -1,0 +1,539 @@
+// Training-side helpers of the dense layers: train-mode BatchNorm2d (batch statistics, running
+// stat update, backward), bias/activation backward, data-gradient weight transform, and the backward of the two
+// resampling ops (bilinear x2 align_corners, HRNet nearest-upsample fuse sum).  All memory-bound: one thread per
+// 16-byte channel group, per-channel sums are reduced in fp64 (block partials -> one finalize launch; no atomics, so
+// the statistics are run-to-run deterministic).
+//
+// Replaces (reference /root/reference/checkerpose): nn.BatchNorm2d in .train() mode inside timm's hrnet
+// (model/backbone.py:48), model/init.py:60 + model/pipeline.py:51 (EdgeConv BN), pipeline.py:189,194,203,208 (decoder
+// BN) and their autograd; nn.UpsamplingBilinear2d backward (pipeline.py:199).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ small plumbing
+extern "C" int cp_memset_zero(cp_stream_t stream, void* p, size_t nbytes) {
+  if (!p) return CP_ERR_INVALID;
+  return hipMemsetAsync(p, 0, nbytes, (hipStream_t)stream) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+
+__global__ void weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int R, int S,
+                                    size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over wt (Cin, Cout, R, S)
+  if (i >= total) return;
+  const int s = (int)(i % S);
+  size_t t = i / S;
+  const int r = (int)(t % R); t /= R;
+  const int co = (int)(t % Cout);
+  const int ci = (int)(t / Cout);
+  wt[i] = w[(((size_t)co * Cin + ci) * R + (R - 1 - r)) * S + (S - 1 - s)];
+}
+
+extern "C" int cp_weight_dgrad(cp_stream_t stream, const float* w, int Cout, int Cin, int R, int S, float* wt) {
+  if (!w || !wt || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return CP_ERR_INVALID;
+  const size_t total = (size_t)Cout * Cin * R * S;
+  CP_LAUNCH(weight_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin,
+            R, S, total);
+  return cp_check_launch();
+}
+
+// EdgeConv weight views (init.py:58-62): w (C', 2C) = [W1 | W2].
+//   mode 0 (forward / weight-gradient view): out (2C', C) = [W1 ; W2 - W1]
+//   mode 1 (data-gradient view):             out (C, 2C') : out[c][c'] = W1[c'][c], out[c][C'+c'] = W2[c'][c]
+__global__ void edge_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int mode, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  if (mode == 0) {
+    const int c = (int)(i % Ci);
+    const int row = (int)(i / Ci);
+    const int co = row < Co ? row : row - Co;
+    const float w1 = w[(size_t)co * 2 * Ci + c], w2 = w[(size_t)co * 2 * Ci + Ci + c];
+    out[i] = row < Co ? w1 : w2 - w1;
+  } else {
+    const int col = (int)(i % (2 * Co));
+    const int c = (int)(i / (2 * Co));
+    out[i] = col < Co ? w[(size_t)col * 2 * Ci + c] : w[(size_t)(col - Co) * 2 * Ci + Ci + c];
+  }
+}
+
+extern "C" int cp_edge_weight_view(cp_stream_t stream, const float* w, int Cout, int Cin, int mode, float* out) {
+  if (!w || !out || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return CP_ERR_INVALID;
+  const size_t total = (size_t)2 * Cout * Cin;
+  CP_LAUNCH(edge_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin,
+            mode, total);
+  return cp_check_launch();
+}
+
+// fp32 tensor with arbitrary element strides -> channels-last `dtype` (B, HW, Cphys), padded channels zero.
+template <typename Tag>
+__global__ void strided_to_nhwc_kernel(const float* __restrict__ src, long long base, long long sb, long long sp, long long sc,
+                                       void* __restrict__ out, int HW, int C, int Cphys, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*Cphys
+  if (i >= total) return;
+  const int c = (int)(i % Cphys);
+  const size_t t = i / Cphys;
+  const int pix = (int)(t % HW);
+  const size_t b = t / HW;
+  const float v = c < C ? src[base + (long long)b * sb + (long long)pix * sp + (long long)c * sc] : 0.f;
+  store_elem<Tag>(out, i, v);
+}
+
+extern "C" int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const float* src, long long base, long long sb, long long sp,
+                                  long long sc, void* out, int B, int HW, int C, int Cphys) {
+  if (!src || !out || B <= 0 || HW <= 0 || C <= 0 || Cphys < C) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const size_t total = (size_t)B * HW * Cphys;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    CP_LAUNCH(strided_to_nhwc_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, base, sb, sp, sc, out, HW, C, Cphys, total);
+  else
+    CP_LAUNCH(strided_to_nhwc_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, base, sb, sp, sc, out, HW, C, Cphys, total);
+  return cp_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// Per-channel sums of two derived quantities over the M rows of a channels-last tensor, fp64 block partials:
+//   mode 0: (x, x^2)                                   -- BatchNorm batch statistics
+//   mode 1: (dz, dz * xhat), dz = dy * act'(y)         -- BatchNorm / bias backward reductions
+struct ColsumParams {
+  const void* a; int a_cs, a_coff;      // mode 0: x ; mode 1: dy
+  const void* y; int y_cs, y_coff;      // mode 1: post-activation output (NULL: no activation)
+  const void* x; int x_cs, x_coff;      // mode 1: raw BN input (NULL: xhat := 0)
+  const float* mean; const float* rstd;
+  float slope; int act;
+  int M, G, RL, rpb;
+  double* partial;                      // [nblk][2][G*E]
+};
+
+template <typename Tag, int MODE>
+__global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
+  constexpr int E = Tag::E;
+  __shared__ double red[256 * 2 * E];
+  const int tid = threadIdx.x;
+  const int rl = tid / p.G, piece = tid - rl * p.G;
+  double s1[E], s2[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
+  if (rl < p.RL) {
+    const int m_end = min((int)(blockIdx.x + 1) * p.rpb, p.M);
+    float mu[E], rs[E];
+    if (MODE == 1 && p.x) {
+#pragma unroll
+      for (int j = 0; j < E; ++j) { mu[j] = p.mean[piece * E + j]; rs[j] = p.rstd[piece * E + j]; }
+    }
+    for (int m = blockIdx.x * p.rpb + rl; m < m_end; m += p.RL) {
+      float a[E];
+      Vec16<Tag>::unpack(*(const u32x4*)((const typename Tag::elem*)p.a + (size_t)m * p.a_cs + p.a_coff + piece * E), a);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) { s1[j] += (double)a[j]; s2[j] += (double)a[j] * (double)a[j]; }
+      } else {
+        if (p.y) {
+          float yv[E];
+          Vec16<Tag>::unpack(*(const u32x4*)((const typename Tag::elem*)p.y + (size_t)m * p.y_cs + p.y_coff + piece * E), yv);
+#pragma unroll
+          for (int j = 0; j < E; ++j) a[j] = yv[j] > 0.f ? a[j] : a[j] * p.slope;
+        }
+        if (p.x) {
+          float xv[E];
+          Vec16<Tag>::unpack(*(const u32x4*)((const typename Tag::elem*)p.x + (size_t)m * p.x_cs + p.x_coff + piece * E), xv);
+#pragma unroll
+          for (int j = 0; j < E; ++j) { s1[j] += (double)a[j]; s2[j] += (double)a[j] * (double)((xv[j] - mu[j]) * rs[j]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < E; ++j) s1[j] += (double)a[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < E; ++j) { red[tid * 2 * E + j] = s1[j]; red[tid * 2 * E + E + j] = s2[j]; }
+  __syncthreads();
+  const int CP = p.G * E;
+  for (int o = tid; o < 2 * CP; o += 256) {
+    const int which = o / CP, c = o - which * CP;
+    const int pc = c / E, j = c - pc * E;
+    double s = 0.0;
+    for (int r = 0; r < p.RL; ++r) s += red[(r * p.G + pc) * 2 * E + which * E + j];
+    p.partial[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
+  }
+}
+
+static int colsum_plan(int M, int Cphys, int E, int* G, int* RL, int* nblk, int* rpb) {
+  *G = Cphys / E;
+  if (*G > 256) return CP_ERR_INVALID;
+  *RL = 256 / *G;
+  int nb = M / 128;
+  nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+  *rpb = (M + nb - 1) / nb;
+  *nblk = (M + *rpb - 1) / *rpb;
+  return CP_OK;
+}
+
+extern "C" size_t cp_bn_workspace_bytes(int C) { return (size_t)512 * 2 * ((size_t)(C + 15) / 16 * 16) * sizeof(double); }
+
+// forward finalize: mean / biased var -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                                       float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cvec) return;
+  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; rstd[c] = 0.f; return; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  mean[c] = (float)mu;
+  rstd[c] = rs;
+  scale[c] = g * rs;
+  shift[c] = bt - (float)mu * g * rs;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+
+// shared by cp_bn_train_stats and the EdgeConv statistics (train_edge.hip)
+int cp_bn_finalize_launch(hipStream_t st, const double* partial, int nblk, int CP, int C, double count, const float* gamma,
+                          const float* beta, float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
+                          float* mean, float* rstd) {
+  const int Cvec = (C + 15) / 16 * 16;
+  CP_LAUNCH(bn_fwd_finalize_kernel, dim3((Cvec + 63) / 64), dim3(64), 0, st, partial, nblk, CP, C, Cvec, count, gamma, beta,
+            eps, momentum, rmean, rvar, scale, shift, mean, rstd);
+  return cp_check_launch();
+}
+
+static int check_cl(int dtype, const void* p, int cs, int coff, int Cphys) {
+  const int E = cp_chan_align(dtype);
+  if (!p) return CP_ERR_INVALID;
+  if (cs % E || coff % E || coff + Cphys > cs || !cp_aligned16(p)) return CP_ERR_ALIGN;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_train_stats(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                                 void* workspace) {
+  if (!scale || !shift || !mean || !rstd || !workspace || M <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E;
+  int rc = check_cl(dtype, x, x_cstride, x_coff, Cphys);
+  if (rc) return rc;
+  ColsumParams p = {};
+  int nblk;
+  if ((rc = colsum_plan(M, Cphys, E, &p.G, &p.RL, &nblk, &p.rpb))) return rc;
+  p.a = x; p.a_cs = x_cstride; p.a_coff = x_coff; p.M = M; p.partial = (double*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 0>), dim3(nblk), dim3(256), 0, st, p);
+  else CP_LAUNCH((colsum2_kernel<BF16Tag, 0>), dim3(nblk), dim3(256), 0, st, p);
+  if ((rc = cp_check_launch())) return rc;
+  return cp_bn_finalize_launch(st, p.partial, nblk, Cphys, C, (double)M, gamma, beta, eps, momentum, running_mean, running_var,
+                               scale, shift, mean, rstd);
+}
+
+// ------------------------------------------------------------------------------------------------ y = act(x*s + t + res)
+struct AffineParams {
+  const void* x; int x_cs, x_coff;
+  const void* res; int r_cs, r_coff;
+  void* y; int y_cs, y_coff;
+  const float* scale; const float* shift;
+  int G, act; float slope; size_t total;
+};
+
+template <typename Tag>
+__global__ void affine_act_kernel(const AffineParams p) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M*G
+  if (i >= p.total) return;
+  const int g = (int)(i % p.G);
+  const size_t m = i / p.G;
+  float v[E], r[E];
+  Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E), v);
+#pragma unroll
+  for (int j = 0; j < E; ++j) v[j] = v[j] * p.scale[g * E + j] + p.shift[g * E + j];
+  if (p.res) {
+    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.res + m * p.r_cs + p.r_coff + g * E), r);
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] += r[j];
+  }
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+    else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+  }
+  *(u32x4*)((T*)p.y + m * p.y_cs + p.y_coff + g * E) = Vec16<Tag>::pack(v);
+}
+
+extern "C" int cp_affine_act(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const float* scale,
+                             const float* shift, const void* res, int res_cstride, int res_coff, void* y, int y_cstride,
+                             int y_coff, int M, int C, int act, float slope) {
+  if (!scale || !shift || M <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E;
+  int rc;
+  if ((rc = check_cl(dtype, x, x_cstride, x_coff, Cphys)) || (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (res && (rc = check_cl(dtype, res, res_cstride, res_coff, Cphys))) return rc;
+  AffineParams p;
+  p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.res = res; p.r_cs = res_cstride; p.r_coff = res_coff;
+  p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.scale = scale; p.shift = shift;
+  p.G = Cphys / E; p.act = act; p.slope = slope; p.total = (size_t)M * p.G;
+  const unsigned blocks = (unsigned)((p.total + 255) / 256);
+  if (dtype == CP_F32) CP_LAUNCH(affine_act_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else CP_LAUNCH(affine_act_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return cp_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ BN / bias backward
+// coef[0..3][Cvec]: a = gamma*rstd, b = mean(dz), c = mean(dz*xhat)*rstd, mu ; dgamma / dbeta written for c < C
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, int has_bn, float* __restrict__ coef,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cvec) return;
+  if (c >= C) { coef[c] = 0.f; coef[Cvec + c] = 0.f; coef[2 * Cvec + c] = 0.f; coef[3 * Cvec + c] = 0.f; return; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (has_bn) {
+    if (dgamma) dgamma[c] = (float)s2;
+    const float g = gamma ? gamma[c] : 1.f;
+    coef[c] = g * rstd[c];
+    coef[Cvec + c] = (float)(s1 / count);
+    coef[2 * Cvec + c] = (float)(s2 / count) * rstd[c];
+    coef[3 * Cvec + c] = mean[c];
+  } else {
+    coef[c] = 1.f; coef[Cvec + c] = 0.f; coef[2 * Cvec + c] = 0.f; coef[3 * Cvec + c] = 0.f;
+  }
+}
+
+int cp_bn_bwd_finalize_launch(hipStream_t st, const double* partial, int nblk, int CP, int C, double count, const float* gamma,
+                              const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta) {
+  const int Cvec = (C + 15) / 16 * 16;
+  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 63) / 64), dim3(64), 0, st, partial, nblk, CP, C, Cvec, count, gamma, mean,
+            rstd, 1, coef, dgamma, dbeta);
+  return cp_check_launch();
+}
+
+struct BnBwdParams {
+  const void* dy; int dy_cs, dy_coff;
+  const void* y; int y_cs, y_coff;
+  const void* x; int x_cs, x_coff;
+  void* dx; int dx_cs, dx_coff;
+  void* dres; int dr_cs, dr_coff, dr_acc;
+  const float* coef; int Cvec;
+  int G; float slope; size_t total;
+};
+
+template <typename Tag>
+__global__ void bn_bwd_dx_kernel(const BnBwdParams p) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.total) return;
+  const int g = (int)(i % p.G);
+  const size_t m = i / p.G;
+  float dz[E], t[E];
+  Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.dy + m * p.dy_cs + p.dy_coff + g * E), dz);
+  if (p.y) {
+    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.y + m * p.y_cs + p.y_coff + g * E), t);
+#pragma unroll
+    for (int j = 0; j < E; ++j) dz[j] = t[j] > 0.f ? dz[j] : dz[j] * p.slope;
+  }
+  if (p.dres) {
+    float o[E];
+    if (p.dr_acc) {
+      Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.dres + m * p.dr_cs + p.dr_coff + g * E), o);
+#pragma unroll
+      for (int j = 0; j < E; ++j) o[j] += dz[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < E; ++j) o[j] = dz[j];
+    }
+    *(u32x4*)((T*)p.dres + m * p.dr_cs + p.dr_coff + g * E) = Vec16<Tag>::pack(o);
+  }
+  float xv[E];
+  if (p.x) Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E), xv);
+  float o[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int c = g * E + j;
+    const float a = p.coef[c], b = p.coef[p.Cvec + c], cr = p.coef[2 * p.Cvec + c], mu = p.coef[3 * p.Cvec + c];
+    o[j] = p.x ? a * (dz[j] - b - (xv[j] - mu) * cr) : dz[j];
+  }
+  *(u32x4*)((T*)p.dx + m * p.dx_cs + p.dx_coff + g * E) = Vec16<Tag>::pack(o);
+}
+
+extern "C" size_t cp_bn_bwd_workspace_bytes(int C) {
+  return cp_bn_workspace_bytes(C) + (size_t)4 * ((size_t)(C + 15) / 16 * 16) * sizeof(float);
+}
+
+extern "C" int cp_bn_train_bwd(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                               int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                               const float* rstd, const float* gamma, int M, int C, int act, float slope, void* dx,
+                               int dx_cstride, int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate,
+                               float* dgamma, float* dbeta, void* workspace) {
+  if (!workspace || M <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (x && (!mean || !rstd)) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
+  int rc;
+  if ((rc = check_cl(dtype, dy, dy_cstride, dy_coff, Cphys)) || (rc = check_cl(dtype, dx, dx_cstride, dx_coff, Cphys))) return rc;
+  const void* yy = act == CP_ACT_NONE ? nullptr : y;
+  if (act != CP_ACT_NONE && (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (x && (rc = check_cl(dtype, x, x_cstride, x_coff, Cphys))) return rc;
+  if (dres && (rc = check_cl(dtype, dres, dres_cstride, dres_coff, Cphys))) return rc;
+  const float sl = act == CP_ACT_RELU ? 0.f : slope;
+  ColsumParams p = {};
+  int nblk;
+  if ((rc = colsum_plan(M, Cphys, E, &p.G, &p.RL, &nblk, &p.rpb))) return rc;
+  p.a = dy; p.a_cs = dy_cstride; p.a_coff = dy_coff; p.y = yy; p.y_cs = y_cstride; p.y_coff = y_coff;
+  p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.mean = mean; p.rstd = rstd; p.slope = sl; p.act = act;
+  p.M = M; p.partial = (double*)workspace;
+  float* coef = (float*)((char*)workspace + cp_bn_workspace_bytes(C));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 1>), dim3(nblk), dim3(256), 0, st, p);
+  else CP_LAUNCH((colsum2_kernel<BF16Tag, 1>), dim3(nblk), dim3(256), 0, st, p);
+  if ((rc = cp_check_launch())) return rc;
+  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 63) / 64), dim3(64), 0, st, p.partial, nblk, Cphys, C, Cvec, (double)M, gamma,
+            mean, rstd, x ? 1 : 0, coef, dgamma, dbeta);
+  if ((rc = cp_check_launch())) return rc;
+  BnBwdParams q;
+  q.dy = dy; q.dy_cs = dy_cstride; q.dy_coff = dy_coff; q.y = yy; q.y_cs = y_cstride; q.y_coff = y_coff;
+  q.x = x; q.x_cs = x_cstride; q.x_coff = x_coff; q.dx = dx; q.dx_cs = dx_cstride; q.dx_coff = dx_coff;
+  q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
+  q.coef = coef; q.Cvec = Cvec; q.G = Cphys / E; q.slope = sl; q.total = (size_t)M * q.G;
+  const unsigned blocks = (unsigned)((q.total + 255) / 256);
+  if (dtype == CP_F32) CP_LAUNCH(bn_bwd_dx_kernel<F32Tag>, dim3(blocks), dim3(256), 0, st, q);
+  else CP_LAUNCH(bn_bwd_dx_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, st, q);
+  return cp_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ resampling backward
+// Adjoint of cp_upsample2x_bilinear_ac in gather form (deterministic): input pixel (y,x) collects every output pixel
+// whose 2x2 footprint touches it, with the forward's own fp32 weights.
+template <typename Tag>
+__global__ void upsample2x_bwd_kernel(const void* __restrict__ dout, void* __restrict__ din, int H, int W, int CG, int o_cs,
+                                      int o_coff, int i_cs, int i_coff, float sy, float sx, int accumulate, size_t total) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W*CG
+  if (i >= total) return;
+  const int g = (int)(i % CG);
+  size_t t = i / CG;
+  const int x = (int)(t % W); t /= W;
+  const int y = (int)(t % H);
+  const size_t b = t / H;
+  float acc[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) acc[j] = 0.f;
+  // candidate outputs: src = s*o in (y-1, y+1)  ->  o in ((y-1)/s, (y+1)/s); scan a safe integer window
+  const int oy_lo = max(0, (int)floorf((y - 1) / fmaxf(sy, 1e-20f)) - 1), oy_hi = min(2 * H - 1, (int)ceilf((y + 1) / fmaxf(sy, 1e-20f)) + 1);
+  const int ox_lo = max(0, (int)floorf((x - 1) / fmaxf(sx, 1e-20f)) - 1), ox_hi = min(2 * W - 1, (int)ceilf((x + 1) / fmaxf(sx, 1e-20f)) + 1);
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float fy = sy * oy;
+    const int y0 = (int)fy, y1 = y0 + (y0 < H - 1);
+    const float ly1 = fy - y0, ly0 = 1.f - ly1;
+    const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
+    if (y0 != y && y1 != y) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = sx * ox;
+      const int x0 = (int)fx, x1 = x0 + (x0 < W - 1);
+      const float lx1 = fx - x0, lx0 = 1.f - lx1;
+      const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+      if (x0 != x && x1 != x) continue;
+      float d[E];
+      Vec16<Tag>::unpack(*(const u32x4*)((const T*)dout + ((b * 2 * H + oy) * 2 * W + ox) * o_cs + o_coff + (size_t)g * E), d);
+      const float w = wy * wx;
+#pragma unroll
+      for (int j = 0; j < E; ++j) acc[j] += w * d[j];
+    }
+  }
+  T* dst = (T*)din + ((b * H + y) * W + x) * i_cs + i_coff + (size_t)g * E;
+  if (accumulate) {
+    float o[E];
+    Vec16<Tag>::unpack(*(const u32x4*)dst, o);
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] += o[j];
+  }
+  *(u32x4*)dst = Vec16<Tag>::pack(acc);
+}
+
+extern "C" int cp_upsample2x_bilinear_ac_bwd(cp_stream_t stream, int dtype, const void* dout, void* din, int B, int H, int W,
+                                             int C, int out_cstride, int out_coff, int in_cstride, int in_coff, int accumulate) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (C % E) return CP_ERR_ALIGN;
+  int rc;
+  if ((rc = check_cl(dtype, dout, out_cstride, out_coff, C)) || (rc = check_cl(dtype, din, in_cstride, in_coff, C))) return rc;
+  const float sy = H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+  const float sx = W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+  const int CG = C / E;
+  const size_t total = (size_t)B * H * W * CG;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    CP_LAUNCH(upsample2x_bwd_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, din, H, W, CG, out_cstride,
+              out_coff, in_cstride, in_coff, sy, sx, accumulate, total);
+  else
+    CP_LAUNCH(upsample2x_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, din, H, W, CG, out_cstride,
+              out_coff, in_cstride, in_coff, sy, sx, accumulate, total);
+  return cp_check_launch();
+}
+
+// Backward of cp_fuse_sum_act for ONE source: dsrc[b,y,x,:] (+)= sum over the 2^sh x 2^sh block of dout * [out > 0]
+template <typename Tag>
+__global__ void fuse_sum_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ out, void* __restrict__ dsrc, int Hs,
+                                    int Ws, int CG, int sh, int relu, int accumulate, size_t total) {
+  constexpr int E = Tag::E;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*Hs*Ws*CG
+  if (i >= total) return;
+  const int g = (int)(i % CG);
+  size_t t = i / CG;
+  const int x = (int)(t % Ws); t /= Ws;
+  const int y = (int)(t % Hs);
+  const size_t b = t / Hs;
+  const int n = 1 << sh, H = Hs << sh, W = Ws << sh;
+  float acc[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) acc[j] = 0.f;
+  for (int dy = 0; dy < n; ++dy)
+    for (int dx = 0; dx < n; ++dx) {
+      const size_t v = ((b * H + (y << sh) + dy) * W + (x << sh) + dx) * CG + g;
+      float d[E], o[E];
+      Vec16<Tag>::unpack(((const u32x4*)dout)[v], d);
+      if (relu) {
+        Vec16<Tag>::unpack(((const u32x4*)out)[v], o);
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[j] += o[j] > 0.f ? d[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[j] += d[j];
+      }
+    }
+  if (accumulate) {
+    float o[E];
+    Vec16<Tag>::unpack(((const u32x4*)dsrc)[i], o);
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] += o[j];
+  }
+  ((u32x4*)dsrc)[i] = Vec16<Tag>::pack(acc);
+}
+
+extern "C" int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs,
+                                   int Ws, int C, int shift, int relu, int accumulate) {
+  if (!dout || !dsrc || (relu && !out) || B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || shift < 0 || shift > 5) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (C % E || !cp_aligned16(dout) || !cp_aligned16(dsrc) || (out && !cp_aligned16(out))) return CP_ERR_ALIGN;
+  const int CG = C / E;
+  const size_t total = (size_t)B * Hs * Ws * CG;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    CP_LAUNCH(fuse_sum_bwd_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, out, dsrc, Hs, Ws, CG, shift, relu, accumulate, total);
+  else
+    CP_LAUNCH(fuse_sum_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, out, dsrc, Hs, Ws, CG, shift, relu, accumulate, total);
+  return cp_check_launch();
+}

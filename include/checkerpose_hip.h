@@ -227,6 +227,92 @@ int cp_code_loss(cp_stream_t stream, int loss_type, const float* pred, long long
 int cp_mask_loss(cp_stream_t stream, const float* pred, long long pred_bstride, const float* gt, int B, int h,
                  int w, int Hm, int Wm, float* loss, float* dpred, long long dpred_bstride, void* workspace);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training side, dense layers (reference train.py:319 `loss.backward()` through every
+ * nn.Conv2d / nn.ConvTranspose2d / nn.Linear of the path).
+ *
+ * Weight gradient:  dw[dw_base + co*dw_sco + ci*dw_sci + r*dw_sr + s*dw_ss] +=
+ *       sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*stride-pad+r, ox*stride-pad+s, ci]          (fp32 atomics)
+ * dy (B,Ho,Wo,dy_cstride) and x (B,H,W,x_cstride) are channels-last `dtype` tensors (channel slices via *_coff);
+ * the caller zeroes dw first.  nn.Conv2d weight (Cout,Cin,R,S): dw_sco = Cin*R*S, dw_sci = R*S, dw_sr = S, dw_ss = 1.
+ * nn.ConvTranspose2d(k3,s2,p1,op1) weight (Cin_t,Cout_t,3,3): pass the layer INPUT as `dy` (coarse grid) and the
+ * output gradient as `x` (fine grid), stride 2, pad 1 -- same strides.  Data-gradients need no entry point of their
+ * own: they are cp_conv2d_igemm / cp_conv3x3_halo / cp_gemm_rows launches over dy with cp_weight_dgrad()'s weights.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct CpWgradDesc {
+  int32_t dtype;
+  int32_t B, H, W;             /* x spatial size */
+  int32_t Ho, Wo;              /* dy spatial size */
+  int32_t Cout, dy_cstride, dy_coff;
+  int32_t Cin, x_cstride, x_coff;
+  int32_t R, S, stride, pad;
+  int64_t dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
+} CpWgradDesc;
+int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw);
+
+/* Weights of the data-gradient of a stride-1 conv: w (Cout,Cin,R,S) fp32 -> wt (Cin,Cout,R,S) fp32 with both taps
+ * flipped (wt[ci][co][r][s] = w[co][ci][R-1-r][S-1-s]); dx = conv(dy, wt, stride 1, pad R-1-pad).  (Stride-2 3x3
+ * convs use the transposed=1 phase packing of cp_pack_conv_weight on w itself; ConvTranspose2d's data-gradient is a
+ * plain stride-2 conv with w read as (Cout'=Cin_t, Cin'=Cout_t, 3, 3).) */
+int cp_weight_dgrad(cp_stream_t stream, const float* w, int Cout, int Cin, int R, int S, float* wt);
+
+/* Train-mode BatchNorm2d (nn.BatchNorm2d defaults: eps 1e-5, momentum 0.1; inside timm hrnet, init.py:60,
+ * pipeline.py:51,189-208) over the M = B*H*W rows of a channels-last tensor, C logical channels.
+ * cp_bn_train_stats: batch mean / biased variance (fp64 sums) -> scale = gamma*rstd, shift = beta - mean*scale (fp32
+ * vectors of ceil16(C) entries, zero beyond C), mean / rstd saved for the backward; running_mean / running_var
+ * updated in place with `momentum` (unbiased variance), NULL = skip.  gamma / beta NULL = 1 / 0.
+ * workspace: cp_bn_workspace_bytes(C). */
+size_t cp_bn_workspace_bytes(int C);
+int cp_bn_train_stats(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                      float eps, float* scale, float* shift, float* mean, float* rstd, void* workspace);
+/* y = act(x * scale[c] + shift[c] + res) elementwise (res optional; y may alias x or res). */
+int cp_affine_act(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const float* scale,
+                  const float* shift, const void* res, int res_cstride, int res_coff, void* y, int y_cstride, int y_coff,
+                  int M, int C, int act, float slope);
+/* Backward of y = act(BN(x) + res):  dz = dy * act'(y);  dres (+)= dz;  dgamma = sum dz*xhat;  dbeta = sum dz;
+ * dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  x == NULL selects the bias-only form (y = act(conv + b)):
+ * dx = dz, dbeta = sum dz.  dx may alias dy.  workspace: cp_bn_bwd_workspace_bytes(C). */
+size_t cp_bn_bwd_workspace_bytes(int C);
+int cp_bn_train_bwd(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                    int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                    const float* rstd, const float* gamma, int M, int C, int act, float slope, void* dx, int dx_cstride,
+                    int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma,
+                    float* dbeta, void* workspace);
+
+/* Train-mode EdgeConv in factored form (StaticGraph_module init.py:54-68 with BatchNorm2d batch statistics over the
+ * B*N*K edges), see csrc/train_edge.hip.  pq (B,N,2C) = raw node GEMM output [P | Q] (W rows [W1 ; W2-W1], no
+ * affine); kstar (B,N,C) uint8 receives the arg-max neighbour slot; scale/shift/mean/rstd: C floats each.
+ * Backward writes dpq (B,N,2C) `dtype` = [dP - dQ | dQ], the operand of the node GEMM's weight- and data-gradient
+ * (cp_edge_weight_view mode 1), plus dgamma / dbeta.  rev_ptr (G,N+1), rev_edge (G,N*K): reverse adjacency as for
+ * cp_edgeconv_gather_max_bwd.  workspace: cp_edge_train_workspace_bytes(B, C).  C % 16 == 0. */
+size_t cp_edge_train_workspace_bytes(int B, int C);
+int cp_edgeconv_train_fwd(cp_stream_t stream, int dtype, const void* pq, const int32_t* idx, const int32_t* graph_ids,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                          float eps, void* out, int out_cstride, int out_coff, uint8_t* kstar, float* scale, float* shift,
+                          float* mean, float* rstd, void* workspace, int B, int N, int K, int C, int G, float slope);
+int cp_edgeconv_train_bwd(cp_stream_t stream, int dtype, const void* pq, const int32_t* idx, const int32_t* rev_ptr,
+                          const int32_t* rev_edge, const int32_t* graph_ids, const void* out, int out_cstride, int out_coff,
+                          const uint8_t* kstar, const void* gout, int gout_cstride, int gout_coff, const float* gamma,
+                          const float* mean, const float* rstd, void* dpq, float* dgamma, float* dbeta, void* workspace,
+                          int B, int N, int K, int C, int G, float slope);
+/* EdgeConv weight views: w (C', 2C) = [W1 | W2] -> mode 0: (2C', C) = [W1 ; W2 - W1] (forward node GEMM);
+ * mode 1: (C, 2C') with out[c][c'] = W1[c'][c], out[c][C'+c'] = W2[c'][c] (data-gradient of the node GEMM over D). */
+int cp_edge_weight_view(cp_stream_t stream, const float* w, int Cout, int Cin, int mode, float* out);
+
+/* Backward of cp_upsample2x_bilinear_ac (gather form, deterministic) and of ONE source of cp_fuse_sum_act
+ * (dsrc (+)= sum over the 2^shift x 2^shift block of dout * [out > 0]). */
+int cp_upsample2x_bilinear_ac_bwd(cp_stream_t stream, int dtype, const void* dout, void* din, int B, int H, int W, int C,
+                                  int out_cstride, int out_coff, int in_cstride, int in_coff, int accumulate);
+int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws,
+                        int C, int shift, int relu, int accumulate);
+
+/* plumbing: stream-ordered zero fill (capturable), and an fp32 tensor with arbitrary element strides (the logit block,
+ * NCHW seg logits, fp32 scatter targets) -> channels-last `dtype` (B, HW, Cphys) with zero padded channels. */
+int cp_memset_zero(cp_stream_t stream, void* p, size_t nbytes);
+int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const float* src, long long base, long long sb, long long sp,
+                       long long sc, void* out, int B, int HW, int C, int Cphys);
+
 /* layout plumbing at the boundary: NCHW fp32 image -> channels-last `dtype` (C padded with zeros to
  * Cphys), and channels-last slice -> NCHW fp32 (for `return_img_feats`, init.py:123-124). */
 int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, void* out, int B, int C, int H, int W,

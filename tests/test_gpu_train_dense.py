@@ -1,0 +1,382 @@
+"""GPU (-m gpu): training-side dense kernels through the C ABI against torch-CPU autograd of the
+same op (fp32 reference of the op; inputs rounded to the storage type first for bf16).
+Tolerances: fp32 2e-4 * (1 + |ref|) (sums over up to ~1e5 pixels in a different order, atomics across slices);
+bf16 3e-2 * (1 + |ref|) relative to the fp32 result on bf16-rounded inputs.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from checkerpose_amd import _abi
+from checkerpose_amd._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc, CpWgradDesc
+from tests.common import det_tensor
+from tests.test_gpu_parity import DT, close, dev, from_cl, pack, rnd, rup, st, to_cl
+
+pytestmark = pytest.mark.gpu
+TOLT = {CP_F32: 2e-4, CP_BF16: 3e-2}
+
+
+def wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, R, S, stride, pad, dy_coff=0, x_coff=0):
+    B, Ho, Wo, dcs = dy_cl.shape
+    _, H, W, xcs = x_cl.shape
+    dw = torch.zeros(Cout, Cin, R, S, dtype=torch.float32, device=dev())
+    d = CpWgradDesc()
+    d.dtype, d.B, d.H, d.W, d.Ho, d.Wo = dtype, B, H, W, Ho, Wo
+    d.Cout, d.dy_cstride, d.dy_coff, d.Cin, d.x_cstride, d.x_coff = Cout, dcs, dy_coff, Cin, xcs, x_coff
+    d.R, d.S, d.stride, d.pad = R, S, stride, pad
+    d.dw_base, d.dw_sco, d.dw_sci, d.dw_sr, d.dw_ss = 0, Cin * R * S, R * S, S, 1
+    _abi.check(lib.cp_conv2d_wgrad(st(), C.byref(d), dy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr()), "wgrad")
+    torch.cuda.synchronize()
+    return dw.cpu()
+
+
+WGRAD_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad)
+    (2, 18, 16, 24, 36, 3, 1, 1),      # ragged channels both sides
+    (3, 64, 16, 16, 64, 3, 1, 1),
+    (1, 256, 8, 8, 256, 3, 1, 1),      # 4x4 channel blocks
+    (2, 3, 32, 32, 64, 3, 2, 1),       # stem, 3 input channels
+    (2, 36, 14, 18, 72, 3, 2, 1),      # stride 2, odd-ish sizes
+    (2, 144, 8, 8, 18, 1, 1, 0),       # fuse 1x1
+    (2, 256, 16, 16, 64, 2, 1, 1),     # patch_generator k=2 pad=1
+    (3, 64, 1, 100, 128, 1, 1, 0),     # linear over keypoints, pixel tail
+    (1, 16, 40, 40, 10, 7, 2, 3),      # 7x7 stride 2
+    (16, 32, 32, 32, 32, 3, 1, 1),     # many pixel slices (atomics across slices)
+]
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_vs_torch_autograd(lib, dtype, case):
+    B, Cin, H, W, Cout, k, stride, pad = case
+    x = rnd(det_tensor("wx%s" % (case,), (B, Cin, H, W)), dtype)
+    w = det_tensor("ww%s" % (case,), (Cout, Cin, k, k), 0.1).requires_grad_(True)
+    with torch.enable_grad():
+        y = F.conv2d(x, w, None, stride, pad)
+    dy = rnd(det_tensor("wd%s" % (case,), tuple(y.shape)), dtype)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    got = wgrad(lib, dtype, to_cl(dy, dtype), to_cl(x, dtype), Cout, Cin, k, k, stride, pad)
+    scale = ref.abs().max().item()
+    close(got / scale, ref / scale, TOLT[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_wgrad_channel_slices(lib, dtype):
+    """operands that are channel slices of wider buffers (concat layouts)"""
+    B, H, W = 2, 8, 8
+    xa = rnd(det_tensor("sl_x", (B, 48, H, W)), dtype)
+    dya = rnd(det_tensor("sl_d", (B, 40, H, W)), dtype)
+    x, dy = xa[:, 16:48], dya[:, 8:32]
+    w = torch.zeros(24, 32, 3, 3, requires_grad=True)
+    with torch.enable_grad():
+        y = F.conv2d(x, w, None, 1, 1)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    got = wgrad(lib, dtype, to_cl(dya, dtype), to_cl(xa, dtype), 24, 32, 3, 3, 1, 1, dy_coff=8, x_coff=16)
+    scale = ref.abs().max().item()
+    close(got / scale, ref / scale, TOLT[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_wgrad_convtranspose(lib, dtype):
+    """ConvTranspose2d(k3,s2,p1,op1) weight gradient = conv wgrad with the layer input as `dy` and dout as `x`"""
+    B, Ci, Co, H = 2, 64, 32, 8
+    x = rnd(det_tensor("ct_x", (B, Ci, H, H)), dtype)
+    w = det_tensor("ct_w", (Ci, Co, 3, 3), 0.1).requires_grad_(True)
+    with torch.enable_grad():
+        y = F.conv_transpose2d(x, w, None, 2, 1, 1)
+    dy = rnd(det_tensor("ct_d", tuple(y.shape)), dtype)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    got = wgrad(lib, dtype, to_cl(x, dtype), to_cl(dy, dtype), Ci, Co, 3, 3, 2, 1)
+    scale = ref.abs().max().item()
+    close(got / scale, ref / scale, TOLT[dtype])
+
+
+def conv_cl(lib, dtype, xin, pw, Cout, R, S, stride, pad, Ho, Wo, ostr=None, out=None):
+    B, H, W, cs = xin.shape
+    E = 8 if dtype == CP_BF16 else 4
+    cop = rup(Cout, E)
+    if out is None:
+        out = torch.zeros(B, Ho, Wo, cop, dtype=DT[dtype], device=dev())
+    n16 = rup(Cout, 16)
+    sc = torch.zeros(n16, device=dev()); sc[:Cout] = 1.0
+    sh = torch.zeros(n16, device=dev())
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = cs, cs, 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = R, S, stride, pad, Ho, Wo, cop, ACT_NONE, 0.0
+    if ostr is None:
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, Ho * Wo * cop, Wo * cop, cop, 1
+    else:
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = ostr
+    _abi.check(lib.cp_conv2d_igemm(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None,
+                                   out.data_ptr()), "conv")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", [(2, 18, 12, 16, 36, 3, 1), (2, 64, 8, 8, 32, 1, 0), (1, 32, 9, 9, 16, 2, 1)])
+def test_dgrad_stride1(lib, dtype, case):
+    """dx of a stride-1 conv = conv(dy, cp_weight_dgrad(w), pad R-1-pad)"""
+    B, Cin, H, W, Cout, k, pad = case
+    x = torch.zeros(B, Cin, H, W, requires_grad=True)
+    w = rnd(det_tensor("dg_w%s" % (case,), (Cout, Cin, k, k), 0.2), dtype)
+    with torch.enable_grad():
+        y = F.conv2d(x, w, None, 1, pad)
+    dy = rnd(det_tensor("dg_d%s" % (case,), tuple(y.shape)), dtype)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    wd = w.to(dev()).contiguous()
+    wt = torch.empty(Cin, Cout, k, k, device=dev())
+    _abi.check(lib.cp_weight_dgrad(st(), wd.data_ptr(), Cout, Cin, k, k, wt.data_ptr()))
+    torch.cuda.synchronize()
+    dyc = to_cl(dy, dtype)
+    pw = pack(lib, dtype, wt.cpu(), dyc.shape[-1], k, k)
+    got = conv_cl(lib, dtype, dyc, pw, Cin, k, k, 1, k - 1 - pad, H, W)
+    close(from_cl(got, Cin), ref, TOLT[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_dgrad_stride2_and_convtranspose(lib, dtype):
+    """dx of a 3x3/s2/p1 conv = the ConvTranspose phase launches on w itself; dx of ConvTranspose2d = 3x3/s2 conv with w"""
+    B, Cin, H, Cout = 2, 36, 16, 72
+    x = torch.zeros(B, Cin, H, H, requires_grad=True)
+    w = rnd(det_tensor("d2_w", (Cout, Cin, 3, 3), 0.2), dtype)
+    with torch.enable_grad():
+        y = F.conv2d(x, w, None, 2, 1)
+    dy = rnd(det_tensor("d2_d", tuple(y.shape)), dtype)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    E = 8 if dtype == CP_BF16 else 4
+    dyc = to_cl(dy, dtype)
+    cop = rup(Cin, E)
+    out = torch.zeros(B, H, H, cop, dtype=DT[dtype], device=dev())
+    for ph in range(4):
+        a, b = ph >> 1, ph & 1
+        pw = pack(lib, dtype, w, dyc.shape[-1], 1 + a, 1 + b, rows=Cin, transposed=1, phase=ph)
+        conv_cl(lib, dtype, dyc, pw, Cin, 1 + a, 1 + b, 1, 0, H // 2, H // 2,
+                ostr=((a * H + b) * cop, H * H * cop, 2 * H * cop, 2 * cop, 1), out=out)
+    close(from_cl(out, Cin), ref, TOLT[dtype])
+    # ConvTranspose2d data-gradient
+    xt = torch.zeros(B, 64, 8, 8, requires_grad=True)
+    wt = rnd(det_tensor("d2_wt", (64, 32, 3, 3), 0.2), dtype)
+    with torch.enable_grad():
+        yt = F.conv_transpose2d(xt, wt, None, 2, 1, 1)
+    dyt = rnd(det_tensor("d2_dt", tuple(yt.shape)), dtype)
+    (reft,) = torch.autograd.grad(yt, xt, dyt)
+    dytc = to_cl(dyt, dtype)
+    pw = pack(lib, dtype, wt, dytc.shape[-1], 3, 3)          # read as conv weight (Cout'=64, Cin'=32, 3, 3)
+    got = conv_cl(lib, dtype, dytc, pw, 64, 3, 3, 2, 1, 8, 8)
+    close(from_cl(got, 64), reft, TOLT[dtype])
+
+
+def _vec(n, t=None):
+    v = torch.zeros(rup(n, 16), device=dev())
+    if t is not None:
+        v[:n] = t.to(dev())
+    return v
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", [(2, 18, 16, 16, ACT_RELU, True), (3, 64, 8, 8, ACT_LEAKY, False), (4, 256, 4, 4, ACT_NONE, False),
+                                  (2, 36, 32, 32, ACT_RELU, False)])
+def test_bn_train_fwd_bwd(lib, dtype, case):
+    B, Cc, H, W, act, has_res = case
+    M = B * H * W
+    x = rnd(det_tensor("bn_x%s" % (case,), (B, Cc, H, W)) * 1.5 + 0.3, dtype).requires_grad_(True)
+    res = rnd(det_tensor("bn_r%s" % (case,), (B, Cc, H, W)), dtype).requires_grad_(True) if has_res else None
+    gamma = (1.0 + 0.5 * det_tensor("bn_g%s" % (case,), (Cc,))).requires_grad_(True)
+    beta = (0.2 * det_tensor("bn_b%s" % (case,), (Cc,))).requires_grad_(True)
+    rm0, rv0 = 0.1 * det_tensor("bn_m%s" % (case,), (Cc,)), 1.0 + 0.3 * det_tensor("bn_v%s" % (case,), (Cc,)).abs()
+    rm, rv = rm0.clone(), rv0.clone()
+    with torch.enable_grad():
+        z = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+        if has_res:
+            z = z + res
+        y = F.relu(z) if act == ACT_RELU else (F.leaky_relu(z, 0.2) if act == ACT_LEAKY else z)
+    dy = rnd(det_tensor("bn_d%s" % (case,), (B, Cc, H, W)), dtype)
+    grads = torch.autograd.grad(y, [x, gamma, beta] + ([res] if has_res else []), dy)
+    # ---- HIP
+    xc = to_cl(x.detach(), dtype)
+    cs = xc.shape[-1]
+    g_d, b_d, rm_d, rv_d = gamma.detach().to(dev()), beta.detach().to(dev()), rm0.to(dev()), rv0.to(dev())
+    scale, shift, mean, rstd = _vec(Cc), _vec(Cc), _vec(Cc), _vec(Cc)
+    ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(Cc), dtype=torch.uint8, device=dev())
+    _abi.check(lib.cp_bn_train_stats(st(), dtype, xc.data_ptr(), M, Cc, cs, 0, g_d.data_ptr(), b_d.data_ptr(), rm_d.data_ptr(),
+                                     rv_d.data_ptr(), 0.1, 1e-5, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                     rstd.data_ptr(), ws.data_ptr()), "bn stats")
+    rc_ = to_cl(res.detach(), dtype) if has_res else None
+    yc = torch.empty_like(xc)
+    _abi.check(lib.cp_affine_act(st(), dtype, xc.data_ptr(), cs, 0, scale.data_ptr(), shift.data_ptr(),
+                                 rc_.data_ptr() if has_res else None, cs, 0, yc.data_ptr(), cs, 0, M, Cc, act, 0.2), "affine")
+    torch.cuda.synchronize()
+    close(from_cl(yc, Cc), y.detach(), TOLT[dtype])
+    close(rm_d.cpu(), rm, 1e-5)
+    close(rv_d.cpu(), rv, 1e-5)
+    if cs > Cc:
+        assert float(yc[..., Cc:].float().abs().max()) == 0.0
+    dyc = to_cl(dy, dtype)
+    dxc = torch.empty_like(xc)
+    dres = torch.zeros_like(xc) if has_res else None
+    dg, db = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    _abi.check(lib.cp_bn_train_bwd(st(), dtype, dyc.data_ptr(), cs, 0, yc.data_ptr(), cs, 0, xc.data_ptr(), cs, 0,
+                                   mean.data_ptr(), rstd.data_ptr(), g_d.data_ptr(), M, Cc, act, 0.2, dxc.data_ptr(), cs, 0,
+                                   dres.data_ptr() if has_res else None, cs, 0, 0, dg.data_ptr(), db.data_ptr(),
+                                   ws.data_ptr()), "bn bwd")
+    torch.cuda.synchronize()
+    tol = TOLT[dtype]
+    sx = grads[0].abs().max().item()
+    close(from_cl(dxc, Cc) / sx, grads[0] / sx, tol)
+    close(dg.cpu() / grads[1].abs().max().item(), grads[1] / grads[1].abs().max().item(), tol)
+    close(db.cpu() / grads[2].abs().max().item(), grads[2] / grads[2].abs().max().item(), tol)
+    if has_res:
+        close(from_cl(dres, Cc), grads[3], tol)
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_bias_act_bwd(lib, dtype):
+    """x == NULL form: y = leaky(conv + b): dx = dy * act'(y), db = column sums"""
+    B, Cc, N = 3, 64, 100
+    y = rnd(det_tensor("ba_y", (B, Cc, 1, N)), dtype)
+    dy = rnd(det_tensor("ba_d", (B, Cc, 1, N)), dtype)
+    dz = torch.where(y > 0, dy, dy * 0.01)
+    yc, dyc = to_cl(y, dtype), to_cl(dy, dtype)
+    dxc = torch.empty_like(dyc)
+    db = torch.zeros(Cc, device=dev())
+    ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(Cc), dtype=torch.uint8, device=dev())
+    _abi.check(lib.cp_bn_train_bwd(st(), dtype, dyc.data_ptr(), Cc, 0, yc.data_ptr(), Cc, 0, None, 0, 0, None, None, None,
+                                   B * N, Cc, ACT_LEAKY, 0.01, dxc.data_ptr(), Cc, 0, None, 0, 0, 0, None, db.data_ptr(),
+                                   ws.data_ptr()), "bias bwd")
+    torch.cuda.synchronize()
+    close(from_cl(dxc, Cc), dz, TOLT[dtype])
+    close(db.cpu(), dz.sum((0, 2, 3)), TOLT[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8), (1, 32, 16, 16), (2, 8, 5, 7)])
+def test_upsample2x_bwd(lib, dtype, shape):
+    B, Cc, H, W = shape
+    x = torch.zeros(B, Cc, H, W, requires_grad=True)
+    with torch.enable_grad():
+        y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    dy = rnd(det_tensor("up_d%s" % (shape,), tuple(y.shape)), dtype)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    dyc = to_cl(dy, dtype)
+    base = rnd(det_tensor("up_b%s" % (shape,), (B, Cc, H, W)), dtype)
+    for acc in (0, 1):
+        dxc = to_cl(base, dtype)
+        _abi.check(lib.cp_upsample2x_bilinear_ac_bwd(st(), dtype, dyc.data_ptr(), dxc.data_ptr(), B, H, W, Cc, Cc, 0, Cc, 0, acc))
+        torch.cuda.synchronize()
+        close(from_cl(dxc, Cc), ref + (base if acc else 0), TOLT[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("shift", [0, 1, 2])
+def test_fuse_sum_bwd(lib, dtype, shift):
+    B, Cc, Hs, Ws = 2, 24, 4, 6
+    H, W = Hs << shift, Ws << shift
+    out = rnd(det_tensor("fs_o%d" % shift, (B, Cc, H, W)), dtype).clamp_min(0)
+    dout = rnd(det_tensor("fs_d%d" % shift, (B, Cc, H, W)), dtype)
+    dz = dout * (out > 0)
+    ref = F.avg_pool2d(dz, 1 << shift) * float(1 << (2 * shift)) if shift else dz
+    oc, dc = to_cl(out, dtype), to_cl(dout, dtype)
+    ds = torch.zeros(B, Hs, Ws, oc.shape[-1], dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_fuse_sum_act_bwd(st(), dtype, dc.data_ptr(), oc.data_ptr(), ds.data_ptr(), B, Hs, Ws, oc.shape[-1], shift, 1, 0))
+    _abi.check(lib.cp_fuse_sum_act_bwd(st(), dtype, dc.data_ptr(), oc.data_ptr(), ds.data_ptr(), B, Hs, Ws, oc.shape[-1], shift, 1, 1))
+    torch.cuda.synchronize()
+    close(from_cl(ds, Cc), 2 * ref, TOLT[dtype])
+
+
+def _rev_graph(idx):
+    from checkerpose_amd.train_ops import reverse_graph
+    return reverse_graph(idx)
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", [(3, 16, 64, 48, 6, 0.2), (2, 64, 64, 64, 20, 0.2), (2, 256, 256, 40, 8, 0.1)])
+def test_edgeconv_train_fwd_bwd(lib, dtype, case):
+    """factored train-mode EdgeConv vs torch autograd of the reference formulation (init.py:36-68): get_graph_feature ->
+    Conv2d(2C->C',1x1) -> BatchNorm2d (batch stats over B*N*K) -> LeakyReLU -> max over K"""
+    B, Cin, Co, N, K, slope = case
+    x = rnd(det_tensor("ec_x%s" % (case,), (B, Cin, N)), dtype)
+    pts = det_tensor("ec_p%s" % (case,), (1, 3, N))
+    idx = (-((pts[:, :, :, None] - pts[:, :, None, :]) ** 2).sum(1)).topk(k=K, dim=-1)[1][0]      # (N,K)
+    w = det_tensor("ec_w%s" % (case,), (Co, 2 * Cin), (1.0 / Cin) ** 0.5)
+    gamma = (1.0 + 0.5 * det_tensor("ec_g%s" % (case,), (Co,)))
+    gamma[::3] *= -1                                          # mixed-sign gammas (min/max switch)
+    beta = 0.2 * det_tensor("ec_b%s" % (case,), (Co,))
+    wpq = torch.cat([w[:, :Cin], w[:, Cin:] - w[:, :Cin]], 0)                    # (2C', C)
+    pq = rnd(torch.einsum("oc,bcn->bno", wpq, x), dtype).requires_grad_(True)   # (B,N,2C') -- the kernel's input
+    gamma.requires_grad_(True); beta.requires_grad_(True)
+    rm, rv = torch.zeros(Co), torch.ones(Co)
+    with torch.enable_grad():
+        P, Q = pq[:, :, :Co], pq[:, :, Co:]
+        e = (P[:, idx, :] + Q[:, :, None, :]).permute(0, 3, 1, 2)                # (B,C',N,K) == conv output
+        z = F.leaky_relu(F.batch_norm(e, rm, rv, gamma, beta, True, 0.1, 1e-5), slope)
+        y = z.max(dim=-1)[0]                                                     # (B,C',N)
+    gout = rnd(det_tensor("ec_d%s" % (case,), (B, Co, N)), dtype)
+    dpq_ref, dg_ref, db_ref = torch.autograd.grad(y, [pq, gamma, beta], gout)
+    # ---- HIP
+    d = dev()
+    pqd = pq.detach().to(DT[dtype]).to(d).contiguous()
+    idx32 = idx.int().to(d).contiguous()[None]
+    rev_ptr, rev_edge = _rev_graph(idx32)
+    out = torch.zeros(B, N, Co, dtype=DT[dtype], device=d)
+    kstar = torch.zeros(B, N, Co, dtype=torch.uint8, device=d)
+    vec = [torch.zeros(Co, device=d) for _ in range(4)]
+    g_d, b_d = gamma.detach().to(d), beta.detach().to(d)
+    rm_d, rv_d = torch.zeros(Co, device=d), torch.ones(Co, device=d)
+    ws = torch.empty(lib.cp_edge_train_workspace_bytes(B, Co), dtype=torch.uint8, device=d)
+    _abi.check(lib.cp_edgeconv_train_fwd(st(), dtype, pqd.data_ptr(), idx32.data_ptr(), None, g_d.data_ptr(), b_d.data_ptr(),
+                                         rm_d.data_ptr(), rv_d.data_ptr(), 0.1, 1e-5, out.data_ptr(), Co, 0, kstar.data_ptr(),
+                                         vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+                                         ws.data_ptr(), B, N, K, Co, 1, slope), "edge fwd")
+    torch.cuda.synchronize()
+    close(out.float().cpu(), y.detach().permute(0, 2, 1), TOLT[dtype])
+    close(rm_d.cpu(), rm, 1e-4)
+    close(rv_d.cpu(), rv, 1e-4)
+    gc = gout.permute(0, 2, 1).contiguous().to(DT[dtype]).to(d)
+    dpq = torch.zeros(B, N, 2 * Co, dtype=DT[dtype], device=d)
+    dg, db = torch.zeros(Co, device=d), torch.zeros(Co, device=d)
+    _abi.check(lib.cp_edgeconv_train_bwd(st(), dtype, pqd.data_ptr(), idx32.data_ptr(), rev_ptr.data_ptr(), rev_edge.data_ptr(),
+                                         None, out.data_ptr(), Co, 0, kstar.data_ptr(), gc.data_ptr(), Co, 0, g_d.data_ptr(),
+                                         vec[2].data_ptr(), vec[3].data_ptr(), dpq.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                         ws.data_ptr(), B, N, K, Co, 1, slope), "edge bwd")
+    torch.cuda.synchronize()
+    D = dpq.float().cpu()
+    dP, dQ = D[:, :, :Co] + D[:, :, Co:], D[:, :, Co:]
+    tol = TOLT[dtype]
+    s = dpq_ref.abs().max().item()
+    close(dQ / s, dpq_ref[:, :, Co:] / s, tol)
+    close(dP / s, dpq_ref[:, :, :Co] / s, 2 * tol)
+    close(dg.cpu() / dg_ref.abs().max().item(), dg_ref / dg_ref.abs().max().item(), tol)
+    close(db.cpu() / db_ref.abs().max().item(), db_ref / db_ref.abs().max().item(), tol)
+
+
+def test_edge_weight_views(lib):
+    Co, Ci = 24, 16
+    w = det_tensor("ewv", (Co, 2 * Ci))
+    wd = w.to(dev())
+    o0 = torch.empty(2 * Co, Ci, device=dev())
+    o1 = torch.empty(Ci, 2 * Co, device=dev())
+    _abi.check(lib.cp_edge_weight_view(st(), wd.data_ptr(), Co, Ci, 0, o0.data_ptr()))
+    _abi.check(lib.cp_edge_weight_view(st(), wd.data_ptr(), Co, Ci, 1, o1.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(o0.cpu(), torch.cat([w[:, :Ci], w[:, Ci:] - w[:, :Ci]], 0))
+    assert torch.equal(o1.cpu(), torch.cat([w[:, :Ci].t(), w[:, Ci:].t()], 1))
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_strided_to_nhwc_and_memset(lib, dtype):
+    B, Cc, N = 2, 3, 10
+    bits = det_tensor("s2n", (B, 13, N))
+    src = bits.to(dev())
+    E = 8 if dtype == CP_BF16 else 4
+    out = torch.full((B, N, E), 7.0, dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_strided_to_nhwc(st(), dtype, src.data_ptr(), 4 * N, 13 * N, 1, N, out.data_ptr(), B, N, Cc, E))
+    torch.cuda.synchronize()
+    ref = torch.zeros(B, N, E)
+    ref[..., :Cc] = rnd(bits[:, 4:7].permute(0, 2, 1), dtype)
+    assert torch.equal(out.float().cpu(), ref)
+    _abi.check(lib.cp_memset_zero(st(), out.data_ptr(), out.numel() * out.element_size()))
+    torch.cuda.synchronize()
+    assert float(out.float().abs().max()) == 0.0
