@@ -82,7 +82,9 @@ SIGNATURES = {
     "cp_upsample2x_bilinear_ac_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_fuse_sum_act_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_memset_zero": (_I, [_P, _P, C.c_size_t]),
-    "cp_strided_to_nhwc": (_I, [_P, _I, _P, _L, _L, _L, _L, _P, _I, _I, _I, _I]),
+    "cp_strided_to_nhwc": (_I, [_P, _I, _P, _I, _L, _L, _L, _L, _P, _I, _I, _I, _I]),
+    "cp_memcpy_d2d": (_I, [_P, _P, _P, C.c_size_t]),
+    "cp_index2feat_gather_bwd_t": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_nchw_to_nhwc": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I]),
     "cp_u8hwc_to_nhwc_norm": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cp_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),

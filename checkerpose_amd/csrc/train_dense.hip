@@ -62,9 +62,9 @@ extern "C" int cp_edge_weight_view(cp_stream_t stream, const float* w, int Cout,
   return cp_check_launch();
 }
 
-// fp32 tensor with arbitrary element strides -> channels-last `dtype` (B, HW, Cphys), padded channels zero.
-template <typename Tag>
-__global__ void strided_to_nhwc_kernel(const float* __restrict__ src, long long base, long long sb, long long sp, long long sc,
+// tensor (fp32 or `dtype`) with arbitrary element strides -> channels-last `dtype` (B, HW, Cphys), padded channels zero.
+template <typename Tag, typename STag>
+__global__ void strided_to_nhwc_kernel(const void* __restrict__ src, long long base, long long sb, long long sp, long long sc,
                                        void* __restrict__ out, int HW, int C, int Cphys, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*Cphys
   if (i >= total) return;
@@ -72,21 +72,30 @@ __global__ void strided_to_nhwc_kernel(const float* __restrict__ src, long long 
   const size_t t = i / Cphys;
   const int pix = (int)(t % HW);
   const size_t b = t / HW;
-  const float v = c < C ? src[base + (long long)b * sb + (long long)pix * sp + (long long)c * sc] : 0.f;
+  const float v = c < C ? load_elem<STag>(src, (size_t)(base + (long long)b * sb + (long long)pix * sp + (long long)c * sc)) : 0.f;
   store_elem<Tag>(out, i, v);
 }
 
-extern "C" int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const float* src, long long base, long long sb, long long sp,
-                                  long long sc, void* out, int B, int HW, int C, int Cphys) {
+extern "C" int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const void* src, int src_dtype, long long base, long long sb,
+                                  long long sp, long long sc, void* out, int B, int HW, int C, int Cphys) {
   if (!src || !out || B <= 0 || HW <= 0 || C <= 0 || Cphys < C) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (src_dtype != CP_F32 && src_dtype != dtype) return CP_ERR_INVALID;
   const size_t total = (size_t)B * HW * Cphys;
-  const unsigned blocks = (unsigned)((total + 255) / 256);
+  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == CP_F32)
-    CP_LAUNCH(strided_to_nhwc_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, base, sb, sp, sc, out, HW, C, Cphys, total);
+    CP_LAUNCH((strided_to_nhwc_kernel<F32Tag, F32Tag>), grid, blk, 0, st, src, base, sb, sp, sc, out, HW, C, Cphys, total);
+  else if (src_dtype == CP_F32)
+    CP_LAUNCH((strided_to_nhwc_kernel<BF16Tag, F32Tag>), grid, blk, 0, st, src, base, sb, sp, sc, out, HW, C, Cphys, total);
   else
-    CP_LAUNCH(strided_to_nhwc_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, base, sb, sp, sc, out, HW, C, Cphys, total);
+    CP_LAUNCH((strided_to_nhwc_kernel<BF16Tag, BF16Tag>), grid, blk, 0, st, src, base, sb, sp, sc, out, HW, C, Cphys, total);
   return cp_check_launch();
+}
+
+extern "C" int cp_memcpy_d2d(cp_stream_t stream, void* dst, const void* src, size_t nbytes) {
+  if (!dst || !src) return CP_ERR_INVALID;
+  return hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? CP_OK : CP_ERR_HIP;
 }
 
 // ------------------------------------------------------------------------------------------------ column sums

@@ -155,7 +155,8 @@ extern "C" int cp_edgeconv_gather_max_bwd(cp_stream_t stream, int dtype, const v
 // Index2Feat backward: dpatches[b, ty, tx, e] += gout[b, i, coff + tap*E + e] * mask[b,i]   (taps as the forward).
 // Several keypoints may share a sub-pixel (ids are predictions), so this is a scatter with collisions: hardware
 // fp32 atomics (global_atomic_add_f32), skipped entirely for keypoints outside the RoI (mask == 0).
-__global__ void index2feat_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ x_id,
+template <typename Tag>
+__global__ void index2feat_bwd_kernel(const void* __restrict__ gout, const int32_t* __restrict__ x_id,
                                       const int32_t* __restrict__ y_id, const float* __restrict__ mask,
                                       float* __restrict__ dpatches, int N, int Hp, int Wp, int EG4, int k, int g_cs, int g_coff,
                                       size_t total) {
@@ -171,26 +172,46 @@ __global__ void index2feat_bwd_kernel(const float* __restrict__ gout, const int3
   const int y = 2 * y_id[kp] + ((tap & 1) ? k : 0);
   const int x = 2 * x_id[kp] + ((tap & 2) ? k : 0);
   if ((unsigned)y >= (unsigned)Hp || (unsigned)x >= (unsigned)Wp) return;
-  const f32x4 gv = *(const f32x4*)(gout + kp * g_cs + g_coff + (size_t)(tap * EG4 + g) * 4);
+  const size_t ge = kp * g_cs + g_coff + (size_t)(tap * EG4 + g) * 4;
+  f32x4 gv;
+  if (Tag::E == 4) gv = *(const f32x4*)((const float*)gout + ge);
+  else {
+    const u32x2 r2 = *(const u32x2*)((const uint16_t*)gout + ge);
+    gv = f32x4{__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xffff0000u), __uint_as_float(r2.y << 16),
+               __uint_as_float(r2.y & 0xffff0000u)};
+  }
   float* dst = dpatches + (((b * Hp + y) * Wp + x) * EG4 + g) * 4;
 #pragma unroll
   for (int c = 0; c < 4; ++c) unsafeAtomicAdd(dst + c, gv[c] * mk);
 }
 
-extern "C" int cp_index2feat_gather_bwd(cp_stream_t stream, const float* gout, const int32_t* x_id, const int32_t* y_id,
-                                        const float* mask, float* dpatches, int B, int N, int Hp, int Wp, int E_ch, int k,
-                                        int gout_cstride, int gout_coff) {
+// gout in `dtype` (the training program keeps activation gradients in the storage type); dpatches stays fp32
+extern "C" int cp_index2feat_gather_bwd_t(cp_stream_t stream, int dtype, const void* gout, const int32_t* x_id,
+                                          const int32_t* y_id, const float* mask, float* dpatches, int B, int N, int Hp, int Wp,
+                                          int E_ch, int k, int gout_cstride, int gout_coff) {
   if (!gout || !x_id || !y_id || !mask || !dpatches || B <= 0 || N <= 0 || Hp <= 0 || Wp <= 0 || E_ch <= 0 || k <= 0)
     return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   if (E_ch % 4 || gout_cstride % 4 || gout_coff % 4 || gout_coff + 4 * E_ch > gout_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(gout) || !cp_aligned16(dpatches)) return CP_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dpatches, 0, (size_t)B * Hp * Wp * E_ch * sizeof(float), st) != hipSuccess) return CP_ERR_HIP;
   const int EG4 = E_ch / 4;
   const size_t total = (size_t)B * N * 4 * EG4;
-  CP_LAUNCH(index2feat_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, x_id, y_id, mask,
-                     dpatches, N, Hp, Wp, EG4, k, gout_cstride, gout_coff, total);
+  if (dtype == CP_F32)
+    CP_LAUNCH(index2feat_bwd_kernel<F32Tag>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, x_id, y_id, mask,
+              dpatches, N, Hp, Wp, EG4, k, gout_cstride, gout_coff, total);
+  else
+    CP_LAUNCH(index2feat_bwd_kernel<BF16Tag>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, x_id, y_id, mask,
+              dpatches, N, Hp, Wp, EG4, k, gout_cstride, gout_coff, total);
   return cp_check_launch();
+}
+
+extern "C" int cp_index2feat_gather_bwd(cp_stream_t stream, const float* gout, const int32_t* x_id, const int32_t* y_id,
+                                        const float* mask, float* dpatches, int B, int N, int Hp, int Wp, int E_ch, int k,
+                                        int gout_cstride, int gout_coff) {
+  return cp_index2feat_gather_bwd_t(stream, CP_F32, gout, x_id, y_id, mask, dpatches, B, N, Hp, Wp, E_ch, k, gout_cstride,
+                                    gout_coff);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@ USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 k
 USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 256-64-64-256 Bottleneck kernel (bf16)
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
+NO_RECYCLE = os.environ.get("CHECKERPOSE_AMD_NO_RECYCLE", "0") == "1"   # debugging aid: every workspace tensor gets its own bytes
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
 
@@ -460,6 +461,8 @@ class Program:
                     if sz > t.nbytes:
                         free.append((off + t.nbytes, sz - t.nbytes))
             for t in deaths.get(i, []):
+                if NO_RECYCLE:
+                    continue
                 free.append((t.offset, t.nbytes))
                 free.sort()
                 merged = []

@@ -11,11 +11,56 @@ from ..engine import DTYPES, Program, ProgramGroup, WeightStore
 from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
 
 
+class _TrainFn(torch.autograd.Function):
+    """autograd hook of the training program (trainer.TrainProgram): forward() replays the forward half of the launch
+    list (train-mode BatchNorm, activations saved in the program's workspace), backward() copies the incoming logit /
+    seg gradients into the program's fp32 input blocks, replays the backward half and hands autograd the parameter
+    gradients (slices of ONE flat fp32 buffer; under torch.distributed that buffer is all-reduced first -- the single
+    collective of the data-parallel step)."""
+
+    @staticmethod
+    def forward(ctx, mod, pr, img, *params):
+        io, prog = pr["io"], pr["prog"]
+        io["img"].copy_(img)
+        st = torch.cuda.current_stream(img.device).cuda_stream
+        prog.run_range(st, 0, prog.n_fwd_ops)
+        if pr["counters"]:
+            torch._foreach_add_(pr["counters"], 1)          # BatchNorm2d.num_batches_tracked
+        ctx.mod, ctx.pr, ctx.nparams = mod, pr, len(params)
+        return io["bits"].clone(), io["seg"].clone() if "seg" in io else io["bits"].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, dbits, dseg):
+        pr, mod = ctx.pr, ctx.mod
+        io, prog = pr["io"], pr["prog"]
+        if pr["busy"] is not ctx:
+            raise RuntimeError("checkerpose_amd: backward() of a train-mode forward whose saved activations were overwritten "
+                               "by a later forward of the same batch size (one backward per forward)")
+        io["dbits"].copy_(dbits)
+        io["dinit"].copy_(torch.cat([dbits[:, 0:4], dbits[:, 7:10]], dim=1))
+        if "dseg" in io:
+            io["dseg"].copy_(dseg)
+        st = torch.cuda.current_stream(dbits.device).cuda_stream
+        prog.run_range(st, prog.n_fwd_ops, len(prog.calls))
+        pg = pr["pgrad"]
+        if mod.dp_allreduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            from ..parallel import allreduce_gradients_
+            allreduce_gradients_([pg], bucket_bytes=1 << 40, average=True)
+        grads = tuple(pg[o:o + p.numel()].view_as(p).clone() if p.requires_grad else None
+                      for (o, p) in zip(pr["offsets"], pr["params"]))
+        pr["busy"] = None
+        return (None, None, None) + grads
+
+
 class HipForwardMixin:
     def _init_runtime(self):
         self._programs = {}
+        self._train_programs = {}
         self._stores = {}
         self._idx_dev = None
+        self._stale_eval = False          # a train step changed the weights / running stats the eval programs folded
+        self.dp_allreduce = True          # all-reduce the flat gradient buffer when torch.distributed is initialised
         self.compute_dtype = os.environ.get("CHECKERPOSE_AMD_DTYPE", "fp32")
         self.use_graph = os.environ.get("CHECKERPOSE_AMD_GRAPH", "1") != "0"
         self.use_lanes = os.environ.get("CHECKERPOSE_AMD_LANES", "1") != "0"   # parallel graph branches
@@ -32,6 +77,7 @@ class HipForwardMixin:
                 for g in pr["graph"]:
                     lib.cp_graph_destroy(g)
         self._programs, self._stores, self._idx_dev = {}, {}, None
+        self._train_programs = {}
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -116,11 +162,108 @@ class HipForwardMixin:
         ws.keep.clear()
         return dict(prog=prog, io=io, graph=None, warm=False, side=None)
 
+    # ---- training program (forward in train mode + backward), see ../trainer.py
+    def _build_train(self, lib, B, size, stage, device):
+        from ..trainer import TrainProgram, TrainWeightStore
+        from ..train_ops import reverse_graph
+        dtype = DTYPES[self.compute_dtype]
+        cfg = self._net_cfg()
+        cfg["img_size"], cfg["stage"], cfg["uint8_input"] = size, stage, False
+        N = cfg["npoint"]
+        sd = self.state_dict()
+        params, offsets, slots, off = [], [], {}, 0
+        for name, p in self.named_parameters():
+            if p.dtype != torch.float32 or p.device != device:
+                raise RuntimeError("parameter %s must be an fp32 tensor on %s" % (name, device))
+            params.append(p)
+            offsets.append(off)
+            slots[name] = off
+            off += (p.numel() + 3) // 4 * 4
+        pgrad = torch.zeros(off, dtype=torch.float32, device=device)
+        ws = TrainWeightStore(lib, sd, dtype, device)
+        if self._idx_dev is None:
+            self._idx_dev = self._knn_table().to(torch.int32).contiguous().to(device)
+        idx = self._idx_dev
+        rev_ptr, rev_edge = reverse_graph(idx)
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)   # noqa: E731
+        io = dict(img=z(B, 3, size, size), bits=z(B, 13, N), mask=z(B, N), xid=z(B, N, dt=torch.int32), yid=z(B, N, dt=torch.int32),
+                  x64=z(B, N, dt=torch.int64), y64=z(B, N, dt=torch.int64), gids=z(B, dt=torch.int32) if self.LM else None,
+                  dbits=z(B, 13, N), dinit=z(B, 7, N))
+        if cfg["kind"] != "init":
+            nref = cfg["res_log2"] - 3
+            fs = (size // 32) << (stage if stage is not None else nref)
+            io["seg"] = z(B, cfg["seg_output_dim"], fs, fs)
+            io["dseg"] = z(B, cfg["seg_output_dim"], fs, fs)
+        prog = TrainProgram(lib, ws, dtype, B, device, pgrad, slots)
+        io["graph"] = dict(idx=idx, gids=io["gids"], K=idx.shape[2], G=idx.shape[0], rev_ptr=rev_ptr, rev_edge=rev_edge)
+        io["bits_tb"] = prog.fixed(io["bits"])
+        em = NetEmitter(prog, sd)
+        if cfg["kind"] == "init":
+            emit_init_net(em, cfg, io, "")
+        else:
+            io["seg_tb"] = prog.fixed(io["seg"])
+            emit_posenet(em, cfg, io)
+        prog.mark_forward_end()
+        nb = pgrad.numel() * 4
+        prog._add(lib.cp_memset_zero, lambda P: (pgrad.data_ptr(), nb), "pgrad_zero", [], [])
+        prog.unwind()
+        prog.finalize()
+        torch.cuda.current_stream(device).synchronize()
+        return dict(prog=prog, io=io, pgrad=pgrad, params=params, offsets=offsets, counters=list(em.bn_counters), busy=None)
+
+    def _run_train(self, img, obj_ids, stage=None):
+        if not (torch.is_tensor(img) and img.is_cuda):
+            raise RuntimeError("checkerpose_amd: input must be a CUDA/HIP tensor on an MI355X; there is no CPU fallback.")
+        if img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.shape[2] != 256 or img.dtype != torch.float32:
+            raise ValueError("expected fp32 img of shape (B, 3, 256, 256), got %s" % (tuple(img.shape),))
+        lib = _abi.load()
+        device = img.device
+        B, size = img.shape[0], img.shape[2]
+        key = (B, size, stage, self.compute_dtype)
+        pr = self._train_programs.get(key)
+        if pr is None:
+            with torch.cuda.device(device):
+                pr = self._build_train(lib, B, size, stage, device)
+            self._train_programs[key] = pr
+        io = pr["io"]
+        self._stale_eval = True
+        with torch.cuda.device(device):
+            if self.LM:
+                if obj_ids is None:
+                    raise ValueError("obj_ids is required for the LM networks")
+                io["gids"].copy_((obj_ids.to(device) - 1).to(torch.int32))
+            if torch.is_grad_enabled():
+                bits, seg = _TrainFn.apply(self, pr, img, *pr["params"])
+                pr["busy"] = bits.grad_fn
+            else:                                     # train-mode statistics without autograd (e.g. under no_grad)
+                io["img"].copy_(img)
+                pr["prog"].run_range(torch.cuda.current_stream(device).cuda_stream, 0, pr["prog"].n_fwd_ops)
+                if pr["counters"]:
+                    torch._foreach_add_(pr["counters"], 1)
+                bits, seg = io["bits"].clone(), io["seg"].clone() if "seg" in io else None
+        out = dict(bits=bits, x64=io["x64"].clone(), y64=io["y64"].clone())
+        if "seg" in io:
+            out["seg"] = seg
+        return out
+
+    def train(self, mode=True):
+        r = super().train(mode)
+        if not mode and getattr(self, "_stale_eval", False):     # eval programs fold BatchNorm / pack weights at build time
+            lib = _abi._lib
+            for pr in self._programs.values():
+                if pr.get("graph") and lib is not None:
+                    for g in pr["graph"]:
+                        lib.cp_graph_destroy(g)
+            self._programs, self._stores = {}, {}
+            self._stale_eval = False
+        return r
+
     # ---- one forward
     def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False, teacher_bits=None):
         if self.training:
-            raise RuntimeError("checkerpose_amd: train-mode forward (batch-statistics BatchNorm + autograd) is not "
-                               "implemented; call .eval().  There is no PyTorch fallback.")
+            if want_feats or want_graph or teacher_bits is not None:
+                raise RuntimeError("checkerpose_amd: return_img_feats / return_graph_feats / teacher forcing are eval-mode only")
+            return self._run_train(img, obj_ids, stage=stage)
         if not (torch.is_tensor(img) and img.is_cuda):
             raise RuntimeError("checkerpose_amd: input must be a CUDA/HIP tensor on an MI355X; there is no CPU fallback "
                                "(the CPU restatement lives in oracle/ and is test infrastructure only).")

@@ -16,6 +16,8 @@ class NetEmitter:
     def __init__(self, prog: Program, sd):
         self.p, self.ws, self.sd = prog, prog.ws, sd
         self.ones = {}
+        self.tp = prog if getattr(prog, "training", False) else None    # trainer.TrainProgram: emit forward + tape
+        self.bn_counters = []                                            # num_batches_tracked buffers touched
 
     def W(self, key):
         return self.ws._w(key)
@@ -28,12 +30,76 @@ class NetEmitter:
     # ---- conv + folded BN (+residual) (+ReLU)
     def conv_bn(self, x, conv, bn, k, stride, pad, relu=True, residual=None, out=None):
         w = self.W(conv + ".weight")
+        if self.tp is not None:
+            return self._conv_bn_train(x, conv, bn, w, k, stride, pad, ACT_RELU if relu else ACT_NONE, residual, out)
         s, t = self.ws.bn_fold(bn)
         return self.p.conv(x, conv, w, s, t, k, k, stride, pad, w.shape[0], ACT_RELU if relu else ACT_NONE,
                            residual=residual, out=out)
 
+    # ---- train mode: raw conv -> batch statistics -> affine+act, backward pushed on the tape
+    def _bn_train(self, raw, bn, act, residual, out, slope=0.0):
+        tp = self.tp
+        Cout = raw.C
+        st = tp.bn_stats(raw, Cout, self.W(bn + ".weight"), self.W(bn + ".bias"), self.sd[bn + ".running_mean"],
+                         self.sd[bn + ".running_var"])
+        self.bn_counters.append(self.sd[bn + ".num_batches_tracked"])
+        y = out if out is not None else tp.act(raw.H, raw.W, Cout)
+        tp.affine_act(raw, st["scale"], st["shift"], residual, y, act, slope)
+        return y, st
+
+    def _conv_bn_train(self, x, conv, bn, w, k, stride, pad, act, residual, out):
+        tp = self.tp
+        Cout = w.shape[0]
+        raw = tp.conv(x, conv, w, tp.const_vec(Cout, True), tp.const_vec(Cout, False), k, k, stride, pad, Cout)
+        y, st = self._bn_train(raw, bn, act, residual, out)
+
+        def bwd():
+            if y.tbuf not in tp.grads:
+                return
+            gy = tp.grad_of(y)
+            gres = tp.grad_of(residual) if residual is not None else None
+            tp.bn_bwd(gy, y, raw, st, act, 0.0, gres, tp.pg_ptr(bn + ".weight"), tp.pg_ptr(bn + ".bias"))
+            tp.conv_backward(conv, w, x, gy, k, k, stride, pad)
+        tp.tape.append(bwd)
+        return y
+
+    def _bias_vec(self, key, n):
+        return self.tp.live_vec(n, [(0, self.W(key + ".bias"), 0, n)])
+
+    def _linear_train(self, x, key, act, slope, out):
+        tp = self.tp
+        w = self.W(key + ".weight")
+        Cout = w.shape[0]
+        w4 = w.view(Cout, w.shape[1], 1, 1)
+        y = tp.conv(x, key, w4, tp.const_vec(Cout, True), self._bias_vec(key, Cout), 1, 1, 1, 0, Cout, act, slope, out=out)
+
+        def bwd():
+            if y.tbuf not in tp.grads:
+                return
+            gy = tp.grad_of(y)
+            tp.bn_bwd(gy, y, None, None, act, slope, None, None, tp.pg_ptr(key + ".bias"))
+            tp.conv_backward(key, w4, x, gy, 1, 1, 1, 0)
+        tp.tape.append(bwd)
+        return y
+
+    def _out_layer_bwd(self, key, w4, x, C_, src, base, sb, sp, sc, k=1, pad=0):
+        """backward of a bias layer whose output went straight into a strided fp32 output block (logits / seg): gather the
+        incoming gradient `src` (fp32 torch tensor, filled by the autograd hook) into channels-last, then bias/weight/data
+        gradients as usual."""
+        tp = self.tp
+
+        def bwd():
+            gy = tp.act(x.H + 2 * pad - k + 1, x.W + 2 * pad - k + 1, C_)
+            tp.keep.append(src)
+            tp.strided_to_act(lambda P: src.data_ptr(), 0, base, sb, sp, sc, gy, C_)
+            tp.bn_bwd(gy, None, None, None, ACT_NONE, 0.0, None, None, tp.pg_ptr(key + ".bias"))
+            tp.conv_backward(key, w4, x, gy, k, k, 1, pad)
+        tp.tape.append(bwd)
+
     def linear(self, x, key, act=ACT_NONE, slope=0.0, out=None, **kw):
         """nn.Linear / 1x1 conv with bias over a (B, 1, N, C) view."""
+        if self.tp is not None and not kw:
+            return self._linear_train(x, key, act, slope, out)
         w = self.W(key + ".weight")
         w4 = w.reshape(w.shape[0], w.shape[1], 1, 1)
         b = self.W(key + ".bias")
@@ -42,7 +108,7 @@ class NetEmitter:
     # ---- timm resnet blocks
     def basic_block(self, pfx, x, stride=1):
         w1 = self.W(pfx + ".conv1.weight")
-        if (stride == 1 and (pfx + ".downsample.0.weight") not in self.sd and w1.shape[0] == w1.shape[1]
+        if (self.tp is None and stride == 1 and (pfx + ".downsample.0.weight") not in self.sd and w1.shape[0] == w1.shape[1]
                 and self.p.can_fuse_basicblock(x, w1.shape[0])):
             s1, t1 = self.ws.bn_fold(pfx + ".bn1")
             s2, t2 = self.ws.bn_fold(pfx + ".bn2")
@@ -56,7 +122,7 @@ class NetEmitter:
     def bottleneck(self, pfx, x, out=None):
         w1, w3 = self.W(pfx + ".conv1.weight"), self.W(pfx + ".conv3.weight")
         has_ds = (pfx + ".downsample.0.weight") in self.sd
-        if (self.p.can_fuse_bottleneck(x, w1.shape[0], w3.shape[0], has_ds) and w1.shape[1] == x.C
+        if (self.tp is None and self.p.can_fuse_bottleneck(x, w1.shape[0], w3.shape[0], has_ds) and w1.shape[1] == x.C
                 and (has_ds or w1.shape[1] == w3.shape[0])):
             keys = [pfx + ".conv%d" % i for i in (1, 2, 3)]
             affs = [self.ws.bn_fold(pfx + ".bn%d" % i) for i in (1, 2, 3)]
@@ -107,9 +173,23 @@ class NetEmitter:
         for i in range(nb):
             p.set_lane(i)
             out = p.act(xs[i].H, xs[i].W, xs[i].C)
-            outs.append(p.fuse_sum(terms[i], [max(j - i, 0) for j in range(nb)], out, relu=True))
+            shifts = [max(j - i, 0) for j in range(nb)]
+            outs.append(p.fuse_sum(terms[i], shifts, out, relu=True))
+            if self.tp is not None:
+                self._fuse_sum_tape(out, list(terms[i]), shifts)
         p.par_end()
         return outs
+
+    def _fuse_sum_tape(self, out, srcs, shifts):
+        tp = self.tp
+
+        def bwd():
+            if out.tbuf not in tp.grads:
+                return
+            go = tp.grad_of(out)
+            for s_, sh in zip(srcs, shifts):
+                tp.fuse_sum_bwd(go, out, tp.grad_of(s_), sh, True)
+        tp.tape.append(bwd)
 
     def hrnet(self, pfx, x, feat_outs=None):
         x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 3, 2, 1)
@@ -143,7 +223,39 @@ class NetEmitter:
         return feats
 
     # ---- EdgeConv: per-node GEMM to [P'|Q'] + neighbour gather-max (factored StaticGraph_module)
+    def _edgeconv_train(self, pfx, x, graph, slope, out):
+        tp = self.tp
+        w = self.W(pfx + ".conv.0.weight")            # (C', 2C, 1, 1)
+        Co, Cc = w.shape[0], w.shape[1] // 2
+        bn = pfx + ".conv.1"
+        wpq = tp.edge_weight_view(w, Co, Cc, 0)       # (2C', C, 1, 1) = [W1 ; W2 - W1], rebuilt from the live weight
+        pq = tp.conv(x, pfx + ".conv.0#pq", wpq, tp.const_vec(2 * Co, True), tp.const_vec(2 * Co, False), 1, 1, 1, 0, 2 * Co)
+        if out is None:
+            out = tp.act(1, x.W, Co)
+        st = tp.edge_train_fwd(pq, graph, self.W(bn + ".weight"), self.W(bn + ".bias"), self.sd[bn + ".running_mean"],
+                               self.sd[bn + ".running_var"], out, Co, slope)
+        self.bn_counters.append(self.sd[bn + ".num_batches_tracked"])
+
+        def bwd():
+            if out.tbuf not in tp.grads:
+                return
+            D = tp.act(1, x.W, 2 * Co)                # [dP - dQ | dQ]
+            tp.debug[pfx] = dict(x=x, pq=pq, out=out, D=D, gout=tp.grad_of(out), st=st)
+            tp.edge_train_bwd(pq, graph, st, out, tp.grad_of(out), D, tp.pg_ptr(bn + ".weight"), tp.pg_ptr(bn + ".bias"), Co, slope)
+            dw = tp.pg_ptr(pfx + ".conv.0.weight")    # (C', 2C): dW1 = D1^T x, dW2 = D2^T x
+            tp.wgrad(D.slice(0, Co), x, dw, Co, Cc, 1, 1, 1, 0, base=0, sco=2 * Cc, sci=1)
+            tp.wgrad(D.slice(Co, Co), x, dw, Co, Cc, 1, 1, 1, 0, base=Cc, sco=2 * Cc, sci=1)
+            if tp.needs_grad(x):
+                gx = tp.grad_of(x)
+                wd = tp.edge_weight_view(w, Co, Cc, 1)    # (C, 2C', 1, 1)
+                tp.conv(D, pfx + ".conv.0#dgrad", wd, tp.const_vec(Cc, True), tp.const_vec(Cc, False), 1, 1, 1, 0, Cc,
+                        residual=gx, out=gx)
+        tp.tape.append(bwd)
+        return out
+
     def edgeconv(self, pfx, x: Act, graph, slope, out: Act = None):
+        if self.tp is not None:
+            return self._edgeconv_train(pfx, x, graph, slope, out)
         w = self.W(pfx + ".conv.0.weight")            # (C', 2C, 1, 1)
         Co, C2 = w.shape[0], w.shape[1]
         Cc = C2 // 2
@@ -168,6 +280,9 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
         x = p.u8_to_nhwc_norm(io["img"], cfg["img_size"], cfg["img_size"])
     else:
         x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
+    tp = em.tp
+    if tp is not None:
+        tp.nograd.add(id(x.tbuf))                           # the image needs no gradient
     bb = pfx + "img_backbone."
     feats = em.hrnet(bb, x) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
     f = feats[-1]                                           # (B, 8, 8, Cb)
@@ -176,8 +291,23 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
     w = em.W(pfx + "conv1x1.weight")
     g0 = p.act(1, N, 64)
     npix = f.H * f.W
-    p.conv(f, pfx + "conv1x1", w, em._unit(N), em.W(pfx + "conv1x1.bias"), 1, 1, 1, 0, N,
-           ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+    if tp is None:
+        p.conv(f, pfx + "conv1x1", w, em._unit(N), em.W(pfx + "conv1x1.bias"), 1, 1, 1, 0, N,
+               ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+    else:
+        p.conv(f, pfx + "conv1x1", w, tp.const_vec(N, True), em._bias_vec(pfx + "conv1x1", N), 1, 1, 1, 0, N,
+               ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+
+        def bwd_conv1x1():
+            if g0.tbuf not in tp.grads:
+                return
+            gg = tp.grad_of(g0)                              # (B, N, 64): gy[b, pix, n] = gg[b, n, pix]
+            gy = tp.act(f.H, f.W, N)
+            ggt = gg.tbuf
+            tp.strided_to_act(lambda P: P(ggt), tp.dtype, gg.coff, N * gg.cstride, 1, gg.cstride, gy, N, reads=[ggt])
+            tp.bn_bwd(gy, None, None, None, ACT_NONE, 0.0, None, None, tp.pg_ptr(pfx + "conv1x1.bias"))
+            tp.conv_backward(pfx + "conv1x1", w, f, gy, 1, 1, 1, 0)
+        tp.tape.append(bwd_conv1x1)
     g = g0
     ng = cfg["init_num_graph_module"]
     for i in range(ng):
@@ -188,11 +318,64 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
         raise RuntimeError("init_network_num_graph_module == 0 is not supported by the fused program")
     # Linear(64 -> 7) (init.py:107,120-122) into the (B,13,N) logit block: rows [roi | x2 x1 x0 | . . . | y2 y1 y0]
     wl = em.W(pfx + "mlp.weight")
-    p.conv(g, pfx + "mlp", wl.reshape(7, 64, 1, 1), em._unit(10),
-           torch.cat([em.W(pfx + "mlp.bias")[:4], torch.zeros(3, device=p.device), em.W(pfx + "mlp.bias")[4:]]),
+    if tp is None:
+        sc10 = em._unit(10)
+        sh10 = torch.cat([em.W(pfx + "mlp.bias")[:4], torch.zeros(3, device=p.device), em.W(pfx + "mlp.bias")[4:]])
+    else:
+        bl = em.W(pfx + "mlp.bias")
+        sc10, sh10 = tp.const_vec(10, True), tp.live_vec(10, [(0, bl, 0, 4), (7, bl, 4, 3)])
+    p.conv(g, pfx + "mlp", wl.view(7, 64, 1, 1), sc10, sh10,
            1, 1, 1, 0, 10, row_map=[0, 1, 2, 3, -1, -1, -1, 4, 5, 6], cout_rows=10, out_f32=True,
            ostr=(0, 13 * N, 0, 1, N), out_tbuf=io["bits_tb"])
+    if tp is not None:       # incoming gradient: rows [roi, x2 x1 x0, y2 y1 y0] gathered by the autograd hook into (B,7,N)
+        em._out_layer_bwd(pfx + "mlp", wl.view(7, 64, 1, 1), g, 7, io["dinit"], 0, 7 * N, 1, N)
     return feats, g
+
+
+def _convt_train_tail(em, up, wt, f, o, nf):
+    """train mode: BatchNorm (batch statistics) + ReLU behind the 4 raw ConvTranspose2d phase launches, and the layer's
+    backward: weight gradient = conv wgrad with the layer input as `dy` (coarse grid) and the output gradient as `x`;
+    data gradient = plain 3x3/s2 conv over the output gradient with w read as (Cout' = Cin_t, Cin' = Cout_t, 3, 3)."""
+    tp = em.tp
+    y, st = em._bn_train(o, up + ".1", ACT_RELU, None, None)
+
+    def bwd():
+        if y.tbuf not in tp.grads:
+            return
+        gy = tp.grad_of(y)
+        tp.bn_bwd(gy, y, o, st, ACT_RELU, 0.0, None, tp.pg_ptr(up + ".1.weight"), tp.pg_ptr(up + ".1.bias"))
+        tp.wgrad(f, gy, tp.pg_ptr(up + ".0.weight"), wt.shape[0], wt.shape[1], 3, 3, 2, 1)
+        gf = tp.grad_of(f)
+        tp.conv(gy, up + ".0#dgrad", wt, tp.const_vec(wt.shape[0], True), tp.const_vec(wt.shape[0], False), 3, 3, 2, 1,
+                wt.shape[0], residual=gf, out=gf)
+    tp.tape.append(bwd)
+    return y
+
+
+def _upsample_tape(tp, src, dst_slice):
+    def bwd():
+        if dst_slice.tbuf not in tp.grads:
+            return
+        tp.upsample2x_bwd(tp.grad_of(dst_slice), tp.grad_of(src))
+    tp.tape.append(bwd)
+
+
+def _patch_tape(em, pgk, wpg, f, patches, lslice, io, N, Ech, k):
+    """backward of Index2Feat (scatter-add of the keypoint gradients into an fp32 patch-map gradient, then into the
+    storage dtype) followed by the patch_generator conv's bias / weight / data gradients."""
+    tp = em.tp
+    dpatch = torch.empty(patches.B * patches.H * patches.W * Ech, dtype=torch.float32, device=tp.device)
+    tp.keep += [dpatch, io["xid"], io["yid"]]
+
+    def bwd():
+        if lslice.tbuf not in tp.grads:
+            return
+        tp.index2feat_bwd(tp.grad_of(lslice), io["xid"], io["yid"], io["mask"], dpatch, N, patches.H, patches.W, Ech, k)
+        gp = tp.act(patches.H, patches.W, Ech)
+        tp.strided_to_act(lambda P: dpatch.data_ptr(), 0, 0, patches.H * patches.W * Ech, Ech, 1, gp, Ech)
+        tp.bn_bwd(gp, None, None, None, ACT_NONE, 0.0, None, None, tp.pg_ptr(pgk + ".bias"))
+        tp.conv_backward(pgk, wpg, f, gp, k, k, 1, k - 1)
+    tp.tape.append(bwd)
 
 
 def emit_posenet(em: NetEmitter, cfg, io):
@@ -207,6 +390,8 @@ def emit_posenet(em: NetEmitter, cfg, io):
     qd = cfg["query_dims"] or (nf, 256, 64)
     k = cfg["local_k"]
     slope = cfg["leaky_slope"]
+
+    tp = em.tp
 
     def local_buf(i):
         gdim = 64 if i == 0 else qd[0]
@@ -226,13 +411,17 @@ def emit_posenet(em: NetEmitter, cfg, io):
         up = "up_net.%d" % i
         if i == 0:   # ConvTranspose2d(k3,s2,p1,op1)+BN+ReLU as 4 sub-pixel phase convs, then 2x conv3x3+BN+ReLU
             wt = em.W(up + ".0.weight")                     # (Cin, Cout, 3, 3)
-            s, t = em.ws.bn_fold(up + ".1")
+            s, t = em.ws.bn_fold(up + ".1") if tp is None else (None, None)
             o = p.act(2 * f.H, 2 * f.W, nf)
+            if tp is not None:
+                s, t = tp.const_vec(nf, True), tp.const_vec(nf, False)
             for ph in range(4):
                 a, b = ph >> 1, ph & 1
-                p.conv(f, up + ".0", wt, s, t, 1 + a, 1 + b, 1, 0, nf, ACT_RELU, transposed=1, phase=ph,
+                p.conv(f, up + ".0", wt, s, t, 1 + a, 1 + b, 1, 0, nf, ACT_RELU if tp is None else ACT_NONE, transposed=1, phase=ph,
                        ostr=((a * o.W + b) * o.cstride, o.H * o.W * o.cstride, 2 * o.W * o.cstride, 2 * o.cstride, 1),
                        out_tbuf=o.tbuf, out_hw=(f.H, f.W))
+            if tp is not None:
+                o = _convt_train_tail(em, up, wt, f, o, nf)
             f = em.conv_bn(o, up + ".3", up + ".4", 3, 1, 1)
             f = em.conv_bn(f, up + ".6", up + ".7", 3, 1, 1)
         else:        # cat[img_feat, img_feats[-i-1]] -> bilinear x2 (align_corners) -> 2x conv3x3+BN+ReLU
@@ -240,6 +429,9 @@ def emit_posenet(em: NetEmitter, cfg, io):
             cat = p.act(2 * f.H, 2 * f.W, f.C + sk.C)
             p.upsample2x(f, cat.slice(0, f.C))
             p.upsample2x(sk, cat.slice(f.Cphys, sk.C))
+            if tp is not None:
+                _upsample_tape(tp, f, cat.slice(0, f.C))
+                _upsample_tape(tp, sk, cat.slice(f.Cphys, sk.C))
             f = em.conv_bn(cat, up + ".1", up + ".2", 3, 1, 1)
             f = em.conv_bn(f, up + ".4", up + ".5", 3, 1, 1)
         # ---- Refine_moduleGNN.forward pipeline.py:262-298
@@ -248,9 +440,19 @@ def emit_posenet(em: NetEmitter, cfg, io):
         rp = "refine_net.%d" % i
         wpg = em.W(rp + ".local_feat_ext_block.patch_generator.weight")     # (E, nf, k, k)
         Ech = wpg.shape[0]
-        patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(rp + ".local_feat_ext_block.patch_generator.bias"),
-                         k, k, 1, k - 1, Ech)
+        pgk = rp + ".local_feat_ext_block.patch_generator"
+        if tp is None:
+            patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(pgk + ".bias"), k, k, 1, k - 1, Ech)
+        else:
+            patches = p.conv(f, rp + ".patch", wpg, tp.const_vec(Ech, True), em._bias_vec(pgk, Ech), k, k, 1, k - 1, Ech)
         p.index2feat(patches, io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, Ech, k)
+        if tp is not None:
+            # the decode ops advance io["xid"/"yid"] in place: keep this stage's gather positions for the backward
+            ids_i = dict(mask=io["mask"])
+            for nm in ("xid", "yid"):
+                ids_i[nm] = torch.empty_like(io[nm])
+                tp.memcpy(ids_i[nm].data_ptr(), io[nm].data_ptr(), io[nm].numel() * 4, "save_ids")
+            _patch_tape(em, pgk, wpg, f, patches, L.slice(0, 4 * Ech), ids_i, N, Ech, k)
         h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)
         h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope)
         Lnext = local_buf(i + 1) if i + 1 < active else None
@@ -263,8 +465,15 @@ def emit_posenet(em: NetEmitter, cfg, io):
         q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope)
         q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope)
         # Linear(64 -> 2): channel 0 = new x bit -> row 4+i, channel 1 = new y bit -> row 10+i  (pipeline.py:375-378)
-        em.linear(q, rp + ".query_block.mlps.4", ACT_NONE, 0.0, out_f32=True,
-                  ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
+        qk = rp + ".query_block.mlps.4"
+        if tp is None:
+            em.linear(q, qk, ACT_NONE, 0.0, out_f32=True, ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
+        else:
+            wq = em.W(qk + ".weight")
+            wq4 = wq.view(wq.shape[0], wq.shape[1], 1, 1)
+            p.conv(q, qk, wq4, tp.const_vec(2, True), em._bias_vec(qk, 2), 1, 1, 1, 0, 2, out_f32=True,
+                   ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
+            em._out_layer_bwd(qk, wq4, q, 2, io["dbits"], (4 + i) * N, 13 * N, 1, 6 * N)
         p.decode(dbits, i, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
         L = Lnext
     # seg_block Conv2d(nf -> seg_dim, 1x1) on the last feature map, NCHW fp32 out (pipeline.py:349,383)
@@ -272,8 +481,13 @@ def emit_posenet(em: NetEmitter, cfg, io):
         p.set_lane(0)
     wseg = em.W("seg_block.weight")
     sd_ = wseg.shape[0]
-    p.conv(f, "seg_block", wseg, em._unit(sd_), em.W("seg_block.bias"), 1, 1, 1, 0, sd_, out_f32=True,
-           ostr=(0, sd_ * f.H * f.W, f.W, 1, f.H * f.W), out_tbuf=io["seg_tb"])
+    if tp is None:
+        p.conv(f, "seg_block", wseg, em._unit(sd_), em.W("seg_block.bias"), 1, 1, 1, 0, sd_, out_f32=True,
+               ostr=(0, sd_ * f.H * f.W, f.W, 1, f.H * f.W), out_tbuf=io["seg_tb"])
+    else:
+        p.conv(f, "seg_block", wseg, tp.const_vec(sd_, True), em._bias_vec("seg_block", sd_), 1, 1, 1, 0, sd_, out_f32=True,
+               ostr=(0, sd_ * f.H * f.W, f.W, 1, f.H * f.W), out_tbuf=io["seg_tb"])
+        em._out_layer_bwd("seg_block", wseg, f, sd_, io["dseg"], 0, sd_ * f.H * f.W, 1, f.H * f.W)
     if active > 0:
         p.par_end()
     return feats, f

@@ -1,0 +1,320 @@
+"""Training-side launch program: the forward in train mode (batch-statistics BatchNorm, live
+weights re-packed inside the program) followed by its own backward, as ONE static launch list over the C ABI.
+
+Design.  TrainProgram extends engine.Program with a *tape*: every forward emitter that has a gradient pushes a closure
+which, when the tape is unwound in reverse, appends the backward launches (BN / bias backward, data-gradient convs --
+the forward conv kernels over transformed weights --, MFMA weight-gradients, graph-op marginals).  Activation
+gradients live in the storage dtype in per-tensor buffers that are zero-filled once and accumulated into (conv
+epilogues accumulate through their `residual` operand), parameter gradients are fp32 slices of ONE flat buffer
+(a single bucket for the data-parallel all-reduce, parallel.allreduce_gradients_).  The liveness planner of the base
+class keeps every saved activation alive until its last backward reader automatically.  Nothing here computes;
+torch supplies memory and the autograd hook (model/_runtime.py: _TrainFn) only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpWgradDesc
+from .engine import Act, Program, WeightStore, _rup
+
+
+class TrainWeightStore(WeightStore):
+    """Weights change every step: packing launches are appended to the program (right before their consumer) instead
+    of being run once at build time; per-channel vectors may be live device tensors passed through unchanged."""
+
+    def __init__(self, lib, sd, dtype, device):
+        super().__init__(lib, sd, dtype, device)
+        self.prog = None
+        self.passthrough = set()
+
+    def _emit(self, fn, args, name):
+        self.prog._add(fn, lambda P: args, name, [], [])
+
+    def pack(self, name, w, Cout, Cin, R, S, cin_phys, cout_rows, transposed=0, phase=0, row_map=None):
+        ck = (name, cin_phys, cout_rows, transposed, phase)
+        if ck in self.cache:
+            return self.cache[ck]
+        out = torch.empty(self.lib.cp_packed_weight_bytes(self.dtype, cout_rows, cin_phys, R, S), dtype=torch.uint8, device=self.device)
+        rm = None
+        if row_map is not None:
+            rm = torch.tensor(row_map, dtype=torch.int32, device=self.device)
+        self.prog.keep += [w, rm, out]
+        self._emit(self.lib.cp_pack_conv_weight, (self.dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
+                                                  rm.data_ptr() if rm is not None else None, cout_rows, out.data_ptr()),
+                   "pack:" + name)
+        self.cache[ck] = out
+        return out
+
+    def pack_halo(self, name, w, Cout, Cin, cin_phys):
+        ck = ("halo", name, cin_phys)
+        if ck in self.cache:
+            return self.cache[ck]
+        out = torch.empty(self.lib.cp_packed_halo_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
+        self.prog.keep += [w, out]
+        self._emit(self.lib.cp_pack_conv3x3_halo_weight, (self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
+                   "pack_halo:" + name)
+        self.cache[ck] = out
+        return out
+
+    def pack_gemm(self, name, w, Cout, Cin, cin_phys):
+        ck = ("gemm", name, cin_phys)
+        if ck in self.cache:
+            return self.cache[ck]
+        out = torch.empty(self.lib.cp_packed_gemm_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
+        self.prog.keep += [w, out]
+        self._emit(self.lib.cp_pack_gemm_weight, (self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()), "pack_gemm:" + name)
+        self.cache[ck] = out
+        return out
+
+    def affine(self, name, scale, shift, rows):
+        if id(scale) in self.passthrough and id(shift) in self.passthrough:
+            return scale, shift
+        return super().affine(name, scale, shift, rows)
+
+
+class TrainProgram(Program):
+    training = True
+
+    def __init__(self, lib, ws, dtype, B, device, pgrad, pslots):
+        super().__init__(lib, ws, dtype, B, device)
+        ws.prog = self
+        self.tape = []
+        self.grads = {}            # forward TBuf -> gradient TBuf
+        self.pgrad = pgrad         # flat fp32 parameter-gradient buffer
+        self.pslots = pslots       # state-dict key -> element offset into pgrad
+        self.nograd = set()        # id(TBuf) of tensors that need no gradient (the input image)
+        self.bn_ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=device)
+        self.n_fwd_ops = None
+        self._ones, self._zeros = {}, {}
+        self.debug = {}            # name -> Acts of interest (tools/train_debug.py with CHECKERPOSE_AMD_NO_RECYCLE=1)
+
+    # ---- lanes are an inference-latency device; the training program is one ordered stream
+    def par_begin(self, nlanes): pass
+    def set_lane(self, k): pass
+    def sync(self, src, dst): pass
+    def par_end(self): pass
+
+    # ---- small helpers
+    def const_vec(self, n, one):
+        d = self._ones if one else self._zeros
+        n = _rup(n, 16)
+        if n not in d:
+            d[n] = (torch.ones if one else torch.zeros)(n, dtype=torch.float32, device=self.device)
+            self.ws.passthrough.add(id(d[n]))
+        return d[n]
+
+    def vec(self, n):
+        t = torch.zeros(_rup(n, 16), dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        self.ws.passthrough.add(id(t))
+        return t
+
+    def pg_ptr(self, key):
+        return self.pgrad.data_ptr() + 4 * self.pslots[key]
+
+    def memset_t(self, tbuf, name="memset"):
+        fn = self.lib.cp_memset_zero
+        nb = tbuf.nbytes
+        self._add(fn, lambda P: (P(tbuf), nb), name, [], [tbuf])
+
+    def memcpy(self, dst_ptr, src_ptr, nbytes, name="memcpy"):
+        self._add(self.lib.cp_memcpy_d2d, lambda P: (dst_ptr, src_ptr, nbytes), name, [], [])
+
+    def live_vec(self, n, segments):
+        """padded fp32 vector refreshed inside the program from live parameter storage: segments = [(dst_off, tensor,
+        src_off, count)]"""
+        t = self.vec(n)
+        for doff, src, soff, cnt in segments:
+            self.keep.append(src)
+            self.memcpy(t.data_ptr() + 4 * doff, src.data_ptr() + 4 * soff, 4 * cnt, "refresh_vec")
+        return t
+
+    def scratch_f32(self, numel):
+        t = torch.empty(numel, dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def grad_of(self, a: Act):
+        """gradient view matching `a` (same geometry) -- buffer created and zero-filled on first request"""
+        g = self.grads.get(a.tbuf)
+        if g is None:
+            g = self.tensor(a.tbuf.nbytes, es=1)
+            g.nbytes = a.tbuf.nbytes
+            self.grads[a.tbuf] = g
+            self.memset_t(g, "grad_zero")
+        return Act(g, a.B, a.H, a.W, a.C, a.Cphys, a.cstride, a.coff)
+
+    def needs_grad(self, a: Act):
+        return id(a.tbuf) not in self.nograd
+
+    # ---- train-mode BatchNorm
+    def bn_stats(self, x: Act, C_, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
+        bn = dict(scale=self.vec(C_), shift=self.vec(C_), mean=self.vec(C_), rstd=self.vec(C_), gamma=gamma, C=C_)
+        self.keep += [gamma, beta, rmean, rvar]
+        xt = x.tbuf
+        M = x.B * x.H * x.W
+        args = (gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), momentum, eps, bn["scale"].data_ptr(),
+                bn["shift"].data_ptr(), bn["mean"].data_ptr(), bn["rstd"].data_ptr(), self.bn_ws.data_ptr())
+        self._add(self.lib.cp_bn_train_stats, lambda P: (self.dtype, P(xt), M, C_, x.cstride, x.coff) + args, "bn_stats", [xt], [])
+        return bn
+
+    def affine_act(self, x: Act, scale, shift, residual, out: Act, act, slope=0.0):
+        xt, ot = x.tbuf, out.tbuf
+        rt = residual.tbuf if residual is not None else None
+        M = x.B * x.H * x.W
+        sp, tp = scale.data_ptr(), shift.data_ptr()
+        rcs, rco = (residual.cstride, residual.coff) if residual is not None else (0, 0)
+        self._add(self.lib.cp_affine_act,
+                  lambda P: (self.dtype, P(xt), x.cstride, x.coff, sp, tp, P(rt) if rt is not None else None, rcs, rco, P(ot),
+                             out.cstride, out.coff, M, x.C, act, slope), "affine_act", [xt, rt], [ot])
+        return out
+
+    def bn_bwd(self, gy: Act, y: Act, raw: Act, bn, act, slope, gres: Act, dgamma_ptr, dbeta_ptr):
+        """in place on gy: gy <- d loss / d raw ; gres += dz ; dgamma / dbeta written.  raw None = bias-only layer."""
+        gt = gy.tbuf
+        yt = y.tbuf if (y is not None and act != ACT_NONE) else None
+        rt = raw.tbuf if raw is not None else None
+        grt = gres.tbuf if gres is not None else None
+        M = gy.B * gy.H * gy.W
+        C_ = gy.C
+        mean_p = bn["mean"].data_ptr() if bn else None
+        rstd_p = bn["rstd"].data_ptr() if bn else None
+        gam_p = bn["gamma"].data_ptr() if bn else None
+        ycs, yco = (y.cstride, y.coff) if yt is not None else (0, 0)
+        rcs, rco = (raw.cstride, raw.coff) if raw is not None else (0, 0)
+        gcs, gco = (gres.cstride, gres.coff) if gres is not None else (0, 0)
+        wsp = self.bn_ws.data_ptr()
+        self._add(self.lib.cp_bn_train_bwd,
+                  lambda P: (self.dtype, P(gt), gy.cstride, gy.coff, P(yt) if yt is not None else None, ycs, yco,
+                             P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, gam_p, M, C_, act, slope, P(gt),
+                             gy.cstride, gy.coff, P(grt) if grt is not None else None, gcs, gco, 1, dgamma_ptr, dbeta_ptr, wsp),
+                  "bn_bwd", [gt, yt, rt, grt], [gt, grt])
+
+    # ---- dense layer backward
+    def wgrad(self, dy: Act, x: Act, dw_ptr, Cout, Cin, R, S, stride, pad, Ho=None, Wo=None, base=0, sco=None, sci=None):
+        d = CpWgradDesc()
+        d.dtype, d.B, d.H, d.W = self.dtype, x.B, x.H, x.W
+        d.Ho, d.Wo = (dy.H, dy.W) if Ho is None else (Ho, Wo)
+        d.Cout, d.dy_cstride, d.dy_coff = Cout, dy.cstride, dy.coff
+        d.Cin, d.x_cstride, d.x_coff = Cin, x.cstride, x.coff
+        d.R, d.S, d.stride, d.pad = R, S, stride, pad
+        d.dw_base, d.dw_sco, d.dw_sci, d.dw_sr, d.dw_ss = base, (Cin * R * S if sco is None else sco), (R * S if sci is None else sci), S, 1
+        self.keep.append(d)
+        dref = C.byref(d)
+        dt, xt = dy.tbuf, x.tbuf
+        self._add(self.lib.cp_conv2d_wgrad, lambda P: (dref, P(dt), P(xt), dw_ptr), "wgrad", [dt, xt], [])
+
+    def weight_dgrad(self, w, Cout, Cin, R, S):
+        wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)
+        self.keep.append(w)
+        self._add(self.lib.cp_weight_dgrad, lambda P: (w.data_ptr(), Cout, Cin, R, S, wt.data_ptr()), "weight_dgrad", [], [])
+        return wt
+
+    def conv_backward(self, key, w, x: Act, g: Act, R, S, stride, pad):
+        """g = d loss / d (raw conv output) in channels-last; accumulates into grad(x), writes the weight gradient."""
+        Cout, Cin = w.shape[0], w.shape[1]
+        self.wgrad(g, x, self.pg_ptr(key + ".weight"), Cout, Cin, R, S, stride, pad)
+        if not self.needs_grad(x):
+            return
+        gx = self.grad_of(x)
+        one, zero = self.const_vec(Cin, True), self.const_vec(Cin, False)
+        if stride == 1:
+            wt = self.weight_dgrad(w, Cout, Cin, R, S)
+            self.conv(g, key + "#dgrad", wt, one, zero, R, S, 1, R - 1 - pad, Cin, residual=gx, out=gx)
+        elif stride == 2 and R == 3 and S == 3 and pad == 1 and x.H == 2 * g.H and x.W == 2 * g.W:
+            for ph in range(4):       # ConvTranspose2d(k3,s2,p1,op1) phases over w read as (Cin_t = Cout, Cout_t = Cin, 3, 3)
+                a, b = ph >> 1, ph & 1
+                self.conv(g, key + "#dgrad", w, one, zero, 1 + a, 1 + b, 1, 0, gx.Cphys, transposed=1, phase=ph, residual=gx,
+                          ostr=(gx.coff + (a * gx.W + b) * gx.cstride, gx.H * gx.W * gx.cstride, 2 * gx.W * gx.cstride,
+                                2 * gx.cstride, 1), out_tbuf=gx.tbuf, out_hw=(g.H, g.W))
+        elif stride == 2 and R == 1 and S == 1 and pad == 0:
+            wt = self.weight_dgrad(w, Cout, Cin, 1, 1)
+            self.conv(g, key + "#dgrad", wt, one, zero, 1, 1, 1, 0, gx.Cphys, residual=gx,
+                      ostr=(gx.coff, gx.H * gx.W * gx.cstride, 2 * gx.W * gx.cstride, 2 * gx.cstride, 1), out_tbuf=gx.tbuf,
+                      out_hw=(g.H, g.W))
+        else:
+            raise RuntimeError("no data-gradient path for conv %s (k=%d, stride=%d, pad=%d)" % (key, R, stride, pad))
+
+    # ---- resampling backward
+    def upsample2x_bwd(self, gout: Act, gin: Act):
+        gt, it = gout.tbuf, gin.tbuf
+        tail = (gin.B, gin.H, gin.W, gin.Cphys, gout.cstride, gout.coff, gin.cstride, gin.coff, 1)
+        self._add(self.lib.cp_upsample2x_bilinear_ac_bwd, lambda P: (self.dtype, P(gt), P(it)) + tail, "upsample2x_bwd", [gt, it], [it])
+
+    def fuse_sum_bwd(self, gout: Act, out: Act, gsrc: Act, shift, relu):
+        gt, ot, st_ = gout.tbuf, out.tbuf, gsrc.tbuf
+        tail = (gsrc.B, gsrc.H, gsrc.W, gsrc.Cphys, int(shift), 1 if relu else 0, 1)
+        self._add(self.lib.cp_fuse_sum_act_bwd, lambda P: (self.dtype, P(gt), P(ot), P(st_)) + tail, "fuse_sum_bwd", [gt, ot, st_], [st_])
+
+    def strided_to_act(self, src_ptr_fn, src_dtype, base, sb, sp, sc, out: Act, C_, reads=()):
+        """strided tensor -> dense channels-last Act (out must be dense: coff 0, cstride == Cphys)"""
+        assert out.coff == 0 and out.cstride == out.Cphys
+        ot = out.tbuf
+        HW = out.H * out.W
+        self._add(self.lib.cp_strided_to_nhwc,
+                  lambda P: (self.dtype, src_ptr_fn(P), src_dtype, base, sb, sp, sc, P(ot), out.B, HW, C_, out.Cphys),
+                  "strided_to_nhwc", list(reads), [ot])
+
+    # ---- train-mode EdgeConv
+    def edge_weight_view(self, w, Co, Ci, mode):
+        out = self.scratch_f32(2 * Co * Ci)
+        self.keep.append(w)
+        self._add(self.lib.cp_edge_weight_view, lambda P: (w.data_ptr(), Co, Ci, mode, out.data_ptr()), "edge_weight_view", [], [])
+        return out.view(2 * Co, Ci, 1, 1) if mode == 0 else out.view(Ci, 2 * Co, 1, 1)
+
+    def edge_train_fwd(self, pq: Act, graph, gamma, beta, rmean, rvar, out: Act, Co, slope, momentum=0.1, eps=1e-5):
+        N = pq.W
+        st_ = dict(scale=self.vec(Co), shift=self.vec(Co), mean=self.vec(Co), rstd=self.vec(Co), gamma=gamma,
+                   kstar=torch.empty(pq.B * N * Co, dtype=torch.uint8, device=self.device),
+                   ws=torch.empty(self.lib.cp_edge_train_workspace_bytes(pq.B, Co), dtype=torch.uint8, device=self.device))
+        self.keep += [st_, gamma, beta, rmean, rvar]
+        pt, ot = pq.tbuf, out.tbuf
+        gp = graph["gids"].data_ptr() if graph["gids"] is not None else None
+        a1 = (graph["idx"].data_ptr(), gp, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), momentum, eps)
+        a2 = (st_["kstar"].data_ptr(), st_["scale"].data_ptr(), st_["shift"].data_ptr(), st_["mean"].data_ptr(),
+              st_["rstd"].data_ptr(), st_["ws"].data_ptr(), pq.B, N, graph["K"], Co, graph["G"], slope)
+        self._add(self.lib.cp_edgeconv_train_fwd, lambda P: (self.dtype, P(pt)) + a1 + (P(ot), out.cstride, out.coff) + a2,
+                  "edge_train_fwd", [pt], [ot])
+        return st_
+
+    def edge_train_bwd(self, pq: Act, graph, st_, out: Act, gout: Act, D: Act, dgamma_ptr, dbeta_ptr, Co, slope):
+        N = pq.W
+        pt, ot, gt, dt = pq.tbuf, out.tbuf, gout.tbuf, D.tbuf
+        gp = graph["gids"].data_ptr() if graph["gids"] is not None else None
+        a1 = (graph["idx"].data_ptr(), graph["rev_ptr"].data_ptr(), graph["rev_edge"].data_ptr(), gp)
+        a3 = (st_["gamma"].data_ptr(), st_["mean"].data_ptr(), st_["rstd"].data_ptr())
+        a4 = (dgamma_ptr, dbeta_ptr, st_["ws"].data_ptr(), pq.B, N, graph["K"], Co, graph["G"], slope)
+        kp = st_["kstar"].data_ptr()
+        self._add(self.lib.cp_edgeconv_train_bwd,
+                  lambda P: (self.dtype, P(pt)) + a1 + (P(ot), out.cstride, out.coff, kp, P(gt), gout.cstride, gout.coff) + a3 +
+                            (P(dt),) + a4, "edge_train_bwd", [pt, ot, gt], [dt])
+
+    def index2feat_bwd(self, gout: Act, xid_t, yid_t, mask_t, dpatch_f32, N, Hp, Wp, E_ch, k):
+        gt = gout.tbuf
+        args = (xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr(), dpatch_f32.data_ptr(), gout.B, N, Hp, Wp, E_ch, k,
+                gout.cstride, gout.coff)
+        self._add(self.lib.cp_index2feat_gather_bwd_t, lambda P: (self.dtype, P(gt)) + args, "index2feat_bwd", [gt], [])
+
+    # ---- tape
+    def mark_forward_end(self):
+        self.n_fwd_ops = len(self.ops)
+
+    def unwind(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    def read_act(self, a: Act):
+        """debug: the current contents of an activation / gradient view as a (B, H, W, C) fp32 CPU tensor"""
+        dt = torch.bfloat16 if self.dtype == CP_BF16 else torch.float32
+        es = 2 if self.dtype == CP_BF16 else 4
+        n = a.B * a.H * a.W * a.cstride
+        flat = self.workspace[a.tbuf.offset:a.tbuf.offset + n * es].view(dt).view(a.B, a.H, a.W, a.cstride)
+        return flat[..., a.coff:a.coff + a.C].float().cpu()
+
+    def run_range(self, stream_ptr, lo, hi):
+        for fn, args, name in self.calls[lo:hi]:
+            rc = fn(stream_ptr, *args[1:])
+            if rc != 0:
+                _abi.check(rc, name)

@@ -210,6 +210,10 @@ int cp_edgeconv_gather_max_bwd(cp_stream_t stream, int dtype, const void* pq, co
 int cp_index2feat_gather_bwd(cp_stream_t stream, const float* gout, const int32_t* x_id, const int32_t* y_id,
                              const float* mask, float* dpatches, int B, int N, int Hp, int Wp, int E, int k,
                              int gout_cstride, int gout_coff);
+/* same with gout stored in `dtype` (the training program keeps activation gradients in the storage type) */
+int cp_index2feat_gather_bwd_t(cp_stream_t stream, int dtype, const void* gout, const int32_t* x_id, const int32_t* y_id,
+                               const float* mask, float* dpatches, int B, int N, int Hp, int Wp, int E, int k,
+                               int gout_cstride, int gout_coff);
 
 /* UnmaskedCodeLoss (mask == NULL; losses/code_loss.py:6-27) / MaskedCodeLoss (mask (B,N); code_loss.py:30-62):
  * pred (B,nbits,N) fp32 logits with batch stride pred_bstride (elements), gt likewise (train.py:312-313 passes the
@@ -307,11 +311,12 @@ int cp_upsample2x_bilinear_ac_bwd(cp_stream_t stream, int dtype, const void* dou
 int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws,
                         int C, int shift, int relu, int accumulate);
 
-/* plumbing: stream-ordered zero fill (capturable), and an fp32 tensor with arbitrary element strides (the logit block,
+/* plumbing: stream-ordered zero fill / device copy (capturable), and a tensor (fp32 or `dtype`: src_dtype) with arbitrary element strides (the logit block,
  * NCHW seg logits, fp32 scatter targets) -> channels-last `dtype` (B, HW, Cphys) with zero padded channels. */
 int cp_memset_zero(cp_stream_t stream, void* p, size_t nbytes);
-int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const float* src, long long base, long long sb, long long sp,
-                       long long sc, void* out, int B, int HW, int C, int Cphys);
+int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const void* src, int src_dtype, long long base, long long sb,
+                       long long sp, long long sc, void* out, int B, int HW, int C, int Cphys);
+int cp_memcpy_d2d(cp_stream_t stream, void* dst, const void* src, size_t nbytes);
 
 /* layout plumbing at the boundary: NCHW fp32 image -> channels-last `dtype` (C padded with zeros to
  * Cphys), and channels-last slice -> NCHW fp32 (for `return_img_feats`, init.py:123-124). */

@@ -34,8 +34,26 @@ CONV1X1_IN_CHANS = {"resnet34": 512, "hrnet_w18": 1024}
 
 
 # --------------------------------------------------------------------------- generic pieces
+BN_TRAIN = {"on": False}     # tests flip this for the train-mode (batch statistics) restatement, see bn_train()
+
+
+class bn_train:
+    """context manager: BatchNorm layers run like nn.BatchNorm2d in .train() mode (batch statistics, running stats of
+    `sd` updated in place with momentum 0.1) -- the state every module is in during reference train.py:300-320."""
+
+    def __enter__(self):
+        BN_TRAIN["on"] = True
+
+    def __exit__(self, *a):
+        BN_TRAIN["on"] = False
+
+
 def _bn(sd, p, x, eps=1e-5):
-    """eval-mode BatchNorm (nn.BatchNorm2d defaults eps=1e-5), any rank, channel dim 1."""
+    """BatchNorm (nn.BatchNorm2d defaults eps=1e-5, momentum 0.1), any rank, channel dim 1; eval mode unless bn_train()."""
+    if BN_TRAIN["on"]:
+        if (p + ".num_batches_tracked") in sd:
+            sd[p + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
     shape = [1, -1] + [1] * (x.dim() - 2)
     s = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + eps)
     return x * s.view(shape) + (sd[p + ".bias"] - sd[p + ".running_mean"] * s).view(shape)
@@ -59,10 +77,16 @@ def knn(x, k):
     return pairwise_distance.topk(k=k, dim=-1)[1]
 
 
+FORCE_KSTAR = {}    # tests only: {module prefix: (B,C',N) int64 neighbour slot} -- teacher-forces the arg-max of the max over K
+
+
 def static_graph_module(sd, p, x, knn_idx, slope=0.2):
     """StaticGraph_module.forward, init.py:54-68 == pipeline.py:45-59, with
     get_graph_feature init.py:36-49.  x (B,C,N), knn_idx (1|B,N,K) -> (B,C',N).
-    Written exactly as the reference does (per-edge 1x1 conv), not factored."""
+    Written exactly as the reference does (per-edge 1x1 conv), not factored.
+    If FORCE_KSTAR holds an entry for `p`, the max over K is replaced by a gather at those slots: the max routes its
+    gradient to ONE neighbour, a discontinuous choice, so gradient-parity tests pin it to the device's choice (the two
+    forwards agree only to ~1e-5 relative and near-ties among the K=20 candidates would otherwise be routed differently)."""
     B, C, N = x.shape
     idx = knn_idx.expand(B, -1, -1) if knn_idx.shape[0] == 1 else knn_idx
     K = idx.shape[2]
@@ -72,6 +96,8 @@ def static_graph_module(sd, p, x, knn_idx, slope=0.2):
     e = torch.cat([nb - ctr, ctr], dim=1)                          # (B,2C,N,K)
     e = F.conv2d(e, sd[p + ".conv.0.weight"])
     e = F.leaky_relu(_bn(sd, p + ".conv.1", e), slope)
+    if p in FORCE_KSTAR:
+        return e.gather(-1, FORCE_KSTAR[p].unsqueeze(-1)).squeeze(-1)
     return e.max(dim=-1)[0]
 
 

@@ -372,7 +372,7 @@ def test_strided_to_nhwc_and_memset(lib, dtype):
     src = bits.to(dev())
     E = 8 if dtype == CP_BF16 else 4
     out = torch.full((B, N, E), 7.0, dtype=DT[dtype], device=dev())
-    _abi.check(lib.cp_strided_to_nhwc(st(), dtype, src.data_ptr(), 4 * N, 13 * N, 1, N, out.data_ptr(), B, N, Cc, E))
+    _abi.check(lib.cp_strided_to_nhwc(st(), dtype, src.data_ptr(), CP_F32, 4 * N, 13 * N, 1, N, out.data_ptr(), B, N, Cc, E))
     torch.cuda.synchronize()
     ref = torch.zeros(B, N, E)
     ref[..., :Cc] = rnd(bits[:, 4:7].permute(0, 2, 1), dtype)
@@ -380,3 +380,72 @@ def test_strided_to_nhwc_and_memset(lib, dtype):
     _abi.check(lib.cp_memset_zero(st(), out.data_ptr(), out.numel() * out.element_size()))
     torch.cuda.synchronize()
     assert float(out.float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [CP_F32])
+def test_edgeconv_train_full_layer_real_graph(lib, dtype):
+    """whole train-mode StaticGraph_module at the real size (ape kNN graph, N=512, K=20, C=256): node GEMM ->
+    cp_edgeconv_train_fwd ; backward: cp_edgeconv_train_bwd -> two wgrad launches + the [W1 W2]-view data-gradient,
+    against torch autograd of the reference formulation w.r.t. x, W, gamma, beta"""
+    from tests.common import ape_p3d
+    from checkerpose_amd.model.init import knn
+    B, Cin, Co, N, K, slope = 2, 256, 256, 512, 20, 0.2
+    idx = knn(ape_p3d(N), K)[0]
+    x = rnd(det_tensor("fl_x", (B, Cin, N)), dtype).requires_grad_(True)
+    w = det_tensor("fl_w", (Co, 2 * Cin), (1.0 / Cin) ** 0.5).requires_grad_(True)
+    gamma = (1.0 + 0.5 * det_tensor("fl_g", (Co,)))
+    gamma[::3] *= -1
+    beta = 0.2 * det_tensor("fl_b", (Co,))
+    gamma.requires_grad_(True); beta.requires_grad_(True)
+    with torch.enable_grad():
+        nb = x[:, :, idx]                                                        # (B,C,N,K)
+        ctr = x[:, :, :, None].expand(-1, -1, -1, K)
+        e = F.conv2d(torch.cat([nb - ctr, ctr], 1), w[:, :, None, None])
+        z = F.leaky_relu(F.batch_norm(e, torch.zeros(Co), torch.ones(Co), gamma, beta, True, 0.1, 1e-5), slope)
+        y = z.max(dim=-1)[0]
+    gout = rnd(det_tensor("fl_d", (B, Co, N)), dtype)
+    dx_ref, dw_ref, dg_ref, db_ref = torch.autograd.grad(y, [x, w, gamma, beta], gout)
+    d = dev()
+    wd = w.detach().to(d)
+    wpq = torch.empty(2 * Co, Cin, 1, 1, device=d)
+    wdg = torch.empty(Cin, 2 * Co, 1, 1, device=d)
+    _abi.check(lib.cp_edge_weight_view(st(), wd.data_ptr(), Co, Cin, 0, wpq.data_ptr()))
+    _abi.check(lib.cp_edge_weight_view(st(), wd.data_ptr(), Co, Cin, 1, wdg.data_ptr()))
+    torch.cuda.synchronize()
+    xc = to_cl(x.detach()[:, :, None, :], dtype)                                 # (B,1,N,C)
+    pq = conv_cl(lib, dtype, xc, pack(lib, dtype, wpq.cpu(), Cin, 1, 1), 2 * Co, 1, 1, 1, 0, 1, N)
+    idx32 = idx.int().to(d).contiguous()[None]
+    rev_ptr, rev_edge = _rev_graph(idx32)
+    out = torch.zeros(B, N, Co, dtype=DT[dtype], device=d)
+    kstar = torch.zeros(B, N, Co, dtype=torch.uint8, device=d)
+    vec = [torch.zeros(Co, device=d) for _ in range(4)]
+    g_d, b_d = gamma.detach().to(d), beta.detach().to(d)
+    ws = torch.empty(lib.cp_edge_train_workspace_bytes(B, Co), dtype=torch.uint8, device=d)
+    _abi.check(lib.cp_edgeconv_train_fwd(st(), dtype, pq.data_ptr(), idx32.data_ptr(), None, g_d.data_ptr(), b_d.data_ptr(),
+                                         None, None, 0.1, 1e-5, out.data_ptr(), Co, 0, kstar.data_ptr(), vec[0].data_ptr(),
+                                         vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), ws.data_ptr(), B, N, K, Co, 1, slope))
+    torch.cuda.synchronize()
+    close(out.float().cpu(), y.detach().permute(0, 2, 1), TOLT[dtype])
+    gc = gout.permute(0, 2, 1).contiguous().to(DT[dtype]).to(d)
+    D = torch.zeros(B, 1, N, 2 * Co, dtype=DT[dtype], device=d)
+    dg, db = torch.zeros(Co, device=d), torch.zeros(Co, device=d)
+    _abi.check(lib.cp_edgeconv_train_bwd(st(), dtype, pq.data_ptr(), idx32.data_ptr(), rev_ptr.data_ptr(), rev_edge.data_ptr(), None,
+                                         out.data_ptr(), Co, 0, kstar.data_ptr(), gc.data_ptr(), Co, 0, g_d.data_ptr(),
+                                         vec[2].data_ptr(), vec[3].data_ptr(), D.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                         ws.data_ptr(), B, N, K, Co, 1, slope))
+    torch.cuda.synchronize()
+    close(dg.cpu() / dg_ref.abs().max().item(), dg_ref / dg_ref.abs().max().item(), TOLT[dtype])
+    dw = torch.zeros(Co, 2 * Cin, device=d)
+    for half in (0, 1):
+        de = CpWgradDesc()
+        de.dtype, de.B, de.H, de.W, de.Ho, de.Wo = dtype, B, 1, N, 1, N
+        de.Cout, de.dy_cstride, de.dy_coff, de.Cin, de.x_cstride, de.x_coff = Co, 2 * Co, half * Co, Cin, Cin, 0
+        de.R, de.S, de.stride, de.pad = 1, 1, 1, 0
+        de.dw_base, de.dw_sco, de.dw_sci, de.dw_sr, de.dw_ss = half * Cin, 2 * Cin, 1, 1, 1
+        _abi.check(lib.cp_conv2d_wgrad(st(), C.byref(de), D.data_ptr(), xc.data_ptr(), dw.data_ptr()))
+    torch.cuda.synchronize()
+    s = dw_ref.abs().max().item()
+    close(dw.cpu() / s, dw_ref / s, TOLT[dtype])
+    dx = conv_cl(lib, dtype, D, pack(lib, dtype, wdg.cpu(), 2 * Co, 1, 1), Cin, 1, 1, 1, 0, 1, N)
+    s = dx_ref.abs().max().item()
+    close(from_cl(dx, Cin)[:, :, 0] / s, dx_ref.detach() / s, TOLT[dtype])
