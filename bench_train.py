@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench_train.py -- training-step throughput of the drop-in CheckerPose modules on MI355X (SURVEY.md 8f row N1 / BASELINE
+config "DP batch sharded across 8 x MI355X with RCCL grad all-reduce").  NOT the headline metric (that is bench.py, the
+forward); same launch contract:
+
+  python bench_train.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench_train.py --gpus N
+
+A "step" = the body of reference train.py:300-320 on one batch of B synthetic 256x256 crops per GPU, already resident in
+HBM: zero_grad, PoseNet_GNNskip forward in train mode (batch-statistics BatchNorm), the five losses, backward through the
+HIP training program, ONE all-reduce of the flat fp32 gradient buffer over RCCL (N > 1), torch's fused Adam step.
+Prints one JSON line on rank 0: crops/s (whole job), ms/step, and the per-kernel device time of the step's launch
+program (HIP events, eager replay) with achieved TFLOP/s of the weight-gradient kernel.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step (reference config: batch_size 32)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--npoint", type=int, default=512)
+    ap.add_argument("--no-breakdown", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("CHECKERPOSE_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", (local % ndev) if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    from checkerpose_amd.losses.code_loss import MaskedCodeLoss, UnmaskedCodeLoss
+    from checkerpose_amd.losses.mask_loss import MaskLoss_interpolate
+    from tests.common import build_net, det_image, det_tensor
+    B, N = a.batch, a.npoint
+    net = build_net(npoint=N, seed=1).to(dev).train()
+    net.set_compute_dtype(a.dtype)
+    img = det_image(B, seed=100 + rank).to(dev)
+    roi_gt = (det_tensor("t_roi", (B, 1, N), seed=rank) > -0.5).float().to(dev)
+    x_gt = (det_tensor("t_x", (B, 16, N), seed=rank) > 0).float().to(dev)
+    y_gt = (det_tensor("t_y", (B, 16, N), seed=rank) > 0).float().to(dev)
+    m_vis = (det_tensor("t_mv", (B, 128, 128), seed=rank) > 0).float().to(dev)
+    m_full = (det_tensor("t_mf", (B, 128, 128), seed=rank) > -0.3).float().to(dev)
+    roi_loss, bit_loss, seg_loss = UnmaskedCodeLoss("BCE"), MaskedCodeLoss("BCE"), MaskLoss_interpolate()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
+    p3d = torch.zeros(1, 3, N, device=dev).expand(B, -1, -1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        roi, xb, yb, seg, _, _ = net(img, p3d, 3)
+        nb = xb.shape[1]
+        loss = roi_loss(roi, roi_gt) + bit_loss(xb, x_gt[:, :nb], roi_gt) + bit_loss(yb, y_gt[:, :nb], roi_gt) \
+            + seg_loss(seg[:, 0:1], m_vis) + seg_loss(seg[:, 1:2], m_full)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(a.warmup, 1)):
+        l0 = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        l1 = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        from checkerpose_amd.parallel import max_over_ranks
+        el = max_over_ranks(el, dev if backend == "nccl" else None)
+    pr = list(net._train_programs.values())[0]
+    prog = pr["prog"]
+    out = {"metric": "crops/sec training step (256x256, npt=%d)" % N, "value": round(world * B * a.steps / el, 1), "unit": "crops/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d: train.py step (forward in train mode, 5 losses, "
+                                  "backward, gradient all-reduce, Adam)" % N,
+                      "crops_per_gpu_per_step": B, "global_batch": world * B,
+                      "parallelism": "dp%d, one all-reduce of the %.1f MB flat fp32 gradient buffer per step" % (world, pr["pgrad"].numel() * 4 / 1e6),
+                      "launches": "%d forward + %d backward kernel launches per step" % (prog.n_fwd_ops, len(prog.calls) - prog.n_fwd_ops)},
+           "loss_first_last": [round(float(l0), 4), round(float(l1), 4)],
+           "workspace_mb": round(prog.workspace_bytes / 2 ** 20, 1)}
+    if rank == 0 and not a.no_breakdown:
+        from checkerpose_amd import _abi
+        lib = _abi.load()
+        stream = torch.cuda.current_stream()
+        sp = stream.cuda_stream
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in prog.calls]
+        syms = []
+        for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+            e0.record(stream)
+            fn(sp, *args[1:])
+            e1.record(stream)
+            syms.append(lib.cp_last_kernel().decode() if not name.startswith(("memset", "grad_zero", "pgrad_zero", "refresh_vec", "save_ids", "memcpy")) else name.split(":")[0])
+        torch.cuda.synchronize()
+        agg = {}
+        for i, ((fn, args, name), (e0, e1), sy) in enumerate(zip(prog.calls, evs, syms)):
+            half = "fwd" if i < prog.n_fwd_ops else "bwd"
+            r = agg.setdefault((half, sy), [0.0, 0])
+            r[0] += e0.elapsed_time(e1)
+            r[1] += 1
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        out["kernel_ms_per_step"] = {"%s:%s" % k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in rows[:24]}
+        out["device_ms_fwd_bwd"] = [round(sum(v[0] for k, v in agg.items() if k[0] == h), 3) for h in ("fwd", "bwd")]
+        wg = sum(v[0] for k, v in agg.items() if k[1].startswith("wgrad_kernel"))
+        if wg > 0:      # weight gradients do the forward's dense FLOPs once more (conv_log covers fwd convs AND dgrad convs)
+            fwd_fl = sum(c[4] for c in prog.conv_log[:]) / 2.0
+            out["wgrad"] = {"ms": round(wg, 3), "approx_tflops": round(fwd_fl / (wg * 1e-3) / 1e12, 1)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,9 +10,28 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ small plumbing
+// zero fill / device copy as plain kernels: they sit inside the captured training graphs between kernel nodes (memset /
+// memcpy graph nodes replayed wrongly here: measured NaNs on the second replay), 16 bytes per thread + byte tail.
+__global__ void fill_zero_kernel(unsigned char* __restrict__ p, size_t nvec, size_t nbytes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nvec) ((u32x4*)p)[i] = u32x4{0u, 0u, 0u, 0u};
+  if (i == 0) for (size_t b = nvec * 16; b < nbytes; ++b) p[b] = 0;
+}
+__global__ void copy_bytes_kernel(unsigned char* __restrict__ d, const unsigned char* __restrict__ s, size_t nvec, size_t nbytes, int vec) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    if (i < nvec) ((u32x4*)d)[i] = ((const u32x4*)s)[i];
+    if (i == 0) for (size_t b = nvec * 16; b < nbytes; ++b) d[b] = s[b];
+  } else if (i < nbytes) d[i] = s[i];
+}
+
 extern "C" int cp_memset_zero(cp_stream_t stream, void* p, size_t nbytes) {
-  if (!p) return CP_ERR_INVALID;
-  return hipMemsetAsync(p, 0, nbytes, (hipStream_t)stream) == hipSuccess ? CP_OK : CP_ERR_HIP;
+  if (!p || ((uintptr_t)p & 15)) return p ? CP_ERR_ALIGN : CP_ERR_INVALID;
+  if (nbytes == 0) return CP_OK;
+  const size_t nvec = nbytes / 16;
+  const size_t n = nvec > 0 ? nvec : 1;
+  CP_LAUNCH(fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, nvec, nbytes);
+  return cp_check_launch();
 }
 
 __global__ void weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int R, int S,
@@ -95,7 +114,13 @@ extern "C" int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const void* src
 
 extern "C" int cp_memcpy_d2d(cp_stream_t stream, void* dst, const void* src, size_t nbytes) {
   if (!dst || !src) return CP_ERR_INVALID;
-  return hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? CP_OK : CP_ERR_HIP;
+  if (nbytes == 0) return CP_OK;
+  const int vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+  const size_t nvec = nbytes / 16;
+  const size_t n = vec ? (nvec > 0 ? nvec : 1) : nbytes;
+  CP_LAUNCH(copy_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst,
+            (const unsigned char*)src, nvec, nbytes, vec);
+  return cp_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
@@ -128,6 +153,7 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
 #pragma unroll
       for (int j = 0; j < E; ++j) { mu[j] = p.mean[piece * E + j]; rs[j] = p.rstd[piece * E + j]; }
     }
+#pragma unroll 4
     for (int m = blockIdx.x * p.rpb + rl; m < m_end; m += p.RL) {
       float a[E];
       Vec16<Tag>::unpack(*(const u32x4*)((const typename Tag::elem*)p.a + (size_t)m * p.a_cs + p.a_coff + piece * E), a);
@@ -170,7 +196,7 @@ static int colsum_plan(int M, int Cphys, int E, int* G, int* RL, int* nblk, int*
   *G = Cphys / E;
   if (*G > 256) return CP_ERR_INVALID;
   *RL = 256 / *G;
-  int nb = M / 128;
+  int nb = M / 64;
   nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
   *rpb = (M + nb - 1) / nb;
   *nblk = (M + *rpb - 1) / *rpb;
@@ -180,16 +206,22 @@ static int colsum_plan(int M, int Cphys, int E, int* G, int* RL, int* nblk, int*
 extern "C" size_t cp_bn_workspace_bytes(int C) { return (size_t)512 * 2 * ((size_t)(C + 15) / 16 * 16) * sizeof(double); }
 
 // forward finalize: mean / biased var -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+// one WAVE per channel: the lanes stride over the block partials, then a shuffle reduction (a serial loop over up to 512
+// partials per channel was latency-bound: ~65 us per BatchNorm layer)
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec,
+                                       double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                        float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
                                        float* __restrict__ rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= Cvec) return;
-  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; rstd[c] = 0.f; return; }
+  if (c >= C) { if (lane == 0) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; rstd[c] = 0.f; } return; }
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+  if (lane != 0) return;
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   var = var > 0.0 ? var : 0.0;
@@ -208,7 +240,7 @@ int cp_bn_finalize_launch(hipStream_t st, const double* partial, int nblk, int C
                           const float* beta, float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
                           float* mean, float* rstd) {
   const int Cvec = (C + 15) / 16 * 16;
-  CP_LAUNCH(bn_fwd_finalize_kernel, dim3((Cvec + 63) / 64), dim3(64), 0, st, partial, nblk, CP, C, Cvec, count, gamma, beta,
+  CP_LAUNCH(bn_fwd_finalize_kernel, dim3((Cvec + 3) / 4), dim3(256), 0, st, partial, nblk, CP, C, Cvec, count, gamma, beta,
             eps, momentum, rmean, rvar, scale, shift, mean, rstd);
   return cp_check_launch();
 }
@@ -296,15 +328,19 @@ extern "C" int cp_affine_act(cp_stream_t stream, int dtype, const void* x, int x
 
 // ------------------------------------------------------------------------------------------------ BN / bias backward
 // coef[0..3][Cvec]: a = gamma*rstd, b = mean(dz), c = mean(dz*xhat)*rstd, mu ; dgamma / dbeta written for c < C
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec,
+                                       double count, const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, int has_bn, float* __restrict__ coef,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per channel
   if (c >= Cvec) return;
-  if (c >= C) { coef[c] = 0.f; coef[Cvec + c] = 0.f; coef[2 * Cvec + c] = 0.f; coef[3 * Cvec + c] = 0.f; return; }
+  if (c >= C) { if (lane == 0) { coef[c] = 0.f; coef[Cvec + c] = 0.f; coef[2 * Cvec + c] = 0.f; coef[3 * Cvec + c] = 0.f; } return; }
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+  if (lane != 0) return;
   if (dbeta) dbeta[c] = (float)s1;
   if (has_bn) {
     if (dgamma) dgamma[c] = (float)s2;
@@ -321,7 +357,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
 int cp_bn_bwd_finalize_launch(hipStream_t st, const double* partial, int nblk, int CP, int C, double count, const float* gamma,
                               const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta) {
   const int Cvec = (C + 15) / 16 * 16;
-  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 63) / 64), dim3(64), 0, st, partial, nblk, CP, C, Cvec, count, gamma, mean,
+  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 3) / 4), dim3(256), 0, st, partial, nblk, CP, C, Cvec, count, gamma, mean,
             rstd, 1, coef, dgamma, dbeta);
   return cp_check_launch();
 }
@@ -406,7 +442,7 @@ extern "C" int cp_bn_train_bwd(cp_stream_t stream, int dtype, const void* dy, in
   if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 1>), dim3(nblk), dim3(256), 0, st, p);
   else CP_LAUNCH((colsum2_kernel<BF16Tag, 1>), dim3(nblk), dim3(256), 0, st, p);
   if ((rc = cp_check_launch())) return rc;
-  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 63) / 64), dim3(64), 0, st, p.partial, nblk, Cphys, C, Cvec, (double)M, gamma,
+  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 3) / 4), dim3(256), 0, st, p.partial, nblk, Cphys, C, Cvec, (double)M, gamma,
             mean, rstd, x ? 1 : 0, coef, dgamma, dbeta);
   if ((rc = cp_check_launch())) return rc;
   BnBwdParams q;

@@ -354,8 +354,7 @@ extern "C" int cp_edgeconv_train_bwd(cp_stream_t stream, int dtype, const void* 
   edge_plan(B, N, KPB, &p.S, &p.npb);
   const int grid = 8 * ((B + 7) / 8) * p.S;
   // coef[3] (mu) must be in place before the reduce kernel runs: copy mean -> coef[3*C] first
-  if (hipMemcpyAsync(coef + 3 * (size_t)C, mean, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return CP_ERR_HIP;
+  if ((rc = cp_memcpy_d2d(stream, coef + 3 * (size_t)C, mean, (size_t)C * sizeof(float)))) return rc;
   const size_t lds_r = (size_t)256 * 2 * E * sizeof(double) + (size_t)KPB * K * sizeof(int32_t);
 #define FN_RED(TAG, T) do { cp_mark_kernel("edge_reduce_kernel<%s, %d, 1>", #TAG, T); \
     hipLaunchKernelGGL((edge_reduce_kernel<TAG, T, 1>), dim3(grid), dim3(256), lds_r, st, p); } while (0)

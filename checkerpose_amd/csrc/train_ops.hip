@@ -195,7 +195,7 @@ extern "C" int cp_index2feat_gather_bwd_t(cp_stream_t stream, int dtype, const v
   if (E_ch % 4 || gout_cstride % 4 || gout_coff % 4 || gout_coff + 4 * E_ch > gout_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(gout) || !cp_aligned16(dpatches)) return CP_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dpatches, 0, (size_t)B * Hp * Wp * E_ch * sizeof(float), st) != hipSuccess) return CP_ERR_HIP;
+  if (cp_memset_zero(stream, dpatches, (size_t)B * Hp * Wp * E_ch * sizeof(float)) != CP_OK) return CP_ERR_HIP;
   const int EG4 = E_ch / 4;
   const size_t total = (size_t)B * N * 4 * EG4;
   if (dtype == CP_F32)

@@ -11,6 +11,35 @@ from ..engine import DTYPES, Program, ProgramGroup, WeightStore
 from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
 
 
+TRAIN_GRAPH = os.environ.get("CHECKERPOSE_AMD_TRAIN_GRAPH", "fwd,bwd").split(",")   # which halves replay as hipGraphs (A/B + debugging)
+
+
+def _replay_half(mod, pr, which, lo, hi, device):
+    """Run ops [lo, hi) of the training program on the current stream: eagerly the first time (also lets one-time
+    kernel attribute setup happen outside a capture), then as one captured hipGraph per half (forward / backward)."""
+    prog = pr["prog"]
+    cur = torch.cuda.current_stream(device)
+    lib = _abi.load()
+    g = pr["graphs"].get(which)
+    if not mod.use_graph or which not in TRAIN_GRAPH or not pr["warm"].get(which):
+        prog.run_range(cur.cuda_stream, lo, hi)
+        pr["warm"][which] = True
+        return
+    if g is None:
+        side = torch.cuda.Stream(device)
+        side.wait_stream(cur)
+        _abi.check(lib.cp_graph_begin_capture(side.cuda_stream), "graph capture begin")
+        try:
+            prog.run_range(side.cuda_stream, lo, hi)
+        finally:
+            gx = C.c_void_p()
+            rc = lib.cp_graph_end_capture(side.cuda_stream, C.byref(gx))
+        _abi.check(rc, "graph capture end")
+        pr["graphs"][which] = g = gx
+        pr["keep_streams"].append(side)
+    _abi.check(lib.cp_graph_launch(g, cur.cuda_stream), "graph launch")
+
+
 class _TrainFn(torch.autograd.Function):
     """autograd hook of the training program (trainer.TrainProgram): forward() replays the forward half of the launch
     list (train-mode BatchNorm, activations saved in the program's workspace), backward() copies the incoming logit /
@@ -22,8 +51,7 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, mod, pr, img, *params):
         io, prog = pr["io"], pr["prog"]
         io["img"].copy_(img)
-        st = torch.cuda.current_stream(img.device).cuda_stream
-        prog.run_range(st, 0, prog.n_fwd_ops)
+        _replay_half(mod, pr, "fwd", 0, prog.n_fwd_ops, img.device)
         if pr["counters"]:
             torch._foreach_add_(pr["counters"], 1)          # BatchNorm2d.num_batches_tracked
         ctx.mod, ctx.pr, ctx.nparams = mod, pr, len(params)
@@ -40,8 +68,7 @@ class _TrainFn(torch.autograd.Function):
         io["dinit"].copy_(torch.cat([dbits[:, 0:4], dbits[:, 7:10]], dim=1))
         if "dseg" in io:
             io["dseg"].copy_(dseg)
-        st = torch.cuda.current_stream(dbits.device).cuda_stream
-        prog.run_range(st, prog.n_fwd_ops, len(prog.calls))
+        _replay_half(mod, pr, "bwd", prog.n_fwd_ops, len(prog.calls), dbits.device)
         pg = pr["pgrad"]
         if mod.dp_allreduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size() > 1:
@@ -75,6 +102,10 @@ class HipForwardMixin:
         for pr in getattr(self, "_programs", {}).values():
             if pr.get("graph") and lib is not None:
                 for g in pr["graph"]:
+                    lib.cp_graph_destroy(g)
+        for pr in getattr(self, "_train_programs", {}).values():
+            for g in pr["graphs"].values():
+                if lib is not None:
                     lib.cp_graph_destroy(g)
         self._programs, self._stores, self._idx_dev = {}, {}, None
         self._train_programs = {}
@@ -209,7 +240,8 @@ class HipForwardMixin:
         prog.unwind()
         prog.finalize()
         torch.cuda.current_stream(device).synchronize()
-        return dict(prog=prog, io=io, pgrad=pgrad, params=params, offsets=offsets, counters=list(em.bn_counters), busy=None)
+        return dict(prog=prog, io=io, pgrad=pgrad, params=params, offsets=offsets, counters=list(em.bn_counters), busy=None,
+                    graphs={}, warm={}, keep_streams=[])
 
     def _run_train(self, img, obj_ids, stage=None):
         if not (torch.is_tensor(img) and img.is_cuda):
@@ -237,7 +269,7 @@ class HipForwardMixin:
                 pr["busy"] = bits.grad_fn
             else:                                     # train-mode statistics without autograd (e.g. under no_grad)
                 io["img"].copy_(img)
-                pr["prog"].run_range(torch.cuda.current_stream(device).cuda_stream, 0, pr["prog"].n_fwd_ops)
+                _replay_half(self, pr, "fwd", 0, pr["prog"].n_fwd_ops, device)
                 if pr["counters"]:
                     torch._foreach_add_(pr["counters"], 1)
                 bits, seg = io["bits"].clone(), io["seg"].clone() if "seg" in io else None

@@ -52,8 +52,8 @@ def test_modules_fail_loudly_without_gpu():
     net = build_net(full=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(det_image(1), None)
-    net.train()
-    with pytest.raises(RuntimeError, match="train-mode"):
+    net.train()                                  # the training program has no CPU fallback either
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(det_image(1), None)
     with pytest.raises(RuntimeError, match="parameter containers"):
         net.init_net.img_backbone(det_image(1))
