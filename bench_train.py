@@ -123,6 +123,13 @@ def main():
             r = agg.setdefault((half, sy), [0.0, 0])
             r[0] += e0.elapsed_time(e1)
             r[1] += 1
+        per_call = {}
+        for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+            if name.startswith(("wgrad", "bn_bwd", "bn_stats")):
+                r = per_call.setdefault(name, [0.0, 0])
+                r[0] += e0.elapsed_time(e1)
+                r[1] += 1
+        out["slowest_named_calls"] = {k: {"ms": round(v[0], 3), "n": v[1]} for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][0])[:16]}
         rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
         out["kernel_ms_per_step"] = {"%s:%s" % k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in rows[:24]}
         out["device_ms_fwd_bwd"] = [round(sum(v[0] for k, v in agg.items() if k[0] == h), 3) for h in ("fwd", "bwd")]

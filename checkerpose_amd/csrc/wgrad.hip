@@ -19,6 +19,8 @@
 //
 // Replaces: autograd of every nn.Conv2d / nn.ConvTranspose2d / nn.Linear weight on the path (reference
 // checkerpose/train.py:319 `loss.backward()`).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -31,6 +33,7 @@ struct WgradParams {
   int R, S, stride, pad;
   int co_blocks, ci_blocks, slice; // pixels per block slice (multiple of 64)
   long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
+  float* ws;                       // per-block partial tiles [slice][blockIdx.y][64][64] (NULL: fp32 atomics into dw)
 };
 
 template <typename Tag> struct WgCfg;
@@ -156,6 +159,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 
   // D[co][ci]: lane holds rows co = 4g+j (j = 0..3), column ci = xl of every tile
+  if (p.ws) {        // plain stores of the block's partial tile; wgrad_reduce_kernel sums the slices (no atomics)
+    float* tile = p.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4096;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[(wco + a * 16 + 4 * g + j) * 64 + wci + b * 16 + xl] = acc[a][b][j];
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -173,7 +186,223 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// dw[co][ci][r][s] += sum over the pixel slices of the partial tiles (deterministic order).  Thread = one dw element,
+// ci fastest (coalesced reads of the 64-float tile rows).
+struct WgradReduceParams {
+  const float* ws; float* dw;
+  int S, GY, co_blocks, ci_blocks, R, Ssz, Cout, Cin, taps_in_block;   // taps_in_block: 9 (all-taps kernel) or 1
+  long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams p) {
+  // block = 16 consecutive dw elements (ci fastest: 64-byte reads) x 16 slice lanes; the lanes stride over the slices
+  // (a serial loop over up to 512 slices per element was latency-bound), then an LDS tree adds the 16 partial sums
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, sl0 = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + e;
+  const size_t total = (size_t)p.R * p.Ssz * p.Cout * p.Cin;
+  const bool ok = i < total;
+  const size_t ii = ok ? i : 0;
+  const int ci = (int)(ii % p.Cin);
+  size_t t = ii / p.Cin;
+  const int co = (int)(t % p.Cout);
+  const int tap = (int)(t / p.Cout);
+  const int cob = co >> 6, cib = ci >> 6;
+  size_t off, stride;
+  if (p.taps_in_block == 1) {
+    const int y = cob + p.co_blocks * (cib + p.ci_blocks * tap);
+    off = (size_t)y * 4096;
+    stride = (size_t)p.GY * 4096;
+  } else {
+    const int y = cob + p.co_blocks * cib;
+    off = ((size_t)y * 9 + tap) * 4096;
+    stride = (size_t)p.GY * 9 * 4096;
+  }
+  off += (size_t)(co & 63) * 64 + (ci & 63);
+  float acc = 0.f;
+  if (ok)
+    for (int sl = sl0; sl < p.S; sl += 16) acc += p.ws[off + (size_t)sl * stride];
+  red[sl0][e] = acc;
+  __syncthreads();
+  if (sl0 == 0 && ok) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][e];
+    float* dst = p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / p.Ssz) * p.dw_sr +
+                 (long long)(tap % p.Ssz) * p.dw_ss;
+    *dst += s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 specialisation (bf16): ALL NINE TAPS in one block.  The per-tap kernel above re-reads dy and x
+// once per tap (9x the traffic; measured 40 TFLOP/s on the 256 -> 256 decoder convs).  Here a block walks tiles of 64
+// output pixels (TH x TW, TH*TW = 64), stages the dy tile and the (TH+2) x (TW+2) x-halo ONCE in LDS and every tap reads
+// its operand fragments from the halo at a shifted row (each lane supplies its own row address to the transposing
+// read, so a shift costs nothing).  A wave owns a 32 x 32 (co x ci) quadrant for all taps: 36 accumulator tiles
+// (144 VGPRs); per 32-pixel sub-chunk 4 + 36 transposed reads feed 36 MFMAs.  Waves whose quadrant lies outside the
+// layer's channels (18/36-channel HRNet branches) skip the MFMAs but keep staging.
+struct Wgrad3Params {
+  const void* dy; const void* x; float* dw;
+  int H, W, TH, TW, tiles_x, tiles_img, n_tiles, tiles_per_block;
+  int Cout, dy_cs, dy_coff, Cin, x_cs, x_coff;
+  int co_blocks, ci_blocks;
+  long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
+  float* ws;                       // [slice][blockIdx.y][tap][64][64]
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
+  constexpr int PITCH = 160, XROWS = 200, NX = 7;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(64 + XROWS) * PITCH];
+  unsigned char* ldy = lds;
+  unsigned char* lx = lds + 64 * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xl = lane & 15, g = lane >> 4, q = xl >> 2, pp = xl & 3;
+  const int cob = blockIdx.y % p.co_blocks, cib = blockIdx.y / p.co_blocks;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const bool active = (co0 + wco < p.Cout) && (ci0 + wci < p.Cin);          // wave-uniform
+  const int TW2 = p.TW + 2, HR = (p.TH + 2) * TW2;
+  const int t_begin = blockIdx.x * p.tiles_per_block;
+  const int t_end = min(t_begin + p.tiles_per_block, p.n_tiles);
+
+  const int prow = tid >> 3, pc = tid & 7;
+  const bool dy_cok = co0 + pc * 8 < p.Cout, x_cok = ci0 + pc * 8 < p.Cin;
+  u32x4 rdy[2], rx[NX];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rdy[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rx[i] = u32x4{0u, 0u, 0u, 0u};
+    if (t >= t_end) return;
+    const int b = t / p.tiles_img;
+    const int rem = t - b * p.tiles_img;
+    const int ty0 = (rem / p.tiles_x) * p.TH, tx0 = (rem % p.tiles_x) * p.TW;
+    if (dy_cok) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int px = i * 32 + prow;
+        const int ty = px / p.TW, tx = px - ty * p.TW;
+        rdy[i] = *(const u32x4*)((const uint16_t*)p.dy + ((size_t)(b * p.H + ty0 + ty) * p.W + tx0 + tx) * p.dy_cs + p.dy_coff + co0 + pc * 8);
+      }
+    }
+    if (x_cok) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int row = i * 32 + prow;
+        if (row < HR) {
+          const int hy = row / TW2, hx = row - hy * TW2;
+          const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            rx[i] = *(const u32x4*)((const uint16_t*)p.x + ((size_t)(b * p.H + iy) * p.W + ix) * p.x_cs + p.x_coff + ci0 + pc * 8);
+        }
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(ldy + (i * 32 + prow) * PITCH + pc * 16) = rdy[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int row = i * 32 + prow;
+      if (row < XROWS) *(u32x4*)(lx + row * PITCH + pc * 16) = rx[i];
+    }
+  };
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  gload(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    gload(t + 1);
+    if (active) {
+#pragma unroll
+      for (int sc = 0; sc < 2; ++sc) {
+        const int p_lo = sc * 32 + 4 * g + q, p_hi = p_lo + 16;
+        const int h_lo = (p_lo / p.TW) * TW2 + (p_lo % p.TW), h_hi = (p_hi / p.TW) * TW2 + (p_hi % p.TW);
+        bf16x8 fa[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int cb = (wco + a * 16 + 4 * pp) * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ldy + p_lo * PITCH + cb));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ldy + p_hi * PITCH + cb));
+          fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int sh = (tap / 3) * TW2 + (tap % 3);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int cb = (wci + b * 16 + 4 * pp) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lx + (h_lo + sh) * PITCH + cb));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lx + (h_hi + sh) * PITCH + cb));
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[tap][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[tap][a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (p.ws) {        // partial tile of this block; quadrants outside the layer's channels are never read back
+    if (!active) return;
+    float* tile = p.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 9 * 4096;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tile[tap * 4096 + (wco + a * 16 + 4 * g + j) * 64 + wci + b * 16 + xl] = acc[tap][a][b][j];
+    return;
+  }
+  if (!active) return;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ci = ci0 + wci + b * 16 + xl;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = co0 + wco + a * 16 + 4 * g + j;
+          if (co >= p.Cout) continue;
+          unsafeAtomicAdd(p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / 3) * p.dw_sr +
+                              (long long)(tap % 3) * p.dw_ss, acc[tap][a][b][j]);
+        }
+      }
+}
+
+static int launch_reduce(hipStream_t st, const float* ws, float* dw, int S, int GY, int co_blocks, int ci_blocks, const CpWgradDesc* d,
+                         int taps_in_block) {
+  WgradReduceParams r;
+  r.ws = ws; r.dw = dw; r.S = S; r.GY = GY; r.co_blocks = co_blocks; r.ci_blocks = ci_blocks; r.R = d->R; r.Ssz = d->S;
+  r.Cout = d->Cout; r.Cin = d->Cin; r.taps_in_block = taps_in_block;
+  r.dw_base = d->dw_base; r.dw_sco = d->dw_sco; r.dw_sci = d->dw_sci; r.dw_sr = d->dw_sr; r.dw_ss = d->dw_ss;
+  const size_t total = (size_t)d->R * d->S * d->Cout * d->Cin;
+  CP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, r);
+  return cp_check_launch();
+}
+
 extern "C" int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw) {
+  return cp_conv2d_wgrad_ws(stream, d, dy, x, dw, nullptr, 0);
+}
+
+extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw,
+                                  void* workspace, size_t workspace_bytes) {
   if (!d || !dy || !x || !dw) return CP_ERR_INVALID;
   if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype);
@@ -187,6 +416,33 @@ extern "C" int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const v
   if (!cp_aligned16(dy) || !cp_aligned16(x) || ((uintptr_t)dw & 3)) return CP_ERR_ALIGN;
   const long long M = (long long)d->B * d->Ho * d->Wo;
   if (M >= (1LL << 31) || (long long)d->B * d->H * d->W >= (1LL << 31)) return CP_ERR_RANGE;
+  // 3x3 / s1 / p1 in bf16 on power-of-two maps: all-taps kernel
+  if (d->dtype == CP_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W &&
+      d->W >= 8 && (d->W & (d->W - 1)) == 0 && !getenv("CP_WGRAD_GENERIC")) {
+    const int TW = d->W < 64 ? d->W : 64, TH = 64 / TW;
+    if (d->H % TH == 0) {
+      Wgrad3Params q;
+      q.dy = dy; q.x = x; q.dw = dw; q.H = d->H; q.W = d->W; q.TH = TH; q.TW = TW;
+      q.tiles_x = d->W / TW; q.tiles_img = q.tiles_x * (d->H / TH); q.n_tiles = d->B * q.tiles_img;
+      q.Cout = d->Cout; q.dy_cs = d->dy_cstride; q.dy_coff = d->dy_coff; q.Cin = d->Cin; q.x_cs = d->x_cstride; q.x_coff = d->x_coff;
+      q.co_blocks = (d->Cout + 63) / 64; q.ci_blocks = (d->Cin + 63) / 64;
+      q.dw_base = d->dw_base; q.dw_sco = d->dw_sco; q.dw_sci = d->dw_sci; q.dw_sr = d->dw_sr; q.dw_ss = d->dw_ss;
+      const int tb = q.co_blocks * q.ci_blocks;
+      const size_t per_slice = (size_t)tb * 9 * 4096 * sizeof(float);
+      const bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
+      int S = (use_ws ? 256 : 1024) / tb;              // one block per CU (400 VGPRs): one round of blocks
+      if (S > q.n_tiles / 2) S = q.n_tiles / 2;
+      if (use_ws && (size_t)S * per_slice > workspace_bytes) S = (int)(workspace_bytes / per_slice);
+      if (S < 1) S = 1;
+      q.tiles_per_block = (q.n_tiles + S - 1) / S;
+      S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
+      q.ws = use_ws ? (float*)workspace : nullptr;
+      CP_LAUNCH(wgrad3x3_kernel, dim3((unsigned)S, (unsigned)tb), dim3(256), 0, (hipStream_t)stream, q);
+      int rc3 = cp_check_launch();
+      if (rc3 || !use_ws) return rc3;
+      return launch_reduce((hipStream_t)stream, q.ws, dw, S, tb, q.co_blocks, q.ci_blocks, d, 9);
+    }
+  }
   WgradParams p;
   p.dy = dy; p.x = x; p.dw = dw;
   p.M = (int)M; p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo; p.H = d->H; p.W = d->W;
@@ -197,15 +453,21 @@ extern "C" int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const v
   p.dw_base = d->dw_base; p.dw_sco = d->dw_sco; p.dw_sci = d->dw_sci; p.dw_sr = d->dw_sr; p.dw_ss = d->dw_ss;
   // pixel slices: enough blocks to fill 256 CUs a few times over, at least 256 pixels (4 stages) per slice
   const long long tiles = (long long)p.co_blocks * p.ci_blocks * d->R * d->S;
-  long long want = (2048 + tiles - 1) / tiles;                    // slices wanted
+  const size_t per_slice = (size_t)tiles * 4096 * sizeof(float);
+  const bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
+  long long want = ((use_ws ? 1024 : 2048) + tiles - 1) / tiles;  // slices wanted
+  if (use_ws && (size_t)want * per_slice > workspace_bytes) want = (long long)(workspace_bytes / per_slice);
   long long slice = (M + want - 1) / want;
   slice = (slice + 63) / 64 * 64;
   if (slice < 256) slice = 256;
   p.slice = (int)slice;
   const unsigned nslice = (unsigned)((M + slice - 1) / slice);
   if (tiles > 65535) return CP_ERR_RANGE;
+  p.ws = use_ws ? (float*)workspace : nullptr;
   dim3 grid(nslice, (unsigned)tiles);
   if (d->dtype == CP_F32) CP_LAUNCH(wgrad_kernel<F32Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else CP_LAUNCH(wgrad_kernel<BF16Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  return cp_check_launch();
+  int rcg = cp_check_launch();
+  if (rcg || !use_ws) return rcg;
+  return launch_reduce((hipStream_t)stream, p.ws, dw, (int)nslice, (int)tiles, p.co_blocks, p.ci_blocks, d, 1);
 }

@@ -85,6 +85,7 @@ class TrainProgram(Program):
         self.pslots = pslots       # state-dict key -> element offset into pgrad
         self.nograd = set()        # id(TBuf) of tensors that need no gradient (the input image)
         self.bn_ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=device)
+        self.wg_ws = torch.empty(160 << 20, dtype=torch.uint8, device=device)     # weight-gradient slice partials
         self.n_fwd_ops = None
         self._ones, self._zeros = {}, {}
         self.debug = {}            # name -> Acts of interest (tools/train_debug.py with CHECKERPOSE_AMD_NO_RECYCLE=1)
@@ -203,7 +204,9 @@ class TrainProgram(Program):
         self.keep.append(d)
         dref = C.byref(d)
         dt, xt = dy.tbuf, x.tbuf
-        self._add(self.lib.cp_conv2d_wgrad, lambda P: (dref, P(dt), P(xt), dw_ptr), "wgrad", [dt, xt], [])
+        wsp, wsn = self.wg_ws.data_ptr(), self.wg_ws.numel()
+        self._add(self.lib.cp_conv2d_wgrad_ws, lambda P: (dref, P(dt), P(xt), dw_ptr, wsp, wsn),
+                  "wgrad:%d->%d k%d s%d %dx%d" % (Cin, Cout, R, stride, x.H, x.W), [dt, xt], [])
 
     def weight_dgrad(self, w, Cout, Cin, R, S):
         wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)

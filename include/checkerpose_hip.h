@@ -253,6 +253,11 @@ typedef struct CpWgradDesc {
   int64_t dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
 } CpWgradDesc;
 int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw);
+/* same, with a caller-owned scratch buffer: the pixel-slice partial sums go through it (plain stores + one reduction
+ * launch, deterministic) instead of through fp32 atomics -- measured ~30 G atomics/s made every launch cost >= 0.6 ms.
+ * dw is still accumulated into (+=).  Any size works (it bounds the number of slices); 160 MiB never limits. */
+int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
+                       size_t workspace_bytes);
 
 /* Weights of the data-gradient of a stride-1 conv: w (Cout,Cin,R,S) fp32 -> wt (Cin,Cout,R,S) fp32 with both taps
  * flipped (wt[ci][co][r][s] = w[co][ci][R-1-r][S-1-s]); dx = conv(dy, wt, stride 1, pad R-1-pad).  (Stride-2 3x3

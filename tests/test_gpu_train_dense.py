@@ -18,7 +18,19 @@ pytestmark = pytest.mark.gpu
 TOLT = {CP_F32: 2e-4, CP_BF16: 3e-2}
 
 
+WG_WS = {}
+
+
 def wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, R, S, stride, pad, dy_coff=0, x_coff=0):
+    """runs both reductions of the pixel-slice partials (fp32 atomics; scratch buffer + reduce launch) and checks they agree"""
+    a = _wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, R, S, stride, pad, dy_coff, x_coff, False)
+    b = _wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, R, S, stride, pad, dy_coff, x_coff, True)
+    sc = float(a.abs().max()) + 1e-30
+    assert float((a - b).abs().max()) / sc < 1e-5
+    return b
+
+
+def _wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, R, S, stride, pad, dy_coff, x_coff, use_ws):
     B, Ho, Wo, dcs = dy_cl.shape
     _, H, W, xcs = x_cl.shape
     dw = torch.zeros(Cout, Cin, R, S, dtype=torch.float32, device=dev())
@@ -27,7 +39,13 @@ def wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, R, S, stride, pad, dy_coff=0, x_co
     d.Cout, d.dy_cstride, d.dy_coff, d.Cin, d.x_cstride, d.x_coff = Cout, dcs, dy_coff, Cin, xcs, x_coff
     d.R, d.S, d.stride, d.pad = R, S, stride, pad
     d.dw_base, d.dw_sco, d.dw_sci, d.dw_sr, d.dw_ss = 0, Cin * R * S, R * S, S, 1
-    _abi.check(lib.cp_conv2d_wgrad(st(), C.byref(d), dy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr()), "wgrad")
+    if use_ws:
+        if "ws" not in WG_WS:
+            WG_WS["ws"] = torch.empty(64 << 20, dtype=torch.uint8, device=dev())
+        _abi.check(lib.cp_conv2d_wgrad_ws(st(), C.byref(d), dy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr(), WG_WS["ws"].data_ptr(),
+                                          WG_WS["ws"].numel()), "wgrad_ws")
+    else:
+        _abi.check(lib.cp_conv2d_wgrad(st(), C.byref(d), dy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr()), "wgrad")
     torch.cuda.synchronize()
     return dw.cpu()
 
@@ -43,6 +61,9 @@ WGRAD_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad)
     (3, 64, 1, 100, 128, 1, 1, 0),     # linear over keypoints, pixel tail
     (1, 16, 40, 40, 10, 7, 2, 3),      # 7x7 stride 2
     (16, 32, 32, 32, 32, 3, 1, 1),     # many pixel slices (atomics across slices)
+    (2, 72, 64, 64, 144, 3, 1, 1),     # all-taps 3x3 kernel: 1 x 64 tiles, ragged channel blocks (72 / 144)
+    (2, 18, 64, 128, 18, 3, 1, 1),     # all-taps kernel, W > 64, one active wave quadrant
+    (3, 256, 16, 16, 128, 3, 1, 1),    # all-taps kernel, 4 x 16 tiles
 ]
 
 
