@@ -74,7 +74,8 @@ class _TrainFn(torch.autograd.Function):
                 and torch.distributed.get_world_size() > 1:
             from ..parallel import allreduce_gradients_
             allreduce_gradients_([pg], bucket_bytes=1 << 40, average=True)
-        grads = tuple(pg[o:o + p.numel()].view_as(p).clone() if p.requires_grad else None
+        pgc = pg.clone()       # ONE copy per step; autograd may keep (steal) the per-parameter views of this fresh buffer
+        grads = tuple(pgc[o:o + p.numel()].view_as(p) if p.requires_grad else None
                       for (o, p) in zip(pr["offsets"], pr["params"]))
         pr["busy"] = None
         return (None, None, None) + grads
