@@ -14,6 +14,10 @@ Pinning status
   restatement was checked against them; the golden vectors under tests/golden/ were
   produced by the REFERENCE modules (tests/golden/make_golden.py) and
   tests/test_oracle.py re-checks this file against them on every run.
+* Train mode (bn_train(): batch-statistics BatchNorm + torch autograd through this file): PINNED for the head.
+  tests/golden/make_golden_trainstep.py ran ONE TRAINING STEP of the reference's own modules in .train() mode with the
+  reference's loss classes combined as train.py:307-318 does; tests/test_oracle_train.py re-checks losses, logits, ids,
+  every parameter gradient and BatchNorm running statistics of this restatement against it (2e-5).
 * Backbone (a1: timm `hrnet_w18` / `resnet34` features_only): PARITY UNPINNED.  The
   arithmetic lives in the third-party package `timm` (version not pinned anywhere in
   the reference; backbone.py:5,35,48-49), which is absent from /root/reference and

@@ -59,3 +59,61 @@ def test_nearest_index_is_torch_nearest():
         ref = torch.nn.functional.interpolate(torch.arange(n_in, dtype=torch.float32)[None, None, None], size=(1, n_out),
                                               mode="nearest")[0, 0, 0].long().numpy()
         np.testing.assert_array_equal(TO.nearest_index(n_out, n_in), ref)
+
+
+def test_oracle_train_mode_step_matches_reference_trainstep_golden():
+    """The oracle restatement under bn_train() (batch-statistics BatchNorm) + the numpy loss head, differentiated by torch
+    autograd on the CPU, against ONE TRAINING STEP of the reference's own modules in .train() mode
+    (tests/golden/trainstep_injected.npz, made by make_golden_trainstep.py): losses, logits, ids, every parameter gradient
+    (in full up to 4096 elements, else sum / abs-sum / 64 strided samples) and BatchNorm running statistics.  Both sides
+    are fp32 torch on the CPU with the same op order, so the tolerance is tight: 2e-5 of each tensor's scale."""
+    import torch
+    from checkerpose_amd.detweights import fill_state_dict_
+    from oracle import checkerpose_oracle as O
+    from tests.common import build_net, inject_feats, oracle_kwargs
+    c = TC.TRAINSTEP
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainstep_injected.npz"))
+    B, N = c["B"], c["N"]
+    net = build_net(seed=c["seed"])
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    params = [k for k, _ in net.named_parameters() if "img_backbone" not in k]
+    for k in params:
+        sd[k].requires_grad_(True)
+    feats = inject_feats(B, seed=c["feat_seed"])
+    roi_gt, x_gt, y_gt, m_vis, m_full = TC.trainstep_targets(c)
+    with torch.enable_grad(), O.bn_train():
+        (roi, xb, yb, seg, x_id, y_id), _ = O.posenet_forward(sd, torch.zeros(B, 3, 256, 256), net.init_net.knn_idx, N,
+                                                            img_feats=feats, **oracle_kwargs())
+        nb = xb.shape[1]
+        l_roi, d_roi = TO.code_loss(roi.detach().numpy(), roi_gt.numpy(), None, "BCE")
+        l_x, d_x = TO.code_loss(xb.detach().numpy(), x_gt[:, :nb].numpy(), roi_gt.numpy(), "BCE")
+        l_y, d_y = TO.code_loss(yb.detach().numpy(), y_gt[:, :nb].numpy(), roi_gt.numpy(), "BCE")
+        l_v, d_v = TO.mask_loss_interpolate(seg[:, 0:1].detach().numpy(), m_vis.numpy())
+        l_f, d_f = TO.mask_loss_interpolate(seg[:, 1:2].detach().numpy(), m_full.numpy())
+        d_seg = np.concatenate([d_v * c["w_vis"], d_f * c["w_full"]], axis=1)
+        seeds = [torch.from_numpy(np.asarray(a, np.float32)) for a in (d_roi, d_x, d_y, d_seg)]
+        grads = torch.autograd.grad([roi, xb, yb, seg], [sd[k] for k in params], seeds)
+    losses = np.array([l_roi, l_x, l_y, l_v, l_f, l_roi + l_x + l_y + l_v * c["w_vis"] + l_f * c["w_full"]])
+    assert np.allclose(losses, g["losses"], rtol=2e-6, atol=1e-6), (losses, g["losses"])
+    for name, t in (("roi", roi), ("xb", xb), ("yb", yb), ("seg", seg)):
+        assert np.abs(t.detach().numpy() - g[name]).max() <= 2e-5, name
+    assert np.array_equal(x_id.numpy(), g["xid"]) and np.array_equal(y_id.numpy(), g["yid"])
+    checked = 0
+    for k, gr in zip(params, grads):
+        ref = g["g:" + k]
+        a = gr.reshape(-1)
+        if a.numel() <= 4096:
+            got = a.numpy()
+        else:
+            idx = torch.arange(64) * (a.numel() // 64)
+            got = np.concatenate([[float(a.double().sum()), float(a.double().abs().sum())], a[idx].double().numpy()])
+            # the two checksums are compared relative to the abs-sum
+            assert abs(got[0] - ref[0]) <= 2e-5 * ref[1] and abs(got[1] - ref[1]) <= 2e-5 * ref[1], k
+            got, ref = got[2:], ref[2:]
+        scale = max(float(np.abs(g["g:" + k]).max()) if a.numel() <= 4096 else float(np.abs(ref).max()), 1e-12)
+        assert np.abs(got - ref).max() <= 2e-5 * scale + 1e-9, (k, float(np.abs(got - ref).max()), scale)
+        checked += 1
+    assert checked == len(params) and checked > 60
+    for k in c["bn_probe"]:
+        assert np.abs(sd[k + ".running_mean"].numpy() - g["rm:" + k]).max() <= 1e-5
+        assert np.abs(sd[k + ".running_var"].numpy() - g["rv:" + k]).max() <= 1e-5 * (1 + np.abs(g["rv:" + k]).max())

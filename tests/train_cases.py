@@ -91,3 +91,18 @@ def edge_folded_weights(c):
     s = sd["conv.1.weight"] / torch.sqrt(sd["conv.1.running_var"] + 1e-5)
     t = sd["conv.1.bias"] - sd["conv.1.running_mean"] * s
     return torch.cat([w1, w2 - w1], 0), torch.cat([s, s]), torch.cat([torch.zeros_like(t), t])
+
+
+# ---- one full training step of the head (reference modules in .train() mode), tests/golden/make_golden_trainstep.py
+TRAINSTEP = dict(B=2, N=512, seed=4, feat_seed=1, w_vis=1.0, w_full=1.0,
+                 bn_probe=("up_net.0.1", "up_net.2.5", "refine_net.1.pre_query_block.0.conv.1", "init_net.pre_query_block.1.conv.1"))
+
+
+def trainstep_targets(c):
+    B, N = c["B"], c["N"]
+    roi_gt = (det_tensor((B, 1, N), 51) > -0.5).float()
+    x_gt = _binary((B, 16, N), 52)
+    y_gt = _binary((B, 16, N), 53)
+    m_vis = _binary((B, 128, 128), 54)
+    m_full = (det_tensor((B, 128, 128), 55) > -0.3).float()
+    return roi_gt, x_gt, y_gt, m_vis, m_full
