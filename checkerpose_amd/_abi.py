@@ -82,6 +82,7 @@ SIGNATURES = {
     "cp_edge_weight_view": (_I, [_P, _P, _I, _I, _I, _P]),
     "cp_upsample2x_bilinear_ac_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_fuse_sum_act_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_maxpool3x3s2_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     "cp_memset_zero": (_I, [_P, _P, C.c_size_t]),
     "cp_strided_to_nhwc": (_I, [_P, _I, _P, _I, _L, _L, _L, _L, _P, _I, _I, _I, _I]),
     "cp_memcpy_d2d": (_I, [_P, _P, _P, C.c_size_t]),

@@ -582,3 +582,73 @@ extern "C" int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* do
     CP_LAUNCH(fuse_sum_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, out, dsrc, Hs, Ws, CG, shift, relu, accumulate, total);
   return cp_check_launch();
 }
+
+// Backward of cp_maxpool3x3s2 (F.max_pool2d(x, 3, 2, 1), resnet34 stem) in gather form: an input pixel belongs to at most
+// four windows; for each it re-scans the window in row-major order (first maximum wins, like ATen's CPU kernel -- ties are
+// common behind a ReLU) and takes the window's gradient if it is the arg-max.
+template <typename Tag>
+__global__ void maxpool3x3s2_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dout, void* __restrict__ din, int H, int W,
+                                        int CG, int accumulate, size_t total) {
+  constexpr int E = Tag::E;
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W*CG
+  if (i >= total) return;
+  const int g = (int)(i % CG);
+  size_t t = i / CG;
+  const int xx = (int)(t % W); t /= W;
+  const int yy = (int)(t % H);
+  const size_t b = t / H;
+  float acc[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) acc[j] = 0.f;
+  for (int oy = yy / 2; oy <= (yy + 1) / 2; ++oy) {
+    if (oy >= Ho) continue;
+    for (int ox = xx / 2; ox <= (xx + 1) / 2; ++ox) {
+      if (ox >= Wo) continue;
+      float m[E], f[E];
+      int arg[E];
+#pragma unroll
+      for (int j = 0; j < E; ++j) { m[j] = -INFINITY; arg[j] = -1; }
+      for (int r = 0; r < 3; ++r) {
+        const int y = 2 * oy - 1 + r;
+        if ((unsigned)y >= (unsigned)H) continue;
+        for (int s = 0; s < 3; ++s) {
+          const int x2 = 2 * ox - 1 + s;
+          if ((unsigned)x2 >= (unsigned)W) continue;
+          Vec16<Tag>::unpack(((const u32x4*)x)[((b * H + y) * W + x2) * CG + g], f);
+#pragma unroll
+          for (int j = 0; j < E; ++j)
+            if (f[j] > m[j]) { m[j] = f[j]; arg[j] = y * W + x2; }
+        }
+      }
+      float d[E];
+      Vec16<Tag>::unpack(((const u32x4*)dout)[((b * Ho + oy) * Wo + ox) * CG + g], d);
+#pragma unroll
+      for (int j = 0; j < E; ++j)
+        if (arg[j] == yy * W + xx) acc[j] += d[j];
+    }
+  }
+  if (accumulate) {
+    float o[E];
+    Vec16<Tag>::unpack(((const u32x4*)din)[i], o);
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] += o[j];
+  }
+  ((u32x4*)din)[i] = Vec16<Tag>::pack(acc);
+}
+
+extern "C" int cp_maxpool3x3s2_bwd(cp_stream_t stream, int dtype, const void* x, const void* dout, void* din, int B, int H, int W,
+                                   int C, int accumulate) {
+  if (!x || !dout || !din || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (C % E || !cp_aligned16(x) || !cp_aligned16(dout) || !cp_aligned16(din)) return CP_ERR_ALIGN;
+  const int CG = C / E;
+  const size_t total = (size_t)B * H * W * CG;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == CP_F32)
+    CP_LAUNCH(maxpool3x3s2_bwd_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dout, din, H, W, CG, accumulate, total);
+  else
+    CP_LAUNCH(maxpool3x3s2_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dout, din, H, W, CG, accumulate, total);
+  return cp_check_launch();
+}

@@ -214,7 +214,15 @@ class NetEmitter:
 
     def resnet34(self, pfx, x, feat_outs=None):
         x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 7, 2, 3)
-        x = self.p.maxpool(x)
+        x0 = x
+        x = self.p.maxpool(x0)
+        if self.tp is not None:
+            tp, xo = self.tp, x
+
+            def bwd_pool():
+                if xo.tbuf in tp.grads:
+                    tp.maxpool_bwd(x0, tp.grad_of(xo), tp.grad_of(x0))
+            tp.tape.append(bwd_pool)
         feats = []
         for li, nblk in enumerate((3, 4, 6, 3)):
             for k in range(nblk):

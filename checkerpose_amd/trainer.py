@@ -250,6 +250,12 @@ class TrainProgram(Program):
         tail = (gsrc.B, gsrc.H, gsrc.W, gsrc.Cphys, int(shift), 1 if relu else 0, 1)
         self._add(self.lib.cp_fuse_sum_act_bwd, lambda P: (self.dtype, P(gt), P(ot), P(st_)) + tail, "fuse_sum_bwd", [gt, ot, st_], [st_])
 
+    def maxpool_bwd(self, x: Act, gout: Act, gin: Act):
+        xt, gt, it = x.tbuf, gout.tbuf, gin.tbuf
+        assert x.coff == 0 and x.cstride == x.Cphys
+        self._add(self.lib.cp_maxpool3x3s2_bwd, lambda P: (self.dtype, P(xt), P(gt), P(it), x.B, x.H, x.W, x.Cphys, 1),
+                  "maxpool_bwd", [xt, gt, it], [it])
+
     def strided_to_act(self, src_ptr_fn, src_dtype, base, sb, sp, sc, out: Act, C_, reads=()):
         """strided tensor -> dense channels-last Act (out must be dense: coff 0, cstride == Cphys)"""
         assert out.coff == 0 and out.cstride == out.Cphys

@@ -315,6 +315,10 @@ int cp_upsample2x_bilinear_ac_bwd(cp_stream_t stream, int dtype, const void* dou
                                   int out_cstride, int out_coff, int in_cstride, int in_coff, int accumulate);
 int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws,
                         int C, int shift, int relu, int accumulate);
+/* Backward of cp_maxpool3x3s2 (resnet34 stem): x (B,H,W,C) forward input, dout (B,H/2,W/2,C), din (+)= routed gradient
+ * (first maximum of each window in row-major order takes it, as ATen's CPU kernel does). */
+int cp_maxpool3x3s2_bwd(cp_stream_t stream, int dtype, const void* x, const void* dout, void* din, int B, int H, int W, int C,
+                        int accumulate);
 
 /* plumbing: stream-ordered zero fill / device copy (capturable), and a tensor (fp32 or `dtype`: src_dtype) with arbitrary element strides (the logit block,
  * NCHW seg logits, fp32 scatter targets) -> channels-last `dtype` (B, HW, Cphys) with zero padded channels. */
