@@ -24,6 +24,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def cpu_baseline(npoint, seconds=20.0, B=2):
+    """The oracle restatement in train mode (bn_train) + torch autograd on the host cores: forward + backward of B=2 crops
+    (the smallest batch with meaningful batch statistics), repeated for ~`seconds`."""
+    from bench import host_threads
+    from oracle import checkerpose_oracle as O
+    from tests.common import build_net, det_image, det_tensor, oracle_kwargs
+    torch.set_num_threads(host_threads())
+    net = build_net(npoint=npoint, seed=1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    params = [k for k, _ in net.named_parameters()]
+    for k in params:
+        sd[k].requires_grad_(True)
+    img = det_image(B, seed=0)
+    seeds = [det_tensor("g_roi", (B, 1, npoint)), det_tensor("g_x", (B, 6, npoint)), det_tensor("g_y", (B, 6, npoint)),
+             det_tensor("g_seg", (B, 2, 64, 64), 0.05)]
+
+    def one():
+        with torch.enable_grad(), O.bn_train():
+            (roi, xb, yb, seg, _, _), _ = O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())
+            torch.autograd.grad([roi, xb, yb, seg], [sd[k] for k in params], seeds, allow_unused=True)
+
+    t0 = time.perf_counter()
+    one()
+    first = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while (time.perf_counter() - t0 < seconds and first < seconds) or n < 1:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * B / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d forward+backward passes at B=%d (fp32, train-mode BatchNorm, torch autograd over the oracle restatement "
+                      "incl. HRNet-W18), %.1f s" % (n, B, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -33,6 +67,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--npoint", type=int, default=512)
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,10 +168,24 @@ def main():
         rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
         out["kernel_ms_per_step"] = {"%s:%s" % k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in rows[:24]}
         out["device_ms_fwd_bwd"] = [round(sum(v[0] for k, v in agg.items() if k[0] == h), 3) for h in ("fwd", "bwd")]
-        wg = sum(v[0] for k, v in agg.items() if k[1].startswith("wgrad_kernel"))
-        if wg > 0:      # weight gradients do the forward's dense FLOPs once more (conv_log covers fwd convs AND dgrad convs)
-            fwd_fl = sum(c[4] for c in prog.conv_log[:]) / 2.0
-            out["wgrad"] = {"ms": round(wg, 3), "approx_tflops": round(fwd_fl / (wg * 1e-3) / 1e12, 1)}
+        # roofline of the dominant dense training kernel: the all-taps weight gradient (MFMA-bound), algorithmic FLOPs
+        # 2*M*9*Cin*Cout of its launches / their measured device time (HIP events on the launch stream)
+        peak = {"bf16": 2500.0, "fp32": 157.3}[a.dtype]
+        w3 = [(i, e0.elapsed_time(e1)) for i, ((fn, args, name), (e0, e1), sy) in enumerate(zip(prog.calls, evs, syms))
+              if sy.startswith("wgrad") and i in prog.wgrad_flops and " k3 s1 " in name]
+        if w3:
+            ms = sum(t for _, t in w3)
+            fl = sum(prog.wgrad_flops[i] for i, _ in w3)
+            big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
+            out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel + wgrad_reduce_kernel (%d launches per step)" % len(w3),
+                               "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                               "algorithmic_gflop_per_step": round(fl / 1e9, 1), "ms_per_step": round(ms, 3),
+                               "largest_launch": {"name": prog.calls[big[0]][2], "gflop": round(prog.wgrad_flops[big[0]] / 1e9, 1),
+                                                  "us": round(big[1] * 1e3, 1),
+                                                  "tflops": round(prog.wgrad_flops[big[0]] / (big[1] * 1e-3) / 1e12, 1)}}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

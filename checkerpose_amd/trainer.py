@@ -86,6 +86,7 @@ class TrainProgram(Program):
         self.nograd = set()        # id(TBuf) of tensors that need no gradient (the input image)
         self.bn_ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=device)
         self.wg_ws = torch.empty(160 << 20, dtype=torch.uint8, device=device)     # weight-gradient slice partials
+        self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._ones, self._zeros = {}, {}
         self.debug = {}            # name -> Acts of interest (tools/train_debug.py with CHECKERPOSE_AMD_NO_RECYCLE=1)
@@ -207,6 +208,7 @@ class TrainProgram(Program):
         wsp, wsn = self.wg_ws.data_ptr(), self.wg_ws.numel()
         self._add(self.lib.cp_conv2d_wgrad_ws, lambda P: (dref, P(dt), P(xt), dw_ptr, wsp, wsn),
                   "wgrad:%d->%d k%d s%d %dx%d" % (Cin, Cout, R, stride, x.H, x.W), [dt, xt], [])
+        self.wgrad_flops[len(self.ops) - 1] = 2 * dy.B * d.Ho * d.Wo * R * S * Cin * Cout      # algorithmic, unpadded
 
     def weight_dgrad(self, w, Cout, Cin, R, S):
         wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)
