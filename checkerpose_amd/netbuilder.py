@@ -45,6 +45,8 @@ class NetEmitter:
         self.bn_counters.append(self.sd[bn + ".num_batches_tracked"])
         y = out if out is not None else tp.act(raw.H, raw.W, Cout)
         tp.affine_act(raw, st["scale"], st["shift"], residual, y, act, slope)
+        if act != ACT_NONE:
+            tp.kinks[bn] = y
         return y, st
 
     def _conv_bn_train(self, x, conv, bn, w, k, stride, pad, act, residual, out):
@@ -72,6 +74,8 @@ class NetEmitter:
         Cout = w.shape[0]
         w4 = w.view(Cout, w.shape[1], 1, 1)
         y = tp.conv(x, key, w4, tp.const_vec(Cout, True), self._bias_vec(key, Cout), 1, 1, 1, 0, Cout, act, slope, out=out)
+        if act != ACT_NONE:
+            tp.kinks[key] = y
 
         def bwd():
             if y.tbuf not in tp.grads:
@@ -176,6 +180,7 @@ class NetEmitter:
             shifts = [max(j - i, 0) for j in range(nb)]
             outs.append(p.fuse_sum(terms[i], shifts, out, relu=True))
             if self.tp is not None:
+                self.tp.kinks["%s.fuse%d" % (pfx, i)] = out
                 self._fuse_sum_tape(out, list(terms[i]), shifts)
         p.par_end()
         return outs
@@ -243,6 +248,7 @@ class NetEmitter:
         st = tp.edge_train_fwd(pq, graph, self.W(bn + ".weight"), self.W(bn + ".bias"), self.sd[bn + ".running_mean"],
                                self.sd[bn + ".running_var"], out, Co, slope)
         self.bn_counters.append(self.sd[bn + ".num_batches_tracked"])
+        tp.kinks[pfx] = out
 
         def bwd():
             if out.tbuf not in tp.grads:

@@ -89,6 +89,7 @@ class TrainProgram(Program):
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._ones, self._zeros = {}, {}
+        self.kinks = {}            # activation key -> Act whose sign is the (Leaky)ReLU branch taken (tests: oracle FORCE_MASK)
         self.debug = {}            # name -> Acts of interest (tools/train_debug.py with CHECKERPOSE_AMD_NO_RECYCLE=1)
 
     # ---- lanes are an inference-latency device; the training program is one ordered stream

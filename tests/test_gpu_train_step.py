@@ -1,11 +1,13 @@
 """GPU (-m gpu): one full training step of the drop-in modules (train-mode forward with batch-statistics BatchNorm +
 backward through the HIP training program) against torch-CPU autograd over the oracle restatement
 in train mode (oracle/checkerpose_oracle.py under bn_train()).
-Tolerance (fp32 path): logits 2e-4 absolute; parameter gradients as documented in _compare() (5e-4 of the tensor's max
-where no activation kink can intervene, 5e-2 / 1.5e-2 relative L2 per tensor / overall); running statistics 1e-4.  ids must be equal (otherwise the gather positions differ and the comparison is void).
-The max over the K neighbours routes its gradient to one of them -- a discontinuous choice: the oracle is teacher-forced to
-the device's arg-max slots (O.FORCE_KSTAR), as the eval-mode tests teacher-force the bit decisions; without that, the
-~1e-5 forward differences flip ~1e-4 of the near-ties and move weight gradients by 1-3 % (measured).
+Tolerance (fp32 path): logits 2e-4 absolute; parameter gradients as documented in _compare() (5e-4 of each tensor's max,
+1e-4 relative L2 overall, with the discontinuous choices pinned to the device's); running statistics 1e-4.  ids must be equal (otherwise the gather positions differ and the comparison is void).
+The max over the K neighbours routes its gradient to one of them and a (Leaky)ReLU switches its derivative at 0 -- both
+discontinuous: the oracle is teacher-forced to the device's arg-max slots (O.FORCE_KSTAR) and activation branches
+(O.FORCE_MASK, read from the program's live activations between forward and backward), as the eval-mode tests teacher-force
+the bit decisions; without that, the ~1e-6 forward differences flip ~1e-4 of the near-ties / near-zeros and move individual
+gradient tensors by percents (measured 4e-2 rel-L2 on a 128-pixel BatchNorm bias).
 """
 import pytest
 import torch
@@ -27,16 +29,36 @@ def _device_kstar(net, prefix=""):
     return out
 
 
-def _oracle_step(net, img, seeds, stage=None, init_only=False, kstar=None):
+def _device_masks(net, prefix=""):
+    """branch every (Leaky)ReLU element took on the device ({oracle key: bool NCHW / (B,C,N) / (B,N,C) tensor}); read between
+    the forward and the backward, while the activations are still live in the program's workspace"""
+    pr = list(net._train_programs.values())[-1]
+    prog = pr["prog"]
+    out = {}
+    for key, a in prog.kinks.items():
+        v = prog.read_act(a) > 0                      # (B,H,W,C)
+        if a.H == 1 and "pre_query_block." in key:    # EdgeConv output: oracle layout (B,C',N)
+            out[prefix + key] = v[:, 0].permute(0, 2, 1).contiguous()
+        elif a.H == 1:                                # per-keypoint MLP: oracle layout (B,N,C)
+            out[prefix + key] = v[:, 0].contiguous()
+        else:
+            out[prefix + key] = v.permute(0, 3, 1, 2).contiguous()
+    return out
+
+
+def _oracle_step(net, img, seeds, stage=None, init_only=False, kstar=None, masks=None, backbone="hrnet_w18"):
     O.FORCE_KSTAR.clear()
     O.FORCE_KSTAR.update(kstar or {})
+    O.FORCE_MASK.clear()
+    O.FORCE_MASK.update(masks or {})
     try:
-        return _oracle_step_(net, img, seeds, stage, init_only)
+        return _oracle_step_(net, img, seeds, stage, init_only, backbone)
     finally:
         O.FORCE_KSTAR.clear()
+        O.FORCE_MASK.clear()
 
 
-def _oracle_step_(net, img, seeds, stage=None, init_only=False):
+def _oracle_step_(net, img, seeds, stage=None, init_only=False, backbone="hrnet_w18"):
     sd = {}
     for k, v in net.state_dict().items():
         sd[k] = v.detach().clone()
@@ -45,7 +67,7 @@ def _oracle_step_(net, img, seeds, stage=None, init_only=False):
         sd[k].requires_grad_(True)
     with torch.enable_grad(), O.bn_train():
         if init_only:
-            out, _, _ = O.init_net_forward(sd, "", img, net.knn_idx, net.npoint, "hrnet_w18", 2, 0.2)
+            out, _, _ = O.init_net_forward(sd, "", img, net.knn_idx, net.npoint, backbone, 2, 0.2)
             outs = [out]
             ids = None
         else:
@@ -56,16 +78,12 @@ def _oracle_step_(net, img, seeds, stage=None, init_only=False):
     return outs, ids, dict(zip(params, grads)), sd
 
 
-EXACT_TAIL = ("refine_net.2.query_block", "seg_block", "refine_net.2.pre_query_block.2")
-
-
-def _compare(net, ref_grads, sd_ref, tol_l2=5e-2, tol_global=1.5e-2, tol_tail=5e-4, tail=EXACT_TAIL):
-    """Gradient parity.  ReLU / LeakyReLU derivatives are discontinuous at 0: among ~1e8 activations a handful sit within
-    the ~1e-6 relative forward difference of 0 and take the other branch on the device, which moves individual small
-    gradient tensors (a BatchNorm bias over 128 pixels) by percents in the max norm although everything is computed
-    exactly (measured: one flipped element of refine_net.2.pre_query_block.1 accounts for its 4.8e-2).  So:
-      * layers behind NO further nonlinearity flip (the tail of the network) must agree to 5e-4 of the tensor's max;
-      * every tensor must agree to 5e-2 in relative L2, and all gradients together to 1.5e-2 in relative L2."""
+def _compare(net, ref_grads, sd_ref, tol_max=5e-4, tol_global=1e-4):
+    """Gradient parity with every discontinuous choice pinned to the device's (bit decisions asserted equal, EdgeConv
+    arg-max slots and (Leaky)ReLU branches teacher-forced into the oracle): every gradient tensor within 5e-4 of the oracle's
+    in the max norm (relative to the tensor's largest entry), all gradients together within 1e-4 in relative L2.
+    Measured on MI355X: 3.7e-5 / 6.7e-6.  (Unforced, ~1e-4 of the near-ties / near-zero pre-activations take the other
+    branch under the ~1e-6 forward differences and move individual small tensors by percents: 4e-2 rel-L2 measured.)"""
     worst, num, den = (0.0, None), 0.0, 0.0
     for k, p in net.named_parameters():
         g_ref = ref_grads[k]
@@ -75,17 +93,13 @@ def _compare(net, ref_grads, sd_ref, tol_l2=5e-2, tol_global=1.5e-2, tol_tail=5e
             continue
         assert g is not None, "no gradient for %s" % k
         d = (g.cpu().double() - g_ref.double())
-        n2, r2 = float((d * d).sum()), float((g_ref.double() ** 2).sum())
-        num, den = num + n2, den + r2
-        rel = (n2 / max(r2, 1e-300)) ** 0.5
-        if rel > worst[0]:
-            worst = (rel, k)
-        if k.startswith(tail):
-            emax = float(d.abs().max()) / max(float(g_ref.abs().max()), 1e-12)
-            assert emax <= tol_tail, "tail gradient %s: max err %.3e > %.1e" % (k, emax, tol_tail)
+        num, den = num + float((d * d).sum()), den + float((g_ref.double() ** 2).sum())
+        em = float(d.abs().max()) / max(float(g_ref.abs().max()), 1e-12)
+        if em > worst[0]:
+            worst = (em, k)
     glob = (num / den) ** 0.5
-    print("gradient parity: global rel-L2 %.3e, worst tensor rel-L2 %.3e (%s)" % (glob, worst[0], worst[1]))
-    assert worst[0] <= tol_l2, "gradient of %s: rel L2 err %.3e > %.1e" % (worst[1], worst[0], tol_l2)
+    print("gradient parity: global rel-L2 %.3e, worst tensor max-norm err %.3e (%s)" % (glob, worst[0], worst[1]))
+    assert worst[0] <= tol_max, "gradient of %s: max err %.3e > %.1e" % (worst[1], worst[0], tol_max)
     assert glob <= tol_global, "all gradients: rel L2 err %.3e > %.1e" % (glob, tol_global)
     bufs = dict(net.named_buffers())
     for k in list(bufs)[:400:7]:
@@ -109,14 +123,15 @@ def test_posenet_train_step_vs_oracle_autograd(stage):
     net = net.cuda()
     with torch.enable_grad():
         res = net(img.cuda(), None, stage)
+        torch.cuda.synchronize()
+        masks = _device_masks(net)
         torch.autograd.backward(list(res[:4]), [s.cuda() for s in seeds])
     torch.cuda.synchronize()
-    outs, ids, ref_grads, sd_ref = _oracle_step(net_cpu, img, seeds, stage=stage, kstar=_device_kstar(net))
+    outs, ids, ref_grads, sd_ref = _oracle_step(net_cpu, img, seeds, stage=stage, kstar=_device_kstar(net), masks=masks)
     for a, b in zip(res[:4], outs):
         assert float((a.detach().cpu() - b.detach()).abs().max()) <= 2e-4
     assert torch.equal(res[4].cpu(), ids[0]) and torch.equal(res[5].cpu(), ids[1]), "discrete ids differ: comparison void"
-    tail = EXACT_TAIL if stage is None else ("refine_net.0.query_block", "seg_block", "refine_net.0.pre_query_block.2")
-    _compare(net, ref_grads, sd_ref, tail=tail)
+    _compare(net, ref_grads, sd_ref)
     # eval after a train step must see the updated running statistics (stale folded-BN caches dropped)
     net.eval()
     with torch.no_grad():
@@ -137,11 +152,13 @@ def test_initnet_train_step_vs_oracle_autograd():
     net = net.cuda()
     with torch.enable_grad():
         out = net(img.cuda())
+        torch.cuda.synchronize()
+        masks = _device_masks(net)
         out.backward(seeds[0].cuda())
     torch.cuda.synchronize()
-    outs, _, ref_grads, sd_ref = _oracle_step(net_cpu, img, seeds, init_only=True, kstar=_device_kstar(net))
+    outs, _, ref_grads, sd_ref = _oracle_step(net_cpu, img, seeds, init_only=True, kstar=_device_kstar(net), masks=masks)
     assert float((out.detach().cpu() - outs[0].detach()).abs().max()) <= 2e-4
-    _compare(net, ref_grads, sd_ref, tail=("mlp", "pre_query_block.1"))
+    _compare(net, ref_grads, sd_ref)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
@@ -192,22 +209,14 @@ def test_resnet34_initnet_train_step_vs_oracle_autograd():
     net = net.cuda()
     with torch.enable_grad():
         out = net(img.cuda())
+        torch.cuda.synchronize()
+        masks = _device_masks(net)
         out.backward(seeds[0].cuda())
     torch.cuda.synchronize()
-    O.FORCE_KSTAR.clear()
-    O.FORCE_KSTAR.update(_device_kstar(net))
-    try:
-        sd = {k: v.detach().clone() for k, v in net_cpu.state_dict().items()}
-        params = [k for k, _ in net_cpu.named_parameters()]
-        for k in params:
-            sd[k].requires_grad_(True)
-        with torch.enable_grad(), O.bn_train():
-            ref, _, _ = O.init_net_forward(sd, "", img, net_cpu.knn_idx, 512, "resnet34", 2, 0.2)
-            grads = torch.autograd.grad([ref], [sd[k] for k in params], seeds, allow_unused=True)
-    finally:
-        O.FORCE_KSTAR.clear()
-    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 2e-4
-    _compare(net, dict(zip(params, grads)), sd, tail=("mlp", "pre_query_block.1"))
+    outs, _, ref_grads, sd_ref = _oracle_step(net_cpu, img, seeds, init_only=True, kstar=_device_kstar(net), masks=masks,
+                                              backbone="resnet34")
+    assert float((out.detach().cpu() - outs[0].detach()).abs().max()) <= 2e-4
+    _compare(net, ref_grads, sd_ref)
 
 
 def test_lm_twin_training_loop_per_sample_graphs():
