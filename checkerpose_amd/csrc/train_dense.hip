@@ -127,6 +127,63 @@ extern "C" int cp_memcpy_d2d(cp_stream_t stream, void* dst, const void* src, siz
 // Per-channel sums of two derived quantities over the M rows of a channels-last tensor, fp64 block partials:
 //   mode 0: (x, x^2)                                   -- BatchNorm batch statistics
 //   mode 1: (dz, dz * xhat), dz = dy * act'(y)         -- BatchNorm / bias backward reductions
+// ---- per-channel finalize of the fp64 block partials (one WAVE per channel: lanes stride over the partial blocks, shuffle
+// reduction), its own launch of ceil(C/4) blocks.  (Fusing it into the last block of the column-sum kernel behind a ticket
+// counter was measured 5x SLOWER: one block then walks all C x 512 partials alone.)
+struct FinArgs {
+  int nblk, CP, C, Cvec, has_bn;
+  double count;
+  const float* gamma; const float* beta; const float* mean_in; const float* rstd_in;
+  float eps, momentum;
+  float *rmean, *rvar, *scale, *shift, *mean, *rstd;     // forward outputs
+  float *coef, *dgamma, *dbeta;                           // backward outputs
+};
+
+__device__ __forceinline__ void fin_sums(const double* partial, int nblk, int CP, int c, int lane, double& s1, double& s2) {
+  s1 = 0.0; s2 = 0.0;
+  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+}
+
+__device__ __forceinline__ void fin_fwd_channel(const double* partial, const FinArgs& f, int c, int lane) {
+  if (c >= f.C) { if (lane == 0) { f.scale[c] = 0.f; f.shift[c] = 0.f; f.mean[c] = 0.f; f.rstd[c] = 0.f; } return; }
+  double s1, s2;
+  fin_sums(partial, f.nblk, f.CP, c, lane, s1, s2);
+  if (lane != 0) return;
+  const double mu = s1 / f.count;
+  double var = s2 / f.count - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)f.eps));
+  const float g = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
+  f.mean[c] = (float)mu;
+  f.rstd[c] = rs;
+  f.scale[c] = g * rs;
+  f.shift[c] = bt - (float)mu * g * rs;
+  if (f.rmean) f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * (float)mu;
+  if (f.rvar) f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)(f.count > 1.0 ? var * f.count / (f.count - 1.0) : var);
+}
+
+// coef[0..3][Cvec]: a = gamma*rstd, b = mean(dz), c = mean(dz*xhat)*rstd, mu ; dgamma / dbeta written for c < C
+__device__ __forceinline__ void fin_bwd_channel(const double* partial, const FinArgs& f, int c, int lane) {
+  const int Cvec = f.Cvec;
+  if (c >= f.C) { if (lane == 0) { f.coef[c] = 0.f; f.coef[Cvec + c] = 0.f; f.coef[2 * Cvec + c] = 0.f; f.coef[3 * Cvec + c] = 0.f; } return; }
+  double s1, s2;
+  fin_sums(partial, f.nblk, f.CP, c, lane, s1, s2);
+  if (lane != 0) return;
+  if (f.dbeta) f.dbeta[c] = (float)s1;
+  if (f.has_bn) {
+    if (f.dgamma) f.dgamma[c] = (float)s2;
+    const float g = f.gamma ? f.gamma[c] : 1.f;
+    f.coef[c] = g * f.rstd_in[c];
+    f.coef[Cvec + c] = (float)(s1 / f.count);
+    f.coef[2 * Cvec + c] = (float)(s2 / f.count) * f.rstd_in[c];
+    f.coef[3 * Cvec + c] = f.mean_in[c];
+  } else {
+    f.coef[c] = 1.f; f.coef[Cvec + c] = 0.f; f.coef[2 * Cvec + c] = 0.f; f.coef[3 * Cvec + c] = 0.f;
+  }
+}
+
 struct ColsumParams {
   const void* a; int a_cs, a_coff;      // mode 0: x ; mode 1: dy
   const void* y; int y_cs, y_coff;      // mode 1: post-activation output (NULL: no activation)
@@ -206,42 +263,25 @@ static int colsum_plan(int M, int Cphys, int E, int* G, int* RL, int* nblk, int*
 extern "C" size_t cp_bn_workspace_bytes(int C) { return (size_t)512 * 2 * ((size_t)(C + 15) / 16 * 16) * sizeof(double); }
 
 // forward finalize: mean / biased var -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
-// one WAVE per channel: the lanes stride over the block partials, then a shuffle reduction (a serial loop over up to 512
-// partials per channel was latency-bound: ~65 us per BatchNorm layer)
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec,
-                                       double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                       float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
-                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
-                                       float* __restrict__ rstd) {
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ partial, const FinArgs f) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= Cvec) return;
-  if (c >= C) { if (lane == 0) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; rstd[c] = 0.f; } return; }
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
-  if (lane != 0) return;
-  const double mu = s1 / count;
-  double var = s2 / count - mu * mu;
-  var = var > 0.0 ? var : 0.0;
-  const float rs = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-  mean[c] = (float)mu;
-  rstd[c] = rs;
-  scale[c] = g * rs;
-  shift[c] = bt - (float)mu * g * rs;
-  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
-  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+  if (c < f.Cvec) fin_fwd_channel(partial, f, c, threadIdx.x & 63);
 }
 
 // shared by cp_bn_train_stats and the EdgeConv statistics (train_edge.hip)
+static FinArgs fin_fwd_args(int nblk, int CP, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
+                            float* rmean, float* rvar, float* scale, float* shift, float* mean, float* rstd) {
+  FinArgs f = {};
+  f.nblk = nblk; f.CP = CP; f.C = C; f.Cvec = (C + 15) / 16 * 16; f.count = count; f.gamma = gamma; f.beta = beta; f.eps = eps;
+  f.momentum = momentum; f.rmean = rmean; f.rvar = rvar; f.scale = scale; f.shift = shift; f.mean = mean; f.rstd = rstd;
+  return f;
+}
+
 int cp_bn_finalize_launch(hipStream_t st, const double* partial, int nblk, int CP, int C, double count, const float* gamma,
                           const float* beta, float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
                           float* mean, float* rstd) {
-  const int Cvec = (C + 15) / 16 * 16;
-  CP_LAUNCH(bn_fwd_finalize_kernel, dim3((Cvec + 3) / 4), dim3(256), 0, st, partial, nblk, CP, C, Cvec, count, gamma, beta,
-            eps, momentum, rmean, rvar, scale, shift, mean, rstd);
+  const FinArgs f = fin_fwd_args(nblk, CP, C, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, mean, rstd);
+  CP_LAUNCH(bn_fwd_finalize_kernel, dim3((f.Cvec + 3) / 4), dim3(256), 0, st, partial, f);
   return cp_check_launch();
 }
 
@@ -328,37 +368,23 @@ extern "C" int cp_affine_act(cp_stream_t stream, int dtype, const void* x, int x
 
 // ------------------------------------------------------------------------------------------------ BN / bias backward
 // coef[0..3][Cvec]: a = gamma*rstd, b = mean(dz), c = mean(dz*xhat)*rstd, mu ; dgamma / dbeta written for c < C
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int CP, int C, int Cvec,
-                                       double count, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ rstd, int has_bn, float* __restrict__ coef,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, const FinArgs f) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per channel
-  if (c >= Cvec) return;
-  if (c >= C) { if (lane == 0) { coef[c] = 0.f; coef[Cvec + c] = 0.f; coef[2 * Cvec + c] = 0.f; coef[3 * Cvec + c] = 0.f; } return; }
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * 2) * CP + c]; s2 += partial[((size_t)b * 2 + 1) * CP + c]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
-  if (lane != 0) return;
-  if (dbeta) dbeta[c] = (float)s1;
-  if (has_bn) {
-    if (dgamma) dgamma[c] = (float)s2;
-    const float g = gamma ? gamma[c] : 1.f;
-    coef[c] = g * rstd[c];
-    coef[Cvec + c] = (float)(s1 / count);
-    coef[2 * Cvec + c] = (float)(s2 / count) * rstd[c];
-    coef[3 * Cvec + c] = mean[c];
-  } else {
-    coef[c] = 1.f; coef[Cvec + c] = 0.f; coef[2 * Cvec + c] = 0.f; coef[3 * Cvec + c] = 0.f;
-  }
+  if (c < f.Cvec) fin_bwd_channel(partial, f, c, threadIdx.x & 63);
+}
+
+static FinArgs fin_bwd_args(int nblk, int CP, int C, double count, const float* gamma, const float* mean, const float* rstd, int has_bn,
+                            float* coef, float* dgamma, float* dbeta) {
+  FinArgs f = {};
+  f.nblk = nblk; f.CP = CP; f.C = C; f.Cvec = (C + 15) / 16 * 16; f.count = count; f.gamma = gamma; f.mean_in = mean; f.rstd_in = rstd;
+  f.has_bn = has_bn; f.coef = coef; f.dgamma = dgamma; f.dbeta = dbeta;
+  return f;
 }
 
 int cp_bn_bwd_finalize_launch(hipStream_t st, const double* partial, int nblk, int CP, int C, double count, const float* gamma,
                               const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta) {
-  const int Cvec = (C + 15) / 16 * 16;
-  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 3) / 4), dim3(256), 0, st, partial, nblk, CP, C, Cvec, count, gamma, mean,
-            rstd, 1, coef, dgamma, dbeta);
+  const FinArgs f = fin_bwd_args(nblk, CP, C, count, gamma, mean, rstd, 1, coef, dgamma, dbeta);
+  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((f.Cvec + 3) / 4), dim3(256), 0, st, partial, f);
   return cp_check_launch();
 }
 
@@ -442,9 +468,11 @@ extern "C" int cp_bn_train_bwd(cp_stream_t stream, int dtype, const void* dy, in
   if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 1>), dim3(nblk), dim3(256), 0, st, p);
   else CP_LAUNCH((colsum2_kernel<BF16Tag, 1>), dim3(nblk), dim3(256), 0, st, p);
   if ((rc = cp_check_launch())) return rc;
-  CP_LAUNCH(bn_bwd_finalize_kernel, dim3((Cvec + 3) / 4), dim3(256), 0, st, p.partial, nblk, Cphys, C, Cvec, (double)M, gamma,
-            mean, rstd, x ? 1 : 0, coef, dgamma, dbeta);
-  if ((rc = cp_check_launch())) return rc;
+  {
+    const FinArgs f = fin_bwd_args(nblk, Cphys, C, (double)M, gamma, mean, rstd, x ? 1 : 0, coef, dgamma, dbeta);
+    CP_LAUNCH(bn_bwd_finalize_kernel, dim3((f.Cvec + 3) / 4), dim3(256), 0, st, p.partial, f);
+    if ((rc = cp_check_launch())) return rc;
+  }
   BnBwdParams q;
   q.dy = dy; q.dy_cs = dy_cstride; q.dy_coff = dy_coff; q.y = yy; q.y_cs = y_cstride; q.y_coff = y_coff;
   q.x = x; q.x_cs = x_cstride; q.x_coff = x_coff; q.dx = dx; q.dx_cs = dx_cstride; q.dx_coff = dx_coff;

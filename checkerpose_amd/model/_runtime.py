@@ -238,6 +238,7 @@ class HipForwardMixin:
         prog.mark_forward_end()
         nb = pgrad.numel() * 4
         prog._add(lib.cp_memset_zero, lambda P: (pgrad.data_ptr(), nb), "pgrad_zero", [], [])
+        prog.zero_grad_arena()
         prog.unwind()
         prog.finalize()
         torch.cuda.current_stream(device).synchronize()

@@ -84,11 +84,13 @@ class TrainProgram(Program):
         self.pgrad = pgrad         # flat fp32 parameter-gradient buffer
         self.pslots = pslots       # state-dict key -> element offset into pgrad
         self.nograd = set()        # id(TBuf) of tensors that need no gradient (the input image)
-        self.bn_ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=device)
+        self.bn_ws = torch.zeros(lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=device)   # zeroed: ticket counter
         self.wg_ws = torch.empty(160 << 20, dtype=torch.uint8, device=device)     # weight-gradient slice partials
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._ones, self._zeros = {}, {}
+        self.arena = []            # gradient TBufs (not recycled: 288 GB of HBM; one zero fill instead of ~370)
+        self.grad_arena = None
         self.kinks = {}            # activation key -> Act whose sign is the (Leaky)ReLU branch taken (tests: oracle FORCE_MASK)
         self.debug = {}            # name -> Acts of interest (tools/train_debug.py with CHECKERPOSE_AMD_NO_RECYCLE=1)
 
@@ -145,7 +147,7 @@ class TrainProgram(Program):
             g = self.tensor(a.tbuf.nbytes, es=1)
             g.nbytes = a.tbuf.nbytes
             self.grads[a.tbuf] = g
-            self.memset_t(g, "grad_zero")
+            self.arena.append(g)       # gradient buffers live in one arena zero-filled by ONE launch (finalize())
         return Act(g, a.B, a.H, a.W, a.C, a.Cphys, a.cstride, a.coff)
 
     def needs_grad(self, a: Act):
@@ -308,6 +310,19 @@ class TrainProgram(Program):
                 gout.cstride, gout.coff)
         self._add(self.lib.cp_index2feat_gather_bwd_t, lambda P: (self.dtype, P(gt)) + args, "index2feat_bwd", [gt], [])
 
+    def finalize(self):
+        total = sum(t.nbytes for t in self.arena)
+        self.grad_arena = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+        off = 0
+        for t in self.arena:
+            t.fixed = self.grad_arena[off:off + t.nbytes]
+            off += t.nbytes
+        return super().finalize()
+
+    def zero_grad_arena(self):
+        """ONE zero fill of every activation-gradient buffer, at the start of the backward half"""
+        self._add(self.lib.cp_memset_zero, lambda P: (self.grad_arena.data_ptr(), self.grad_arena.numel()), "grad_zero", [], [])
+
     # ---- tape
     def mark_forward_end(self):
         self.n_fwd_ops = len(self.ops)
@@ -322,7 +337,8 @@ class TrainProgram(Program):
         dt = torch.bfloat16 if self.dtype == CP_BF16 else torch.float32
         es = 2 if self.dtype == CP_BF16 else 4
         n = a.B * a.H * a.W * a.cstride
-        flat = self.workspace[a.tbuf.offset:a.tbuf.offset + n * es].view(dt).view(a.B, a.H, a.W, a.cstride)
+        raw = a.tbuf.fixed if a.tbuf.fixed is not None else self.workspace[a.tbuf.offset:a.tbuf.offset + a.tbuf.nbytes]
+        flat = raw[:n * es].view(dt).view(a.B, a.H, a.W, a.cstride)
         return flat[..., a.coff:a.coff + a.C].float().cpu()
 
     def run_range(self, stream_ptr, lo, hi):

@@ -270,7 +270,7 @@ int cp_weight_dgrad(cp_stream_t stream, const float* w, int Cout, int Cin, int R
  * cp_bn_train_stats: batch mean / biased variance (fp64 sums) -> scale = gamma*rstd, shift = beta - mean*scale (fp32
  * vectors of ceil16(C) entries, zero beyond C), mean / rstd saved for the backward; running_mean / running_var
  * updated in place with `momentum` (unbiased variance), NULL = skip.  gamma / beta NULL = 1 / 0.
- * workspace: cp_bn_workspace_bytes(C). */
+ * workspace: cp_bn_workspace_bytes(C); one workspace may serve many layers on one stream. */
 size_t cp_bn_workspace_bytes(int C);
 int cp_bn_train_stats(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff,
                       const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,

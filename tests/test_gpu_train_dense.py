@@ -221,7 +221,7 @@ def test_bn_train_fwd_bwd(lib, dtype, case):
     cs = xc.shape[-1]
     g_d, b_d, rm_d, rv_d = gamma.detach().to(dev()), beta.detach().to(dev()), rm0.to(dev()), rv0.to(dev())
     scale, shift, mean, rstd = _vec(Cc), _vec(Cc), _vec(Cc), _vec(Cc)
-    ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(Cc), dtype=torch.uint8, device=dev())
+    ws = torch.zeros(lib.cp_bn_bwd_workspace_bytes(Cc), dtype=torch.uint8, device=dev())
     _abi.check(lib.cp_bn_train_stats(st(), dtype, xc.data_ptr(), M, Cc, cs, 0, g_d.data_ptr(), b_d.data_ptr(), rm_d.data_ptr(),
                                      rv_d.data_ptr(), 0.1, 1e-5, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), ws.data_ptr()), "bn stats")
@@ -263,7 +263,7 @@ def test_bias_act_bwd(lib, dtype):
     yc, dyc = to_cl(y, dtype), to_cl(dy, dtype)
     dxc = torch.empty_like(dyc)
     db = torch.zeros(Cc, device=dev())
-    ws = torch.empty(lib.cp_bn_bwd_workspace_bytes(Cc), dtype=torch.uint8, device=dev())
+    ws = torch.zeros(lib.cp_bn_bwd_workspace_bytes(Cc), dtype=torch.uint8, device=dev())
     _abi.check(lib.cp_bn_train_bwd(st(), dtype, dyc.data_ptr(), Cc, 0, yc.data_ptr(), Cc, 0, None, 0, 0, None, None, None,
                                    B * N, Cc, ACT_LEAKY, 0.01, dxc.data_ptr(), Cc, 0, None, 0, 0, 0, None, db.data_ptr(),
                                    ws.data_ptr()), "bias bwd")
