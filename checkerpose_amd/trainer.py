@@ -84,7 +84,7 @@ class TrainProgram(Program):
         self.pgrad = pgrad         # flat fp32 parameter-gradient buffer
         self.pslots = pslots       # state-dict key -> element offset into pgrad
         self.nograd = set()        # id(TBuf) of tensors that need no gradient (the input image)
-        self.bn_ws = torch.zeros(lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=device)   # zeroed: ticket counter
+        self._bn_ws = {}           # lane -> BatchNorm partial-sum workspace
         self.wg_ws = torch.empty(160 << 20, dtype=torch.uint8, device=device)     # weight-gradient slice partials
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
@@ -94,13 +94,16 @@ class TrainProgram(Program):
         self.kinks = {}            # activation key -> Act whose sign is the (Leaky)ReLU branch taken (tests: oracle FORCE_MASK)
         self.debug = {}            # name -> Acts of interest (tools/train_debug.py with CHECKERPOSE_AMD_NO_RECYCLE=1)
 
-    # ---- lanes are an inference-latency device; the training program is one ordered stream
-    def par_begin(self, nlanes): pass
-    def set_lane(self, k): pass
-    def sync(self, src, dst): pass
-    def par_end(self): pass
-
+    # ---- lanes: the FORWARD half keeps the eval program's fork/join structure (HRNet branches, decoder || refinement run as
+    # parallel hipGraph branches: the latency-bound small-map kernels overlap the 64x64 ones); the backward half is emitted
+    # after the last join and stays one ordered stream.  Scratch that is shared between launches is per lane (bn_ws).
     # ---- small helpers
+    @property
+    def bn_ws(self):
+        if self.lane not in self._bn_ws:
+            self._bn_ws[self.lane] = torch.empty(self.lib.cp_bn_bwd_workspace_bytes(4096), dtype=torch.uint8, device=self.device)
+        return self._bn_ws[self.lane]
+
     def const_vec(self, n, one):
         d = self._ones if one else self._zeros
         n = _rup(n, 16)
@@ -317,7 +320,10 @@ class TrainProgram(Program):
         for t in self.arena:
             t.fixed = self.grad_arena[off:off + t.nbytes]
             off += t.nbytes
-        return super().finalize()
+        super().finalize()
+        # n_fwd_ops was recorded in units of emitted ops (launches + fork/sync/join markers): convert to launches
+        self.n_fwd_ops = sum(1 for op in self.ops[:self.n_fwd_ops] if op[0] not in ("__fork__", "__sync__", "__join__"))
+        return self
 
     def zero_grad_arena(self):
         """ONE zero fill of every activation-gradient buffer, at the start of the backward half"""
@@ -340,6 +346,47 @@ class TrainProgram(Program):
         raw = a.tbuf.fixed if a.tbuf.fixed is not None else self.workspace[a.tbuf.offset:a.tbuf.offset + a.tbuf.nbytes]
         flat = raw[:n * es].view(dt).view(a.B, a.H, a.W, a.cstride)
         return flat[..., a.coff:a.coff + a.C].float().cpu()
+
+    def run_lanes_range(self, streams, lo, hi):
+        """launches [lo, hi) with the fork/join structure of the schedule (streams[0] being captured into a hipGraph)"""
+        ptr = [st.cuda_stream for st in streams]
+        active, events = 1, []
+
+        def new_event():
+            events.append(torch.cuda.Event())
+            return events[-1]
+
+        ci = 0
+        for item in self.sched:
+            kind = item[0]
+            if kind == "op":
+                if lo <= ci < hi:
+                    fn, args, name = self.calls[item[1]]
+                    rc = fn(ptr[item[2] if item[2] < len(ptr) else 0], *args[1:])
+                    if rc != 0:
+                        _abi.check(rc, name)
+                ci += 1
+                continue
+            if not (lo <= ci < hi or (kind == "join" and ci == hi)):     # the join that closes the range's last region
+                continue
+            if kind == "fork":
+                active = min(item[1], len(streams))
+                ev = new_event()
+                ev.record(streams[0])
+                for k in range(1, active):
+                    streams[k].wait_event(ev)
+            elif kind == "sync":
+                if item[1] < len(streams) and item[2] < len(streams):
+                    ev = new_event()
+                    ev.record(streams[item[1]])
+                    streams[item[2]].wait_event(ev)
+            else:
+                for k in range(1, active):
+                    ev = new_event()
+                    ev.record(streams[k])
+                    streams[0].wait_event(ev)
+                active = 1
+        return events
 
     def run_range(self, stream_ptr, lo, hi):
         for fn, args, name in self.calls[lo:hi]:
