@@ -88,6 +88,17 @@ def test_state_dict_keys_match_reference_layout():
     assert abs(head - 10.39e6) < 0.05e6      # head params 10.39 M at N=512
 
 
+def test_pc_normalize_matches_reference_definition():
+    """aux_utils/pointnet2_utils.py:11-20 on the reference's own FPS keypoints (fixture copy of lmo obj_000001.pkl)"""
+    import numpy as np
+    from checkerpose_amd.aux_utils.pointnet2_utils import pc_normalize
+    from tests.common import GOLDEN, pc_normalize as ref_def
+    xyz = np.load(os.path.join(GOLDEN, "fps_lmo_obj01.npy"))[:512]
+    out = pc_normalize(xyz.copy())
+    assert np.array_equal(out, ref_def(xyz.copy()))
+    assert np.abs(out.mean(0)).max() < 1e-12 and abs(np.sqrt((out ** 2).sum(1)).max() - 1.0) < 1e-12
+
+
 def test_common_ops_helpers():
     from checkerpose_amd.common_ops import from_dim_str_to_tuple, get_batch_size
     assert get_batch_size(0.75, 32) == (8, 24)
