@@ -103,6 +103,9 @@ def load():
     """Load the library once; raise loudly if it was not built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64: it must be resident BEFORE our library is dlopen()ed, otherwise the loader binds
+        # us to /opt/rocm's copy and the process ends up with two HIP runtimes (every launch on a torch stream then fails)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("checkerpose_amd: HIP library %s is missing -- build it with "
                                "`make -C checkerpose_amd/csrc` (there is no CPU/PyTorch fallback)" % LIB_PATH)
