@@ -249,7 +249,12 @@ class HipForwardMixin:
         prog.finalize()
         torch.cuda.current_stream(device).synchronize()
         return dict(prog=prog, io=io, pgrad=pgrad, params=params, offsets=offsets, counters=list(em.bn_counters), busy=None,
-                    graphs={}, warm={}, keep_streams=[])
+                    graphs={}, warm={}, keep_streams=[], ptrs=self._storage_signature())
+
+    def _storage_signature(self):
+        """the launch program holds raw pointers into the parameter / buffer storage (live weights): if anything re-assigned a
+        tensor (`p.data = ...`, a non-in-place optimizer) the program must be rebuilt"""
+        return tuple(t.data_ptr() for t in self.parameters()) + tuple(t.data_ptr() for t in self.buffers())
 
     def _run_train(self, img, obj_ids, stage=None):
         if not (torch.is_tensor(img) and img.is_cuda):
@@ -261,6 +266,10 @@ class HipForwardMixin:
         B, size = img.shape[0], img.shape[2]
         key = (B, size, stage, self.compute_dtype)
         pr = self._train_programs.get(key)
+        if pr is not None and pr["ptrs"] != self._storage_signature():
+            for g in pr["graphs"].values():
+                lib.cp_graph_destroy(g)
+            pr = None
         if pr is None:
             with torch.cuda.device(device):
                 pr = self._build_train(lib, B, size, stage, device)

@@ -242,3 +242,22 @@ def test_lm_twin_training_loop_per_sample_graphs():
             losses.append(float(loss))
     print("lm losses", ["%.4f" % v for v in losses])
     assert all(v == v for v in losses) and losses[-1] < 0.9 * losses[0], losses
+
+
+def test_train_program_follows_reassigned_parameter_storage():
+    """the training program reads the LIVE parameter storage; re-assigning a parameter's tensor must not leave it on stale
+    pointers: same forward as a fresh net with the new values"""
+    B = 2
+    img = det_image(B, seed=7).cuda()
+    net = build_net(seed=3).cuda().train()
+    with torch.no_grad():
+        a = net(img, None, 1)
+        w = net.seg_block.bias                                 # (a conv weight in front of a train-mode BatchNorm would be
+        w.data = (w.data + 1.0).clone()                        #  normalised away) -- new storage
+        b = net(img, None, 1)
+    ref = build_net(seed=3).cuda().train()
+    with torch.no_grad():
+        ref.seg_block.bias.add_(1.0)
+        c = ref(img, None, 1)
+    assert float((a[3] - b[3]).abs().max()) > 1e-3          # the change is visible
+    assert float((b[3] - c[3]).abs().max()) <= 1e-5 and float((b[0] - c[0]).abs().max()) <= 1e-5
