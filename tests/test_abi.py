@@ -148,6 +148,40 @@ def test_descriptor_validation_without_gpu(lib):
     assert lib.cp_packed_gemm_weight_bytes(_abi.CP_F32, 512, 256) == 16 * 16 * 2 * 1024
 
 
+def test_training_entry_points_validate_before_launch(lib):
+    """SURVEY 8f row N1 entry points: bad arguments are rejected before anything touches the device"""
+    A = 0x10000
+    wd = _abi.CpWgradDesc()
+    for k, v in dict(dtype=_abi.CP_BF16, B=1, H=8, W=8, Ho=8, Wo=8, Cout=16, dy_cstride=16, dy_coff=0, Cin=16, x_cstride=16, x_coff=0,
+                     R=3, S=3, stride=1, pad=1, dw_base=0, dw_sco=144, dw_sci=9, dw_sr=3, dw_ss=1).items():
+        setattr(wd, k, v)
+    assert lib.cp_conv2d_wgrad(None, C.byref(wd), None, A, A) == -1                                   # null dy
+    wd.dy_cstride = 12
+    assert lib.cp_conv2d_wgrad(None, C.byref(wd), A, A, A) == -3                                      # stride not a 16-byte multiple
+    wd.dy_cstride, wd.Cout = 16, 24
+    assert lib.cp_conv2d_wgrad(None, C.byref(wd), A, A, A) == -3                                      # channels outside the pixel row
+    wd.Cout, wd.dtype = 16, 7
+    assert lib.cp_conv2d_wgrad_ws(None, C.byref(wd), A, A, A, A, 1 << 20) == -1                       # unknown dtype
+    assert lib.cp_weight_dgrad(None, None, 4, 4, 3, 3, A) == -1
+    assert lib.cp_bn_train_stats(None, 0, A, 64, 18, 18, 0, None, None, None, None, 0.1, 1e-5, A, A, A, A, A) == -3   # cstride % 4
+    assert lib.cp_bn_train_stats(None, 0, A, 0, 16, 16, 0, None, None, None, None, 0.1, 1e-5, A, A, A, A, A) == -1    # M == 0
+    assert lib.cp_bn_train_bwd(None, 0, A, 16, 0, A, 16, 0, A, 16, 0, None, None, None, 64, 16, 1, 0.0, A, 16, 0, None, 0, 0, 0,
+                               None, None, A) == -1                                                     # raw x without mean/rstd
+    assert lib.cp_affine_act(None, 1, A, 16, 0, A, A, None, 0, 0, A + 2, 16, 0, 64, 16, 1, 0.0) == -3 # misaligned output
+    assert lib.cp_edgeconv_train_fwd(None, 0, A, A, None, A, A, None, None, 0.1, 1e-5, A, 24, 0, A, A, A, A, A, A, 2, 64, 8, 24, 1, 0.2) == -3   # C % 16
+    assert lib.cp_edgeconv_train_bwd(None, 0, A, A, None, None, None, A, 32, 0, A, A, 32, 0, A, A, A, A, A, A, A, 2, 64, 8, 32, 1, 0.2) == -1    # no reverse graph
+    assert lib.cp_edge_weight_view(None, A, 8, 8, 2, A) == -1                                          # unknown mode
+    assert lib.cp_upsample2x_bilinear_ac_bwd(None, 0, A, A, 1, 4, 4, 18, 20, 0, 20, 0, 0) == -3
+    assert lib.cp_fuse_sum_act_bwd(None, 0, A, None, A, 1, 4, 4, 16, 1, 1, 0) == -1                    # relu mask without `out`
+    assert lib.cp_maxpool3x3s2_bwd(None, 0, A, A, A, 1, 7, 8, 16, 0) == -1
+    assert lib.cp_memset_zero(None, A + 4, 64) == -3 and lib.cp_memset_zero(None, None, 64) == -1
+    assert lib.cp_memcpy_d2d(None, None, A, 16) == -1
+    assert lib.cp_strided_to_nhwc(None, 0, A, 1, 0, 1, 1, 1, A, 1, 4, 3, 4) == -1                      # src dtype neither fp32 nor dtype
+    assert lib.cp_index2feat_gather_bwd_t(None, 1, A, A, A, A, A, 1, 8, 9, 9, 6, 2, 24, 0) == -3       # E % 4
+    assert lib.cp_bn_workspace_bytes(18) == 512 * 2 * 32 * 8 and lib.cp_bn_bwd_workspace_bytes(18) == 512 * 2 * 32 * 8 + 4 * 32 * 4
+    assert lib.cp_edge_train_workspace_bytes(2, 64) == 512 * 2 * 64 * 8 + 4 * 64 * 4
+
+
 def test_workspace_planner_never_aliases_live_tensors():
     """engine.Program.finalize(): linear-scan placement -- tensors whose live ranges overlap never overlap in memory,
     and fork/join regions pin every tensor they touch until the join (host logic only: no device needed)."""
