@@ -177,9 +177,13 @@ def main():
             ms = sum(t for _, t in w3)
             fl = sum(prog.wgrad_flops[i] for i, _ in w3)
             big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
+            from bench import pmc_traffic_mb
+            tr = [pmc_traffic_mb(k, a.dtype, B) for k in ("wgrad3x3_kernel", "wgrad_reduce_kernel")]
             out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel + wgrad_reduce_kernel (%d launches per step)" % len(w3),
                                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                               "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+                               "traffic": round(sum(tr), 2) if all(t is not None for t in tr) else None,
+                               "traffic_unit": "MB of HBM read+write per launch pair (rocprofv3 PMC, profiles/)",
                                "algorithmic_gflop_per_step": round(fl / 1e9, 1), "ms_per_step": round(ms, 3),
                                "largest_launch": {"name": prog.calls[big[0]][2], "gflop": round(prog.wgrad_flops[big[0]] / 1e9, 1),
                                                   "us": round(big[1] * 1e3, 1),
