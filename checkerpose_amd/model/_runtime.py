@@ -201,12 +201,12 @@ class HipForwardMixin:
         return dict(prog=prog, io=io, graph=None, warm=False, side=None)
 
     # ---- training program (forward in train mode + backward), see ../trainer.py
-    def _build_train(self, lib, B, size, stage, device):
+    def _build_train(self, lib, B, size, stage, device, u8=False):
         from ..trainer import TrainProgram, TrainWeightStore
         from ..train_ops import reverse_graph
         dtype = DTYPES[self.compute_dtype]
         cfg = self._net_cfg()
-        cfg["img_size"], cfg["stage"], cfg["uint8_input"] = size, stage, False
+        cfg["img_size"], cfg["stage"], cfg["uint8_input"] = size, stage, u8
         N = cfg["npoint"]
         sd = self.state_dict()
         params, offsets, slots, off = [], [], {}, 0
@@ -224,7 +224,7 @@ class HipForwardMixin:
         idx = self._idx_dev
         rev_ptr, rev_edge = reverse_graph(idx)
         z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)   # noqa: E731
-        io = dict(img=z(B, 3, size, size), bits=z(B, 13, N), mask=z(B, N), xid=z(B, N, dt=torch.int32), yid=z(B, N, dt=torch.int32),
+        io = dict(img=(z(B, size, size, 3, dt=torch.uint8) if u8 else z(B, 3, size, size)), bits=z(B, 13, N), mask=z(B, N), xid=z(B, N, dt=torch.int32), yid=z(B, N, dt=torch.int32),
                   x64=z(B, N, dt=torch.int64), y64=z(B, N, dt=torch.int64), gids=z(B, dt=torch.int32) if self.LM else None,
                   dbits=z(B, 13, N), dinit=z(B, 7, N))
         if cfg["kind"] != "init":
@@ -259,12 +259,16 @@ class HipForwardMixin:
     def _run_train(self, img, obj_ids, stage=None):
         if not (torch.is_tensor(img) and img.is_cuda):
             raise RuntimeError("checkerpose_amd: input must be a CUDA/HIP tensor on an MI355X; there is no CPU fallback.")
-        if img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.shape[2] != 256 or img.dtype != torch.float32:
+        u8 = img.dtype == torch.uint8       # raw (B,256,256,3) uint8 crops, normalised on the device (row N3), as in eval mode
+        if u8:
+            if img.dim() != 4 or img.shape[3] != 3 or img.shape[1] != img.shape[2] or img.shape[1] != 256:
+                raise ValueError("expected uint8 img of shape (B, 256, 256, 3), got %s" % (tuple(img.shape),))
+        elif img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.shape[2] != 256 or img.dtype != torch.float32:
             raise ValueError("expected fp32 img of shape (B, 3, 256, 256), got %s" % (tuple(img.shape),))
         lib = _abi.load()
         device = img.device
         B, size = img.shape[0], img.shape[2]
-        key = (B, size, stage, self.compute_dtype)
+        key = (B, size, stage, self.compute_dtype, u8)
         pr = self._train_programs.get(key)
         if pr is not None and pr["ptrs"] != self._storage_signature():
             for g in pr["graphs"].values():
@@ -272,7 +276,7 @@ class HipForwardMixin:
             pr = None
         if pr is None:
             with torch.cuda.device(device):
-                pr = self._build_train(lib, B, size, stage, device)
+                pr = self._build_train(lib, B, size, stage, device, u8)
             self._train_programs[key] = pr
         io = pr["io"]
         self._stale_eval = True

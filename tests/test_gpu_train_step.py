@@ -261,3 +261,21 @@ def test_train_program_follows_reassigned_parameter_storage():
         c = ref(img, None, 1)
     assert float((a[3] - b[3]).abs().max()) > 1e-3          # the change is visible
     assert float((b[3] - c[3]).abs().max()) <= 1e-5 and float((b[0] - c[0]).abs().max()) <= 1e-5
+
+
+def test_train_mode_accepts_uint8_crops():
+    """row N3 in train mode: raw uint8 HWC crops are normalised on the device; same logits / gradients as the fp32 crops"""
+    B = 2
+    u8 = (det_image(B, seed=4) * 40 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    f32 = O.preprocess_uint8(u8)
+    seeds = [det_tensor("g_roi", (B, 1, 512)).cuda(), det_tensor("g_x", (B, 4, 512)).cuda(), det_tensor("g_y", (B, 4, 512)).cuda(),
+             det_tensor("g_seg", (B, 2, 16, 16), 0.05).cuda()]
+    grads = []
+    for inp in (u8, f32):
+        net = build_net(seed=3).cuda().train()
+        with torch.enable_grad():
+            res = net(inp.cuda(), None, 1)
+            torch.autograd.backward(list(res[:4]), seeds)
+        grads.append((res[1].detach(), net.up_net[0][3].weight.grad.clone(), net.init_net.img_backbone.conv1.weight.grad.clone()))
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-5 * (1 + float(b.abs().max()))
