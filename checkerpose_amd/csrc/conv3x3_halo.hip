@@ -1010,7 +1010,7 @@ __global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __r
   store_elem<Tag>(out, i, v);
 }
 
-static inline bool halo_small(int Cout) { return Cout <= 80; }
+static inline bool halo_small(int Cout) { static const int mx = getenv("CP_HALO_S_MAX") ? atoi(getenv("CP_HALO_S_MAX")) : 80; return Cout <= mx; }
 
 // ---- packing: [group g (32 ch)][chunk c][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
 // channel g*32 + 8*qr + 4*nt + reg (the permutation that makes the epilogue stores 16 bytes wide).
