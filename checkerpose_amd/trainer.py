@@ -29,7 +29,7 @@ class TrainWeightStore(WeightStore):
         self.passthrough = set()
 
     def _emit(self, fn, args, name):
-        self.prog._add(fn, lambda P: args, name, [], [])
+        self.prog.add_prep(fn, lambda P: args, name)
 
     def pack(self, name, w, Cout, Cin, R, S, cin_phys, cout_rows, transposed=0, phase=0, row_map=None):
         ck = (name, cin_phys, cout_rows, transposed, phase)
@@ -89,6 +89,7 @@ class TrainProgram(Program):
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._ones, self._zeros = {}, {}
+        self.prep_idx = set()      # op indices of weight-preparation launches
         self.arena = []            # gradient TBufs (not recycled: 288 GB of HBM; one zero fill instead of ~370)
         self.grad_arena = None
         self.kinks = {}            # activation key -> Act whose sign is the (Leaky)ReLU branch taken (tests: oracle FORCE_MASK)
@@ -97,6 +98,13 @@ class TrainProgram(Program):
     # ---- lanes: the FORWARD half keeps the eval program's fork/join structure (HRNet branches, decoder || refinement run as
     # parallel hipGraph branches: the latency-bound small-map kernels overlap the 64x64 ones); the backward half is emitted
     # after the last join and stays one ordered stream.  Scratch that is shared between launches is per lane (bn_ws).
+    # ---- weight preparation ops (packing, data-gradient / EdgeConv weight views, bias refreshes) read ONLY parameters and
+    # write buffers nobody but their one consumer touches: under graph capture they run on a second stream, chunks ahead of
+    # the compute stream (run_prep_range), instead of ~1100 serialized 4 us launches on the critical path.
+    def add_prep(self, fn, argb, name):
+        self.prep_idx.add(len(self.ops))
+        self._add(fn, argb, name, [], [])
+
     # ---- small helpers
     @property
     def bn_ws(self):
@@ -126,8 +134,11 @@ class TrainProgram(Program):
         nb = tbuf.nbytes
         self._add(fn, lambda P: (P(tbuf), nb), name, [], [tbuf])
 
-    def memcpy(self, dst_ptr, src_ptr, nbytes, name="memcpy"):
-        self._add(self.lib.cp_memcpy_d2d, lambda P: (dst_ptr, src_ptr, nbytes), name, [], [])
+    def memcpy(self, dst_ptr, src_ptr, nbytes, name="memcpy", prep=False):
+        if prep:
+            self.add_prep(self.lib.cp_memcpy_d2d, lambda P: (dst_ptr, src_ptr, nbytes), name)
+        else:
+            self._add(self.lib.cp_memcpy_d2d, lambda P: (dst_ptr, src_ptr, nbytes), name, [], [])
 
     def live_vec(self, n, segments):
         """padded fp32 vector refreshed inside the program from live parameter storage: segments = [(dst_off, tensor,
@@ -135,7 +146,7 @@ class TrainProgram(Program):
         t = self.vec(n)
         for doff, src, soff, cnt in segments:
             self.keep.append(src)
-            self.memcpy(t.data_ptr() + 4 * doff, src.data_ptr() + 4 * soff, 4 * cnt, "refresh_vec")
+            self.memcpy(t.data_ptr() + 4 * doff, src.data_ptr() + 4 * soff, 4 * cnt, "refresh_vec", prep=True)
         return t
 
     def scratch_f32(self, numel):
@@ -219,7 +230,7 @@ class TrainProgram(Program):
     def weight_dgrad(self, w, Cout, Cin, R, S):
         wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)
         self.keep.append(w)
-        self._add(self.lib.cp_weight_dgrad, lambda P: (w.data_ptr(), Cout, Cin, R, S, wt.data_ptr()), "weight_dgrad", [], [])
+        self.add_prep(self.lib.cp_weight_dgrad, lambda P: (w.data_ptr(), Cout, Cin, R, S, wt.data_ptr()), "weight_dgrad")
         return wt
 
     def conv_backward(self, key, w, x: Act, g: Act, R, S, stride, pad):
@@ -277,7 +288,7 @@ class TrainProgram(Program):
     def edge_weight_view(self, w, Co, Ci, mode):
         out = self.scratch_f32(2 * Co * Ci)
         self.keep.append(w)
-        self._add(self.lib.cp_edge_weight_view, lambda P: (w.data_ptr(), Co, Ci, mode, out.data_ptr()), "edge_weight_view", [], [])
+        self.add_prep(self.lib.cp_edge_weight_view, lambda P: (w.data_ptr(), Co, Ci, mode, out.data_ptr()), "edge_weight_view")
         return out.view(2 * Co, Ci, 1, 1) if mode == 0 else out.view(Ci, 2 * Co, 1, 1)
 
     def edge_train_fwd(self, pq: Act, graph, gamma, beta, rmean, rvar, out: Act, Co, slope, momentum=0.1, eps=1e-5):
@@ -322,7 +333,16 @@ class TrainProgram(Program):
             off += t.nbytes
         super().finalize()
         # n_fwd_ops was recorded in units of emitted ops (launches + fork/sync/join markers): convert to launches
-        self.n_fwd_ops = sum(1 for op in self.ops[:self.n_fwd_ops] if op[0] not in ("__fork__", "__sync__", "__join__"))
+        markers = ("__fork__", "__sync__", "__join__")
+        self.n_fwd_ops = sum(1 for op in self.ops[:self.n_fwd_ops] if op[0] not in markers)
+        ci, prep_calls = 0, set()
+        for i, op in enumerate(self.ops):
+            if op[0] in markers:
+                continue
+            if i in self.prep_idx:
+                prep_calls.add(ci)
+            ci += 1
+        self.prep_calls = prep_calls
         return self
 
     def zero_grad_arena(self):
@@ -386,6 +406,55 @@ class TrainProgram(Program):
                     ev.record(streams[k])
                     streams[0].wait_event(ev)
                 active = 1
+        return events
+
+    def run_prep_range(self, main, side, lo, hi, chunk=48):
+        """launches [lo, hi) with the weight-preparation ops on `side`, chunks ahead of the compute ops on `main` (both
+        torch.cuda.Stream; `main` is being captured).  Compute op j waits (one event per chunk) for every prep op < j."""
+        prep = [i for i in range(lo, hi) if i in self.prep_calls]
+        events = []
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        side.wait_event(ev0)
+        events.append(ev0)
+        launched, waited = 0, 0               # prep ops launched on `side` / covered by a wait on `main`
+        chunk_ev = []                         # (number of prep ops covered, event)
+
+        def launch_chunk():
+            nonlocal launched
+            end = min(launched + chunk, len(prep))
+            for k in range(launched, end):
+                fn, args, name = self.calls[prep[k]]
+                rc = fn(side.cuda_stream, *args[1:])
+                if rc != 0:
+                    _abi.check(rc, name)
+            launched = end
+            ev = torch.cuda.Event()
+            ev.record(side)
+            chunk_ev.append((end, ev))
+            events.append(ev)
+
+        need = 0
+        for i in range(lo, hi):
+            if i in self.prep_calls:
+                need += 1
+                continue
+            while launched < min(len(prep), need + chunk):      # keep the side stream at least one chunk ahead
+                launch_chunk()
+            if waited < need:
+                for covered, ev in chunk_ev:
+                    if covered >= need:
+                        main.wait_event(ev)
+                        waited = covered
+                        break
+            fn, args, name = self.calls[i]
+            rc = fn(main.cuda_stream, *args[1:])
+            if rc != 0:
+                _abi.check(rc, name)
+        while launched < len(prep):
+            launch_chunk()
+        if chunk_ev:                          # join: the capture must end with every forked stream merged back
+            main.wait_event(chunk_ev[-1][1])
         return events
 
     def run_range(self, stream_ptr, lo, hi):
