@@ -184,6 +184,10 @@ __device__ __forceinline__ void fin_bwd_channel(const double* partial, const Fin
   }
 }
 
+// the fp64 accumulators of the two-launch forms are replicated CP_BN_ACC_SETS times (block b adds into set b % SETS, the
+// consumer sums the sets): 512 blocks hitting the same 48 addresses serialised in the L2 atomic unit
+constexpr int CP_BN_ACC_SETS = 8;
+
 struct ColsumParams {
   const void* a; int a_cs, a_coff;      // mode 0: x ; mode 1: dy
   const void* y; int y_cs, y_coff;      // mode 1: post-activation output (NULL: no activation)
@@ -192,6 +196,7 @@ struct ColsumParams {
   float slope; int act;
   int M, G, RL, rpb;
   double* partial;                      // [nblk][2][G*E]
+  double* acc; int acc_stride;          // non-NULL: fp64 atomics into acc[which*acc_stride + c] instead of block partials
 };
 
 template <typename Tag, int MODE>
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
     const int pc = c / E, j = c - pc * E;
     double s = 0.0;
     for (int r = 0; r < p.RL; ++r) s += red[(r * p.G + pc) * 2 * E + which * E + j];
-    p.partial[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
+    if (p.acc) unsafeAtomicAdd(p.acc + ((blockIdx.x & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
+    else p.partial[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
   }
 }
 
@@ -678,5 +684,252 @@ extern "C" int cp_maxpool3x3s2_bwd(cp_stream_t stream, int dtype, const void* x,
     CP_LAUNCH(maxpool3x3s2_bwd_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dout, din, H, W, CG, accumulate, total);
   else
     CP_LAUNCH(maxpool3x3s2_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dout, din, H, W, CG, accumulate, total);
+  return cp_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ two-launch BatchNorm
+// Variant without the finalize launch (the training program's 670 finalize launches were 8.5 % of a step): the column sums
+// go straight into a per-layer fp64 accumulator pair (hardware fp64 atomics, <= 128 blocks per launch; the caller zeroes
+// all accumulators of a step with ONE fill), and the consumer kernel derives the per-channel coefficients in its prologue
+// (the thread that owns row 0 of a channel group also writes the saved statistics / running stats / dgamma, dbeta).
+static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, int* rpb) {
+  *G = Cphys / E;
+  if (*G > 256) return CP_ERR_INVALID;
+  *RL = 256 / *G;
+  int nb = M / 64;                                        // as many blocks as the partial-sum variant ...
+  int cap = 65536 / (2 * Cphys);                          // ... but at most ~64k atomics per launch (~30 G atomics/s)
+  cap = cap < 32 ? 32 : (cap > 512 ? 512 : cap);
+  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  *rpb = (M + nb - 1) / nb;
+  *nblk = (M + *rpb - 1) / *rpb;
+  return CP_OK;
+}
+
+extern "C" size_t cp_bn_acc_doubles(int C) { return (size_t)CP_BN_ACC_SETS * 2 * ((size_t)(C + 15) / 16 * 16); }
+
+extern "C" int cp_bn_stats_accumulate(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff,
+                                      double* acc) {
+  if (!acc || M <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
+  int rc = check_cl(dtype, x, x_cstride, x_coff, Cphys);
+  if (rc) return rc;
+  ColsumParams p = {};
+  int nblk;
+  if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, &nblk, &p.rpb))) return rc;
+  p.a = x; p.a_cs = x_cstride; p.a_coff = x_coff; p.M = M; p.acc = acc; p.acc_stride = Cvec;
+  if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else CP_LAUNCH((colsum2_kernel<BF16Tag, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  return cp_check_launch();
+}
+
+struct BnApplyParams {
+  const void* x; int x_cs, x_coff;
+  const void* res; int r_cs, r_coff;
+  void* y; int y_cs, y_coff;
+  const double* acc; int Cvec, C;
+  double count;
+  const float* gamma; const float* beta;
+  float eps, momentum;
+  float *rmean, *rvar, *mean, *rstd;
+  int G, act; float slope; size_t total;
+};
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  extern __shared__ float s_coef[];                  // [2][Cphys]: scale | shift, computed once per block
+  const int Cphys = p.G * E;
+  const double inv = 1.0 / p.count;
+  for (int c = threadIdx.x; c < Cphys; c += 256) {
+    float sc = 0.f, sh = 0.f;
+    if (c < p.C) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < CP_BN_ACC_SETS; ++k) { a1 += p.acc[(2 * k) * p.Cvec + c]; a2 += p.acc[(2 * k + 1) * p.Cvec + c]; }
+      const double mu = a1 * inv;
+      double var = a2 * inv - mu * mu;
+      var = var > 0.0 ? var : 0.0;
+      const float rs = 1.0f / sqrtf((float)var + p.eps);
+      const float gm = p.gamma ? p.gamma[c] : 1.f, bt = p.beta ? p.beta[c] : 0.f;
+      sc = gm * rs;
+      sh = bt - (float)mu * sc;
+      if (blockIdx.x == 0) {                       // one block writes the saved statistics + running stats
+        p.mean[c] = (float)mu;
+        p.rstd[c] = rs;
+        if (p.rmean) p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)mu;
+        if (p.rvar) p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)(p.count > 1.0 ? var * p.count / (p.count - 1.0) : var);
+      }
+    }
+    s_coef[c] = sc;
+    s_coef[Cphys + c] = sh;
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M*G
+  if (i >= p.total) return;
+  const int g = (int)(i % p.G);
+  const size_t m = i / p.G;
+  float v[E], r[E];
+  Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E), v);
+#pragma unroll
+  for (int j = 0; j < E; ++j) v[j] = v[j] * s_coef[g * E + j] + s_coef[Cphys + g * E + j];
+  if (p.res) {
+    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.res + m * p.r_cs + p.r_coff + g * E), r);
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] += r[j];
+  }
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+    else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+  }
+  *(u32x4*)((T*)p.y + m * p.y_cs + p.y_coff + g * E) = Vec16<Tag>::pack(v);
+}
+
+extern "C" int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const double* acc,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                           float eps, const void* res, int res_cstride, int res_coff, void* y, int y_cstride, int y_coff, int M,
+                           int C, int act, float slope, float* mean, float* rstd) {
+  if (!acc || !mean || !rstd || M <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E;
+  int rc;
+  if ((rc = check_cl(dtype, x, x_cstride, x_coff, Cphys)) || (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (res && (rc = check_cl(dtype, res, res_cstride, res_coff, Cphys))) return rc;
+  BnApplyParams p;
+  p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.res = res; p.r_cs = res_cstride; p.r_coff = res_coff;
+  p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = (C + 15) / 16 * 16; p.C = C; p.count = (double)M;
+  p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum; p.rmean = running_mean; p.rvar = running_var;
+  p.mean = mean; p.rstd = rstd; p.G = Cphys / E; p.act = act; p.slope = slope; p.total = (size_t)M * p.G;
+  const unsigned blocks = (unsigned)((p.total + 255) / 256);
+  const size_t lds = (size_t)2 * Cphys * sizeof(float);
+  if (dtype == CP_F32) CP_LAUNCH(bn_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
+  else CP_LAUNCH(bn_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
+  return cp_check_launch();
+}
+
+extern "C" int cp_bn_bwd_accumulate(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                                    int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                                    const float* rstd, int M, int C, int act, float slope, double* acc) {
+  if (!acc || M <= 0 || C <= 0 || (x && (!mean || !rstd))) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
+  int rc;
+  if ((rc = check_cl(dtype, dy, dy_cstride, dy_coff, Cphys))) return rc;
+  const void* yy = act == CP_ACT_NONE ? nullptr : y;
+  if (act != CP_ACT_NONE && (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (x && (rc = check_cl(dtype, x, x_cstride, x_coff, Cphys))) return rc;
+  ColsumParams p = {};
+  int nblk;
+  if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, &nblk, &p.rpb))) return rc;
+  p.a = dy; p.a_cs = dy_cstride; p.a_coff = dy_coff; p.y = yy; p.y_cs = y_cstride; p.y_coff = y_coff;
+  p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.mean = mean; p.rstd = rstd; p.slope = act == CP_ACT_RELU ? 0.f : slope; p.act = act;
+  p.M = M; p.acc = acc; p.acc_stride = Cvec;
+  if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else CP_LAUNCH((colsum2_kernel<BF16Tag, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  return cp_check_launch();
+}
+
+struct BnBwdApplyParams {
+  BnBwdParams q;
+  const double* acc; int C; double count;
+  const float* gamma; const float* mean; const float* rstd;
+  float* dgamma; float* dbeta;
+};
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParams pp) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const BnBwdParams& p = pp.q;
+  extern __shared__ float s_cf[];                    // [4][Cphys]: a | b | cr | mu, once per block
+  const int Cphys = p.G * E;
+  const double inv = 1.0 / pp.count;
+  for (int c = threadIdx.x; c < Cphys; c += 256) {
+    float ca = 0.f, cb = 0.f, cr = 0.f, mu = 0.f;
+    if (c < pp.C) {
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < CP_BN_ACC_SETS; ++k) { s1 += pp.acc[(2 * k) * p.Cvec + c]; s2 += pp.acc[(2 * k + 1) * p.Cvec + c]; }
+      if (p.x) {
+        const float rs = pp.rstd[c];
+        ca = (pp.gamma ? pp.gamma[c] : 1.f) * rs;
+        cb = (float)(s1 * inv);
+        cr = (float)(s2 * inv) * rs;
+        mu = pp.mean[c];
+      }
+      if (blockIdx.x == 0) {
+        if (pp.dbeta) pp.dbeta[c] = (float)s1;
+        if (p.x && pp.dgamma) pp.dgamma[c] = (float)s2;
+      }
+    }
+    s_cf[c] = ca; s_cf[Cphys + c] = cb; s_cf[2 * Cphys + c] = cr; s_cf[3 * Cphys + c] = mu;
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.total) return;
+  const int g = (int)(i % p.G);
+  const size_t m = i / p.G;
+  float dz[E], t[E];
+  Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.dy + m * p.dy_cs + p.dy_coff + g * E), dz);
+  if (p.y) {
+    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.y + m * p.y_cs + p.y_coff + g * E), t);
+#pragma unroll
+    for (int j = 0; j < E; ++j) dz[j] = t[j] > 0.f ? dz[j] : dz[j] * p.slope;
+  }
+  if (p.dres) {
+    float o[E];
+    if (p.dr_acc) {
+      Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.dres + m * p.dr_cs + p.dr_coff + g * E), o);
+#pragma unroll
+      for (int j = 0; j < E; ++j) o[j] += dz[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < E; ++j) o[j] = dz[j];
+    }
+    *(u32x4*)((T*)p.dres + m * p.dr_cs + p.dr_coff + g * E) = Vec16<Tag>::pack(o);
+  }
+  float o[E];
+  if (p.x) {
+    float xv[E];
+    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E), xv);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const int c = g * E + j;
+      o[j] = s_cf[c] * (dz[j] - s_cf[Cphys + c] - (xv[j] - s_cf[3 * Cphys + c]) * s_cf[2 * Cphys + c]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < E; ++j) o[j] = dz[j];
+  }
+  *(u32x4*)((T*)p.dx + m * p.dx_cs + p.dx_coff + g * E) = Vec16<Tag>::pack(o);
+}
+
+extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                               int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                               const float* rstd, const float* gamma, const double* acc, int M, int C, int act, float slope,
+                               void* dx, int dx_cstride, int dx_coff, void* dres, int dres_cstride, int dres_coff,
+                               int dres_accumulate, float* dgamma, float* dbeta) {
+  if (!acc || M <= 0 || C <= 0 || (x && (!mean || !rstd))) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E;
+  int rc;
+  if ((rc = check_cl(dtype, dy, dy_cstride, dy_coff, Cphys)) || (rc = check_cl(dtype, dx, dx_cstride, dx_coff, Cphys))) return rc;
+  const void* yy = act == CP_ACT_NONE ? nullptr : y;
+  if (act != CP_ACT_NONE && (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (x && (rc = check_cl(dtype, x, x_cstride, x_coff, Cphys))) return rc;
+  if (dres && (rc = check_cl(dtype, dres, dres_cstride, dres_coff, Cphys))) return rc;
+  BnBwdApplyParams pp;
+  BnBwdParams& q = pp.q;
+  q.dy = dy; q.dy_cs = dy_cstride; q.dy_coff = dy_coff; q.y = yy; q.y_cs = y_cstride; q.y_coff = y_coff;
+  q.x = x; q.x_cs = x_cstride; q.x_coff = x_coff; q.dx = dx; q.dx_cs = dx_cstride; q.dx_coff = dx_coff;
+  q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
+  q.coef = nullptr; q.Cvec = (C + 15) / 16 * 16; q.G = Cphys / E; q.slope = act == CP_ACT_RELU ? 0.f : slope; q.total = (size_t)M * q.G;
+  pp.acc = acc; pp.C = C; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
+  const unsigned blocks = (unsigned)((q.total + 255) / 256);
+  const size_t lds = (size_t)4 * Cphys * sizeof(float);
+  if (dtype == CP_F32) CP_LAUNCH(bn_bwd_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
+  else CP_LAUNCH(bn_bwd_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
   return cp_check_launch();
 }

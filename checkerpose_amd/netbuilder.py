@@ -44,7 +44,7 @@ class NetEmitter:
                          self.sd[bn + ".running_var"])
         self.bn_counters.append(self.sd[bn + ".num_batches_tracked"])
         y = out if out is not None else tp.act(raw.H, raw.W, Cout)
-        tp.affine_act(raw, st["scale"], st["shift"], residual, y, act, slope)
+        tp.bn_apply(raw, st, residual, y, act, slope)
         if act != ACT_NONE:
             tp.kinks[bn] = y
         return y, st

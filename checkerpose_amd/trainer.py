@@ -89,6 +89,9 @@ class TrainProgram(Program):
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._ones, self._zeros = {}, {}
+        self.acc_total = 0         # fp64 BatchNorm accumulators (elements), one arena zero-filled at the start of a step
+        self.acc_arena = None
+        self._add(lib.cp_memset_zero, lambda P: (self.acc_arena.data_ptr(), self.acc_arena.numel() * 8), "acc_zero", [], [])
         self.prep_idx = set()      # op indices of weight-preparation launches
         self.arena = []            # gradient TBufs (not recycled: 288 GB of HBM; one zero fill instead of ~370)
         self.grad_arena = None
@@ -167,16 +170,40 @@ class TrainProgram(Program):
     def needs_grad(self, a: Act):
         return id(a.tbuf) not in self.nograd
 
-    # ---- train-mode BatchNorm
+    # ---- train-mode BatchNorm: two launches per pass (column sums by fp64 atomics into a per-layer accumulator pair, then the
+    # consumer kernel derives the coefficients itself) -- the accumulators of the whole step are zero-filled by ONE launch
+    def _acc_slot(self, C_):
+        off = self.acc_total
+        self.acc_total += int(self.lib.cp_bn_acc_doubles(C_))
+        return off
+
+    def _acc_ptr(self, off):
+        return self.acc_arena.data_ptr() + 8 * off
+
     def bn_stats(self, x: Act, C_, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
-        bn = dict(scale=self.vec(C_), shift=self.vec(C_), mean=self.vec(C_), rstd=self.vec(C_), gamma=gamma, C=C_)
+        bn = dict(mean=self.vec(C_), rstd=self.vec(C_), gamma=gamma, beta=beta, rmean=rmean, rvar=rvar, C=C_, acc=self._acc_slot(C_),
+                  momentum=momentum, eps=eps)
         self.keep += [gamma, beta, rmean, rvar]
         xt = x.tbuf
         M = x.B * x.H * x.W
-        args = (gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), momentum, eps, bn["scale"].data_ptr(),
-                bn["shift"].data_ptr(), bn["mean"].data_ptr(), bn["rstd"].data_ptr(), self.bn_ws.data_ptr())
-        self._add(self.lib.cp_bn_train_stats, lambda P: (self.dtype, P(xt), M, C_, x.cstride, x.coff) + args, "bn_stats", [xt], [])
+        off = bn["acc"]
+        self._add(self.lib.cp_bn_stats_accumulate, lambda P: (self.dtype, P(xt), M, C_, x.cstride, x.coff, self._acc_ptr(off)),
+                  "bn_stats", [xt], [])
         return bn
+
+    def bn_apply(self, x: Act, bn, residual, out: Act, act, slope=0.0):
+        xt, ot = x.tbuf, out.tbuf
+        rt = residual.tbuf if residual is not None else None
+        M = x.B * x.H * x.W
+        rcs, rco = (residual.cstride, residual.coff) if residual is not None else (0, 0)
+        off = bn["acc"]
+        a1 = (bn["gamma"].data_ptr(), bn["beta"].data_ptr(), bn["rmean"].data_ptr(), bn["rvar"].data_ptr(), bn["momentum"], bn["eps"])
+        mp, rp = bn["mean"].data_ptr(), bn["rstd"].data_ptr()
+        self._add(self.lib.cp_bn_apply,
+                  lambda P: (self.dtype, P(xt), x.cstride, x.coff, self._acc_ptr(off)) + a1 +
+                            (P(rt) if rt is not None else None, rcs, rco, P(ot), out.cstride, out.coff, M, x.C, act, slope, mp, rp),
+                  "bn_apply", [xt, rt], [ot])
+        return out
 
     def affine_act(self, x: Act, scale, shift, residual, out: Act, act, slope=0.0):
         xt, ot = x.tbuf, out.tbuf
@@ -203,11 +230,15 @@ class TrainProgram(Program):
         ycs, yco = (y.cstride, y.coff) if yt is not None else (0, 0)
         rcs, rco = (raw.cstride, raw.coff) if raw is not None else (0, 0)
         gcs, gco = (gres.cstride, gres.coff) if gres is not None else (0, 0)
-        wsp = self.bn_ws.data_ptr()
-        self._add(self.lib.cp_bn_train_bwd,
+        off = self._acc_slot(C_)
+        self._add(self.lib.cp_bn_bwd_accumulate,
                   lambda P: (self.dtype, P(gt), gy.cstride, gy.coff, P(yt) if yt is not None else None, ycs, yco,
-                             P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, gam_p, M, C_, act, slope, P(gt),
-                             gy.cstride, gy.coff, P(grt) if grt is not None else None, gcs, gco, 1, dgamma_ptr, dbeta_ptr, wsp),
+                             P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, M, C_, act, slope, self._acc_ptr(off)),
+                  "bn_bwd_acc", [gt, yt, rt], [])
+        self._add(self.lib.cp_bn_bwd_apply,
+                  lambda P: (self.dtype, P(gt), gy.cstride, gy.coff, P(yt) if yt is not None else None, ycs, yco,
+                             P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, gam_p, self._acc_ptr(off), M, C_, act, slope,
+                             P(gt), gy.cstride, gy.coff, P(grt) if grt is not None else None, gcs, gco, 1, dgamma_ptr, dbeta_ptr),
                   "bn_bwd", [gt, yt, rt, grt], [gt, grt])
 
     # ---- dense layer backward
@@ -325,6 +356,7 @@ class TrainProgram(Program):
         self._add(self.lib.cp_index2feat_gather_bwd_t, lambda P: (self.dtype, P(gt)) + args, "index2feat_bwd", [gt], [])
 
     def finalize(self):
+        self.acc_arena = torch.zeros(max(self.acc_total, 2), dtype=torch.float64, device=self.device)
         total = sum(t.nbytes for t in self.arena)
         self.grad_arena = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
         off = 0

@@ -289,6 +289,26 @@ int cp_bn_train_bwd(cp_stream_t stream, int dtype, const void* dy, int dy_cstrid
                     int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma,
                     float* dbeta, void* workspace);
 
+/* Two-launch forms of the same BatchNorm forward / backward (what the training program uses): the column sums go into a
+ * caller-zeroed fp64 accumulator block of cp_bn_acc_doubles(C) doubles (8 replicated [sum | sum of squares] resp.
+ * [sum dz | sum dz*xhat] pairs of ceil16(C) entries: block b adds into replica b % 8 to spread the atomic traffic) by hardware
+ * fp64 atomics, and the consumer launch derives the per-channel coefficients in its prologue -- no finalize launch (670 of them
+ * were 8.5 % of a training step).  cp_bn_apply also writes mean / rstd (C floats each) and updates the running statistics;
+ * cp_bn_bwd_apply writes dgamma / dbeta.  One accumulator pair per layer and pass; zero them all with one cp_memset_zero. */
+size_t cp_bn_acc_doubles(int C);
+int cp_bn_stats_accumulate(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff, double* acc);
+int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const double* acc, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, float momentum, float eps, const void* res,
+                int res_cstride, int res_coff, void* y, int y_cstride, int y_coff, int M, int C, int act, float slope,
+                float* mean, float* rstd);
+int cp_bn_bwd_accumulate(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                         int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                         const float* rstd, int M, int C, int act, float slope, double* acc);
+int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride,
+                    int y_coff, const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd,
+                    const float* gamma, const double* acc, int M, int C, int act, float slope, void* dx, int dx_cstride,
+                    int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma, float* dbeta);
+
 /* Train-mode EdgeConv in factored form (StaticGraph_module init.py:54-68 with BatchNorm2d batch statistics over the
  * B*N*K edges), see csrc/train_edge.hip.  pq (B,N,2C) = raw node GEMM output [P | Q] (W rows [W1 ; W2-W1], no
  * affine); kstar (B,N,C) uint8 receives the arg-max neighbour slot; scale/shift/mean/rstd: C floats each.

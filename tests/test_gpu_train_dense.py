@@ -470,3 +470,56 @@ def test_edgeconv_train_full_layer_real_graph(lib, dtype):
     dx = conv_cl(lib, dtype, D, pack(lib, dtype, wdg.cpu(), 2 * Co, 1, 1), Cin, 1, 1, 1, 0, 1, N)
     s = dx_ref.abs().max().item()
     close(from_cl(dx, Cin)[:, :, 0] / s, dx_ref.detach() / s, TOLT[dtype])
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", [(2, 18, 16, 16, ACT_RELU, True), (3, 64, 8, 8, ACT_LEAKY, False), (2, 36, 32, 32, ACT_RELU, False)])
+def test_bn_two_launch_forms(lib, dtype, case):
+    """cp_bn_stats_accumulate + cp_bn_apply / cp_bn_bwd_accumulate + cp_bn_bwd_apply (fp64 atomics, no finalize launch)
+    against torch autograd -- the forms the training program uses"""
+    B, Cc, H, W, act, has_res = case
+    M = B * H * W
+    x = rnd(det_tensor("b2_x%s" % (case,), (B, Cc, H, W)) * 1.5 + 0.3, dtype).requires_grad_(True)
+    res = rnd(det_tensor("b2_r%s" % (case,), (B, Cc, H, W)), dtype).requires_grad_(True) if has_res else None
+    gamma = (1.0 + 0.5 * det_tensor("b2_g%s" % (case,), (Cc,))).requires_grad_(True)
+    beta = (0.2 * det_tensor("b2_b%s" % (case,), (Cc,))).requires_grad_(True)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    with torch.enable_grad():
+        z = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+        if has_res:
+            z = z + res
+        y = F.relu(z) if act == ACT_RELU else F.leaky_relu(z, 0.2)
+    dy = rnd(det_tensor("b2_d%s" % (case,), (B, Cc, H, W)), dtype)
+    grads = torch.autograd.grad(y, [x, gamma, beta] + ([res] if has_res else []), dy)
+    xc = to_cl(x.detach(), dtype)
+    cs = xc.shape[-1]
+    g_d, b_d = gamma.detach().to(dev()), beta.detach().to(dev())
+    rm_d, rv_d = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    mean, rstd = _vec(Cc), _vec(Cc)
+    acc = torch.zeros(2, lib.cp_bn_acc_doubles(Cc), dtype=torch.float64, device=dev())       # [fwd | bwd] accumulator blocks
+    rc_ = to_cl(res.detach(), dtype) if has_res else None
+    yc = torch.empty_like(xc)
+    _abi.check(lib.cp_bn_stats_accumulate(st(), dtype, xc.data_ptr(), M, Cc, cs, 0, acc[0].data_ptr()), "stats acc")
+    _abi.check(lib.cp_bn_apply(st(), dtype, xc.data_ptr(), cs, 0, acc[0].data_ptr(), g_d.data_ptr(), b_d.data_ptr(), rm_d.data_ptr(),
+                               rv_d.data_ptr(), 0.1, 1e-5, rc_.data_ptr() if has_res else None, cs, 0, yc.data_ptr(), cs, 0, M, Cc, act,
+                               0.2, mean.data_ptr(), rstd.data_ptr()), "bn apply")
+    torch.cuda.synchronize()
+    close(from_cl(yc, Cc), y.detach(), TOLT[dtype])
+    close(rm_d.cpu(), rm, 1e-5)
+    close(rv_d.cpu(), rv, 1e-5)
+    dyc = to_cl(dy, dtype)
+    dres = torch.zeros_like(xc) if has_res else None
+    dg, db = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    _abi.check(lib.cp_bn_bwd_accumulate(st(), dtype, dyc.data_ptr(), cs, 0, yc.data_ptr(), cs, 0, xc.data_ptr(), cs, 0, mean.data_ptr(),
+                                        rstd.data_ptr(), M, Cc, act, 0.2, acc[1].data_ptr()), "bwd acc")
+    _abi.check(lib.cp_bn_bwd_apply(st(), dtype, dyc.data_ptr(), cs, 0, yc.data_ptr(), cs, 0, xc.data_ptr(), cs, 0, mean.data_ptr(),
+                                   rstd.data_ptr(), g_d.data_ptr(), acc[1].data_ptr(), M, Cc, act, 0.2, dyc.data_ptr(), cs, 0,
+                                   dres.data_ptr() if has_res else None, cs, 0, 1, dg.data_ptr(), db.data_ptr()), "bwd apply")
+    torch.cuda.synchronize()
+    tol = TOLT[dtype]
+    sx = grads[0].abs().max().item()
+    close(from_cl(dyc, Cc) / sx, grads[0] / sx, tol)                      # dx written in place over dy
+    close(dg.cpu() / grads[1].abs().max().item(), grads[1] / grads[1].abs().max().item(), tol)
+    close(db.cpu() / grads[2].abs().max().item(), grads[2] / grads[2].abs().max().item(), tol)
+    if has_res:
+        close(from_cl(dres, Cc), grads[3], tol)
