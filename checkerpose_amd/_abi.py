@@ -25,6 +25,11 @@ class CpConvDesc(C.Structure):
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 
+class CpPackItem(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32 * 9), ("src", C.c_void_p), ("dst", C.c_void_p), ("row_map", C.c_void_p),
+                ("total", C.c_uint64)]
+
+
 class CpWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
@@ -74,6 +79,13 @@ SIGNATURES = {
     "cp_bn_bwd_workspace_bytes": (C.c_size_t, [_I]),
     "cp_bn_train_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
                              _I, _P, _P, _P]),
+    "cp_pack_item_conv": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, C.POINTER(CpPackItem)]),
+    "cp_pack_item_halo": (_I, [_I, _P, _I, _I, _I, _P, C.POINTER(CpPackItem)]),
+    "cp_pack_item_gemm": (_I, [_I, _P, _I, _I, _I, _P, C.POINTER(CpPackItem)]),
+    "cp_pack_item_dgrad_view": (_I, [_P, _I, _I, _I, _I, _P, C.POINTER(CpPackItem)]),
+    "cp_pack_item_edge_view": (_I, [_P, _I, _I, _I, _P, C.POINTER(CpPackItem)]),
+    "cp_pack_item_copy_f32": (_I, [_P, _P, _I, C.POINTER(CpPackItem)]),
+    "cp_pack_batch": (_I, [_P, _I, _P, _P, _I, C.c_uint32]),
     "cp_bn_acc_doubles": (C.c_size_t, [_I]),
     "cp_bn_stats_accumulate": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "cp_bn_apply": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),

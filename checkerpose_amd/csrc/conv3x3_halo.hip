@@ -1074,6 +1074,20 @@ extern "C" int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const 
   return cp_check_launch();
 }
 
+extern "C" int cp_pack_item_halo(int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed, CpPackItem* it) {
+  if (!w || !packed || !it || Cout <= 0 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
+  for (int k = 0; k < 9; ++k) it->a[k] = 0;
+  it->src = w; it->dst = packed; it->row_map = nullptr;
+  it->total = cp_packed_halo_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
+  it->a[0] = Cout; it->a[1] = Cin;
+  if (halo_small(Cout)) { it->kind = CP_PACK_HALO_S; it->a[2] = (Cout + 15) / 16; it->a[3] = 1; }
+  else { it->kind = halo_wide(Cout) ? CP_PACK_HALO4 : CP_PACK_HALO; it->a[2] = (cin_phys + 4 * E - 1) / (4 * E); }
+  return CP_OK;
+}
+
 extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                                const float* scale, const float* shift, const void* residual, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;

@@ -389,6 +389,18 @@ extern "C" int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w
   return cp_check_launch();
 }
 
+extern "C" int cp_pack_item_gemm(int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed, CpPackItem* it) {
+  if (!w || !packed || !it || Cout <= 0 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
+  for (int k = 0; k < 9; ++k) it->a[k] = 0;
+  it->kind = CP_PACK_GEMM; it->src = w; it->dst = packed; it->row_map = nullptr;
+  it->a[0] = Cout; it->a[1] = Cin; it->a[2] = (cin_phys + 4 * E - 1) / (4 * E);
+  it->total = cp_packed_gemm_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
+  return CP_OK;
+}
+
 extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                             const float* scale, const float* shift, const void* residual, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;

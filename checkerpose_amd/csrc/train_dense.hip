@@ -7,6 +7,8 @@
 // Replaces (reference /root/reference/checkerpose): nn.BatchNorm2d in .train() mode inside timm's hrnet
 // (model/backbone.py:48), model/init.py:60 + model/pipeline.py:51 (EdgeConv BN), pipeline.py:189,194,203,208 (decoder
 // BN) and their autograd; nn.UpsamplingBilinear2d backward (pipeline.py:199).
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ small plumbing
@@ -696,9 +698,11 @@ static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, 
   *G = Cphys / E;
   if (*G > 256) return CP_ERR_INVALID;
   *RL = 256 / *G;
-  int nb = M / 64;                                        // as many blocks as the partial-sum variant ...
+  static const int max_blocks = getenv("CP_BN_ACC_BLOCKS") ? atoi(getenv("CP_BN_ACC_BLOCKS")) : 512;
+  static const int rows_per_block = getenv("CP_BN_ACC_ROWS") ? atoi(getenv("CP_BN_ACC_ROWS")) : 64;
+  int nb = M / rows_per_block;                            // as many blocks as the partial-sum variant ...
   int cap = 65536 / (2 * Cphys);                          // ... but at most ~64k atomics per launch (~30 G atomics/s)
-  cap = cap < 32 ? 32 : (cap > 512 ? 512 : cap);
+  cap = cap < 32 ? 32 : (cap > max_blocks ? max_blocks : cap);
   nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
   *rpb = (M + nb - 1) / nb;
   *nblk = (M + *rpb - 1) / *rpb;

@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpWgradDesc
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc
 from .engine import Act, Program, WeightStore, _rup
 
 
@@ -28,8 +28,9 @@ class TrainWeightStore(WeightStore):
         self.prog = None
         self.passthrough = set()
 
-    def _emit(self, fn, args, name):
-        self.prog.add_prep(fn, lambda P: args, name)
+    def _item(self, rc, item, what):
+        _abi.check(rc, what)
+        self.prog.add_item("packs", item)
 
     def pack(self, name, w, Cout, Cin, R, S, cin_phys, cout_rows, transposed=0, phase=0, row_map=None):
         ck = (name, cin_phys, cout_rows, transposed, phase)
@@ -40,9 +41,10 @@ class TrainWeightStore(WeightStore):
         if row_map is not None:
             rm = torch.tensor(row_map, dtype=torch.int32, device=self.device)
         self.prog.keep += [w, rm, out]
-        self._emit(self.lib.cp_pack_conv_weight, (self.dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
-                                                  rm.data_ptr() if rm is not None else None, cout_rows, out.data_ptr()),
-                   "pack:" + name)
+        it = CpPackItem()
+        self._item(self.lib.cp_pack_item_conv(self.dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
+                                              rm.data_ptr() if rm is not None else None, cout_rows, out.data_ptr(), C.byref(it)),
+                   it, "pack:" + name)
         self.cache[ck] = out
         return out
 
@@ -52,7 +54,8 @@ class TrainWeightStore(WeightStore):
             return self.cache[ck]
         out = torch.empty(self.lib.cp_packed_halo_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
         self.prog.keep += [w, out]
-        self._emit(self.lib.cp_pack_conv3x3_halo_weight, (self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
+        it = CpPackItem()
+        self._item(self.lib.cp_pack_item_halo(self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr(), C.byref(it)), it,
                    "pack_halo:" + name)
         self.cache[ck] = out
         return out
@@ -63,7 +66,9 @@ class TrainWeightStore(WeightStore):
             return self.cache[ck]
         out = torch.empty(self.lib.cp_packed_gemm_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
         self.prog.keep += [w, out]
-        self._emit(self.lib.cp_pack_gemm_weight, (self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()), "pack_gemm:" + name)
+        it = CpPackItem()
+        self._item(self.lib.cp_pack_item_gemm(self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr(), C.byref(it)), it,
+                   "pack_gemm:" + name)
         self.cache[ck] = out
         return out
 
@@ -92,6 +97,13 @@ class TrainProgram(Program):
         self.acc_total = 0         # fp64 BatchNorm accumulators (elements), one arena zero-filled at the start of a step
         self.acc_arena = None
         self._add(lib.cp_memset_zero, lambda P: (self.acc_arena.data_ptr(), self.acc_arena.numel() * 8), "acc_zero", [], [])
+        # weight preparation (packing, data-gradient / EdgeConv views, bias refreshes) reads only parameters: all items of a
+        # half are processed by TWO launches at its start (views, then the packs that may consume them) -- cp_pack_batch
+        self.items = {("views", 0): [], ("packs", 0): [], ("views", 1): [], ("packs", 1): []}
+        self.item_tabs = {}
+        self.half = 0
+        for kind in ("views", "packs"):
+            self._add(lib.cp_pack_batch, (lambda k: lambda P: self._batch_args(k, 0))(kind), "prep_%s_fwd" % kind, [], [])
         self.prep_idx = set()      # op indices of weight-preparation launches
         self.arena = []            # gradient TBufs (not recycled: 288 GB of HBM; one zero fill instead of ~370)
         self.grad_arena = None
@@ -107,6 +119,15 @@ class TrainProgram(Program):
     def add_prep(self, fn, argb, name):
         self.prep_idx.add(len(self.ops))
         self._add(fn, argb, name, [], [])
+
+    def add_item(self, kind, item):
+        self.items[(kind, self.half)].append(item)
+
+    def _batch_args(self, kind, half):
+        tab = self.item_tabs.get((kind, half))
+        if tab is None:
+            return (self.dtype, None, None, 0, 0)
+        return (self.dtype, tab[0].data_ptr(), tab[1].data_ptr(), tab[2], tab[3])
 
     # ---- small helpers
     @property
@@ -139,7 +160,9 @@ class TrainProgram(Program):
 
     def memcpy(self, dst_ptr, src_ptr, nbytes, name="memcpy", prep=False):
         if prep:
-            self.add_prep(self.lib.cp_memcpy_d2d, lambda P: (dst_ptr, src_ptr, nbytes), name)
+            it = CpPackItem()
+            _abi.check(self.lib.cp_pack_item_copy_f32(src_ptr, dst_ptr, nbytes // 4, C.byref(it)), name)
+            self.add_item("views", it)
         else:
             self._add(self.lib.cp_memcpy_d2d, lambda P: (dst_ptr, src_ptr, nbytes), name, [], [])
 
@@ -261,7 +284,9 @@ class TrainProgram(Program):
     def weight_dgrad(self, w, Cout, Cin, R, S):
         wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)
         self.keep.append(w)
-        self.add_prep(self.lib.cp_weight_dgrad, lambda P: (w.data_ptr(), Cout, Cin, R, S, wt.data_ptr()), "weight_dgrad")
+        it = CpPackItem()
+        _abi.check(self.lib.cp_pack_item_dgrad_view(w.data_ptr(), Cout, Cin, R, S, wt.data_ptr(), C.byref(it)), "weight_dgrad")
+        self.add_item("views", it)
         return wt
 
     def conv_backward(self, key, w, x: Act, g: Act, R, S, stride, pad):
@@ -319,7 +344,9 @@ class TrainProgram(Program):
     def edge_weight_view(self, w, Co, Ci, mode):
         out = self.scratch_f32(2 * Co * Ci)
         self.keep.append(w)
-        self.add_prep(self.lib.cp_edge_weight_view, lambda P: (w.data_ptr(), Co, Ci, mode, out.data_ptr()), "edge_weight_view")
+        it = CpPackItem()
+        _abi.check(self.lib.cp_pack_item_edge_view(w.data_ptr(), Co, Ci, mode, out.data_ptr(), C.byref(it)), "edge_weight_view")
+        self.add_item("views", it)
         return out.view(2 * Co, Ci, 1, 1) if mode == 0 else out.view(Ci, 2 * Co, 1, 1)
 
     def edge_train_fwd(self, pq: Act, graph, gamma, beta, rmean, rvar, out: Act, Co, slope, momentum=0.1, eps=1e-5):
@@ -356,6 +383,17 @@ class TrainProgram(Program):
         self._add(self.lib.cp_index2feat_gather_bwd_t, lambda P: (self.dtype, P(gt)) + args, "index2feat_bwd", [gt], [])
 
     def finalize(self):
+        for key, items in self.items.items():
+            if not items:
+                continue
+            arr = (CpPackItem * len(items))(*items)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            pre, acc = [0], 0
+            for it in items:
+                acc += (int(it.total) + 255) // 256
+                pre.append(acc)
+            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)      # uint32 on the device
+            self.item_tabs[key] = (raw, prefix, len(items), acc)
         self.acc_arena = torch.zeros(max(self.acc_total, 2), dtype=torch.float64, device=self.device)
         total = sum(t.nbytes for t in self.arena)
         self.grad_arena = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
@@ -384,6 +422,9 @@ class TrainProgram(Program):
     # ---- tape
     def mark_forward_end(self):
         self.n_fwd_ops = len(self.ops)
+        self.half = 1
+        for kind in ("views", "packs"):
+            self._add(self.lib.cp_pack_batch, (lambda k: lambda P: self._batch_args(k, 1))(kind), "prep_%s_bwd" % kind, [], [])
 
     def unwind(self):
         for fn in reversed(self.tape):

@@ -347,6 +347,33 @@ int cp_strided_to_nhwc(cp_stream_t stream, int dtype, const void* src, int src_d
                        long long sp, long long sc, void* out, int B, int HW, int C, int Cphys);
 int cp_memcpy_d2d(cp_stream_t stream, void* dst, const void* src, size_t nbytes);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batched weight preparation (training): a step re-packs ~1100 live weight tensors; as individual ~4 us launches that
+ * was a fifth of the step.  cp_pack_item_*() fill one CpPackItem each on the HOST (same arguments and the same packed
+ * image as the single-launch entry points they mirror), the caller keeps the items in DEVICE memory together with an
+ * exclusive prefix sum of their 256-thread block counts, and cp_pack_batch() processes all of them in ONE launch.
+ * Items of one batch must be independent: views (dgrad / EdgeConv / copies) that feed packs go into an earlier batch.
+ * ------------------------------------------------------------------------------------------- */
+enum { CP_PACK_GENERIC = 0, CP_PACK_HALO_S = 1, CP_PACK_HALO = 2, CP_PACK_HALO4 = 3, CP_PACK_GEMM = 4,
+       CP_PACK_DGRAD_VIEW = 5, CP_PACK_EDGE_VIEW = 6, CP_PACK_COPY_F32 = 7 };
+typedef struct CpPackItem {
+  int32_t kind;
+  int32_t a[9];
+  const void* src;
+  void* dst;
+  const int32_t* row_map;
+  uint64_t total;              /* elements = threads of this item */
+} CpPackItem;
+int cp_pack_item_conv(int dtype, const float* w, int Cout, int Cin, int R, int S, int cin_phys, int transposed, int phase,
+                      const int32_t* row_map, int cout_rows, void* packed, CpPackItem* item);      /* cp_pack_conv_weight */
+int cp_pack_item_halo(int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed, CpPackItem* item);  /* cp_pack_conv3x3_halo_weight */
+int cp_pack_item_gemm(int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed, CpPackItem* item);  /* cp_pack_gemm_weight */
+int cp_pack_item_dgrad_view(const float* w, int Cout, int Cin, int R, int S, float* wt, CpPackItem* item);          /* cp_weight_dgrad */
+int cp_pack_item_edge_view(const float* w, int Cout, int Cin, int mode, float* out, CpPackItem* item);              /* cp_edge_weight_view */
+int cp_pack_item_copy_f32(const float* src, float* dst, int count, CpPackItem* item);
+int cp_pack_batch(cp_stream_t stream, int dtype, const CpPackItem* items_dev, const uint32_t* block_prefix_dev, int n_items,
+                  uint32_t total_blocks);
+
 /* layout plumbing at the boundary: NCHW fp32 image -> channels-last `dtype` (C padded with zeros to
  * Cphys), and channels-last slice -> NCHW fp32 (for `return_img_feats`, init.py:123-124). */
 int cp_nchw_to_nhwc(cp_stream_t stream, int dtype, const float* in, void* out, int B, int C, int H, int W,

@@ -523,3 +523,87 @@ def test_bn_two_launch_forms(lib, dtype, case):
     close(db.cpu() / grads[2].abs().max().item(), grads[2] / grads[2].abs().max().item(), tol)
     if has_res:
         close(from_cl(dres, Cc), grads[3], tol)
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_pack_batch_matches_single_launch_packers(lib, dtype):
+    """cp_pack_batch (one launch over a device table of items) produces bit-identical images to the single-launch entry points
+    for every item kind: generic (plain, row-mapped, ConvTranspose phase), halo small / regular / wide, GEMM, dgrad view,
+    EdgeConv views, float copy"""
+    from checkerpose_amd._abi import CpPackItem
+    d = dev()
+    E = 8 if dtype == CP_BF16 else 4
+    es = 2 if dtype == CP_BF16 else 4
+    items, expect, keep = [], [], []
+
+    def W(name, shape):
+        t = det_tensor(name, shape).to(d).contiguous()
+        keep.append(t)
+        return t
+
+    def out_bytes(n):
+        t = torch.full((n,), 0x5A, dtype=torch.uint8, device=d)
+        keep.append(t)
+        return t
+
+    # generic: plain 3x3, row-mapped 1x1, transposed phase 3
+    for (co, ci, r, s, tr, ph, rmap, rows) in [(36, 18, 3, 3, 0, 0, None, 36), (7, 64, 1, 1, 0, 0, [0, 1, 2, 3, -1, -1, -1, 4, 5, 6], 10),
+                                               (24, 40, 2, 2, 1, 3, None, 24)]:
+        w = W("pb_g%d%d" % (co, tr), (ci, co, 3, 3) if tr else (co, ci, r, s))
+        cphys = rup(ci, E)
+        nb = lib.cp_packed_weight_bytes(dtype, rows, cphys, r, s)
+        a, b = out_bytes(nb), out_bytes(nb)
+        rm = torch.tensor(rmap, dtype=torch.int32, device=d) if rmap else None
+        keep.append(rm)
+        _abi.check(lib.cp_pack_conv_weight(st(), dtype, w.data_ptr(), co, ci, r, s, cphys, tr, ph, rm.data_ptr() if rmap else None, rows, a.data_ptr()))
+        it = CpPackItem()
+        _abi.check(lib.cp_pack_item_conv(dtype, w.data_ptr(), co, ci, r, s, cphys, tr, ph, rm.data_ptr() if rmap else None, rows, b.data_ptr(), C.byref(it)))
+        items.append(it); expect.append((a, b))
+    for co, ci in [(18, 18), (72, 36), (128, 64), (256, 32)]:          # halo: small, small, regular, wide
+        w = W("pb_h%d" % co, (co, ci, 3, 3))
+        cphys = rup(ci, E)
+        nb = lib.cp_packed_halo_weight_bytes(dtype, co, cphys)
+        a, b = out_bytes(nb), out_bytes(nb)
+        _abi.check(lib.cp_pack_conv3x3_halo_weight(st(), dtype, w.data_ptr(), co, ci, cphys, a.data_ptr()))
+        it = CpPackItem()
+        _abi.check(lib.cp_pack_item_halo(dtype, w.data_ptr(), co, ci, cphys, b.data_ptr(), C.byref(it)))
+        items.append(it); expect.append((a, b))
+    w = W("pb_gemm", (200, 96))
+    nb = lib.cp_packed_gemm_weight_bytes(dtype, 200, 96)
+    a, b = out_bytes(nb), out_bytes(nb)
+    _abi.check(lib.cp_pack_gemm_weight(st(), dtype, w.data_ptr(), 200, 96, 96, a.data_ptr()))
+    it = CpPackItem()
+    _abi.check(lib.cp_pack_item_gemm(dtype, w.data_ptr(), 200, 96, 96, b.data_ptr(), C.byref(it)))
+    items.append(it); expect.append((a, b))
+    w = W("pb_dg", (24, 16, 3, 3))
+    a, b = out_bytes(24 * 16 * 9 * 4), out_bytes(24 * 16 * 9 * 4)
+    _abi.check(lib.cp_weight_dgrad(st(), w.data_ptr(), 24, 16, 3, 3, a.data_ptr()))
+    it = CpPackItem()
+    _abi.check(lib.cp_pack_item_dgrad_view(w.data_ptr(), 24, 16, 3, 3, b.data_ptr(), C.byref(it)))
+    items.append(it); expect.append((a, b))
+    w = W("pb_ev", (24, 32))
+    for mode in (0, 1):
+        a, b = out_bytes(2 * 24 * 16 * 4), out_bytes(2 * 24 * 16 * 4)
+        _abi.check(lib.cp_edge_weight_view(st(), w.data_ptr(), 24, 16, mode, a.data_ptr()))
+        it = CpPackItem()
+        _abi.check(lib.cp_pack_item_edge_view(w.data_ptr(), 24, 16, mode, b.data_ptr(), C.byref(it)))
+        items.append(it); expect.append((a, b))
+    src = W("pb_cp", (37,))
+    a, b = out_bytes(37 * 4), out_bytes(37 * 4)
+    a.copy_(src.view(torch.uint8).flatten())
+    it = CpPackItem()
+    _abi.check(lib.cp_pack_item_copy_f32(src.data_ptr(), b.data_ptr(), 37, C.byref(it)))
+    items.append(it); expect.append((a, b))
+
+    arr = (CpPackItem * len(items))(*items)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(d)
+    pre, acc = [0], 0
+    for it in items:
+        acc += (int(it.total) + 255) // 256
+        pre.append(acc)
+    prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(d)
+    _abi.check(lib.cp_pack_batch(st(), dtype, tab.data_ptr(), prefix.data_ptr(), len(items), acc), "pack batch")
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(expect):
+        assert torch.equal(a, b), "item %d (kind %d) differs from its single-launch packer" % (k, items[k].kind)
+    assert es in (2, 4)
