@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcheckerpose_hip.so")
+LIB_PATH = os.environ.get("CHECKERPOSE_AMD_LIB") or os.path.join(_HERE, "libcheckerpose_hip.so")   # override: kernel A/B builds
 
 CP_F32, CP_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2

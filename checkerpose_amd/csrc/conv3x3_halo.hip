@@ -825,7 +825,13 @@ __global__ __launch_bounds__(256) void basicblock_fused_kernel(const HaloParams 
 //   * the finished tile is written back over the x tile in LDS and leaves in full-line order.
 // LDS reads per tile drop from 324 KB to 156 KB.  Tile order as in the fused Bottleneck (crops b == xcd (mod 8) on
 // XCD blockIdx % 8).
-constexpr int PBX_PITCH = 256 * 16 + 16, PBT_PITCH = 192 * 16 + 16;      // x halo planes (240 px) / t1 planes (180 px)
+#ifndef CP_PB_PADX
+#define CP_PB_PADX 16
+#endif
+#ifndef CP_PB_PADT
+#define CP_PB_PADT 16
+#endif
+constexpr int PBX_PITCH = 256 * 16 + CP_PB_PADX, PBT_PITCH = 192 * 16 + CP_PB_PADT;      // x halo planes (240 px) / t1 planes (180 px)
 constexpr int PB_LDS = 4 * PBX_PITCH + 4 * PBT_PITCH;                    // 28 800 B
 
 __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloParams p, const void* __restrict__ w2,
