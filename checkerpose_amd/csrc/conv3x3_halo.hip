@@ -831,7 +831,14 @@ __global__ __launch_bounds__(256) void basicblock_fused_kernel(const HaloParams 
 #ifndef CP_PB_PADT
 #define CP_PB_PADT 16
 #endif
-constexpr int PBX_PITCH = 256 * 16 + CP_PB_PADX, PBT_PITCH = 192 * 16 + CP_PB_PADT;      // x halo planes (240 px) / t1 planes (180 px)
+#ifndef CP_PB_FXW
+#define CP_PB_FXW 20
+#endif
+// x-halo row pitch in pixels (A/B knob).  conv1's fragments are 16 consecutive pixels of the FLATTENED 10 x 18 ring, so a
+// fragment that wraps to the next ring row jumps (PFXW - 18) pixels in the plane; PFXW = 34 makes that jump one full bank
+// sweep (conflict-free wrap) -- measured +-0 against 20 (2.118 vs 2.127 ms per step), so the compact 20 stays.
+constexpr int PFXW = CP_PB_FXW;
+constexpr int PBX_PITCH = FXH * PFXW * 16 + CP_PB_PADX, PBT_PITCH = 192 * 16 + CP_PB_PADT;      // x halo planes (240 px) / t1 planes (180 px)
 constexpr int PB_LDS = 4 * PBX_PITCH + 4 * PBT_PITCH;                    // 28 800 B
 
 __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloParams p, const void* __restrict__ w2,
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloPa
     const int pc = p1 < HPH * HPW ? p1 : 0;
     p1y[i] = p1 < HPH * HPW ? pc / HPW : -64;                  // pad pixels: never inside the image
     p1x[i] = pc - (pc / HPW) * HPW;
-    xb[i] = (uint32_t)(q * PBX_PITCH + ((pc / HPW) * FXW + p1x[i]) * 16);
+    xb[i] = (uint32_t)(q * PBX_PITCH + ((pc / HPW) * PFXW + p1x[i]) * 16);
   }
 
   u32x4 xv[4];
@@ -900,7 +907,8 @@ __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloPa
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int i = tid + 256 * it;
-      *(u32x4*)(sX + (i & 3) * PBX_PITCH + (i >> 2) * 16) = xv[it];     // i >> 2 <= 255: inside the padded plane
+      const int hp = i >> 2, hy = hp / FXW;                            // (hy, hx) of the 12 x 20 halo -> row pitch PFXW
+      if (hp < FXH * FXW) *(u32x4*)(sX + (i & 3) * PBX_PITCH + (hy * PFXW + (hp - hy * FXW)) * 16) = xv[it];
     }
     __syncthreads();
 
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloPa
         const int r = tap / 3, s2 = tap - 3 * r;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const u32x4 a = *(const u32x4*)(sX + xb[i] + (r * FXW + s2) * 16);
+          const u32x4 a = *(const u32x4*)(sX + xb[i] + (r * PFXW + s2) * 16);
           MmaH<BF16Tag>::run(W1[tap][0], a, acc[i][0]);
           MmaH<BF16Tag>::run(W1[tap][1], a, acc[i][1]);
         }
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloPa
         const f32x4 sc = *(const f32x4*)(scale2 + c2), sh = *(const f32x4*)(shift2 + c2);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          u32x2* rp = (u32x2*)(sX + (c2 >> 3) * PBX_PITCH + ((2 * wave + mt + 2) * FXW + x + 2) * 16 + (c2 & 7) * 2);
+          u32x2* rp = (u32x2*)(sX + (c2 >> 3) * PBX_PITCH + ((2 * wave + mt + 2) * PFXW + x + 2) * 16 + (c2 & 7) * 2);
           const u32x2 r2 = *rp;
           float v[4];
           v[0] = fmaxf(acc[mt][nt][0] * sc[0] + sh[0] + __uint_as_float(r2.x << 16), 0.f);
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloPa
         const int pxl = i / opc, pc = i - pxl * opc;
         const int row = pxl >> 4, col = pxl & 15;
         const int oy = y0 + row, ox = x0 + col;
-        const u32x4 v = *(const u32x4*)(sX + pc * PBX_PITCH + ((row + 2) * FXW + col + 2) * 16);
+        const u32x4 v = *(const u32x4*)(sX + pc * PBX_PITCH + ((row + 2) * PFXW + col + 2) * 16);
         if (oy < p.H && ox < p.W)
           *(u32x4*)((uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + pc * 8) = v;
       }
