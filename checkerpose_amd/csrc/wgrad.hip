@@ -386,6 +386,123 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
       }
 }
 
+// <= 32 x 32 channel layers (the 18-channel HRNet branch): in the kernel above only ONE wave has a non-empty quadrant.  Here
+// the four waves split the nine TAPS of the single 32 x 32 quadrant (wave w: taps w, w+4, w+8), rows are 32 channels wide
+// (pitch 96 B: 8 consecutive rows still fall on disjoint bank octets), 12 accumulator tiles per wave -> ~100 VGPRs and
+// 25 KB of LDS, so several blocks share a CU and hide each other's global -> LDS latency.
+__global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Params p) {
+  constexpr int PITCH = 96, XROWS = 200, NX = 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(64 + XROWS) * PITCH];
+  unsigned char* ldy = lds;
+  unsigned char* lx = lds + 64 * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xl = lane & 15, g = lane >> 4, q = xl >> 2, pp = xl & 3;
+  const int TW2 = p.TW + 2, HR = (p.TH + 2) * TW2;
+  const int t_begin = blockIdx.x * p.tiles_per_block;
+  const int t_end = min(t_begin + p.tiles_per_block, p.n_tiles);
+  const int prow = tid >> 2, pc = tid & 3;              // 4 pieces (32 channels) per row
+  const bool dy_cok = pc * 8 < p.Cout, x_cok = pc * 8 < p.Cin;
+  u32x4 rdy, rx[NX];
+  auto gload = [&](int t) {
+    rdy = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rx[i] = u32x4{0u, 0u, 0u, 0u};
+    if (t >= t_end) return;
+    const int b = t / p.tiles_img;
+    const int rem = t - b * p.tiles_img;
+    const int ty0 = (rem / p.tiles_x) * p.TH, tx0 = (rem % p.tiles_x) * p.TW;
+    if (dy_cok) {
+      const int ty = prow / p.TW, tx = prow - ty * p.TW;
+      rdy = *(const u32x4*)((const uint16_t*)p.dy + ((size_t)(b * p.H + ty0 + ty) * p.W + tx0 + tx) * p.dy_cs + p.dy_coff + pc * 8);
+    }
+    if (x_cok) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int row = i * 64 + prow;
+        if (row < HR) {
+          const int hy = row / TW2, hx = row - hy * TW2;
+          const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            rx[i] = *(const u32x4*)((const uint16_t*)p.x + ((size_t)(b * p.H + iy) * p.W + ix) * p.x_cs + p.x_coff + pc * 8);
+        }
+      }
+    }
+  };
+  auto lstore = [&]() {
+    *(u32x4*)(ldy + prow * PITCH + pc * 16) = rdy;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int row = i * 64 + prow;
+      if (row < XROWS) *(u32x4*)(lx + row * PITCH + pc * 16) = rx[i];
+    }
+  };
+  f32x4 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  gload(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    gload(t + 1);
+#pragma unroll
+    for (int sc = 0; sc < 2; ++sc) {
+      const int p_lo = sc * 32 + 4 * g + q, p_hi = p_lo + 16;
+      const int h_lo = (p_lo / p.TW) * TW2 + (p_lo % p.TW), h_hi = (p_hi / p.TW) * TW2 + (p_hi % p.TW);
+      bf16x8 fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int cb = (a * 16 + 4 * pp) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ldy + p_lo * PITCH + cb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ldy + p_hi * PITCH + cb));
+        fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int tap = wave + 4 * i;                  // wave-uniform
+        if (tap < 9) {
+          const int sh = (tap / 3) * TW2 + (tap % 3);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int cb = (b * 16 + 4 * pp) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lx + (h_lo + sh) * PITCH + cb));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lx + (h_hi + sh) * PITCH + cb));
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[i][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[i][a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap >= 9) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ci = b * 16 + xl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = a * 16 + 4 * g + j;
+          if (p.ws) p.ws[((size_t)blockIdx.x * 9 + tap) * 4096 + co * 64 + ci] = acc[i][a][b][j];
+          else if (co < p.Cout && ci < p.Cin)
+            unsafeAtomicAdd(p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / 3) * p.dw_sr +
+                                (long long)(tap % 3) * p.dw_ss, acc[i][a][b][j]);
+        }
+      }
+  }
+}
+
 static int launch_reduce(hipStream_t st, const float* ws, float* dw, int S, int GY, int co_blocks, int ci_blocks, const CpWgradDesc* d,
                          int taps_in_block) {
   WgradReduceParams r;
@@ -437,6 +554,16 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
       q.tiles_per_block = (q.n_tiles + S - 1) / S;
       S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
       q.ws = use_ws ? (float*)workspace : nullptr;
+      const bool small = d->Cout <= 32 && d->Cin <= 32 && !getenv("CP_WGRAD_NO_SMALL");
+      if (small) {                                    // tap-split variant: more, lighter blocks (several per CU)
+        S = (use_ws ? 512 : 1024);
+        if (S > q.n_tiles / 2) S = q.n_tiles / 2;
+        if (use_ws && (size_t)S * per_slice > workspace_bytes) S = (int)(workspace_bytes / per_slice);
+        if (S < 1) S = 1;
+        q.tiles_per_block = (q.n_tiles + S - 1) / S;
+        S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
+        CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
+      } else
       CP_LAUNCH(wgrad3x3_kernel, dim3((unsigned)S, (unsigned)tb), dim3(256), 0, (hipStream_t)stream, q);
       int rc3 = cp_check_launch();
       if (rc3 || !use_ws) return rc3;

@@ -405,14 +405,17 @@ class TrainProgram(Program):
         # n_fwd_ops was recorded in units of emitted ops (launches + fork/sync/join markers): convert to launches
         markers = ("__fork__", "__sync__", "__join__")
         self.n_fwd_ops = sum(1 for op in self.ops[:self.n_fwd_ops] if op[0] not in markers)
-        ci, prep_calls = 0, set()
+        ci, prep_calls, flops = 0, set(), {}
         for i, op in enumerate(self.ops):
             if op[0] in markers:
                 continue
             if i in self.prep_idx:
                 prep_calls.add(ci)
+            if i in self.wgrad_flops:
+                flops[ci] = self.wgrad_flops[i]
             ci += 1
         self.prep_calls = prep_calls
+        self.wgrad_flops = flops           # re-keyed by launch (call) index, like everything bench_train reads
         return self
 
     def zero_grad_arena(self):

@@ -64,6 +64,8 @@ WGRAD_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad)
     (2, 72, 64, 64, 144, 3, 1, 1),     # all-taps 3x3 kernel: 1 x 64 tiles, ragged channel blocks (72 / 144)
     (2, 18, 64, 128, 18, 3, 1, 1),     # all-taps kernel, W > 64, one active wave quadrant
     (3, 256, 16, 16, 128, 3, 1, 1),    # all-taps kernel, 4 x 16 tiles
+    (4, 32, 32, 32, 24, 3, 1, 1),      # tap-split small-channel kernel (<= 32 x 32), 2 x 32 tiles
+    (5, 18, 8, 8, 18, 3, 1, 1),        # tap-split kernel, 8 x 8 tiles, odd tile count
 ]
 
 
