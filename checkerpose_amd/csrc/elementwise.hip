@@ -5,18 +5,20 @@
 // ---- nn.UpsamplingBilinear2d(scale_factor=2)  (pipeline.py:199; == F.interpolate(align_corners=True)).
 // ATen (UpSample.h, align_corners): scale = (in-1)/(out-1); src = scale*dst; i0 = floor(src); i1 = i0 + (i0 < in-1);
 // l1 = src - i0; l0 = 1 - l1;  out = l0h*(l0w*x00 + l1w*x01) + l1h*(l0w*x10 + l1w*x11)   -- all in fp32.
+// grid.y = one output row (b, oy): the row weights / source rows are block-uniform and the only per-thread index split is
+// (ox, channel group) -- a shift when the group count is a power of two (the decoder's 256 / 512 channels).
 template <typename Tag>
-__global__ void upsample2x_bilinear_kernel(const void* __restrict__ in, void* __restrict__ out, int H, int W, int CG,
-                                           int in_cs, int in_coff, int out_cs, int out_coff, float sy, float sx,
-                                           size_t total) {
+__global__ void upsample2x_bilinear_kernel(const void* __restrict__ in, void* __restrict__ out, int H, int W, int CG, int cg_shift,
+                                           int in_cs, int in_coff, int out_cs, int out_coff, float sy, float sx, unsigned rows) {
   constexpr int E = Tag::E;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * 2H * 2W * CG
-  if (i >= total) return;
-  const int g = (int)(i % CG);
-  size_t t = i / CG;
-  const int ox = (int)(t % (2 * W)); t /= (2 * W);
-  const int oy = (int)(t % (2 * H));
-  const size_t b = t / (2 * H);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;           // over 2W * CG
+  if (idx >= 2 * W * CG) return;
+  const int ox = cg_shift >= 0 ? idx >> cg_shift : idx / CG;
+  const int g = idx - ox * CG;
+  const unsigned row = blockIdx.z * gridDim.y + blockIdx.y;        // (b, oy); rows beyond B*2H come from the grid round-up
+  if (row >= rows) return;
+  const int oy = (int)(row % (unsigned)(2 * H));
+  const size_t b = row / (unsigned)(2 * H);
   const float fy = sy * oy, fx = sx * ox;
   const int y0 = (int)fy, x0 = (int)fx;
   const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
@@ -45,14 +47,19 @@ extern "C" int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const vo
   const float sy = H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
   const float sx = W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
   const int CG = C / E;
-  const size_t total = (size_t)B * 2 * H * 2 * W * CG;
-  const unsigned blocks = (unsigned)((total + 255) / 256);
+  int cg_shift = -1;
+  for (int k = 0; k < 16; ++k) if ((1 << k) == CG) cg_shift = k;
+  const long long rows = (long long)B * 2 * H;
+  if (rows >= (1LL << 31)) return CP_ERR_RANGE;
+  const unsigned gy = rows > 65535 ? 65535u : (unsigned)rows, gz = (unsigned)((rows + gy - 1) / gy);
+  if (gz > 65535) return CP_ERR_RANGE;
+  const dim3 grid((unsigned)((2 * W * CG + 255) / 256), gy, gz);
   if (dtype == CP_F32)
-    CP_LAUNCH(upsample2x_bilinear_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
-                       CG, in_cstride, in_coff, out_cstride, out_coff, sy, sx, total);
+    CP_LAUNCH(upsample2x_bilinear_kernel<F32Tag>, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+                       CG, cg_shift, in_cstride, in_coff, out_cstride, out_coff, sy, sx, (unsigned)rows);
   else
-    CP_LAUNCH(upsample2x_bilinear_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
-                       CG, in_cstride, in_coff, out_cstride, out_coff, sy, sx, total);
+    CP_LAUNCH(upsample2x_bilinear_kernel<BF16Tag>, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+                       CG, cg_shift, in_cstride, in_coff, out_cstride, out_coff, sy, sx, (unsigned)rows);
   return cp_check_launch();
 }
 
