@@ -581,7 +581,7 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
   // pixel slices: enough blocks to fill 256 CUs a few times over, at least 256 pixels (4 stages) per slice
   const long long tiles = (long long)p.co_blocks * p.ci_blocks * d->R * d->S;
   const size_t per_slice = (size_t)tiles * 4096 * sizeof(float);
-  const bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
+  bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
   long long want = ((use_ws ? 1024 : 2048) + tiles - 1) / tiles;  // slices wanted
   if (use_ws && (size_t)want * per_slice > workspace_bytes) want = (long long)(workspace_bytes / per_slice);
   long long slice = (M + want - 1) / want;
@@ -589,6 +589,10 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
   if (slice < 256) slice = 256;
   p.slice = (int)slice;
   const unsigned nslice = (unsigned)((M + slice - 1) / slice);
+  // small layers: with few valid elements the atomics are cheaper than a second (reduction) launch -- the ~30 G atomics/s
+  // limit only bites from ~1e5 atomics per launch on
+  static const long long atomics_max = getenv("CP_WGRAD_ATOMICS_MAX") ? atoll(getenv("CP_WGRAD_ATOMICS_MAX")) : 32768;
+  if (use_ws && (long long)d->Cout * d->Cin * d->R * d->S * nslice <= atomics_max) use_ws = false;
   if (tiles > 65535) return CP_ERR_RANGE;
   p.ws = use_ws ? (float*)workspace : nullptr;
   dim3 grid(nslice, (unsigned)tiles);
