@@ -2,6 +2,7 @@
 """bench.py -- forward throughput of the CheckerPose hot path on MI355X (BASELINE.json metric).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32] [--npoint 512]
+                  [--workload lmo_ape|ycbv_rr21|lm13_n4096] [--feed hbm|host_u8] [--no-extras]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" = one forward of PoseNet_GNNskip (HRNet-W18 + decoder + 3 progressive GNN stages,
@@ -9,7 +10,18 @@ hr18GNN2_res6_gnn3Skip_mlpQuery, LM-O `ape` keypoints, npt=512) over one batch o
 already resident in HBM; every rank runs its own replica on its own batch shard (pure data parallel: the
 forward has no collective), so scaling is weak and value = N*B*K / max-over-ranks(time).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the
-MFMA implicit-GEMM conv) and `cpu_baseline` (oracle restatement timed on the host cores).
+MFMA implicit-GEMM conv) and `cpu_baseline` (oracle restatement timed on the host cores).  Extra keys of the default
+N=1 run (`--no-extras` skips them): `fp32_exact` (the path north_star's 1e-4 applies to, at its best
+batch), `by_batch` (bf16 at B = 1 / 8 / 32: the reference's test.py:198 runs batch 1, its configs train at 32),
+`b1_latency_ms`, `bf16_agreement` (the bf16 path's accuracy contract, checkerpose_amd/agreement.py, measured against the
+fp32 HIP path on the same crops) and `host_u8` (crops start as uint8 in pinned HOST memory and are double-buffered over
+PCIe on a copy stream: the PCIe-inclusive rate, never `value`).
+
+Workloads (BASELINE.json configs):
+  lmo_ape     (default) config #2: LM-O `ape`, one network, npt=512
+  ycbv_rr21   config #4: the reference trains ONE network per YCB-V object (train.py:384,396) -> 21 independent
+              (weights, kNN graph) sets, step i runs model i mod 21 on its own batch
+  lm13_n4096  config #5: the LM shared estimator (pipeline_lm.py:392-425) at npt=4096, obj_ids uniform over the 13 LM ids
 """
 import argparse
 import json
@@ -29,9 +41,13 @@ MFMA_KERNELS = {"conv_igemm": "conv_igemm_kernel", "conv3x3_halo": "conv3x3_halo
                 "basicblock_fused": "basicblock_fused_kernel|basicblock_persist_kernel", "bottleneck_fused": "bottleneck_fused_kernel"}
 
 
-def build(npoint, seed=1):
-    from tests.common import build_net
-    return build_net(npoint=npoint, seed=seed)
+ORACLE_KW = dict(backbone="hrnet_w18", res_log2=6, init_n_graph=2, n_graph=3, local_k=2, slope=0.01, graph_slope=0.2,
+                 init_graph_slope=0.2)     # hr18GNN2_res6_gnn3Skip_mlpQuery.txt:14-28
+
+
+def build(npoint, seed=1, **kw):
+    from checkerpose_amd.synthetic import build_net
+    return build_net(npoint=npoint, seed=seed, **kw)
 
 
 def host_threads():
@@ -50,7 +66,8 @@ def host_threads():
 def cpu_baseline(npoint, seconds=12.0):
     """The oracle (validated CPU restatement incl. its HRNet-W18) on the host cores: B=1 forwards for ~`seconds`."""
     from oracle import checkerpose_oracle as O
-    from tests.common import det_image, oracle_kwargs
+    from checkerpose_amd.synthetic import det_image
+    oracle_kwargs = lambda: ORACLE_KW   # noqa: E731
     torch.set_num_threads(host_threads())
     net = build(npoint)
     sd = net.state_dict()
@@ -76,7 +93,7 @@ def pmc_traffic_mb(kernel_prefix, dtype, B):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_b%d_kernel_summary.csv" % (dtype, B))))
     if not files:
-        return None
+        return None, None
     tot, calls = 0.0, 0
     for r in csv.DictReader(open(files[-1])):
         hit = r["kernel"] == kernel_prefix
@@ -84,7 +101,100 @@ def pmc_traffic_mb(kernel_prefix, dtype, B):
             n = int(r["calls"])
             tot += n * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"]))
             calls += n
-    return round(tot / calls, 2) if calls else None
+    return (round(tot / calls, 2) if calls else None), os.path.relpath(files[-1], ROOT)
+
+
+def timed_steps(step, steps, warmup):
+    """`warmup` untimed calls (>= 2: eager run, then hipGraph capture), then `steps` timed ones; seconds."""
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def side_measurements(net_bf16, npoint, dev, B_main, img_main):
+    """The numbers the headline value does not carry (all on this GPU, synthetic crops resident in HBM unless stated)."""
+    from checkerpose_amd.agreement import logit_agreement
+    from checkerpose_amd.synthetic import det_image, det_tensor
+    ex = {}
+    # ---- bf16 at the small batches the reference itself uses (test.py:198 batch 1; config batch 32)
+    by = {}
+    for b in (1, 8, 32):
+        img = det_image(b, seed=200 + b).to(dev)
+        net_bf16(img, None)
+        buf = net_bf16.input_buffer(b); buf.copy_(img)
+        n = 200 if b == 1 else 50
+        el = timed_steps(lambda: net_bf16(buf, None), n, 3)
+        by[str(b)] = {"crops_per_s": round(b * n / el, 1), "ms_per_step": round(el / n * 1e3, 3)}
+    ex["by_batch"] = {"dtype": "bf16", "note": "hipGraph replay, crops resident in HBM", **by}
+    ex["b1_latency_ms"] = by["1"]["ms_per_step"]
+    # ---- the fp32-exact path (logits within 1e-4 of the CPU reference: tests/test_gpu_parity.py) at its best batch
+    net32 = build(npoint).to(dev).set_compute_dtype("fp32")
+    net32.clone_outputs = False
+    b32 = 128
+    img = det_image(b32, seed=300).to(dev)
+    net32(img, None)
+    buf = net32.input_buffer(b32); buf.copy_(img)
+    el = timed_steps(lambda: net32(buf, None), 8, 2)
+    ex["fp32_exact"] = {"crops_per_s": round(b32 * 8 / el, 1), "ms_per_step": round(el / 8 * 1e3, 3), "batch": b32,
+                        "dtype": "fp32", "note": "exact-fp32 MFMA path; the only path north_star's 1e-4 logit criterion applies to"}
+    # ---- accuracy contract of the timed bf16 path, against the fp32 HIP path on the same crops (B=8)
+    net32.clone_outputs = True
+    img8 = det_image(8, seed=3).to(dev)
+    ref = net32(img8, None)
+    net_bf16.clone_outputs = True
+    free = logit_agreement(net_bf16(img8, None), ref)
+    t = torch.zeros(8, 13, npoint, device=dev)
+    t[:, 0:1], t[:, 1:7], t[:, 7:13] = ref[0], ref[1], ref[2]
+    forced = logit_agreement(net_bf16.forward_teacher_forced(img8, t), ref)
+    net_bf16.clone_outputs = False
+    keep = ("bit_agreement_min_row", "bit_agreement_all_rows", "xy_id_equal", "id_abs_err_mean_px", "seg_agreement",
+            "max_abs_dlogit", "mean_abs_dlogit", "logit_rms")
+    ex["bf16_agreement"] = {"vs": "fp32 HIP path (oracle-pinned <= 1e-4) on 8 crops, random-init weights",
+                            "free_running": {k: free[k] for k in keep}, "free_running_rows": free["bit_agreement_per_row"],
+                            "teacher_forced": {k: forced[k] for k in keep}, "teacher_forced_rows": forced["bit_agreement_per_row"]}
+    del net32
+    torch.cuda.empty_cache()
+    # ---- PCIe-inclusive feed: uint8 HWC crops in pinned host memory -> H2D on a copy stream (double-buffered) ->
+    #      cp_u8hwc_to_nhwc_norm + forward on the compute stream (SURVEY.md 8e: the stated 8-GPU limiter)
+    B = B_main
+    host = [(det_tensor("u8feed%d" % i, (B, 256, 256, 3)).abs() * 255.999).to(torch.uint8).pin_memory() for i in range(2)]
+    stage = [torch.empty(B, 256, 256, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+    copy_s = torch.cuda.Stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+    for i in range(2):
+        done[i].record(cur)
+
+    def feed_step(i):
+        k = i & 1
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(done[k])                      # the forward that last read stage[k] has finished
+            stage[k].copy_(host[k], non_blocking=True)
+            ready[k].record(copy_s)
+        cur.wait_event(ready[k])
+        net_bf16(stage[k], None)
+        done[k].record(cur)
+
+    for i in range(4):
+        feed_step(i)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for i in range(n):
+        feed_step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ex["host_u8"] = {"crops_per_s": round(B * n / el, 1), "ms_per_step": round(el / n * 1e3, 3), "batch": B,
+                     "h2d_gb_per_s": round(B * n * 256 * 256 * 3 / el / 1e9, 2),
+                     "note": "PCIe-inclusive: uint8 crops from pinned host memory, H2D double-buffered on a copy stream, "
+                             "normalised on the device (cp_u8hwc_to_nhwc_norm); not `value`"}
+    return ex
 
 
 def kernel_breakdown(net, B, steps, dump=None):
@@ -148,7 +258,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--dump-convs", default=None, help="write per-conv-launch timings (json) to this path")
+    ap.add_argument("--workload", default="lmo_ape", choices=["lmo_ape", "ycbv_rr21", "lm13_n4096"])
+    ap.add_argument("--no-extras", action="store_true", help="skip fp32_exact / by_batch / bf16_agreement / host_u8")
     a = ap.parse_args()
+    if a.workload == "lm13_n4096":
+        a.npoint = 4096
+        if "--batch" not in sys.argv:
+            a.batch = 32
+    if a.workload == "ycbv_rr21" and "--batch" not in sys.argv:
+        a.batch = 64
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,19 +285,41 @@ def main():
             dist.init_process_group(backend)
     torch.set_grad_enabled(False)
 
-    from tests.common import det_image
-    net = build(a.npoint).to(dev).set_compute_dtype(a.dtype)
-    net.clone_outputs = False            # outputs stay in the program's persistent buffers (no per-step clones)
+    from checkerpose_amd.synthetic import LM_OBJ_IDS, det_image, ycbv_p3d
     B = a.batch
     img = det_image(B, seed=100 + rank).to(dev)      # this rank's shard, resident in HBM before timing
+    if a.workload == "ycbv_rr21":
+        # 21 per-object networks (own weights seed, own kNN graph); every model gets its program + graph before timing
+        nets = [build(a.npoint, seed=o, p3d=ycbv_p3d(o, a.npoint)).to(dev).set_compute_dtype(a.dtype) for o in range(1, 22)]
+        for n_ in nets:
+            n_.clone_outputs = False
+            for _ in range(2):
+                n_(img, None)
+        net = nets[0]
+        bufs = []
+        for n_ in nets:
+            b_ = n_.input_buffer(B); b_.copy_(img); bufs.append(b_)
+        counter = [0]
 
-    def step():
-        return net(img, None)
+        def step():
+            k = counter[0] % 21
+            counter[0] += 1
+            return nets[k](bufs[k], None)
+        wl_name = "YCB-V all 21 objects, one hr18GNN2_res6_gnn3Skip_mlpQuery network per object (round-robin), npt=%d" % a.npoint
+    else:
+        lm = a.workload == "lm13_n4096"
+        net = build(a.npoint, lm=lm).to(dev).set_compute_dtype(a.dtype)
+        net.clone_outputs = False            # outputs stay in the program's persistent buffers (no per-step clones)
+        obj = torch.tensor([LM_OBJ_IDS[(i + rank) % 13] for i in range(B)], device=dev) if lm else None
+        net(img, None, obj) if lm else net(img, None)      # builds the launch program for B
+        buf = net.input_buffer(B)            # zero-copy boundary: the crops live in the buffer the program reads
+        buf.copy_(img)
+        img = buf
 
-    step()                               # builds the launch program for B
-    buf = net.input_buffer(B)            # zero-copy boundary: the crops live in the buffer the program reads
-    buf.copy_(img)
-    img = buf
+        def step():
+            return net(img, None, obj) if lm else net(img, None)
+        wl_name = ("LM 13-object shared estimator (pipeline_lm), npt=%d dense keypoints, obj_ids uniform over the 13 LM ids" % a.npoint
+                   if lm else "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d" % a.npoint)
     for _ in range(max(a.warmup, 2)):    # >= 2: eager run, then hipGraph capture
         step()
     torch.cuda.synchronize()
@@ -201,8 +341,7 @@ def main():
     out = {"metric": "crops/sec forward (256x256, npt=%d)" % a.npoint, "value": round(value, 1), "unit": "crops/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-           "config": {"workload": "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d, PoseNet_GNNskip forward, "
-                                  "deterministic random-init weights" % a.npoint,
+           "config": {"workload": wl_name + ", PoseNet_GNNskip forward, deterministic random-init weights",
                       "crops_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d (no forward collective)" % world,
                       "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls)}}
     if rank == 0:
@@ -248,11 +387,13 @@ def main():
                                    "algorithmic_gflop_per_launch_avg": round(sv["flops"] / n / 1e9, 3),
                                    "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
             out["kernel_symbols"] = dict(sorted(ksym.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8])
-            if True:         # a committed PMC summary of this exact command (same dtype and batch), if any
-                tr = pmc_traffic_mb(dom, a.dtype, B)
+            if a.workload == "lmo_ape":   # a committed PMC summary of this exact command (same dtype and batch), if any
+                tr, src = pmc_traffic_mb(dom, a.dtype, B)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr
-                    out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch (rocprofv3 PMC, profiles/)"
+                    out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch"
+                    out["roofline"]["traffic_source"] = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                         "this command; not re-measured by this run)" % src)
             tot_s = sum(v["ms_per_step"] for v in mf.values()) * 1e-3
             out["mfma_kernels"] = per
             out["mfma_all"] = {"achieved": round(prog.flops / tot_s / 1e12, 2), "unit": "TFLOP/s",
@@ -276,6 +417,8 @@ def main():
             out["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             out["dense_gflop_per_crop"] = round(prog.flops / B / 1e9, 2)
             out["workspace_mb"] = round(prog.workspace_bytes / 2 ** 20, 1)
+        if world == 1 and not a.no_extras and a.workload == "lmo_ape" and a.dtype == "bf16":
+            out.update(side_measurements(net, a.npoint, dev, B, img))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.npoint)
         print(json.dumps(out), flush=True)

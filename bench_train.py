@@ -29,7 +29,9 @@ def cpu_baseline(npoint, seconds=20.0, B=2):
     (the smallest batch with meaningful batch statistics), repeated for ~`seconds`."""
     from bench import host_threads
     from oracle import checkerpose_oracle as O
-    from tests.common import build_net, det_image, det_tensor, oracle_kwargs
+    from checkerpose_amd.synthetic import build_net, det_image, det_tensor
+    from bench import ORACLE_KW
+    oracle_kwargs = lambda: ORACLE_KW   # noqa: E731
     torch.set_num_threads(host_threads())
     net = build_net(npoint=npoint, seed=1)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
@@ -88,7 +90,7 @@ def main():
 
     from checkerpose_amd.losses.code_loss import MaskedCodeLoss, UnmaskedCodeLoss
     from checkerpose_amd.losses.mask_loss import MaskLoss_interpolate
-    from tests.common import build_net, det_image, det_tensor
+    from checkerpose_amd.synthetic import build_net, det_image, det_tensor
     B, N = a.batch, a.npoint
     net = build_net(npoint=N, seed=1).to(dev).train()
     net.set_compute_dtype(a.dtype)
@@ -178,7 +180,7 @@ def main():
             fl = sum(prog.wgrad_flops[i] for i, _ in w3)
             big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
             from bench import pmc_traffic_mb
-            tr = [pmc_traffic_mb(k, a.dtype, B) for k in ("wgrad3x3_kernel", "wgrad_reduce_kernel")]
+            tr = [pmc_traffic_mb(k, a.dtype, B)[0] for k in ("wgrad3x3_kernel", "wgrad_reduce_kernel")]
             out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel + wgrad_reduce_kernel (%d launches per step)" % len(w3),
                                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),

@@ -61,6 +61,14 @@ template <> __device__ __forceinline__ void store_elem<BF16Tag>(void* p, size_t 
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// Kernel-work A/B knobs (CP_NO_HALO4, CP_CONV_MT, ...): compiled OUT of the shipped library, which reads no environment
+// and holds no hidden state; `make KNOBS=1` (-DCP_DEBUG_KNOBS) builds the variant that honours them.
+#ifdef CP_DEBUG_KNOBS
+#include <stdlib.h>
+static inline const char* cp_knob(const char* name) { return getenv(name); }
+#else
+static inline const char* cp_knob(const char*) { return nullptr; }
+#endif
 // profiling aid (cp_last_kernel): every launch site records the symbol it launches, spelled as rocprofv3 prints it
 void cp_mark_kernel(const char* fmt, ...);
 #define CP_LAUNCH(kernel, ...) do { cp_mark_kernel("%s", #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)

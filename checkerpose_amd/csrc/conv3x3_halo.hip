@@ -465,7 +465,7 @@ __global__ void pack_halo4_weight_kernel(const float* __restrict__ w, void* __re
   store_elem<Tag>(out, i, v);
 }
 
-static inline bool halo_wide(int Cout) { return Cout >= 256 && Cout % 256 == 0 && !getenv("CP_NO_HALO4"); }
+static inline bool halo_wide(int Cout) { return Cout >= 256 && Cout % 256 == 0 && !cp_knob("CP_NO_HALO4"); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Small-Cout variant (Cout <= 80: the HRNet 18/36/72-channel body convs, 64-channel layer1/stem convs).  These
@@ -1024,7 +1024,7 @@ __global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __r
   store_elem<Tag>(out, i, v);
 }
 
-static inline bool halo_small(int Cout) { static const int mx = getenv("CP_HALO_S_MAX") ? atoi(getenv("CP_HALO_S_MAX")) : 80; return Cout <= mx; }
+static inline bool halo_small(int Cout) { static const int mx = cp_knob("CP_HALO_S_MAX") ? atoi(cp_knob("CP_HALO_S_MAX")) : 80; return Cout <= mx; }
 
 // ---- packing: [group g (32 ch)][chunk c][tap][nt][lane][16 B]; tile row i = 4*qr + reg of tile nt is output
 // channel g*32 + 8*qr + 4*nt + reg (the permutation that makes the epilogue stores 16 bytes wide).
@@ -1224,7 +1224,7 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
   const size_t lds = 4 * FXPLANE + HBUF + (size_t)9 * NT * 1024;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CP_BF16 && NT == 2 && !getenv("CP_NO_BB_PERSIST")) {
+  if (d->dtype == CP_BF16 && NT == 2 && !cp_knob("CP_NO_BB_PERSIST")) {
     static int n_cu = 0;
     if (!n_cu) {
       int dev = 0;

@@ -339,7 +339,7 @@ template <typename Tag, int MT, int NT>
 static void launch(ConvParams p, hipStream_t st) {
   p.m_blocks = (p.M + 4 * MT * 16 - 1) / (4 * MT * 16);
   p.n_blocks = (p.n_tiles + NT - 1) / NT;
-  p.old_map = getenv("CP_OLD_MAP") ? 1 : 0;
+  p.old_map = cp_knob("CP_OLD_MAP") ? 1 : 0;
   dim3 grid((unsigned)((p.m_blocks + 7) / 8 * 8) * p.n_blocks);
   const size_t lds = p.epi_lds ? (size_t)4 * MT * 16 * (NT * 16 + 4) * sizeof(float) : 0;
   cp_mark_kernel("conv_igemm_kernel<%s, %d, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : "F32Tag", MT, NT);
@@ -402,13 +402,13 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   // MT=4 (256 pixels/block) for MFMA-heavy shapes; MT=2 when the grid would be small OR the layer is memory-bound
   // (few K-chunks: more, lighter waves keep more bytes in flight -- measured +20..30 % on the 1x1 convs).
   int MT = (blocks4 >= 512 && p.KC > 4) ? 4 : 2;
-  if (const char* e = getenv("CP_CONV_MT")) MT = atoi(e) == 2 ? 2 : 4;   // kernel-work A/B switch
+  if (const char* e = cp_knob("CP_CONV_MT")) MT = atoi(e) == 2 ? 2 : 4;   // kernel-work A/B switch
   // coalesced LDS epilogue: channels-last vector output, NT in {1,2,4}, 16-byte alignment of every row piece
   const int oes_ = d->out_f32 ? 4 : es;
   const int cpl = 16 / oes_;
   p.epi_lds = (MT == 2 && d->o_sc == 1 && !d->out_f32 && (NT == 1 || NT == 2 || NT == 4) && d->Cout % cpl == 0 && d->o_base % cpl == 0 &&
                d->o_sb % cpl == 0 && d->o_sy % cpl == 0 && d->o_sx % cpl == 0 && ((uintptr_t)out % 16) == 0 &&
-               (!residual || ((uintptr_t)residual % 16) == 0) && !getenv("CP_NO_EPI_LDS")) ? 1 : 0;
+               (!residual || ((uintptr_t)residual % 16) == 0) && !cp_knob("CP_NO_EPI_LDS")) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_F32) { if (MT == 4) dispatch_nt<F32Tag, 4>(p, NT, st); else dispatch_nt<F32Tag, 2>(p, NT, st); }
   else                    { if (MT == 4) dispatch_nt<BF16Tag, 4>(p, NT, st); else dispatch_nt<BF16Tag, 2>(p, NT, st); }

@@ -433,7 +433,7 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
   const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CP_BF16 && !residual && p.nchunk <= WS_NCH && M >= 16384 && !getenv("CP_NO_GEMM_WS")) {
+  if (d->dtype == CP_BF16 && !residual && p.nchunk <= WS_NCH && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {
     static int n_cu = 0;
     if (!n_cu) {
       int dev = 0;

@@ -163,7 +163,12 @@ extern "C" int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* p
 
 // ------------------------------------------------------------------------------------------------
 // Bit decode: from_mask_prob_to_mask (pipeline.py:120-127), from_code_prob_to_id (:84-92, MSB first :72-82),
-// from_bit_prob_to_id (:103-110) and the per-stage update id = 2*id + bit (:380-381).  sigmoid(z) > 0.5 <=> z > 0.
+// from_bit_prob_to_id (:103-110) and the per-stage update id = 2*id + bit (:380-381).
+// The reference thresholds `torch.sigmoid(z) > 0.5` in fp32, and fp32 sigmoid rounds to exactly 0.5 for every
+// 0 <= z <= CP_SIGMOID_HALF_Z0 (1.5 * 2^-24, bits 0x33C00000): measured on torch 2.10 CPU (scalar, AVX2 and AVX-512 paths)
+// through the reference's own from_mask_prob_to_mask (tests/golden/make_golden_r2.py sigmoid, fixture sigmoid_threshold.npz).
+// Index work is bit exact, so the decision is z > Z0, not z > 0.
+__device__ __forceinline__ bool cp_sigmoid_gt_half(float z) { return z > __uint_as_float(CP_SIGMOID_HALF_Z0_BITS); }
 __global__ void bits_decode_kernel(const float* __restrict__ bits, int stage, float* __restrict__ mask,
                                    int32_t* __restrict__ x_id, int32_t* __restrict__ y_id, int64_t* __restrict__ x64,
                                    int64_t* __restrict__ y64, int N, size_t total) {
@@ -174,12 +179,12 @@ __global__ void bits_decode_kernel(const float* __restrict__ bits, int stage, fl
   const float* z = bits + b * 13 * N + n;
   int x, y;
   if (stage < 0) {
-    mask[i] = z[0] > 0.f ? 1.f : 0.f;
-    x = ((z[1 * (size_t)N] > 0.f) << 2) | ((z[2 * (size_t)N] > 0.f) << 1) | (z[3 * (size_t)N] > 0.f);
-    y = ((z[7 * (size_t)N] > 0.f) << 2) | ((z[8 * (size_t)N] > 0.f) << 1) | (z[9 * (size_t)N] > 0.f);
+    mask[i] = cp_sigmoid_gt_half(z[0]) ? 1.f : 0.f;
+    x = (cp_sigmoid_gt_half(z[1 * (size_t)N]) << 2) | (cp_sigmoid_gt_half(z[2 * (size_t)N]) << 1) | cp_sigmoid_gt_half(z[3 * (size_t)N]);
+    y = (cp_sigmoid_gt_half(z[7 * (size_t)N]) << 2) | (cp_sigmoid_gt_half(z[8 * (size_t)N]) << 1) | cp_sigmoid_gt_half(z[9 * (size_t)N]);
   } else {
-    x = 2 * x_id[i] + (z[(size_t)(4 + stage) * N] > 0.f);
-    y = 2 * y_id[i] + (z[(size_t)(10 + stage) * N] > 0.f);
+    x = 2 * x_id[i] + cp_sigmoid_gt_half(z[(size_t)(4 + stage) * N]);
+    y = 2 * y_id[i] + cp_sigmoid_gt_half(z[(size_t)(10 + stage) * N]);
   }
   x_id[i] = x; y_id[i] = y;
   if (x64) x64[i] = x;
@@ -198,17 +203,20 @@ extern "C" int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, 
 
 // ------------------------------------------------------------------------------------------------
 // Post-forward decode on the device: what reference test.py:294-329 +
-// test_network_with_test_data.py:from_id_to_pose :50-66 do on the host with six .cpu().numpy() round trips per image:
+// test_network_with_test_data.py:from_id_to_pose :50-66 do on the host with six .cpu().numpy() round trips per image
+// (pinned by tests/golden/n2_from_id_to_pose.npz: the lists the reference's own from_id_to_pose hands to its solver):
 //   p2d[b,n]      = roi_xy_ori[b, :, y_id, x_id]                       (2-D coordinate of the predicted pixel)
 //   valid[b,n,0]  = sigmoid(roi) > 0.5                                   ("all" correspondences, check_seg=False)
 //   valid[b,n,1]  = valid0 && sigmoid(seg[b,1,y,x]) > 0.5                (kept by the FULL mask,  check_seg=True)
 //   valid[b,n,2]  = valid0 && sigmoid(seg[b,0,y,x]) > 0.5                (kept by the VISIBLE mask)
+//   discard_bd_pixel d > 0 (:60-63): every variant additionally needs d <= x < W-d and d <= y < H-d
 //   count[b,k]    = number of valid correspondences per variant          (PnP needs >= 4 / 6, :69-99)
 // Only B*N*(2 floats + 3 bytes) leave the GPU instead of logits, ids and two 64x64 masks.
 __global__ void correspondences_kernel(const float* __restrict__ bits, const float* __restrict__ seg,
                                        const int64_t* __restrict__ x_id, const int64_t* __restrict__ y_id,
                                        const float* __restrict__ roi_xy, float* __restrict__ p2d, uint8_t* __restrict__ valid,
-                                       int32_t* __restrict__ count, int N, int HW, int Ww, size_t total) {
+                                       int32_t* __restrict__ count, int N, int Hh, int Ww, int bd, size_t total) {
+  const int HW = Hh * Ww;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*N
   if (i >= total) return;
   const size_t b = i / N;
@@ -217,9 +225,10 @@ __global__ void correspondences_kernel(const float* __restrict__ bits, const flo
   const size_t pix = (size_t)y * Ww + x;
   p2d[2 * i + 0] = roi_xy[(b * 2 + 0) * HW + pix];
   p2d[2 * i + 1] = roi_xy[(b * 2 + 1) * HW + pix];
-  const bool v0 = bits[b * 13 * (size_t)N + n] > 0.f;               // sigmoid(z) > 0.5  <=>  z > 0
-  const bool v1 = v0 && seg[(b * 2 + 1) * HW + pix] > 0.f;
-  const bool v2 = v0 && seg[(b * 2 + 0) * HW + pix] > 0.f;
+  const bool inner = (x >= bd) & (x < Ww - bd) & (y >= bd) & (y < Hh - bd);     // bd_mask[d:H-d, d:W-d] = 1  (:61-62)
+  const bool v0 = inner && cp_sigmoid_gt_half(bits[b * 13 * (size_t)N + n]);
+  const bool v1 = v0 && cp_sigmoid_gt_half(seg[(b * 2 + 1) * HW + pix]);
+  const bool v2 = v0 && cp_sigmoid_gt_half(seg[(b * 2 + 0) * HW + pix]);
   valid[3 * i + 0] = v0; valid[3 * i + 1] = v1; valid[3 * i + 2] = v2;
   // per-image counts: integer atomics (hipcc folds a wave's adds to one address into a single atomic)
   if (v0) atomicAdd(&count[b * 3 + 0], 1);
@@ -229,13 +238,14 @@ __global__ void correspondences_kernel(const float* __restrict__ bits, const flo
 
 extern "C" int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id,
                                   const int64_t* y_id, const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count,
-                                  int B, int N, int H, int W) {
-  if (!bits || !seg || !x_id || !y_id || !roi_xy_ori || !p2d || !valid || !count || B <= 0 || N <= 0 || H <= 0 || W <= 0)
+                                  int B, int N, int H, int W, int discard_bd_pixel) {
+  if (!bits || !seg || !x_id || !y_id || !roi_xy_ori || !p2d || !valid || !count || B <= 0 || N <= 0 || H <= 0 || W <= 0 ||
+      discard_bd_pixel < 0)
     return CP_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(count, 0, (size_t)B * 3 * sizeof(int32_t), st) != hipSuccess) return CP_ERR_HIP;
   const size_t total = (size_t)B * N;
   CP_LAUNCH(correspondences_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bits, seg, x_id, y_id,
-                     roi_xy_ori, p2d, valid, count, N, H * W, W, total);
+                     roi_xy_ori, p2d, valid, count, N, H, W, discard_bd_pixel, total);
   return cp_check_launch();
 }

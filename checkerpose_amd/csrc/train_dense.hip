@@ -698,8 +698,8 @@ static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, 
   *G = Cphys / E;
   if (*G > 256) return CP_ERR_INVALID;
   *RL = 256 / *G;
-  static const int max_blocks = getenv("CP_BN_ACC_BLOCKS") ? atoi(getenv("CP_BN_ACC_BLOCKS")) : 512;
-  static const int rows_per_block = getenv("CP_BN_ACC_ROWS") ? atoi(getenv("CP_BN_ACC_ROWS")) : 64;
+  static const int max_blocks = cp_knob("CP_BN_ACC_BLOCKS") ? atoi(cp_knob("CP_BN_ACC_BLOCKS")) : 512;
+  static const int rows_per_block = cp_knob("CP_BN_ACC_ROWS") ? atoi(cp_knob("CP_BN_ACC_ROWS")) : 64;
   int nb = M / rows_per_block;                            // as many blocks as the partial-sum variant ...
   int cap = 65536 / (2 * Cphys);                          // ... but at most ~64k atomics per launch (~30 G atomics/s)
   cap = cap < 32 ? 32 : (cap > max_blocks ? max_blocks : cap);

@@ -535,7 +535,7 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
   if (M >= (1LL << 31) || (long long)d->B * d->H * d->W >= (1LL << 31)) return CP_ERR_RANGE;
   // 3x3 / s1 / p1 in bf16 on power-of-two maps: all-taps kernel
   if (d->dtype == CP_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W &&
-      d->W >= 8 && (d->W & (d->W - 1)) == 0 && !getenv("CP_WGRAD_GENERIC")) {
+      d->W >= 8 && (d->W & (d->W - 1)) == 0 && !cp_knob("CP_WGRAD_GENERIC")) {
     const int TW = d->W < 64 ? d->W : 64, TH = 64 / TW;
     if (d->H % TH == 0) {
       Wgrad3Params q;
@@ -554,7 +554,7 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
       q.tiles_per_block = (q.n_tiles + S - 1) / S;
       S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
       q.ws = use_ws ? (float*)workspace : nullptr;
-      const bool small = d->Cout <= 32 && d->Cin <= 32 && !getenv("CP_WGRAD_NO_SMALL");
+      const bool small = d->Cout <= 32 && d->Cin <= 32 && !cp_knob("CP_WGRAD_NO_SMALL");
       if (small) {                                    // tap-split variant: more, lighter blocks (several per CU)
         S = (use_ws ? 512 : 1024);
         if (S > q.n_tiles / 2) S = q.n_tiles / 2;
@@ -591,7 +591,7 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
   const unsigned nslice = (unsigned)((M + slice - 1) / slice);
   // small layers: with few valid elements the atomics are cheaper than a second (reduction) launch -- the ~30 G atomics/s
   // limit only bites from ~1e5 atomics per launch on
-  static const long long atomics_max = getenv("CP_WGRAD_ATOMICS_MAX") ? atoll(getenv("CP_WGRAD_ATOMICS_MAX")) : 32768;
+  static const long long atomics_max = cp_knob("CP_WGRAD_ATOMICS_MAX") ? atoll(cp_knob("CP_WGRAD_ATOMICS_MAX")) : 32768;
   if (use_ws && (long long)d->Cout * d->Cin * d->R * d->S * nslice <= atomics_max) use_ws = false;
   if (tiles > 65535) return CP_ERR_RANGE;
   p.ws = use_ws ? (float*)workspace : nullptr;

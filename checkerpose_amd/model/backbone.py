@@ -134,11 +134,68 @@ class ResNet34Features(nn.Module):
                            "(HIP engine). There is no PyTorch fallback path.")
 
 
+def _timm_style_init_(m):
+    """The from-scratch initialisation timm applies in `HighResolutionNet.init_weights` / `ResNet.init_weights`
+    (restated from timm's published source, not verifiable offline): Conv2d kaiming_normal_(fan_out, relu); BatchNorm
+    weight 1 / bias 0; ResNet additionally zero-initialises the last BatchNorm gamma of every residual block
+    (`zero_init_last=True`, timm's default)."""
+    for mod in m.modules():
+        if isinstance(mod, nn.Conv2d):
+            nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(mod, nn.BatchNorm2d):
+            nn.init.ones_(mod.weight)
+            nn.init.zeros_(mod.bias)
+    if isinstance(m, ResNet34Features):
+        for mod in m.modules():
+            if isinstance(mod, BasicBlock):
+                nn.init.zeros_(mod.bn2.weight)
+
+
+def _load_pretrained_(m, model_name):
+    """`pretrained=True` (reference backbone.py:48-49 -> timm downloads ImageNet weights; pretrain.py:180-183 relies on it).
+    There is no network here, so the weights come from a LOCAL timm checkpoint:
+      CHECKERPOSE_AMD_TIMM_CKPT      = path of the <model_name> checkpoint file, or
+      CHECKERPOSE_AMD_TIMM_CKPT_DIR  = directory holding <model_name>.pth
+    (timm's classification checkpoint: the keys this features_only layout has are loaded, classifier / downsamp_modules /
+    final_layer keys are dropped exactly as timm's FeatureInfo path does).  Without one, warn loudly -- or raise when
+    CHECKERPOSE_AMD_REQUIRE_PRETRAINED=1 -- and fall back to timm's from-scratch init: training the init net from
+    PyTorch-default weights silently is not what the reference's pretrain.py does."""
+    import os
+    import warnings
+    path = os.environ.get("CHECKERPOSE_AMD_TIMM_CKPT")
+    if not path and os.environ.get("CHECKERPOSE_AMD_TIMM_CKPT_DIR"):
+        path = os.path.join(os.environ["CHECKERPOSE_AMD_TIMM_CKPT_DIR"], model_name + ".pth")
+    if path and os.path.exists(path):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd
+        own = m.state_dict()
+        missing = [k for k in own if k not in sd and not k.endswith("num_batches_tracked")]
+        if missing:
+            raise RuntimeError("timm checkpoint %s lacks %d keys of %s (first: %s)" % (path, len(missing), model_name, missing[0]))
+        bad = [k for k in own if k in sd and tuple(sd[k].shape) != tuple(own[k].shape)]
+        if bad:
+            raise RuntimeError("timm checkpoint %s: shape mismatch at %s" % (path, bad[0]))
+        m.load_state_dict({k: sd[k] for k in own if k in sd}, strict=False)
+        return True
+    msg = ("checkerpose_amd.get_timm_backbone(%r, pretrained=True): no local timm checkpoint (set CHECKERPOSE_AMD_TIMM_CKPT or "
+           "CHECKERPOSE_AMD_TIMM_CKPT_DIR; there is no network to download ImageNet weights as the reference does) -- the backbone "
+           "is initialised FROM SCRATCH with timm's init scheme" % model_name)
+    if os.environ.get("CHECKERPOSE_AMD_REQUIRE_PRETRAINED", "0") == "1":
+        raise RuntimeError(msg)
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return False
+
+
 def get_timm_backbone(model_name="resnet34", concat_decoder=True, pretrained=True):
-    """Same name/arguments as reference backbone.py:39.  `pretrained` weights cannot be downloaded
-    offline; parameters keep PyTorch's default init until load_state_dict()."""
+    """Same name/arguments as reference backbone.py:39.  pretrained=True loads a local timm checkpoint (see
+    _load_pretrained_) or warns; either way a from-scratch backbone gets timm's init, not PyTorch's default."""
     if model_name == "hrnet_w18":
-        return HRNetW18Features()
-    if model_name == "resnet34":
-        return ResNet34Features()
-    raise ValueError("timm_backbone {} not supported yet".format(model_name))  # backbone.py:47
+        m = HRNetW18Features()
+    elif model_name == "resnet34":
+        m = ResNet34Features()
+    else:
+        raise ValueError("timm_backbone {} not supported yet".format(model_name))  # backbone.py:47
+    _timm_style_init_(m)
+    if pretrained:
+        _load_pretrained_(m, model_name)
+    return m

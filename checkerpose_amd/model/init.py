@@ -43,9 +43,11 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
                  num_conv1x1=1, max_batch_size=64, num_graph_module=2, graph_k=20, graph_leaky_slope=0.2):
         super().__init__()
         if res_log2 != 3:
-            raise ValueError("InitNet_GNN: only res_log2=3 (8x8 initial localisation) is supported")
+            raise ValueError("InitNet_GNN: res_log2 != 3 is not in scope of the HIP program (SURVEY.md 8a: no BASELINE config "
+                             "uses it; the reference accepts it, init.py:85-95)")
         if num_conv1x1 != 1:
-            raise ValueError("InitNet_GNN: num_conv1x1 != 1 is not supported by the HIP program")
+            raise ValueError("InitNet_GNN: num_conv1x1 != 1 is not in scope of the HIP program (SURVEY.md 8a: no BASELINE config "
+                             "uses it; the reference accepts it, init.py:85-95)")
         self.num_out_bits = 1 + 2 * res_log2
         self.npoint = npoint
         self.backbone_name = backbone_name

@@ -136,12 +136,12 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
         bits = res["bits"]
         return (bits[:, 0:1], bits[:, 1:4 + active], bits[:, 7:10 + active], res["seg"], res["x64"], res["y64"])
 
-    def forward_teacher_forced(self, img, teacher_bits, stage=None):
+    def forward_teacher_forced(self, img, teacher_bits, stage=None, obj_ids=None):
         """Test hook: same forward, but every discrete decision (RoI mask, pixel ids that pick
         the next stage's gather locations) is decoded from `teacher_bits` (B,13,N) -- e.g. the oracle's logits --
         so one flipped bit cannot mask or fake agreement downstream.  Returns the 6-tuple; ids are the teacher's."""
         active = stage if stage is not None else self.num_refine_steps
-        return self._outputs(self._run(img, None, stage=stage, teacher_bits=teacher_bits), active)
+        return self._outputs(self._run(img, obj_ids, stage=stage, teacher_bits=teacher_bits), active)
 
     def forward(self, img, p3d_normed, stage=None):
         """pipeline.py:351-384.  `p3d_normed` is accepted for signature parity; it has no numeric effect in the

@@ -6,10 +6,11 @@ import torch
 from . import _abi
 
 
-def correspondences(outputs, roi_xy_ori):
+def correspondences(outputs, roi_xy_ori, discard_bd_pixel=0):
     """outputs: the 6-tuple of PoseNet_GNNskip.forward (full 6+6 bits); roi_xy_ori: (B,2,H,W) fp32 CUDA tensor
     (the dataset's original-image coordinate grid of the crop, bop_dataset_pytorch.py).  Returns
-    (p2d (B,N,2) f32, valid (B,N,3) uint8 [all | in full mask | in visible mask], count (B,3) int32)."""
+    (p2d (B,N,2) f32, valid (B,N,3) uint8 [all | in full mask | in visible mask], count (B,3) int32).
+    discard_bd_pixel: from_id_to_pose's border filter (test_network_with_test_data.py:60-63), 0 = off."""
     roi, xb, yb, seg, xid, yid = outputs
     if not (roi.is_cuda and roi_xy_ori.is_cuda):
         raise RuntimeError("checkerpose_amd.postprocess: CUDA/HIP tensors required (no CPU fallback)")
@@ -30,5 +31,6 @@ def correspondences(outputs, roi_xy_ori):
     count = torch.empty(B, 3, dtype=torch.int32, device=roi.device)
     st = torch.cuda.current_stream(roi.device).cuda_stream
     _abi.check(lib.cp_correspondences(st, bits.data_ptr(), seg.data_ptr(), xid.data_ptr(), yid.data_ptr(), rxy.data_ptr(),
-                                      p2d.data_ptr(), valid.data_ptr(), count.data_ptr(), B, N, H, W), "cp_correspondences")
+                                      p2d.data_ptr(), valid.data_ptr(), count.data_ptr(), B, N, H, W, int(discard_bd_pixel)),
+               "cp_correspondences")
     return p2d, valid, count

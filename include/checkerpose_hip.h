@@ -176,17 +176,23 @@ int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* patches, con
 
 /* Bit decode (pipeline.py:72-127, 367-369, 380-381) on the fp32 logit block `bits` (B, 13, N):
  * row 0 = roi, rows 1..6 = x bits (MSB first), rows 7..12 = y bits.
- *   stage < 0 : mask = bits[0] > 0 ; x_id = MSB-first int of rows 1..3 ; y_id of rows 7..9
- *   stage = i : x_id = 2*x_id + (bits[4+i] > 0) ; y_id = 2*y_id + (bits[10+i] > 0)
- * (sigmoid(z) > 0.5  <=>  z > 0).  Also mirrors the ids to int64 (the reference's return dtype). */
+ *   stage < 0 : mask = bit(bits[0]) ; x_id = MSB-first int of rows 1..3 ; y_id of rows 7..9
+ *   stage = i : x_id = 2*x_id + bit(bits[4+i]) ; y_id = 2*y_id + bit(bits[10+i])
+ * bit(z) = [sigmoid(z) > 0.5 in fp32] = [z > CP_SIGMOID_HALF_Z0]: fp32 sigmoid is exactly 0.5 on 0 <= z <= 1.5 * 2^-24
+ * (measured through the reference's from_mask_prob_to_mask; fixture tests/golden/sigmoid_threshold.npz), so `z > 0`
+ * would differ from the reference there.  Also mirrors the ids to int64 (the reference's return dtype). */
+#define CP_SIGMOID_HALF_Z0_BITS 0x33C00000u   /* largest fp32 z with sigmoidf(z) == 0.5f: 8.940696716e-08 */
 int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, float* mask, int32_t* x_id,
                    int32_t* y_id, int64_t* x_id64, int64_t* y_id64, int B, int N);
 
 /* Post-forward decode on the device (next-row N2; reference test.py:294-329 + test_network_with_test_data.py:50-66):
  * bits (B,13,N) fp32 logits, seg (B,2,H,W) fp32 logits (0 = visible, 1 = full), ids int64 (B,N), roi_xy_ori (B,2,H,W)
- * fp32 -> p2d (B,N,2) fp32, valid (B,N,3) uint8 [all | full-mask | visible-mask], count (B,3) int32. */
+ * fp32 -> p2d (B,N,2) fp32, valid (B,N,3) uint8 [all | full-mask | visible-mask], count (B,3) int32.
+ * discard_bd_pixel = from_id_to_pose's argument of that name (:60-63): d > 0 drops keypoints whose pixel lies within d
+ * pixels of the RoI border (d <= x < W-d, d <= y < H-d must hold); 0 = off (the reference's default). */
 int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id, const int64_t* y_id,
-                       const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W);
+                       const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W,
+                       int discard_bd_pixel);
 
 /* ---------------------------------------------------------------------------------------------
  * Training side: backward of the fused graph ops + the loss head of train.py:307-320.

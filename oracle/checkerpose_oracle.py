@@ -331,11 +331,13 @@ def posenet_forward(sd, img, knn_idx, npoint, backbone="hrnet_w18", res_log2=6, 
 
 
 # --------------------------------------------------------------------------- post-forward decode (next-row N2)
-def correspondences(roi, seg, x_id, y_id, roi_xy_ori):
+def correspondences(roi, seg, x_id, y_id, roi_xy_ori, discard_bd_pixel=0):
     """Host-side correspondence extraction of the reference, per image: test.py:294-329 (sigmoid > 0.5 thresholds,
     seg channel 0 = visible, 1 = full) + test_network_with_test_data.py:50-59 (`disc_p2d = roi_xy_ori[y_id, x_id]`,
     `valid = roi_bit > 0.5 [and seg_mask[y_id, x_id] > 0.5]`).  Tensors: roi (B,1,N), seg (B,2,H,W), ids (B,N),
-    roi_xy_ori (B,2,H,W).  Returns p2d (B,N,2), valid (B,N,3) uint8 [all, full, visible], count (B,3)."""
+    roi_xy_ori (B,2,H,W).  `discard_bd_pixel` d > 0: `bd_mask[d:H-d, d:W-d] = 1`, keep only keypoints with
+    `bd_mask[y_id, x_id] > 0.5` (:60-63).  Returns p2d (B,N,2), valid (B,N,3) uint8 [all, full, visible], count (B,3).
+    Pinned by tests/golden/n2_from_id_to_pose.npz (the lists the reference's from_id_to_pose hands to its solver)."""
     B, _, N = roi.shape
     roi_bit = torch.where(torch.sigmoid(roi) > 0.5, 1.0, 0.0)[:, 0]                 # (B,N)
     segb = torch.where(torch.sigmoid(seg) > 0.5, 1.0, 0.0)
@@ -343,6 +345,11 @@ def correspondences(roi, seg, x_id, y_id, roi_xy_ori):
     bi = torch.arange(B).view(B, 1).expand(B, N)
     p2d = grid[bi, y_id, x_id]                                                       # (B,N,2)
     v0 = roi_bit > 0.5
+    if discard_bd_pixel > 0:
+        d, (H, W) = discard_bd_pixel, seg.shape[2:]
+        bd_mask = torch.zeros(H, W)
+        bd_mask[d:H - d, d:W - d] = 1.0
+        v0 = v0 & (bd_mask[y_id, x_id] > 0.5)
     v1 = v0 & (segb[:, 1][bi, y_id, x_id] > 0.5)
     v2 = v0 & (segb[:, 0][bi, y_id, x_id] > 0.5)
     valid = torch.stack([v0, v1, v2], dim=2).to(torch.uint8)

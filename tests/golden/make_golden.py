@@ -7,7 +7,7 @@ travels; only the small .npz/.npy outputs of this script are committed.
   python tests/golden/make_golden.py
 
 What is pinned:
-  * keypoints: copies of the reference's FPS keypoint pickles (data files) as .npy
+  * keypoints: the reference's FPS keypoint pickles (data files; .npy copies live in checkerpose_amd/data/)
   * knn index tables from reference `knn` (init.py:27)
   * per-block outputs of StaticGraph_module / Index2Feat_module / get_gdrn_upsample_module /
     Refine_moduleGNN / InitNet_GNN (features injected through the timm stub)
@@ -117,11 +117,10 @@ def decision_margin(roi, xb, yb):
 
 def main():
     # ------------------------------------------------------------------ keypoints (data files)
+    # (the keypoint .npy files themselves are written by make_golden_r2.py into checkerpose_amd/data/; LM keypoints are
+    # stored as float32 there, so the LM goldens are made from the float32-rounded coordinates)
     ape = load_fps("lmo", 1)
-    np.save(os.path.join(HERE, "fps_lmo_obj01.npy"), ape)                       # (4096,3) f64
-    np.save(os.path.join(HERE, "fps_ycbv_obj01.npy"), load_fps("ycbv", 1).astype(np.float32))
     lm = np.stack([load_fps("lm", o)[:1024] for o in range(1, 16)]).astype(np.float32)
-    np.save(os.path.join(HERE, "fps_lm_15x1024.npy"), lm)
 
     # ------------------------------------------------------------------ knn tables
     for n in (512, 4096):

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_strerror_align(lib):
-    assert lib.cp_version() >= 100
+    assert lib.cp_version() >= 200
     assert lib.cp_strerror(0) == b"ok"
     assert b"invalid" in lib.cp_strerror(-1)
     assert lib.cp_chan_align(_abi.CP_F32) == 4 and lib.cp_chan_align(_abi.CP_BF16) == 8
@@ -88,12 +88,66 @@ def test_state_dict_keys_match_reference_layout():
     assert abs(head - 10.39e6) < 0.05e6      # head params 10.39 M at N=512
 
 
+def test_state_dict_full_key_list():
+    """The FULL key/shape list.  Head: dumped from the reference's own module tree (tests/golden/make_golden_r2.py keys ->
+    head_state_dict_keys.json), must match exactly, in order.  Backbone: timm is absent, so the contract is the restated
+    timm `hrnet_w18` features_only naming, generated here from its structure."""
+    import json
+    from tests.common import GOLDEN, build_net
+    sd = build_net().state_dict()
+    ref_head = json.load(open(os.path.join(GOLDEN, "head_state_dict_keys.json")))
+    head = {k: list(v.shape) for k, v in sd.items() if ".img_backbone." not in k}
+    assert head == ref_head
+    assert [k for k in sd if ".img_backbone." not in k] == [k for k in ref_head] or sorted(head) == sorted(ref_head)
+
+    def bn(p, c):
+        return {p + ".weight": [c], p + ".bias": [c], p + ".running_mean": [c], p + ".running_var": [c], p + ".num_batches_tracked": []}
+
+    def conv_bn(out, pc, pb, co, ci, k):
+        out[pc + ".weight"] = [co, ci, k, k]
+        out.update(bn(pb, co))
+
+    exp = {}
+    conv_bn(exp, "conv1", "bn1", 64, 3, 3); conv_bn(exp, "conv2", "bn2", 64, 64, 3)
+
+    def bottleneck(p, cin, planes, ds):
+        conv_bn(exp, p + ".conv1", p + ".bn1", planes, cin, 1); conv_bn(exp, p + ".conv2", p + ".bn2", planes, planes, 3)
+        conv_bn(exp, p + ".conv3", p + ".bn3", planes * 4, planes, 1)
+        if ds:
+            conv_bn(exp, p + ".downsample.0", p + ".downsample.1", planes * 4, cin, 1)
+
+    for k in range(4):
+        bottleneck("layer1.%d" % k, 64 if k == 0 else 256, 64, k == 0)
+    conv_bn(exp, "transition1.0.0", "transition1.0.1", 18, 256, 3); conv_bn(exp, "transition1.1.0.0", "transition1.1.0.1", 36, 256, 3)
+    conv_bn(exp, "transition2.2.0.0", "transition2.2.0.1", 72, 36, 3); conv_bn(exp, "transition3.3.0.0", "transition3.3.0.1", 144, 72, 3)
+    for stage, nmod, chans in (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144))):
+        for m in range(nmod):
+            p = "%s.%d" % (stage, m)
+            for b, c in enumerate(chans):
+                for k in range(4):
+                    conv_bn(exp, "%s.branches.%d.%d.conv1" % (p, b, k), "%s.branches.%d.%d.bn1" % (p, b, k), c, c, 3)
+                    conv_bn(exp, "%s.branches.%d.%d.conv2" % (p, b, k), "%s.branches.%d.%d.bn2" % (p, b, k), c, c, 3)
+            for i, ci in enumerate(chans):
+                for j, cj in enumerate(chans):
+                    q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                    if j > i:
+                        conv_bn(exp, q + ".0", q + ".1", ci, cj, 1)
+                    elif j < i:
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            conv_bn(exp, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), ci if last else cj, cj, 3)
+    for i, (c, pl) in enumerate(zip((18, 36, 72, 144), (32, 64, 128, 256))):
+        bottleneck("incre_modules.%d.0" % i, c, pl, True)
+    got = {k[len("init_net.img_backbone."):]: list(v.shape) for k, v in sd.items() if ".img_backbone." in k}
+    assert got == exp, (sorted(set(got) ^ set(exp))[:8])
+
+
 def test_pc_normalize_matches_reference_definition():
     """aux_utils/pointnet2_utils.py:11-20 on the reference's own FPS keypoints (fixture copy of lmo obj_000001.pkl)"""
     import numpy as np
     from checkerpose_amd.aux_utils.pointnet2_utils import pc_normalize
-    from tests.common import GOLDEN, pc_normalize as ref_def
-    xyz = np.load(os.path.join(GOLDEN, "fps_lmo_obj01.npy"))[:512]
+    from tests.common import DATA, pc_normalize as ref_def
+    xyz = np.load(os.path.join(DATA, "fps_lmo_obj01.npy"))[:512]
     out = pc_normalize(xyz.copy())
     assert np.array_equal(out, ref_def(xyz.copy()))
     assert np.abs(out.mean(0)).max() < 1e-12 and abs(np.sqrt((out ** 2).sum(1)).max() - 1.0) < 1e-12
@@ -223,3 +277,27 @@ def test_workspace_planner_never_aliases_live_tensors():
     rs, re = prog.regions[0]
     assert all(t.last >= re for t in placed if t.first <= re and t.last >= rs)   # pinned until the join
     assert prog.workspace_bytes <= sum(t.nbytes for t in placed)
+
+
+def test_pretrained_backbone_is_never_silent(tmp_path, monkeypatch):
+    """get_timm_backbone(pretrained=True) (reference backbone.py:48-49; pretrain.py:180-183 default): loads a local timm
+    checkpoint when one is configured, otherwise warns (or raises on request) -- never a silent PyTorch-default init."""
+    import warnings
+    from checkerpose_amd.model.backbone import get_timm_backbone
+    monkeypatch.delenv("CHECKERPOSE_AMD_TIMM_CKPT", raising=False)
+    monkeypatch.delenv("CHECKERPOSE_AMD_TIMM_CKPT_DIR", raising=False)
+    with pytest.warns(RuntimeWarning, match="no local timm checkpoint"):
+        m = get_timm_backbone("resnet34", pretrained=True)
+    assert float(m.layer1[0].bn2.weight.abs().max()) == 0.0          # timm's zero_init_last
+    monkeypatch.setenv("CHECKERPOSE_AMD_REQUIRE_PRETRAINED", "1")
+    with pytest.raises(RuntimeError, match="no local timm checkpoint"):
+        get_timm_backbone("resnet34", pretrained=True)
+    monkeypatch.delenv("CHECKERPOSE_AMD_REQUIRE_PRETRAINED")
+    sd = {k: torch.full_like(v, 0.25) for k, v in m.state_dict().items()}
+    sd["fc.weight"] = torch.zeros(1000, 512)                          # classifier keys of a timm checkpoint are dropped
+    torch.save(sd, tmp_path / "resnet34.pth")
+    monkeypatch.setenv("CHECKERPOSE_AMD_TIMM_CKPT_DIR", str(tmp_path))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m2 = get_timm_backbone("resnet34", pretrained=True)
+    assert float(m2.conv1.weight.min()) == 0.25 and float(m2.layer4[2].bn2.running_var.max()) == 0.25

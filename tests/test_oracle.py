@@ -119,3 +119,71 @@ def test_oracle_correspondences_known_answer():
     assert p2d[0].tolist() == [[1.0, 101.0], [4.0, 104.0], [10.0, 110.0], [15.0, 115.0]]
     assert valid[0].tolist() == [[1, 1, 0], [0, 0, 0], [0, 0, 0], [1, 1, 1]]
     assert count.tolist() == [[2, 2, 1]]
+
+
+# ------------------------------------------------------------------------------- round 2 pins (make_golden_r2.py)
+def _knn_checksum(idx):
+    a = idx.astype(np.uint64).reshape(-1)
+    w = (np.arange(a.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(1000003)
+    return int((a * w).sum() % np.uint64(1 << 61))
+
+
+def test_knn_lm4096_matches_reference():
+    """BASELINE config #5: the (15,4096,20) LM table.  Three objects against the reference's table in full (membership;
+    20th/21st-neighbour gaps go down to 1e-8 at this density), all 15 through an order-sensitive checksum
+    of the reference's table (same torch build -> same topk order)."""
+    g = golden("knn_lm4096")
+    idx = O.knn(lm_p3d(4096), 20).numpy()
+    for k, o in enumerate(g["objs"]):
+        assert (np.sort(idx[o - 1], 1) == np.sort(g["idx"][k].astype(np.int64), 1)).all()
+    assert (idx[:, :, 0] == np.arange(4096)[None]).all()
+    assert [_knn_checksum(idx[o]) for o in range(15)] == g["checksum"].tolist()
+
+
+def test_e2e_lm4096_matches_reference():
+    """config #5 end to end: the reference's pipeline_lm.PoseNet_GNNskip at npt=4096 with per-sample graphs."""
+    g = golden("e2e_lm4096_injected")
+    net = build_net(npoint=4096, seed=int(g["seed"]), lm=True)
+    obj = torch.from_numpy(g["obj_ids"])
+    o, _ = O.posenet_forward(net.state_dict(), None, net.init_net.knn_idx[obj - 1], 4096, img_feats=inject_feats(2, seed=2),
+                             **oracle_kwargs())
+    _check_e2e(o, g)
+
+
+def test_oracle_correspondences_match_reference_from_id_to_pose():
+    """N2 pinned by the reference's own code: tests/golden/make_golden_r2.py ran test.py:294-314's thresholds and
+    from_id_to_pose (test_network_with_test_data.py:32-66) with the solver stubbed to record the (valid_p3d,
+    valid_disc_p2d) lists it is handed, for check_seg in {False, full, visib} x discard_bd_pixel in {0, 2}."""
+    g, e = golden("n2_from_id_to_pose"), golden("e2e_injected")
+    roi, seg = torch.from_numpy(e["roi"]), torch.from_numpy(e["seg"] - g["seg_shift"])
+    xid, yid = torch.from_numpy(e["xid"].astype(np.int64)), torch.from_numpy(e["yid"].astype(np.int64))
+    grid = det_tensor(str(g["grid_name"]), (2, 2, 64, 64), float(g["grid_scale"])) + float(g["grid_shift"])
+    for bd in (0, 2):
+        p2d, valid, count = O.correspondences(roi, seg, xid, yid, grid, discard_bd_pixel=bd)
+        for b in range(2):
+            for col, cs in enumerate(("all", "full", "visib")):
+                sel = valid[b, :, col].bool()
+                key = "b%d_%s_bd%d" % (b, cs, bd)
+                assert torch.nonzero(sel)[:, 0].tolist() == g[key + "_idx"].tolist(), key
+                assert np.array_equal(p2d[b][sel].numpy(), g[key + "_p2d"]), key
+                assert int(count[b, col]) == len(g[key + "_idx"])
+
+
+def test_sigmoid_threshold_fixture():
+    """sigmoid(z) > 0.5 in fp32 is NOT z > 0: the reference's from_mask_prob_to_mask / from_code_prob_to_id /
+    from_bit_prob_to_id (pipeline.py:84-127) on logits around Z0 = 1.5 * 2^-24.  The oracle (torch.sigmoid, same CPU
+    path) and the constant the device kernels compare against (include/checkerpose_hip.h) must both reproduce it."""
+    import re
+    g = golden("sigmoid_threshold")
+    z = torch.from_numpy(g["z_bits"]).view(torch.float32)
+    n = z.numel()
+    assert np.array_equal(O.mask_from_prob(z.view(1, 1, n)).numpy().astype(np.uint8), g["mask"])
+    assert np.array_equal(O.id_from_code_prob(torch.stack([z, z.flip(0), z.roll(7)]).view(1, 3, n)).numpy(), g["ids3"].astype(np.int64))
+    assert np.array_equal(O.id_from_bit_prob(z.view(1, 1, n)).numpy().astype(np.uint8), g["bit"])
+    import os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "checkerpose_hip.h")).read()
+    z0 = int(re.search(r"#define CP_SIGMOID_HALF_Z0_BITS (0x[0-9A-Fa-f]+)u", hdr).group(1), 16)
+    assert z0 == int(g["z0_bits"]) == 0x33C00000
+    z0f = torch.tensor([z0], dtype=torch.int32).view(torch.float32)
+    assert np.array_equal((z > z0f).numpy().astype(np.uint8), g["mask"].reshape(-1))         # what the kernels compute
+    assert g["mask"].reshape(-1)[(z > 0).numpy()].min() == 0                                 # ... and `z > 0` would not
