@@ -167,6 +167,15 @@ class HipForwardMixin:
             io["decode_bits"] = torch.zeros(B, 13, N, dtype=torch.float32, device=device)
         # batch slices: independent sub-programs that the captured graph runs concurrently (see ProgramGroup)
         nsplit = self.batch_splits if (B >= 8 * self.batch_splits and B % self.batch_splits == 0) else 1
+        # the kernels address every tensor through 32-bit buffer descriptors (< 2 GiB): the widest one is the last decoder
+        # stage's input concat (size/4)^2 x (num_filters + skip channels) -> fp32 batches beyond 255 crops run as slices
+        from ..netbuilder import IMG_FEATS_DIMS
+        widest = (size // 4) ** 2 * (cfg.get("num_filters", 0) + IMG_FEATS_DIMS[cfg["backbone"]][1]) * (4 if self.compute_dtype in ("fp32", "f32", "float32") else 2)
+        need = -(-B * widest // ((1 << 31) - 1))
+        if need > nsplit:
+            nsplit = need
+            while B % nsplit:
+                nsplit += 1
         Bs = B // nsplit
         fs = None
         if cfg["kind"] != "init":

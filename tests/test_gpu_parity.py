@@ -635,11 +635,13 @@ def test_e2e_bf16_accuracy_contract(lib):
     """bf16 path (BASELINE config #2, the path bench.py times): not a 1e-4 path -- its written contract
     (checkerpose_amd/agreement.py), checked against the CPU oracle at B=4 on random-init weights:
       teacher-forced (discrete feedback taken from the oracle, so one flipped bit cannot compound):
-        every one of the 13 logit rows and both seg masks agree on >= 97 % of the thresholded bits,
+        every one of the 13 logit rows agrees on >= 98 % of the thresholded bits, both seg masks on >= 99 %,
         mean |dlogit| <= 2 % of the logit RMS, max |dlogit| <= 0.5;
       free-running (what a user sees; flips of an early bit change later stages' gather positions):
-        roi + the 3+3 InitNet bits >= 97 %, every later row >= 90 %, final (x_id, y_id) pairs equal for >= 75 % of the
-        keypoints, mean id error <= 1.5 px."""
+        roi + the 3+3 InitNet bits >= 98 %, every later row >= 95 %, final (x_id, y_id) pairs equal for >= 90 % of the
+        keypoints, mean id error <= 0.5 px.
+    (measured, round 2, vs the fp32 HIP path on 8 crops: teacher-forced min row 0.9895, mean |dlogit| 0.74 % of RMS,
+    max 0.35; free-running min row 0.984, id pairs equal 96.2 %, 0.16 px)"""
     from checkerpose_amd.agreement import logit_agreement
     net = build_net(seed=1)
     img = det_image(4, seed=3)
@@ -649,13 +651,13 @@ def test_e2e_bf16_accuracy_contract(lib):
     fr = logit_agreement(net(img.to(dev()), None), ref)
     print("bf16 teacher-forced:", tf)
     print("bf16 free-running  :", fr)
-    assert tf["bit_agreement_min_row"] >= 0.97 and tf["seg_agreement"] >= 0.97
-    assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5
+    assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99, tf
+    assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, tf
     rows = fr["bit_agreement_per_row"]
     for r in ("roi", "x5", "x4", "x3", "y5", "y4", "y3"):
-        assert rows[r] >= 0.97, (r, rows[r])
-    assert fr["bit_agreement_min_row"] >= 0.90 and fr["seg_agreement"] >= 0.97
-    assert fr["xy_id_equal"] >= 0.75 and fr["id_abs_err_mean_px"] <= 1.5
+        assert rows[r] >= 0.98, (r, rows[r])
+    assert fr["bit_agreement_min_row"] >= 0.95 and fr["seg_agreement"] >= 0.99, fr
+    assert fr["xy_id_equal"] >= 0.90 and fr["id_abs_err_mean_px"] <= 0.5, fr
 
 
 def test_e2e_teacher_forced_per_stage(lib):
