@@ -19,6 +19,8 @@ USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 k
 USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 256-64-64-256 Bottleneck kernel (bf16)
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
+USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
+CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "16"))   # below: per-conv launches (a crop's chain runs on ONE CU)
 NO_RECYCLE = os.environ.get("CHECKERPOSE_AMD_NO_RECYCLE", "0") == "1"   # debugging aid: every workspace tensor gets its own bytes
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
@@ -122,6 +124,25 @@ class WeightStore:
         self.cache[ck] = out
         return out
 
+    def pack_chain(self, name, ws, affs, C_, H, W):
+        """the 8 convs of an HRNet branch chain: one packed weight blob + one [8][2][AFF] fp32 affine tensor"""
+        ck = ("chain", name)
+        if ck in self.cache:
+            return self.cache[ck]
+        blob = torch.empty(self.lib.cp_hr_chain_weight_bytes(C_, H, W), dtype=torch.uint8, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for i, w in enumerate(ws):
+            w = w.contiguous()
+            self.keep.append(w)
+            _abi.check(self.lib.cp_pack_hr_chain_weight(st, w.data_ptr(), C_, H, W, i, blob.data_ptr()), "cp_pack_hr_chain_weight(%s)" % name)
+        n = self.lib.cp_hr_chain_affine_floats(C_, H, W)
+        aff = torch.zeros(8, 2, n, dtype=torch.float32, device=self.device)
+        for i, (s_, t_) in enumerate(affs):
+            aff[i, 0, :C_] = s_
+            aff[i, 1, :C_] = t_
+        self.cache[ck] = (blob, aff)
+        return self.cache[ck]
+
     def affine(self, name, scale, shift, rows):
         """fp32 scale/shift vectors padded with zeros to a multiple of 16 entries (rows >= len)."""
         ck = ("aff", name, rows)
@@ -205,6 +226,17 @@ class Program:
         """lane `dst` waits for everything launched on lane `src` so far"""
         assert self._open is not None and src != dst
         self.ops.append(("__sync__", src, dst))
+
+    def mark(self, lane):
+        """remember the current tail of `lane`; wait(token, dst) later makes lane `dst` wait for exactly that point"""
+        assert self._open is not None
+        self._nmarks = getattr(self, "_nmarks", 0) + 1
+        self.ops.append(("__mark__", self._nmarks, lane))
+        return self._nmarks
+
+    def wait(self, token, dst):
+        assert self._open is not None
+        self.ops.append(("__wait__", token, dst))
 
     def par_end(self):
         assert self._open is not None
@@ -305,6 +337,37 @@ class Program:
         nb = x.B * x.H * x.W * C_ * self.es
         self.flops += 2 * fl
         self.conv_log.append((k1, x.B * x.H * x.W, C_, 9 * C_, 2 * fl, "basicblock_fused", 2 * nb + 2 * 9 * C_ * C_ * self.es))
+        return out
+
+    def can_chain(self, C_, H, W):
+        return (USE_CHAIN and self.dtype == CP_BF16 and self.B >= CHAIN_MIN_BATCH and bool(self.lib.cp_hr_chain_supported(C_, H, W)))
+
+    def hr_chain(self, name, srcs, shifts, relu_in, ws, affs, C_, H, W):
+        """4 BasicBlocks of an HRNet branch on relu(sum of `srcs` (nearest-upsampled by 2^shift)) in ONE launch
+        (cp_hr_branch_chain): ws / affs = the 8 fp32 conv weights and folded-BN (scale, shift) pairs in execution order."""
+        blob, aff = self.ws.pack_chain(name, ws, affs, C_, H, W)
+        out = self.act(H, W, C_)
+        n = len(srcs)
+        arr_p = (C.c_void_p * 4)()
+        arr_s = (C.c_int32 * 4)(*([int(v) for v in shifts] + [0] * (4 - n)))
+        self.keep += [arr_p, arr_s, blob, aff]
+        for s_, sh in zip(srcs, shifts):
+            assert s_.coff == 0 and s_.cstride == s_.Cphys == out.Cphys and (s_.H << sh, s_.W << sh) == (H, W)
+        tbs = [s_.tbuf for s_ in srcs]
+        ot = out.tbuf
+        fn = self.lib.cp_hr_branch_chain
+        bp, ap = blob.data_ptr(), aff.data_ptr()
+
+        def argb(P):
+            for i, t in enumerate(tbs):
+                arr_p[i] = P(t)
+            return (self.B, C_, H, W, n, arr_p, arr_s, 1 if relu_in else 0, bp, ap, P(ot))
+
+        self._add(fn, argb, "hr_chain:" + name, tbs, [ot])
+        fl = 8 * 2 * self.B * H * W * 9 * C_ * C_
+        self.flops += fl
+        nb = self.B * H * W * C_ * self.es
+        self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es))
         return out
 
     def can_fuse_bottleneck(self, x: Act, planes, cout, has_ds):
@@ -490,6 +553,10 @@ class Program:
                 self.sched.append(("sync", op[1], op[2]))
             elif op[0] == "__join__":
                 self.sched.append(("join",))
+            elif op[0] == "__mark__":
+                self.sched.append(("mark", op[1], op[2]))
+            elif op[0] == "__wait__":
+                self.sched.append(("wait", op[1], op[2]))
             else:
                 fn, argb, name, lane = op
                 self.sched.append(("op", len(self.calls), lane))
@@ -509,6 +576,7 @@ class Program:
         ptr = [s.cuda_stream for s in streams]
         active = 1
         events = []          # returned: the caller keeps them alive until the capture has ended
+        marks = {}
 
         def new_event():
             events.append(torch.cuda.Event())
@@ -531,6 +599,11 @@ class Program:
                 ev = new_event()
                 ev.record(streams[item[1]])
                 streams[item[2]].wait_event(ev)
+            elif kind == "mark":
+                marks[item[1]] = new_event()
+                marks[item[1]].record(streams[item[2]])
+            elif kind == "wait":
+                streams[item[2]].wait_event(marks[item[1]])
             else:   # join
                 for k in range(1, active):
                     ev = new_event()

@@ -149,29 +149,74 @@ class NetEmitter:
         return self.conv_bn(y, pfx + ".conv3", pfx + ".bn3", 1, 1, 0, relu=True, residual=sc, out=out)
 
     # ---- HRNet-W18 features (timm HighResolutionNetFeatures)
-    def hr_module(self, pfx, xs):
+    def _materialize(self, x):
+        """a module output that is still the un-summed list of fuse terms -> one activation (cp_fuse_sum_act)"""
+        if isinstance(x, Act):
+            return x
+        terms, shifts = x
+        out = self.p.act(terms[0].H << shifts[0], terms[0].W << shifts[0], terms[0].C)
+        return self.p.fuse_sum(terms, shifts, out, relu=True)
+
+    def hr_module(self, pfx, xs, lazy=False):
+        """One timm HighResolutionModule.  xs[j]: an Act, or (terms, shifts) = the previous module's fuse terms of branch j
+        still un-summed.  With lazy=True the outputs are returned in that un-summed form too: a branch that runs as ONE
+        chain launch (engine.hr_chain, bf16) sums + ReLUs them while staging its map into LDS, other consumers
+        materialise them (fuse_sum launch)."""
         nb = len(xs)
         xs = list(xs)
         p = self.p
-        # lane j: branch j's four BasicBlocks, then every fuse-layer conv chain that is fed by branch j
+        # lane j: branch j's four BasicBlocks; then lane i runs the fuse-layer conv chains INTO branch i (it waits for the
+        # source branch j): the long stride-2 chains fed by the 64x64 branch -- the module's critical path -- then run beside
+        # each other on the lanes whose own (low-resolution) branch finished early, not one after the other behind branch 0
         terms = [[None] * nb for _ in range(nb)]
         p.par_begin(nb)
         for j in range(nb):
             p.set_lane(j)
-            for k in range(4):
-                xs[j] = self.basic_block("%s.branches.%d.%d" % (pfx, j, k), xs[j])
-            for i in range(nb):
-                q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
-                if j == i:
-                    t = xs[j]
-                elif j > i:
-                    t = self.conv_bn(xs[j], q + ".0", q + ".1", 1, 1, 0, relu=False)
-                else:
-                    t = xs[j]
-                    for k in range(i - j):
-                        t = self.conv_bn(t, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), 3, 2, 1, relu=(k != i - j - 1))
-                terms[i][j] = t
+            if isinstance(xs[j], Act):
+                C_, H, W = xs[j].C, xs[j].H, xs[j].W
+            else:
+                t0, sh0 = xs[j][0][0], xs[j][1][0]
+                C_, H, W = t0.C, t0.H << sh0, t0.W << sh0
+            if self.tp is None and p.can_chain(C_, H, W):
+                srcs, shifts = ([xs[j]], [0]) if isinstance(xs[j], Act) else xs[j]
+                bp = "%s.branches.%d" % (pfx, j)
+                ws = [self.W("%s.%d.conv%d.weight" % (bp, k, c)) for k in range(4) for c in (1, 2)]
+                affs = [self.ws.bn_fold("%s.%d.bn%d" % (bp, k, c)) for k in range(4) for c in (1, 2)]
+                xs[j] = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W)
+            else:
+                xs[j] = self._materialize(xs[j])
+                for k in range(4):
+                    xs[j] = self.basic_block("%s.branches.%d.%d" % (pfx, j, k), xs[j])
+        if self.tp is not None:              # training program: lane j also runs the fuse chains fed by branch j (program order)
+            sched = [(j, i, j) for j in range(nb) for i in range(nb) if i != j]
+        else:
+            # eval: the fuse-layer conv chains run in a second fork/join region, spread over the lanes by length (the three
+            # stride-2 chains fed by the 64x64 branch used to queue up behind it on ONE lane: the module's critical path).
+            # (Cross-lane event edges inside one region would express this without the join, but a capture in which two
+            # streams wait on each other's events crashes hipStreamEndCapture on ROCm 7.2.)
+            p.par_end()
+            p.par_begin(nb)
+            load = [0.0] * nb
+            sched = []
+            for cost, i, j in sorted([((i - j) if j < i else 0.3, i, j) for i in range(nb) for j in range(nb) if i != j], reverse=True):
+                ln = min(range(nb), key=lambda k: load[k])
+                load[ln] += cost
+                sched.append((ln, i, j))
+        for i in range(nb):
+            terms[i][i] = xs[i]
+        for ln, i, j in sched:
+            p.set_lane(ln)
+            q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+            if j > i:
+                t = self.conv_bn(xs[j], q + ".0", q + ".1", 1, 1, 0, relu=False)
+            else:
+                t = xs[j]
+                for k in range(i - j):
+                    t = self.conv_bn(t, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), 3, 2, 1, relu=(k != i - j - 1))
+            terms[i][j] = t
         p.par_end()
+        if lazy and self.tp is None:
+            return [(terms[i], [max(j - i, 0) for j in range(nb)]) for i in range(nb)]
         outs = []
         p.par_begin(nb)                      # the nb fuse sums are independent of each other
         for i in range(nb):
@@ -207,8 +252,8 @@ class NetEmitter:
             if si > 0:
                 t = "%stransition%d.%d.0" % (pfx, si + 1, len(chans) - 1)
                 xs = xs + [self.conv_bn(xs[-1], t + ".0", t + ".1", 3, 2, 1)]
-            for m in range(nmod):
-                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs)
+            for m in range(nmod):           # inside a stage the fuse sums stay un-summed for the next module's chain launches
+                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs, lazy=(m + 1 < nmod))
         feats = []
         self.p.par_begin(len(xs))            # the four incre bottlenecks are independent
         for i, f in enumerate(xs):

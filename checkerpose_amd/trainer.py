@@ -403,7 +403,7 @@ class TrainProgram(Program):
             off += t.nbytes
         super().finalize()
         # n_fwd_ops was recorded in units of emitted ops (launches + fork/sync/join markers): convert to launches
-        markers = ("__fork__", "__sync__", "__join__")
+        markers = ("__fork__", "__sync__", "__join__", "__mark__", "__wait__")
         self.n_fwd_ops = sum(1 for op in self.ops[:self.n_fwd_ops] if op[0] not in markers)
         ci, prep_calls, flops = 0, set(), {}
         for i, op in enumerate(self.ops):
@@ -476,6 +476,8 @@ class TrainProgram(Program):
                     ev = new_event()
                     ev.record(streams[item[1]])
                     streams[item[2]].wait_event(ev)
+            elif kind in ("mark", "wait"):
+                raise RuntimeError("mark/wait lane edges are not emitted in training programs")
             else:
                 for k in range(1, active):
                     ev = new_event()

@@ -174,6 +174,24 @@ int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* patches, con
                          const int32_t* y_id, const float* mask, void* out, int B, int N, int Hp, int Wp,
                          int E, int k, int out_cstride, int out_coff);
 
+/* ---------------------------------------------------------------------------------------------
+ * One launch per HRNet branch chain (bf16): the four BasicBlocks of `HighResolutionModule.branches[j]` (inside
+ * timm.create_model("hrnet_w18", features_only=True), reference backbone.py:48-49; restated oracle/checkerpose_oracle.py
+ * _hr_module) preceded by the previous module's fuse sum, with the crop's whole branch map resident in LDS.
+ *   x   = [relu]( sum_k upsample_nearest(src_k, 2^shift_k) )        srcs (B, H>>shift, W>>shift, Cphys) bf16, Cphys = ceil8(C)
+ *   for blk in 0..3:  x = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )
+ *   out = x                                                           (B, H, W, Cphys) bf16, pad channels exactly zero
+ * Supported (C, H, W): (36, 32, 32), (72, 16, 16), (144, 8, 8) -- the HRNet-W18 branches 1..3 of a 256 x 256 crop
+ * (cp_hr_chain_supported).  Weights: cp_pack_hr_chain_weight() packs conv `conv_index` (0..7 = block.conv1, block.conv2, ...)
+ * of fp32 (C, C, 3, 3) weights into the caller-owned blob of cp_hr_chain_weight_bytes() bytes; `affine` = fp32
+ * [8][2][cp_hr_chain_affine_floats()] folded-BN (scale, shift) per conv, zero beyond C.  out must not alias a source. */
+int cp_hr_chain_supported(int C, int H, int W);
+size_t cp_hr_chain_weight_bytes(int C, int H, int W);
+int cp_hr_chain_affine_floats(int C, int H, int W);
+int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, int C, int H, int W, int conv_index, void* blob);
+int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
+                       const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out);
+
 /* Bit decode (pipeline.py:72-127, 367-369, 380-381) on the fp32 logit block `bits` (B, 13, N):
  * row 0 = roi, rows 1..6 = x bits (MSB first), rows 7..12 = y bits.
  *   stage < 0 : mask = bit(bits[0]) ; x_id = MSB-first int of rows 1..3 ; y_id of rows 7..9

@@ -226,6 +226,63 @@ def test_basicblock_fused_vs_torch_cpu(lib, dtype, Cc, shape):
                                    pw2.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), xin.data_ptr()) == -1   # in-place refused
 
 
+@pytest.mark.parametrize("nsrc", [1, 3])
+@pytest.mark.parametrize("cfg", [(36, 32, 32, 3), (72, 16, 16, 5), (144, 8, 8, 3), (36, 32, 32, 1)])
+def test_hr_branch_chain_vs_torch_cpu(lib, cfg, nsrc):
+    """cp_hr_branch_chain (one launch, map resident in LDS, K packed across taps) == the previous module's fuse sum
+    (nearest-upsampled terms, ReLU) followed by the 4 BasicBlocks of an HRNet branch, every stored tensor rounded to bf16
+    (timm HighResolutionModule.branches[j], restated oracle _hr_module).  Odd batches (two crops per workgroup on the
+    72/144-channel branches), pad channels exactly zero, in-place refused."""
+    Cc, H, W, B = cfg
+    assert lib.cp_hr_chain_supported(Cc, H, W) == 1 and lib.cp_hr_chain_supported(18, 64, 64) == 0
+    dtype = CP_BF16
+    v4 = lambda v: v.view(1, -1, 1, 1)   # noqa: E731
+    terms = [det_tensor("ct0%d" % Cc, (B, Cc, H, W))]
+    shifts = [0]
+    if nsrc == 3:
+        terms += [det_tensor("ct1%d" % Cc, (B, Cc, H // 2, W // 2)), det_tensor("ct2%d" % Cc, (B, Cc, H, W), 0.5)]
+        shifts += [1, 0]
+    x = None
+    for t, sh in zip(terms, shifts):
+        u = rnd(t, dtype)
+        if sh:
+            u = F.interpolate(u, scale_factor=2 ** sh, mode="nearest")
+        x = u if x is None else x + u
+    x = rnd(F.relu(x) if nsrc > 1 else x, dtype)
+    ws = [det_tensor("cw%d_%d" % (i, Cc), (Cc, Cc, 3, 3), (2.0 / (Cc * 9)) ** 0.5 * 1.5) for i in range(8)]
+    affs = [(1.0 + 0.3 * det_tensor("cs%d_%d" % (i, Cc), (Cc,)), 0.2 * det_tensor("cb%d_%d" % (i, Cc), (Cc,))) for i in range(8)]
+    for i in range(1, 8, 2):
+        affs[i] = (affs[i][0] * 0.4, affs[i][1])               # damp the residual branch like a trained net's last BN
+    for k in range(4):
+        t = rnd(F.relu(F.conv2d(x, rnd(ws[2 * k], dtype), None, 1, 1) * v4(affs[2 * k][0]) + v4(affs[2 * k][1])), dtype)
+        x = rnd(F.relu(F.conv2d(t, rnd(ws[2 * k + 1], dtype), None, 1, 1) * v4(affs[2 * k + 1][0]) + v4(affs[2 * k + 1][1]) + x), dtype)
+    ref = x
+    blob = torch.empty(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev())
+    for i, w in enumerate(ws):
+        wd = w.contiguous().to(dev())
+        _abi.check(lib.cp_pack_hr_chain_weight(st(), wd.data_ptr(), Cc, H, W, i, blob.data_ptr()))
+        torch.cuda.synchronize()
+    n = lib.cp_hr_chain_affine_floats(Cc, H, W)
+    aff = torch.zeros(8, 2, n)
+    for i, (s_, t_) in enumerate(affs):
+        aff[i, 0, :Cc], aff[i, 1, :Cc] = s_, t_
+    aff = aff.to(dev())
+    srcs = [to_cl(t, dtype) for t in terms]
+    cp = srcs[0].shape[-1]
+    out = torch.full((B, H, W, cp), float("nan"), dtype=DT[dtype], device=dev())
+    arr_p = (C.c_void_p * 4)(*([s_.data_ptr() for s_ in srcs] + [None] * (4 - nsrc)))
+    arr_s = (C.c_int32 * 4)(*(shifts + [0] * (4 - nsrc)))
+    _abi.check(lib.cp_hr_branch_chain(st(), B, Cc, H, W, nsrc, arr_p, arr_s, 1 if nsrc > 1 else 0, blob.data_ptr(), aff.data_ptr(),
+                                      out.data_ptr()), "hr chain")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    if cp > Cc:
+        assert float(out[..., Cc:].float().abs().max()) == 0.0
+    close(from_cl(out, Cc), ref, 4e-2)
+    arr_p[0] = out.data_ptr()
+    assert lib.cp_hr_branch_chain(st(), B, Cc, H, W, nsrc, arr_p, arr_s, 0, blob.data_ptr(), aff.data_ptr(), out.data_ptr()) == -1
+
+
 @pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 13, 21), (9, 8, 16), (3, 64, 64)])
 def test_bottleneck_fused_vs_torch_cpu(lib, shape, ds):
@@ -698,9 +755,11 @@ def test_e2e_resnet34_backbone(lib):
     _cmp_e2e(net(img.to(dev()), None), ref)
 
 
-def test_batch_slices_concurrent_graphs_bitwise(lib):
+def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     """B=16 is run as two concurrent 8-crop slice graphs (CHECKERPOSE_AMD_SPLITS=2): identical, bit for bit, to the
     unsplit sequential replay; bf16 so the test is cheap on the CPU side (no oracle needed: pure scheduling check)."""
+    from checkerpose_amd import engine
+    monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)      # slices and the unsplit batch must pick the same kernels
     img = det_image(16, seed=3).to(dev())
     net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
     net.batch_splits = 2
