@@ -688,7 +688,8 @@ def test_e2e_lm13_n4096_config5(lib):
     assert tuple(out[1].shape) == (2, 6, 4096) and out[4].dtype == torch.int64
 
 
-def test_e2e_bf16_accuracy_contract(lib):
+@pytest.mark.parametrize("chain", [False, True])
+def test_e2e_bf16_accuracy_contract(lib, monkeypatch, chain):
     """bf16 path (BASELINE config #2, the path bench.py times): not a 1e-4 path -- its written contract
     (checkerpose_amd/agreement.py), checked against the CPU oracle at B=4 on random-init weights:
       teacher-forced (discrete feedback taken from the oracle, so one flipped bit cannot compound):
@@ -699,7 +700,10 @@ def test_e2e_bf16_accuracy_contract(lib):
         keypoints, mean id error <= 0.5 px.
     (measured, round 2, vs the fp32 HIP path on 8 crops: teacher-forced min row 0.9895, mean |dlogit| 0.74 % of RMS,
     max 0.35; free-running min row 0.984, id pairs equal 96.2 %, 0.16 px)"""
+    from checkerpose_amd import engine
     from checkerpose_amd.agreement import logit_agreement
+    # both kernel selections of the HRNet branches: per-conv launches (small batches) / one LDS-resident chain launch each
+    monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1 if chain else 1 << 30)
     net = build_net(seed=1)
     img = det_image(4, seed=3)
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
@@ -833,11 +837,14 @@ def test_uint8_input_path_on_device(lib):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_full_batch_size_property_batch_independence(lib, dt):
+def test_full_batch_size_property_batch_independence(lib, dt, monkeypatch):
     """Size-independent property at the BENCH batch size (bench.py default: 256 crops): a crop's outputs must not depend on
     its batch mates or on the batch size (different grids, tiles, persistent-block schedules, workspace placement, graph
     lanes).  256 crops = 4 distinct crops x 64 copies: every copy must equal, bit for bit, the B=4 forward -- which
     test_e2e_* pins to the oracle (fp32) and test_e2e_bf16_accuracy_contract bounds (bf16)."""
+    from checkerpose_amd import engine
+    monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)    # same kernel selection at B=4 and B=256 (below 16 crops the engine
+    #                                                      would pick per-conv launches: other K order, other bf16 roundings)
     net = build_net(seed=1).to(dev()).set_compute_dtype(dt)
     img4 = det_image(4, seed=3 if dt == "bf16" else 21).to(dev())     # bf16: the crops of the accuracy-contract test
     ref4 = net(img4, None)
