@@ -21,7 +21,7 @@ def _replay_half(mod, pr, which, lo, hi, device):
     cur = torch.cuda.current_stream(device)
     lib = _abi.load()
     g = pr["graphs"].get(which)
-    if not mod.use_graph or which not in TRAIN_GRAPH or not pr["warm"].get(which):
+    if not mod.use_graph or which[:3] not in TRAIN_GRAPH or not pr["warm"].get(which):
         prog.run_range(cur.cuda_stream, lo, hi)
         pr["warm"][which] = True
         return
@@ -75,15 +75,24 @@ class _TrainFn(torch.autograd.Function):
         io["dinit"].copy_(torch.cat([dbits[:, 0:4], dbits[:, 7:10]], dim=1))
         if "dseg" in io:
             io["dseg"].copy_(dseg)
-        _replay_half(mod, pr, "bwd", prog.n_fwd_ops, len(prog.calls), dbits.device)
         pg = pr["pgrad"]
-        if mod.dp_allreduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            from ..parallel import allreduce_gradients_
-            allreduce_gradients_([pg], bucket_bytes=1 << 40, average=True)
-        pgc = pg.clone()       # ONE copy per step; autograd may keep (steal) the per-parameter views of this fresh buffer
-        grads = tuple(pgc[o:o + p.numel()].view_as(p) if p.requires_grad else None
-                      for (o, p) in zip(pr["offsets"], pr["params"]))
+        # autograd may have stolen last step's views of this buffer as param.grad (zero_grad(set_to_none=False) or gradient
+        # accumulation): the backward is about to overwrite it, so such gradients get storage of their own first
+        lo_p, hi_p = pg.data_ptr(), pg.data_ptr() + pg.numel() * 4
+        for p_ in pr["params"]:
+            if p_.grad is not None and lo_p <= p_.grad.data_ptr() < hi_p:
+                p_.grad = p_.grad.clone()
+        dist_on = (mod.dp_allreduce and torch.distributed.is_available() and torch.distributed.is_initialized()
+                   and torch.distributed.get_world_size() > 1)
+        if dist_on:       # the ONE exchange of the data-parallel step: bucketed, each bucket overlapped with the rest of the backward
+            from ..parallel import backward_with_bucketed_allreduce_
+            backward_with_bucketed_allreduce_(pg, pr["segments"],
+                                              lambda k, lo, hi: _replay_half(mod, pr, "bwd%d" % k, lo, hi, dbits.device))
+        else:
+            _replay_half(mod, pr, "bwd", prog.n_fwd_ops, len(prog.calls), dbits.device)
+        live = pr["live_params"]      # parameters the (B, stage) program writes; the rest keep grad None (as in the reference)
+        grads = tuple(pg[o:o + p.numel()].view_as(p) if (p.requires_grad and lv) else None
+                      for (o, p, lv) in zip(pr["offsets"], pr["params"], live))
         pr["busy"] = None
         return (None, None, None) + grads
 
@@ -121,6 +130,11 @@ class HipForwardMixin:
                     lib.cp_graph_destroy(g)
         self._programs, self._stores, self._idx_dev = {}, {}, None
         self._train_programs = {}
+        # the owning PoseNet folded this init net's weights into ITS programs, and vice versa: drop those too
+        for other in (getattr(self, "_owner", None), getattr(self, "init_net", None)):
+            other = other() if callable(other) and not isinstance(other, torch.nn.Module) else other
+            if other is not None and hasattr(other, "_programs") and (other._programs or other._train_programs or other._stores):
+                other.invalidate()
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -262,8 +276,11 @@ class HipForwardMixin:
         prog.unwind()
         prog.finalize()
         torch.cuda.current_stream(device).synchronize()
+        names = [n for n, _ in self.named_parameters()]
         return dict(prog=prog, io=io, pgrad=pgrad, params=params, offsets=offsets, counters=list(em.bn_counters), busy=None,
-                    graphs={}, warm={}, keep_streams=[], ptrs=self._storage_signature())
+                    graphs={}, warm={}, keep_streams=[], ptrs=self._storage_signature(),
+                    segments=prog.gradient_buckets(int(os.environ.get("CHECKERPOSE_AMD_GRAD_BUCKETS", "4"))),
+                    live_params=[n in prog.pslot_done for n in names])
 
     def _storage_signature(self):
         """the launch program holds raw pointers into the parameter / buffer storage (live weights): if anything re-assigned a
@@ -289,11 +306,23 @@ class HipForwardMixin:
                 lib.cp_graph_destroy(g)
             pr = None
         if pr is None:
+            dist = torch.distributed
+            if (self.dp_allreduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                    and not getattr(self, "_dp_synced", False)):
+                # data-parallel replicas must start from identical parameters AND BatchNorm buffers: rank 0's are broadcast
+                # once (replicas that were not seeded identically would otherwise diverge silently)
+                for t in list(self.parameters()) + list(self.buffers()):
+                    dist.broadcast(t.data, 0)
+                self._dp_synced = True
             with torch.cuda.device(device):
                 pr = self._build_train(lib, B, size, stage, device, u8)
             self._train_programs[key] = pr
         io = pr["io"]
-        self._stale_eval = True
+        self._stale_eval = True                 # ... of this module, of the init net inside it and of the PoseNet around it
+        for other in (getattr(self, "_owner", None), getattr(self, "init_net", None)):
+            other = other() if callable(other) and not isinstance(other, torch.nn.Module) else other
+            if other is not None and hasattr(other, "_stale_eval"):
+                other._stale_eval = True
         with torch.cuda.device(device):
             if self.LM:
                 if obj_ids is None:

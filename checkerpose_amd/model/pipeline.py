@@ -117,6 +117,8 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
                                                     knn_idx=knn_idx))
         self.seg_block = nn.Conv2d(num_filters, seg_output_dim, kernel_size=1, padding=0, bias=True)
         self._init_runtime()
+        import weakref
+        object.__setattr__(init_net, "_owner", weakref.ref(self))     # init_net.load_state_dict() must drop OUR folded weights too
 
     def _net_cfg(self):
         c = dict(self.cfg)

@@ -71,6 +71,11 @@ def allreduce_gradients_(tensors, bucket_bytes=64 << 20, average=True, group=Non
     if cur:
         buckets.append(cur)
     for b in buckets:
+        if len(b) == 1 and b[0].is_contiguous():          # a single flat tensor: reduce it in place, no staging copy
+            dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=group)
+            if average:
+                b[0].div_(world)
+            continue
         flat = torch.cat([t.reshape(-1) for t in b])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
@@ -81,3 +86,49 @@ def allreduce_gradients_(tensors, bucket_bytes=64 << 20, average=True, group=Non
             t.copy_(flat[off:off + n].view_as(t))
             off += n
     return len(buckets)
+
+
+def plan_gradient_buckets(slots, total, done_call, first_call, n_calls, nbuckets=4):
+    """slots: parameter name -> element offset into the flat gradient buffer of `total` elements (module order);
+    done_call[name] = index of the first backward launch by which that parameter's gradient is final (absent: never written).
+    Returns [(call_lo, call_hi, elem_lo, elem_hi)]: ~equal contiguous buckets, cut from the buffer's tail (the backward runs
+    head first, so the tail -- decoder / refinement parameters -- is final long before the backbone's gradients), with the
+    launches [first_call, n_calls) split into as many consecutive segments such that bucket k is final after segment k."""
+    keys = sorted(slots, key=slots.get)
+    starts = [slots[k] for k in keys]
+    ends = starts[1:] + [total]
+    target = max(total // max(nbuckets, 1), 1)
+    buckets, hi, done, size = [], total, first_call, 0
+    for k, lo_k, hi_k in reversed(list(zip(keys, starts, ends))):
+        done = max(done, done_call.get(k, first_call))
+        size += hi_k - lo_k
+        if size >= target and len(buckets) < nbuckets - 1 and lo_k > 0:
+            buckets.append((done, lo_k, hi))
+            hi, done, size = lo_k, first_call, 0
+    buckets.append((done, 0, hi))
+    buckets.sort()
+    segs, lo = [], first_call
+    for i, (d, a, b) in enumerate(buckets):
+        d = n_calls if i == len(buckets) - 1 else min(max(d, lo), n_calls)
+        segs.append((lo, d, a, b))
+        lo = d
+    return segs
+
+
+def backward_with_bucketed_allreduce_(flat, segments, run_segment, average=True, group=None):
+    """The data-parallel backward: `segments` = [(lo, hi, a, b)] in launch order; run_segment(k, lo, hi) enqueues the backward
+    launches [lo, hi) on the current stream, after which flat[a:b] is final.  Each bucket's all-reduce is issued
+    asynchronously right behind its segment, so it travels (RCCL ring over xGMI / gloo in the tests) while the later
+    segments compute; all are awaited at the end and the buffer is averaged in place -- no staging copy of the 85 MB
+    buffer.  Every rank issues the same collectives in the same order.  Returns the number of collectives."""
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    works = []
+    for k, (lo, hi, a, b) in enumerate(segments):
+        run_segment(k, lo, hi)
+        if on and b > a:
+            works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    if on and average:
+        flat.div_(dist.get_world_size(group))
+    return len(works)

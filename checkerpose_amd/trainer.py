@@ -93,6 +93,7 @@ class TrainProgram(Program):
         self.wg_ws = torch.empty(160 << 20, dtype=torch.uint8, device=device)     # weight-gradient slice partials
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
+        self._touched, self.pslot_done, self.pslot_done_call = [], {}, {}
         self._ones, self._zeros = {}, {}
         self.acc_total = 0         # fp64 BatchNorm accumulators (elements), one arena zero-filled at the start of a step
         self.acc_arena = None
@@ -151,6 +152,7 @@ class TrainProgram(Program):
         return t
 
     def pg_ptr(self, key):
+        self._touched.append(key)          # the tape closure being unwound writes this parameter's gradient
         return self.pgrad.data_ptr() + 4 * self.pslots[key]
 
     def memset_t(self, tbuf, name="memset"):
@@ -404,6 +406,12 @@ class TrainProgram(Program):
         super().finalize()
         # n_fwd_ops was recorded in units of emitted ops (launches + fork/sync/join markers): convert to launches
         markers = ("__fork__", "__sync__", "__join__", "__mark__", "__wait__")
+        nmark, before = 0, []
+        for op in self.ops:                     # before[i] = launches among ops[:i]
+            before.append(nmark)
+            nmark += 0 if op[0] in markers else 1
+        before.append(nmark)
+        self.pslot_done_call = {k: before[i] for k, i in self.pslot_done.items()}
         self.n_fwd_ops = sum(1 for op in self.ops[:self.n_fwd_ops] if op[0] not in markers)
         ci, prep_calls, flops = 0, set(), {}
         for i, op in enumerate(self.ops):
@@ -430,9 +438,21 @@ class TrainProgram(Program):
             self._add(self.lib.cp_pack_batch, (lambda k: lambda P: self._batch_args(k, 1))(kind), "prep_%s_bwd" % kind, [], [])
 
     def unwind(self):
+        """append the backward launches; remember, per parameter, the op index after which its gradient is final"""
         for fn in reversed(self.tape):
+            self._touched = []
             fn()
+            for key in self._touched:
+                self.pslot_done[key] = len(self.ops)
         self.tape = []
+
+    def gradient_buckets(self, nbuckets=4):
+        """Cut the flat gradient buffer into ~equal contiguous buckets and the backward launches into as many segments, such
+        that bucket k is final once segment k has run: [(call_lo, call_hi, elem_lo, elem_hi)], segments in launch order.  The
+        backward runs head first, so the buffer's tail (decoder / refinement parameters) completes long before the
+        backbone's -- its all-reduce can travel over xGMI under the remaining backward."""
+        from .parallel import plan_gradient_buckets
+        return plan_gradient_buckets(self.pslots, self.pgrad.numel(), self.pslot_done_call, self.n_fwd_ops, len(self.calls), nbuckets)
 
     def read_act(self, a: Act):
         """debug: the current contents of an activation / gradient view as a (B, H, W, C) fp32 CPU tensor"""

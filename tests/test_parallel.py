@@ -61,3 +61,59 @@ def test_two_rank_gloo_aggregation():
     assert abs(thr0 - 7 / mx0) < 1e-6 and thr0 == thr1             # whole-job crops / max time
     assert full0 == full1 == [[float(i)] * 3 for i in range(7)]    # rank-ordered ragged gather
     assert nb0 == nb1 == 2 and g0 == g1 == [[1.5] * 5, [15.0] * 6, [-0.5] * 4]     # bucketed mean all-reduce
+
+
+def test_plan_gradient_buckets_covers_buffer_and_orders_segments():
+    from checkerpose_amd.parallel import plan_gradient_buckets
+    # module order: backbone (largest, final LAST in the backward), init head, decoder, refinement, seg (final FIRST)
+    slots = {"bb.a": 0, "bb.b": 400, "init.c": 1000, "up.d": 1100, "ref.e": 1700, "seg.f": 1990, "unused.g": 1996}
+    done = {"seg.f": 12, "ref.e": 30, "up.d": 45, "init.c": 60, "bb.b": 80, "bb.a": 95}
+    segs = plan_gradient_buckets(slots, 2000, done, first_call=10, n_calls=100, nbuckets=4)
+    assert segs[0][0] == 10 and segs[-1][1] == 100
+    assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))                       # consecutive launch segments
+    spans = sorted((a, b) for _, _, a, b in segs)
+    assert spans[0][0] == 0 and spans[-1][1] == 2000 and all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+    for lo, hi, a, b in segs:                                                       # a bucket is reduced only once it is final
+        for k, off in slots.items():
+            if a <= off < b:
+                assert done.get(k, 10) <= hi
+    assert segs[0][2] >= 1000 and segs[-1][2] == 0                                  # tail first, backbone last
+    assert plan_gradient_buckets(slots, 2000, done, 10, 100, nbuckets=1) == [(10, 100, 0, 2000)]
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from checkerpose_amd.parallel import backward_with_bucketed_allreduce_, plan_gradient_buckets
+    slots = {"bb": 0, "head": 300, "seg": 650}
+    segs = plan_gradient_buckets(slots, 1000, {"seg": 3, "head": 5, "bb": 9}, first_call=2, n_calls=10, nbuckets=3)
+    flat = torch.zeros(1000)
+    log = []
+
+    def run_segment(k, lo, hi):                    # the "backward launches" [lo, hi): bucket k's slice becomes final
+        a, b = segs[k][2], segs[k][3]
+        assert float(flat[a:b].abs().max()) == 0.0                                 # not reduced / written before its segment
+        flat[a:b] = float(rank + 1) * (k + 1)
+        log.append((k, lo, hi))
+
+    n = backward_with_bucketed_allreduce_(flat, segs, run_segment)
+    q.put((rank, segs, n, log, [float(flat[a]) for _, _, a, _ in segs], float(flat.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_backward_allreduce():
+    """the data-parallel backward path of _TrainFn.backward (model/_runtime.py) under gloo: segments run in order, one
+    async all-reduce per bucket right behind its segment, mean over ranks in place, identical on both ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, segs0, n0, log0, vals0, sum0), (_, segs1, n1, log1, vals1, sum1) = res
+    assert segs0 == segs1 and n0 == n1 == 3 and log0 == log1 == [(k, lo, hi) for k, (lo, hi, _, _) in enumerate(segs0)]
+    assert vals0 == vals1 == [1.5 * (k + 1) for k in range(3)]                      # mean of (1, 2) * (k + 1)
+    assert sum0 == sum1
