@@ -25,6 +25,13 @@
 
 #include "common.h"
 
+// the 64x64x18 branch has its own kernel (hr_chain0.hip: banded in-place update, residual through HBM)
+size_t cp_chain0_conv_bytes();
+int cp_chain0_aff();
+int cp_chain0_pack(hipStream_t st, const float* w, int conv_index, void* blob);
+int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
+                     const void* packed_w, const float* affine, void* out);
+
 namespace {
 
 template <int C_, int H_, int W_, int CPW_, int NWC_, int S_, int RL_>
@@ -380,6 +387,7 @@ bool chain_info(int C, int H, int W, ChainInfo* o) {
 #define CP_CI(CFG) if (C == CFG::C && H == CFG::H && W == CFG::W) { *o = ChainInfo{C, H, W, CFG::KCP, CFG::NT_ALL, CFG::CG, CFG::AFF, CFG::CONV_W}; return true; }
   CP_CI(CfgB1) CP_CI(CfgB2) CP_CI(CfgB3)
 #undef CP_CI
+  if (C == 18 && H == 64 && W == 64) { *o = ChainInfo{C, H, W, 7, 2, 3, cp_chain0_aff(), cp_chain0_conv_bytes()}; return true; }
   return false;
 }
 
@@ -404,6 +412,7 @@ extern "C" int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, int C
   ChainInfo ci;
   if (!w || !blob || conv_index < 0 || conv_index > 7 || !chain_info(C, H, W, &ci)) return CP_ERR_INVALID;
   if (!cp_aligned16(blob)) return CP_ERR_ALIGN;
+  if (C == 18) return cp_chain0_pack((hipStream_t)stream, w, conv_index, blob);
   const size_t total = ci.conv_w / 2;
   uint16_t* dst = (uint16_t*)((unsigned char*)blob + (size_t)conv_index * ci.conv_w);
   CP_LAUNCH(pack_chain_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, dst, C, ci.CG, ci.NT_ALL, total);
@@ -424,6 +433,7 @@ extern "C" int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W
     if (srcs[k] == out) return CP_ERR_INVALID;
     p.src[k] = srcs[k]; p.shift[k] = shifts[k];
   }
+  if (C == 18) return cp_chain0_launch((hipStream_t)stream, B, nsrc, srcs, shifts, relu_in, packed_w, affine, out);
   p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0;
   p.w = packed_w; p.aff = affine; p.out = out; p.B = B;
   p.dbg = cp_knob("CP_CHAIN_DBG") ? atoi(cp_knob("CP_CHAIN_DBG")) : 0;

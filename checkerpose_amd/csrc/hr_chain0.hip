@@ -1,0 +1,290 @@
+// The 64x64x18 branch of an HRNet module (branch 0: 4 BasicBlocks = 8 convs) as ONE launch per crop with the map in LDS.
+//
+// The other branches (hr_chain.hip) keep a conv's whole output in registers and write it back over the input map.  Here the
+// map alone fills the LDS (66 x 66 ring pixels x 36 B = 157 KB) and a conv's output does not fit in registers (4096 px x 32
+// accumulator rows), so a conv walks the map in 8 BANDS of 8 rows (wave w owns row 8 band + w = 4 fragments of 16 pixels):
+//   band: 7 K-chunks x 4 fragments x 2 tiles of MFMAs -> epilogue in registers -> barrier -> the band's rows are written
+//   back over the input rows, EXCEPT the band's last row, which the next band still needs as its top neighbour: wave 7 holds
+//   it in registers (16 VGPRs) for one band and writes it one barrier later (lagged in-place update, one barrier per band).
+// The BasicBlock residual cannot stay on chip: every block output also goes to the output tensor in HBM (it is the final
+// result for the last block) and the next block's second conv reads its residual back from there, pixel for pixel by the
+// lane that then overwrites it (prefetched at the start of the band, consumed in its epilogue).
+// LDS image: channel groups as planes -- [ch 0-7][px][16 B], [ch 8-15][px][16 B], [ch 16-17][px][4 B] -- so a crop costs
+// 36 B per pixel.  GEMM K order: the 18 (tap, 8-channel group) slots first, then the 9 (tap, 2 channels) slots: chunks 0-3 are
+// pure ds_read_b128, chunk 4 is mixed, chunks 5-6 read 4 bytes per lane (216 K slots -> 7 chunks instead of 9 x 32 -> 9).
+// Both tiles' weight fragments of a conv (14 KB) live in registers; the next conv's are loaded chunk by chunk during the
+// last band, each behind the last use of the fragment it replaces.
+#include "common.h"
+
+namespace {
+
+constexpr int ZH = 64, ZW = 64, ZC = 18, ZCP = 24, ZWP = 66, ZHP = 66;
+constexpr int ZPLPX = (ZHP * ZWP + 15) / 16 * 16;        // 4368 ring pixels per plane (padded)
+constexpr int ZPL16 = ZPLPX * 16, ZPL4 = ZPLPX * 4;
+constexpr int ZAFF = 32;                                 // floats per scale / shift vector
+constexpr int ZLDS = 2 * ZPL16 + ZPL4 + 2 * 2 * ZAFF * 4;
+constexpr int ZKC = 7;
+constexpr size_t ZCONV_W = (size_t)ZKC * 2 * 1024;
+static_assert(ZLDS <= 160 * 1024, "LDS budget");
+
+struct Chain0Params {
+  const void* src[4];
+  int shift[4];
+  int nsrc, relu_in;
+  const void* w;          // [8][7][2][64][16 B]
+  const float* aff;       // [8][2][32]
+  void* out;              // (B, 64, 64, 24) bf16: block outputs (residual of the next block), finally the result
+  int B;
+};
+
+__device__ __forceinline__ void mma16z(const u32x4& w, const u32x4& a, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+
+// x0 = [relu](sum of the fuse terms) -> LDS planes AND the output tensor (it is block 0's residual)
+template <int NSRC>
+__device__ __forceinline__ void stage0(const Chain0Params& p, unsigned char* smem, int tid, int b) {
+  constexpr int U = 4, TOTAL = ZH * ZW * 3;
+  for (int i0 = tid; i0 < TOTAL; i0 += U * 512) {
+    u32x4 v[U][NSRC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 512;
+      const int g = i % 3, px = i / 3;
+      const int y = px >> 6, xx = px & 63;
+#pragma unroll
+      for (int k = 0; k < NSRC; ++k) {
+        const int sh = p.shift[k];
+        const size_t o = (((size_t)b * (ZH >> sh) + (y >> sh)) * (ZW >> sh) + (xx >> sh)) * 3 + g;
+        v[u][k] = ((const u32x4*)p.src[k])[o];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 512;
+      const int g = i % 3, px = i / 3;
+      const int y = px >> 6, xx = px & 63;
+      float acc[8], f[8];
+#pragma unroll
+      for (int k = 0; k < NSRC; ++k) {
+        Vec16<BF16Tag>::unpack(v[u][k], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (k == 0) ? f[j] : acc[j] + f[j];
+      }
+      if (p.relu_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      }
+      const u32x4 pk = Vec16<BF16Tag>::pack(acc);
+      const int pc = (y + 1) * ZWP + xx + 1;
+      if (g < 2) *(u32x4*)(smem + g * ZPL16 + pc * 16) = pk;
+      else *(uint32_t*)(smem + 2 * ZPL16 + pc * 4) = pk.x;
+      ((u32x4*)p.out)[((size_t)b * ZH * ZW + px) * 3 + g] = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const sAff = (float*)(smem + 2 * ZPL16 + ZPL4);          // [2][2][32]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+
+  // ---- this conv's weight fragments: registers
+  const u32x4* const wg = (const u32x4*)p.w;
+  u32x4 Wf[ZKC][2];
+#pragma unroll
+  for (int kc = 0; kc < ZKC; ++kc)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) Wf[kc][nt] = wg[(kc * 2 + nt) * 64 + lane];
+
+  // ---- zero ring + plane padding, stage x0
+  for (int i = tid; i < ZPLPX; i += 512) {
+    const int ry = i / ZWP, rx = i - ry * ZWP;
+    if (ry == 0 || ry >= ZH + 1 || rx == 0 || rx == ZW + 1) {
+      *(u32x4*)(smem + i * 16) = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)(smem + ZPL16 + i * 16) = u32x4{0u, 0u, 0u, 0u};
+      *(uint32_t*)(smem + 2 * ZPL16 + i * 4) = 0u;
+    }
+  }
+  switch (p.nsrc) {
+    case 1: stage0<1>(p, smem, tid, b); break;
+    case 2: stage0<2>(p, smem, tid, b); break;
+    case 3: stage0<3>(p, smem, tid, b); break;
+    default: stage0<4>(p, smem, tid, b); break;
+  }
+  if (tid < 2 * ZAFF) sAff[tid] = p.aff[tid];
+  __syncthreads();
+
+  // ---- per-lane K-group geometry per chunk: byte offsets relative to the fragment's window-top-left pixel index pb
+  //      (16-byte planes: + pb * 16; 4-byte plane: + pb * 4)
+  uint32_t o16[5], o4[3];                      // chunks 0..4 (b128 lanes), chunks 4..6 (b32 lanes)
+#pragma unroll
+  for (int kc = 0; kc < 5; ++kc) {
+    const int G = 4 * kc + q;
+    const int tap = G >> 1, cg = G & 1;
+    const int r = (tap * 11) >> 5, s = tap - 3 * r;                 // tap / 3 for tap < 9
+    o16[kc] = G < 18 ? (uint32_t)(cg * ZPL16 + (r * ZWP + s) * 16) : 0u;
+  }
+#pragma unroll
+  for (int kc = 4; kc < 7; ++kc) {
+    const int G = 4 * kc + q;
+    const int tap = G - 18;
+    const int r = (tap * 11) >> 5, s = tap - 3 * r;
+    o4[kc - 4] = (G >= 18 && G < 27) ? (uint32_t)(2 * ZPL16 + (r * ZWP + s) * 4) : (uint32_t)(2 * ZPL16);
+  }
+  const bool small4 = q >= 2;                  // chunk 4: lanes q = 2, 3 read the 2-channel plane
+
+  auto load_frags = [&](u32x4* a, int kc, uint32_t pb) {           // pb: window-top-left ring pixel index of fragment 0, this lane
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint32_t px = pb + f * 16;
+      if (kc < 4) a[f] = *(const u32x4*)(smem + o16[kc] + px * 16);
+      else if (kc == 4) {
+        const u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
+        const uint32_t sm = *(const uint32_t*)(smem + o4[0] + px * 4);
+        a[f] = small4 ? u32x4{sm, 0u, 0u, 0u} : big;
+      } else {
+        const uint32_t sm = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);
+        a[f] = u32x4{sm, 0u, 0u, 0u};
+      }
+    }
+  };
+
+  u32x4 hold[4];                               // wave 7: the band's last row, written one band later
+#pragma unroll
+  for (int f = 0; f < 4; ++f) hold[f] = u32x4{0u, 0u, 0u, 0u};
+  const size_t gpix0 = (size_t)b * ZH * ZW;
+
+#pragma unroll 1
+  for (int cv = 0; cv < 8; ++cv) {
+    float affv = 0.f;
+    if (cv + 1 < 8 && tid < 2 * ZAFF) affv = p.aff[(cv + 1) * 2 * ZAFF + tid];
+    const float* const sc = sAff + (cv & 1) * 2 * ZAFF + q * 8;
+    const float* const sh = sc + ZAFF;
+    const bool second = cv & 1;
+#pragma unroll 1
+    for (int band = 0; band < 8; ++band) {
+      const int row = band * 8 + wave;
+      const uint32_t pb = (uint32_t)(row * ZWP + x);               // window top-left of fragment 0 (ring coordinates)
+      u32x4 rres[4];
+      if (second && q < 3) {                                       // residual = previous block's output, from HBM/L2
+#pragma unroll
+        for (int f = 0; f < 4; ++f) rres[f] = ((const u32x4*)p.out)[(gpix0 + row * ZW + f * 16 + x) * 3 + q];
+      }
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      u32x4 af[2][4];
+      load_frags(af[0], 0, pb);
+#pragma unroll
+      for (int kc = 0; kc < ZKC; ++kc) {
+        if (kc + 1 < ZKC) load_frags(af[(kc + 1) & 1], kc + 1, pb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          mma16z(Wf[kc][0], af[kc & 1][f], acc[f][0]);
+          mma16z(Wf[kc][1], af[kc & 1][f], acc[f][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (band == 7 && cv + 1 < 8) {                             // next conv's fragments behind the last use of this conv's
+          Wf[kc][0] = wg[(((cv + 1) * ZKC + kc) * 2 + 0) * 64 + lane];
+          Wf[kc][1] = wg[(((cv + 1) * ZKC + kc) * 2 + 1) * 64 + lane];
+        }
+      }
+      // ---- epilogue: lane (x, q) holds channels 8q .. 8q+7 of pixel (row, 16 f + x)
+      u32x4 v[4];
+      if (q < 3) {
+        const f32x4 s0 = *(const f32x4*)(sc), s1 = *(const f32x4*)(sc + 4), t0 = *(const f32x4*)(sh), t1 = *(const f32x4*)(sh + 4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          float e[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j] * s0[j] + t0[j]; e[4 + j] = acc[f][1][j] * s1[j] + t1[j]; }
+          if (second) {
+            float r8[8];
+            Vec16<BF16Tag>::unpack(rres[f], r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] += r8[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = fmaxf(e[j], 0.f);
+          v[f] = Vec16<BF16Tag>::pack(e);
+          if (second) ((u32x4*)p.out)[(gpix0 + row * ZW + f * 16 + x) * 3 + q] = v[f];
+        }
+      }
+      __syncthreads();                 // every wave has read this band's input rows (8 band - 1 .. 8 band + 8)
+      // ---- lagged write-back: rows 8 band .. 8 band + 6 now; row 8 band + 7 (wave 7) one band later
+      auto put = [&](const u32x4* vv, int r) {
+        if (q < 3) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const int pc = (r + 1) * ZWP + f * 16 + x + 1;
+            if (q < 2) *(u32x4*)(smem + q * ZPL16 + pc * 16) = vv[f];
+            else *(uint32_t*)(smem + 2 * ZPL16 + pc * 4) = vv[f].x;
+          }
+        }
+      };
+      if (wave != 7) put(v, row);
+      else {
+        if (band > 0) put(hold, row - 8);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) hold[f] = v[f];
+        if (band == 7) put(v, row);
+      }
+    }
+    if (tid < 2 * ZAFF) sAff[((cv + 1) & 1) * 2 * ZAFF + tid] = affv;
+    __syncthreads();                   // the conv's output map is complete
+  }
+}
+
+// [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
+//   G < 18: tap G >> 1, input channel 8 (G & 1) + e;   18 <= G < 27: tap G - 18, input channel 16 + e (e < 2);   else zero.
+// tile row `row` of tile nt is output channel (row >> 2) * 8 + 4 nt + (row & 3).
+__global__ void pack_chain0_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % 8);
+  const int lane = (int)((i / 8) % 64);
+  const int nt = (int)((i / 512) % 2);
+  const int kc = (int)(i / 1024);
+  const int row = lane & 15, q = lane >> 4;
+  const int G = kc * 4 + q;
+  int tap = -1, cin = 0;
+  if (G < 18) { tap = G >> 1; cin = (G & 1) * 8 + e; }
+  else if (G < 27 && e < 2) { tap = G - 18; cin = 16 + e; }
+  const int n = (row >> 2) * 8 + nt * 4 + (row & 3);
+  float v = 0.f;
+  if (tap >= 0 && n < ZC && cin < ZC) v = w[((size_t)n * ZC + cin) * 9 + tap];
+  out[i] = (uint16_t)f32_to_bf16_bits(v);
+}
+
+}  // namespace
+
+// entry points used by hr_chain.hip's dispatcher for (C, H, W) = (18, 64, 64)
+size_t cp_chain0_conv_bytes() { return ZCONV_W; }
+int cp_chain0_aff() { return ZAFF; }
+
+int cp_chain0_pack(hipStream_t st, const float* w, int conv_index, void* blob) {
+  const size_t total = ZCONV_W / 2;
+  uint16_t* dst = (uint16_t*)((unsigned char*)blob + (size_t)conv_index * ZCONV_W);
+  CP_LAUNCH(pack_chain0_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, dst, total);
+  return cp_check_launch();
+}
+
+int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
+                     const void* packed_w, const float* affine, void* out) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)hr_chain0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ZLDS) != hipSuccess) return CP_ERR_HIP;
+    attr_done = true;
+  }
+  Chain0Params p;
+  for (int k = 0; k < 4; ++k) { p.src[k] = k < nsrc ? srcs[k] : nullptr; p.shift[k] = k < nsrc ? shifts[k] : 0; }
+  p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0; p.w = packed_w; p.aff = affine; p.out = out; p.B = B;
+  CP_LAUNCH(hr_chain0_kernel, dim3((unsigned)B), dim3(512), ZLDS, st, p);
+  return cp_check_launch();
+}

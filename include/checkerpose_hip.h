@@ -181,8 +181,9 @@ int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* patches, con
  *   x   = [relu]( sum_k upsample_nearest(src_k, 2^shift_k) )        srcs (B, H>>shift, W>>shift, Cphys) bf16, Cphys = ceil8(C)
  *   for blk in 0..3:  x = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )
  *   out = x                                                           (B, H, W, Cphys) bf16, pad channels exactly zero
- * Supported (C, H, W): (36, 32, 32), (72, 16, 16), (144, 8, 8) -- the HRNet-W18 branches 1..3 of a 256 x 256 crop
- * (cp_hr_chain_supported).  Weights: cp_pack_hr_chain_weight() packs conv `conv_index` (0..7 = block.conv1, block.conv2, ...)
+ * Supported (C, H, W): (18, 64, 64), (36, 32, 32), (72, 16, 16), (144, 8, 8) -- the four HRNet-W18 branches of a 256 x 256
+ * crop (cp_hr_chain_supported).  The 64 x 64 branch keeps its BasicBlock residuals in `out` between blocks (its map alone fills
+ * the LDS), the others keep them on chip.  Weights: cp_pack_hr_chain_weight() packs conv `conv_index` (0..7 = block.conv1, block.conv2, ...)
  * of fp32 (C, C, 3, 3) weights into the caller-owned blob of cp_hr_chain_weight_bytes() bytes; `affine` = fp32
  * [8][2][cp_hr_chain_affine_floats()] folded-BN (scale, shift) per conv, zero beyond C.  out must not alias a source. */
 int cp_hr_chain_supported(int C, int H, int W);

@@ -7,7 +7,7 @@ from checkerpose_amd import _abi
 lib = _abi.load()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for (Cc, H, W) in ((36, 32, 32), (72, 16, 16), (144, 8, 8)):
+for (Cc, H, W) in ((18, 64, 64), (36, 32, 32), (72, 16, 16), (144, 8, 8)):
     cp = (Cc + 7) // 8 * 8
     for nsrc in (1, 3):
         srcs = [torch.randn(B, H, W, cp, device=dev).to(torch.bfloat16) for _ in range(nsrc)]
