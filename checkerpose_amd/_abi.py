@@ -63,7 +63,7 @@ SIGNATURES = {
     "cp_pack_hr_chain_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cp_hr_branch_chain": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P]),
     "cp_upsample2x_bilinear_ac": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
-    "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I]),
+    "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_maxpool3x3s2": (_I, [_P, _I, _P, _P, _I, _I, _I, _I]),
     "cp_edgeconv_gather_max": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F]),
     "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),

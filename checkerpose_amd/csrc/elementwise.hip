@@ -69,7 +69,8 @@ extern "C" int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const vo
 struct FuseSrcs { const void* p[4]; int sh[4]; };
 
 template <typename Tag>
-__global__ void fuse_sum_kernel(FuseSrcs s, int nsrc, void* __restrict__ out, int H, int W, int CG, int relu, size_t total) {
+__global__ void fuse_sum_kernel(FuseSrcs s, int nsrc, void* __restrict__ out, int H, int W, int CG, int relu, size_t total,
+                                int out_sg, int out_og) {
   constexpr int E = Tag::E;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W*CG
   if (i >= total) return;
@@ -92,15 +93,16 @@ __global__ void fuse_sum_kernel(FuseSrcs s, int nsrc, void* __restrict__ out, in
 #pragma unroll
     for (int j = 0; j < E; ++j) acc[j] = fmaxf(acc[j], 0.f);
   }
-  ((u32x4*)out)[i] = Vec16<Tag>::pack(acc);
+  ((u32x4*)out)[(i / CG) * out_sg + out_og + g] = Vec16<Tag>::pack(acc);     // channel slice [out_coff, out_coff + C) of out_cstride
 }
 
 extern "C" int cp_fuse_sum_act(cp_stream_t stream, int dtype, int nsrc, const void* const* srcs, const int32_t* shifts,
-                               void* out, int B, int H, int W, int C, int relu) {
+                               void* out, int B, int H, int W, int C, int relu, int out_cstride, int out_coff) {
   if (!srcs || !shifts || !out || nsrc < 1 || nsrc > 4 || B <= 0 || H <= 0 || W <= 0 || C <= 0) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype);
   if (C % E || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  if (out_cstride % E || out_coff % E || out_coff < 0 || out_coff + C > out_cstride) return CP_ERR_ALIGN;
   FuseSrcs s;
   for (int k = 0; k < 4; ++k) { s.p[k] = nullptr; s.sh[k] = 0; }
   for (int k = 0; k < nsrc; ++k) {
@@ -112,9 +114,11 @@ extern "C" int cp_fuse_sum_act(cp_stream_t stream, int dtype, int nsrc, const vo
   const size_t total = (size_t)B * H * W * CG;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
-    CP_LAUNCH(fuse_sum_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
+    CP_LAUNCH(fuse_sum_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total,
+              out_cstride / E, out_coff / E);
   else
-    CP_LAUNCH(fuse_sum_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total);
+    CP_LAUNCH(fuse_sum_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, nsrc, out, H, W, CG, relu, total,
+              out_cstride / E, out_coff / E);
   return cp_check_launch();
 }
 

@@ -432,7 +432,7 @@ class Program:
         def argb(P):
             for i, t in enumerate(tbs):
                 arr_p[i] = P(t)
-            return (self.dtype, n, arr_p, arr_s, P(ot), out.B, out.H, out.W, out.Cphys, 1 if relu else 0)
+            return (self.dtype, n, arr_p, arr_s, P(ot), out.B, out.H, out.W, out.Cphys, 1 if relu else 0, out.cstride, out.coff)
 
         self._add(fn, argb, "fuse_sum", tbs, [ot])
         return out

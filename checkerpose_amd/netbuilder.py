@@ -149,13 +149,34 @@ class NetEmitter:
         return self.conv_bn(y, pfx + ".conv3", pfx + ".bn3", 1, 1, 0, relu=True, residual=sc, out=out)
 
     # ---- HRNet-W18 features (timm HighResolutionNetFeatures)
-    def _materialize(self, x):
-        """a module output that is still the un-summed list of fuse terms -> one activation (cp_fuse_sum_act)"""
+    def _materialize(self, x, out=None):
+        """a module output that is still the un-summed list of fuse terms -> one activation (cp_fuse_sum_act), optionally
+        written into the channel slice `out` of a wider buffer"""
         if isinstance(x, Act):
+            assert out is None
             return x
         terms, shifts = x
-        out = self.p.act(terms[0].H << shifts[0], terms[0].W << shifts[0], terms[0].C)
+        if out is None:
+            out = self.p.act(terms[0].H << shifts[0], terms[0].W << shifts[0], terms[0].C)
         return self.p.fuse_sum(terms, shifts, out, relu=True)
+
+    def bottleneck_incre(self, pfx, cat: Act, planes, out=None):
+        """timm Bottleneck with a projection shortcut (HRNet incre_modules) whose input x already sits in channels
+        [planes, planes + C) of `cat`: conv2's output goes into channels [0, planes) of the same buffer and the block's tail
+            relu(bn3(conv3(t2)) + bn_d(conv_d(x)))  =  relu([s3 W3 | sd Wd] [t2 ; x] + (t3 + td))
+        is ONE 1x1 conv over the concatenated channels -- the shortcut conv, its 4*planes-channel output tensor and the
+        residual read disappear (the 64x64 one alone moved 0.8 GB per step at batch 256)."""
+        x = cat.slice(planes, cat.C - planes, _rup(cat.C - planes, self.p.E))
+        y = self.conv_bn(x, pfx + ".conv1", pfx + ".bn1", 1, 1, 0)
+        self.conv_bn(y, pfx + ".conv2", pfx + ".bn2", 3, 1, 1, out=cat.slice(0, planes))
+        ck = pfx + ".conv3#merged"
+        if ck not in self.ws.cache:
+            s3, t3 = self.ws.bn_fold(pfx + ".bn3")
+            sd, td = self.ws.bn_fold(pfx + ".downsample.1")
+            w3, wd = self.W(pfx + ".conv3.weight"), self.W(pfx + ".downsample.0.weight")
+            self.ws.cache[ck] = (torch.cat([w3 * s3.view(-1, 1, 1, 1), wd * sd.view(-1, 1, 1, 1)], dim=1).contiguous(), t3 + td)
+        wm, shift = self.ws.cache[ck]
+        return self.p.conv(cat, ck, wm, self._unit(wm.shape[0]), shift, 1, 1, 1, 0, wm.shape[0], ACT_RELU, out=out)
 
     def hr_module(self, pfx, xs, lazy=False):
         """One timm HighResolutionModule.  xs[j]: an Act, or (terms, shifts) = the previous module's fuse terms of branch j
@@ -246,19 +267,35 @@ class NetEmitter:
         x = self.conv_bn(x, pfx + "conv2", pfx + "bn2", 3, 2, 1)
         for k in range(4):
             x = self.bottleneck("%slayer1.%d" % (pfx, k), x)
-        xs = [self.conv_bn(x, pfx + "transition1.0.0", pfx + "transition1.0.1", 3, 1, 1),
-              self.conv_bn(x, pfx + "transition1.1.0.0", pfx + "transition1.1.0.1", 3, 2, 1)]
+        if self.tp is None:                  # the two transition convs are independent: two lanes
+            self.p.par_begin(2)
+            xs = [self.conv_bn(x, pfx + "transition1.0.0", pfx + "transition1.0.1", 3, 1, 1)]
+            self.p.set_lane(1)
+            xs.append(self.conv_bn(x, pfx + "transition1.1.0.0", pfx + "transition1.1.0.1", 3, 2, 1))
+            self.p.par_end()
+        else:
+            xs = [self.conv_bn(x, pfx + "transition1.0.0", pfx + "transition1.0.1", 3, 1, 1),
+                  self.conv_bn(x, pfx + "transition1.1.0.0", pfx + "transition1.1.0.1", 3, 2, 1)]
         for si, (stage, nmod, chans) in enumerate(HR_STAGES):
             if si > 0:
                 t = "%stransition%d.%d.0" % (pfx, si + 1, len(chans) - 1)
                 xs = xs + [self.conv_bn(xs[-1], t + ".0", t + ".1", 3, 2, 1)]
+            last_stage = si == len(HR_STAGES) - 1
             for m in range(nmod):           # inside a stage the fuse sums stay un-summed for the next module's chain launches
-                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs, lazy=(m + 1 < nmod))
+                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs, lazy=(m + 1 < nmod) or (last_stage and self.tp is None))
         feats = []
         self.p.par_begin(len(xs))            # the four incre bottlenecks are independent
         for i, f in enumerate(xs):
             self.p.set_lane(i)
-            feats.append(self.bottleneck("%sincre_modules.%d.0" % (pfx, i), f, out=(feat_outs[i] if feat_outs else None)))
+            q = "%sincre_modules.%d.0" % (pfx, i)
+            if isinstance(f, Act):
+                feats.append(self.bottleneck(q, f, out=(feat_outs[i] if feat_outs else None)))
+            else:                            # eval: the last module's fuse sum lands right beside the bottleneck's conv2 output
+                terms, shifts = f
+                planes = self.W(q + ".conv1.weight").shape[0]
+                cat = self.p.act(terms[0].H << shifts[0], terms[0].W << shifts[0], planes + terms[0].C)
+                self._materialize(f, out=cat.slice(planes, terms[0].C, _rup(terms[0].C, self.p.E)))
+                feats.append(self.bottleneck_incre(q, cat, planes, out=(feat_outs[i] if feat_outs else None)))
         self.p.par_end()
         return feats
 
@@ -464,7 +501,16 @@ def emit_posenet(em: NetEmitter, cfg, io):
     # lane 0: decoder chain up_net[0..2] -> seg (MFMA-bound) ; lane 1: refine stages (latency-bound graph kernels).
     # refine[i] needs up_net[i]'s output (sync 0 -> 1) and refine[i-1]; up_net[i+1] needs only up_net[i].
     if active > 0:
-        p.par_begin(2)
+        p.par_begin(6 if tp is None else 2)      # 0 decoder, 1 refinement, 2 skip upsamples, 3-5 transposed-conv phases
+    # the skip features' bilinear x2 halves of the decoder's concat buffers do not depend on the decoder: they run on a lane
+    # of their own right away (lane 2 never waits for anybody) instead of on the decoder's critical path
+    cats = {}
+    if tp is None:
+        for i in range(1, active):
+            sk = feats[-i - 1]
+            cats[i] = p.act(2 * sk.H, 2 * sk.W, nf + sk.C)
+            p.set_lane(2)
+            p.upsample2x(sk, cats[i].slice(_rup(nf, p.E), sk.C))
     for i in range(active):
         p.set_lane(0)
         up = "up_net.%d" % i
@@ -474,20 +520,29 @@ def emit_posenet(em: NetEmitter, cfg, io):
             o = p.act(2 * f.H, 2 * f.W, nf)
             if tp is not None:
                 s, t = tp.const_vec(nf, True), tp.const_vec(nf, False)
-            for ph in range(4):
+            for ph in range(4):          # the four sub-pixel phases are independent: eval runs them on lanes 0, 3, 4, 5
                 a, b = ph >> 1, ph & 1
+                if tp is None and ph > 0:
+                    p.set_lane(2 + ph)
                 p.conv(f, up + ".0", wt, s, t, 1 + a, 1 + b, 1, 0, nf, ACT_RELU if tp is None else ACT_NONE, transposed=1, phase=ph,
                        ostr=((a * o.W + b) * o.cstride, o.H * o.W * o.cstride, 2 * o.W * o.cstride, 2 * o.cstride, 1),
                        out_tbuf=o.tbuf, out_hw=(f.H, f.W))
+            if tp is None:
+                p.set_lane(0)
+                for ph in range(1, 4):
+                    p.sync(2 + ph, 0)
             if tp is not None:
                 o = _convt_train_tail(em, up, wt, f, o, nf)
             f = em.conv_bn(o, up + ".3", up + ".4", 3, 1, 1)
             f = em.conv_bn(f, up + ".6", up + ".7", 3, 1, 1)
         else:        # cat[img_feat, img_feats[-i-1]] -> bilinear x2 (align_corners) -> 2x conv3x3+BN+ReLU
             sk = feats[-i - 1]
-            cat = p.act(2 * f.H, 2 * f.W, f.C + sk.C)
+            cat = cats[i] if i in cats else p.act(2 * f.H, 2 * f.W, f.C + sk.C)
+            if i == 1 and i in cats:
+                p.sync(2, 0)             # all skip halves (lane 2) are in place
             p.upsample2x(f, cat.slice(0, f.C))
-            p.upsample2x(sk, cat.slice(f.Cphys, sk.C))
+            if i not in cats:
+                p.upsample2x(sk, cat.slice(f.Cphys, sk.C))
             if tp is not None:
                 _upsample_tape(tp, f, cat.slice(0, f.C))
                 _upsample_tape(tp, sk, cat.slice(f.Cphys, sk.C))

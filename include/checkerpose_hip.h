@@ -148,9 +148,10 @@ int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, voi
                               int C, int in_cstride, int in_coff, int out_cstride, int out_coff);
 
 /* HRNet fuse layer sum (timm HighResolutionModule.forward): out = relu?( sum_t nearest_up(src_t, 2^shift_t) ),
- * all (B, H>>shift_t, W>>shift_t, C) contiguous.  nsrc <= 4. */
+ * sources (B, H>>shift_t, W>>shift_t, C) contiguous, nsrc <= 4; written to channels [out_coff, out_coff + C) of the
+ * (B, H, W, out_cstride) tensor `out` (out_cstride = C, out_coff = 0: a plain tensor). */
 int cp_fuse_sum_act(cp_stream_t stream, int dtype, int nsrc, const void* const* srcs, const int32_t* shifts,
-                    void* out, int B, int H, int W, int C, int relu);
+                    void* out, int B, int H, int W, int C, int relu, int out_cstride, int out_coff);
 
 /* max_pool2d(3, 2, 1) for the resnet34 stem (timm resnet). (B,H,W,C) -> (B,H/2,W/2,C) */
 int cp_maxpool3x3s2(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W, int C);

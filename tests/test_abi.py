@@ -194,7 +194,7 @@ def test_descriptor_validation_without_gpu(lib):
     assert lib.cp_edgeconv_gather_max(None, 0, A, A, None, A, 1, 512, 20, 30, 1, 32, 0, 0.2) == -3      # C not a 16-B multiple
     assert lib.cp_edgeconv_gather_max(None, 0, A, A, None, A, 1, 512, 100, 64, 1, 64, 0, 0.2) == -1     # K > 64
     assert lib.cp_index2feat_gather(None, 0, A, A, A, A, A, 1, 512, 17, 17, 64, 2, 200, 0) == -3        # 4*E > out stride
-    assert lib.cp_fuse_sum_act(None, 0, 5, None, None, A, 1, 8, 8, 16, 1) == -1                          # nsrc > 4
+    assert lib.cp_fuse_sum_act(None, 0, 5, None, None, A, 1, 8, 8, 16, 1, 16, 0) == -1                          # nsrc > 4
     assert lib.cp_upsample2x_bilinear_ac(None, 0, A, A, 1, 4, 4, 18, 20, 0, 20, 0) == -3
     assert lib.cp_maxpool3x3s2(None, 0, A, A, 1, 7, 8, 16) == -1                                          # odd height
     assert lib.cp_packed_halo_weight_bytes(_abi.CP_BF16, 256, 512) == 8 * 16 * 18 * 1024               # 8 groups x 16 chunks

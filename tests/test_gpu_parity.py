@@ -436,11 +436,15 @@ def test_upsample_fuse_maxpool(lib, dtype):
     o = torch.empty(2, 8, 8, cp, dtype=DT[dtype], device=dev())
     arr = (C.c_void_p * 4)(*[s.data_ptr() for s in srcs], None)
     sh = (C.c_int32 * 4)(0, 1, 2, 0)
-    _abi.check(lib.cp_fuse_sum_act(st(), dtype, 3, arr, sh, o.data_ptr(), 2, 8, 8, cp, 1))
+    _abi.check(lib.cp_fuse_sum_act(st(), dtype, 3, arr, sh, o.data_ptr(), 2, 8, 8, cp, 1, cp, 0))
     torch.cuda.synchronize()
     ref = F.relu(rnd(a, dtype) + F.interpolate(rnd(b, dtype), scale_factor=2, mode="nearest")
                  + F.interpolate(rnd(c, dtype), scale_factor=4, mode="nearest"))
     close(from_cl(o, 20), ref, tol)
+    wide = torch.full((2, 8, 8, cp + 16), 7.0, dtype=DT[dtype], device=dev())     # into the channel slice [8, 8 + cp) of a wider tensor
+    _abi.check(lib.cp_fuse_sum_act(st(), dtype, 3, arr, sh, wide.data_ptr(), 2, 8, 8, cp, 1, cp + 16, 8))
+    torch.cuda.synchronize()
+    assert torch.equal(wide[..., 8:8 + cp], o) and float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cp:] - 7).abs().max()) == 0
     # max pool 3x3 s2 p1
     x = det_tensor("mp", (2, 16, 12, 10))
     xin = to_cl(x, dtype)
