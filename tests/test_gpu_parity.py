@@ -136,6 +136,9 @@ HALO_CASES = [  # (B, Cin, H, W, Cout, act, residual)
     (1, 36, 13, 21, 72, ACT_NONE, False),      # H, W not tile multiples (masked stores, zero halo)
     (3, 144, 8, 16, 40, ACT_LEAKY, True),      # single tile row, Cout = 40 (second half of a lane's 8 channels absent)
     (1, 512, 8, 16, 32, ACT_RELU, False),      # deep K (16/32 chunks), odd/even chunk counts
+    (2, 64, 24, 40, 256, ACT_RELU, True),      # wide (Cout % 256 == 0) kernel: ragged tile rows / cols, residual, 2..4 chunks
+    (1, 40, 17, 16, 512, ACT_LEAKY, False),    # ... two 256-channel blocks, partial chunk
+    (3, 256, 32, 32, 256, ACT_RELU, False),    # ... decoder shape class
 ]
 
 
