@@ -66,6 +66,10 @@ SIGNATURES = {
     "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_maxpool3x3s2": (_I, [_P, _I, _P, _P, _I, _I, _I, _I]),
     "cp_edgeconv_gather_max": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_edgeconv_fused_supported": (_I, [_I, _I, _I, _I]),
+    "cp_edgeconv_fused_weight_bytes": (C.c_size_t, [_I, _I]),
+    "cp_pack_edgeconv_fused_weight": (_I, [_P, _P, _I, _I, _P]),
+    "cp_edgeconv_fused": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
     "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_bits_decode": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
     "cp_correspondences": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -1,0 +1,260 @@
+// EdgeConv (StaticGraph_module: reference init.py:54-68 == pipeline.py:45-59, LM twin pipeline_lm.py:55-57) as ONE launch per
+// layer for N = 512 keypoints: per-node GEMM to [P' | Q'] on MFMA + neighbour gather-max out of LDS.
+//
+// The factored form (graph_ops.hip) ran as a row GEMM that wrote the (B, N, 2C') table to HBM (134 MB per layer at batch 256)
+// and a gather kernel that read it back through L2 (K = 20 neighbour rows per keypoint): 94 + 68 us per layer, both far from
+// any roof.  A crop's P' table for 64 output channels is 512 x 64 x 2 B = 64 KB: it fits in LDS.  One 8-wave workgroup per
+// crop, wave w owns keypoints [64 w, 64 w + 64) = 4 MFMA fragments:
+//   * the crop's x rows (512 x Cin bf16) live in REGISTERS for the whole layer (the B operand of every MFMA: 128 VGPRs at
+//     Cin = 256), loaded once;
+//   * per 64-channel slice: the P and the Q half of the weights (32 KB each) stream L2 -> LDS by LDS-DMA, double-buffered
+//     under the other half's MFMAs; P' = s * (W1 x) is written to the LDS table as ORDER-PRESERVING int16 keys of its bf16
+//     value (so the K-way max is v_pk_max_i16, two channels per instruction), Q' = s * ((W2 - W1) x) + t stays in the fp32
+//     accumulators;
+//   * gather: a lane owns 16 channels of a keypoint: 2 ds_read_b128 per neighbour row (row pitch 144 B = 9 slots), index
+//     lists staged once per layer as int16; out = leaky(max_k P'_j(k) + Q'_i) leaves as 32 B per lane.
+// Two barriers per slice.  Numerics: P' rounded to bf16 as before, Q' no longer rounded to bf16 (one rounding less).
+#include "common.h"
+
+namespace {
+
+constexpr int EF_N = 512, EF_KMAX = 20;
+constexpr int EF_PITCH = 144;                               // bytes per P' row (64 channels + 16 B pad: odd number of slots)
+constexpr int EF_TABLE = EF_N * EF_PITCH;                   // 73 728
+constexpr int EF_WBUF = 32 * 1024;                          // one (slice, half) of weights at Cin = 256
+constexpr int EF_IDX = EF_N * EF_KMAX * 2;                  // 20 480
+constexpr int EF_AFF = 2 * 512 * 4;                         // scale | shift of the 2 C' <= 512 GEMM rows
+constexpr int EF_LDS = EF_TABLE + 2 * EF_WBUF + EF_IDX + EF_AFF;     // 163 840 = all 160 KiB of the CU
+
+struct EdgeFusedParams {
+  const void* x; const void* w; const float* scale; const float* shift;
+  const int32_t* idx; const int32_t* gids; void* out;
+  int in_cs, in_coff, out_cs, out_coff, B, K, Cout;
+  float slope;
+};
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sortable(uint32_t w) {         // two bf16 -> two int16 keys, monotone in the float value
+  return w ^ (((w >> 15) & 0x00010001u) * 0x7fffu);                // (involution: the same call maps keys back)
+}
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+
+template <int CIN>
+__global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedParams p) {
+  constexpr int KC = CIN / 32;                              // 32-deep K chunks
+  constexpr int HALF = KC * 4 * 1024;                       // bytes of one (slice, half) weight image
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sP = smem;
+  unsigned char* const sW = smem + EF_TABLE;
+  int16_t* const sIdx = (int16_t*)(smem + EF_TABLE + 2 * EF_WBUF);
+  float* const sScale = (float*)(smem + EF_TABLE + 2 * EF_WBUF + EF_IDX);      // [2 Cout] then shift [2 Cout] at + 512
+  float* const sShift = sScale + 512;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+  const int nslice = p.Cout / 64;
+
+  const u32x4* const wg = (const u32x4*)p.w;
+  auto w_issue = [&](int u) {                               // u = 2 slice + half -> buffer u & 1
+    constexpr int PIECES = HALF / 16;
+#pragma unroll
+    for (int k = 0; k < (PIECES + 511) / 512; ++k) {
+      const int i0 = wave * 64 + 512 * k;
+      if (i0 < PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)u * PIECES + i0 + lane),
+                                         (__attribute__((address_space(3))) void*)(sW + (u & 1) * EF_WBUF + i0 * 16), 16, 0, 0);
+    }
+  };
+  w_issue(0);
+
+  // ---- neighbour lists of this crop's graph -> int16 in LDS
+  {
+    const int g = p.gids ? p.gids[b] : 0;
+    const int32_t* gi = p.idx + (size_t)g * EF_N * p.K;
+    for (int i = tid; i < EF_N * p.K; i += 512) sIdx[(i / p.K) * EF_KMAX + (i % p.K)] = (int16_t)gi[i];
+  }
+  for (int i = tid; i < 2 * p.Cout; i += 512) { sScale[i] = p.scale[i]; sShift[i] = p.shift[i]; }
+  // ---- this wave's 64 x rows: registers
+  u32x4 xa[4][KC];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const size_t row = (size_t)b * EF_N + wave * 64 + f * 16 + x;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + row * p.in_cs + p.in_coff + kc * 32 + q * 8);
+  }
+  __syncthreads();
+
+  f32x4 acc[4][4];
+  for (int s = 0; s < nslice; ++s) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int u = 2 * s + half;
+      if (u + 1 < 2 * nslice) w_issue(u + 1);               // the other buffer: its last readers passed the previous barrier
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned char* const wb = sW + (u & 1) * EF_WBUF + lane * 16;
+      u32x4 wf[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *(const u32x4*)(wb + nt * 1024);
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        if (kc + 1 < KC) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) wf[(kc + 1) & 1][nt] = *(const u32x4*)(wb + ((kc + 1) * 4 + nt) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
+                                                                 acc[f][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // lane (x, q): keypoint 64 wave + 16 f + x, channels 64 s + 16 q + 4 nt + reg
+      const int c0 = (half ? p.Cout : 0) + s * 64 + q * 16;
+      if (half == 0) {                                      // P' -> bf16 -> sortable keys -> LDS table
+        float sc[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4 s4 = *(const f32x4*)(sScale + c0 + 4 * nt);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sc[4 * nt + j] = s4[j];
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          u32x4 lo, hi;
+          lo.x = sortable(pack_bf16x2(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+          lo.y = sortable(pack_bf16x2(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+          lo.z = sortable(pack_bf16x2(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+          lo.w = sortable(pack_bf16x2(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+          hi.x = sortable(pack_bf16x2(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+          hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+          hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+          hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+          unsigned char* dst = sP + (wave * 64 + f * 16 + x) * EF_PITCH + q * 32;
+          *(u32x4*)dst = lo;
+          *(u32x4*)(dst + 16) = hi;
+        }
+        __syncthreads();                                    // table complete; the Q half of the weights has landed
+      } else {                                              // Q' stays in the accumulators (fp32)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4 s4 = *(const f32x4*)(sScale + c0 + 4 * nt), t4 = *(const f32x4*)(sShift + c0 + 4 * nt);
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][nt][j] = acc[f][nt][j] * s4[j] + t4[j];
+        }
+      }
+    }
+    // ---- gather-max over the K neighbours out of the LDS table, + Q', LeakyReLU, store
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int n = wave * 64 + f * 16 + x;
+      const int16_t* my = sIdx + n * EF_KMAX;
+      uint32_t m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = 0x80008000u;        // int16 minimum
+      for (int k = 0; k < p.K; k += 4) {                     // K is a multiple of 4 (20)
+        const u32x2 i4 = *(const u32x2*)(my + k);
+        const int r0 = (int)(i4.x & 0xffffu), r1 = (int)(i4.x >> 16), r2 = (int)(i4.y & 0xffffu), r3 = (int)(i4.y >> 16);
+        const unsigned char* b0 = sP + r0 * EF_PITCH + q * 32;
+        const unsigned char* b1 = sP + r1 * EF_PITCH + q * 32;
+        const unsigned char* b2 = sP + r2 * EF_PITCH + q * 32;
+        const unsigned char* b3 = sP + r3 * EF_PITCH + q * 32;
+        const u32x4 a0 = *(const u32x4*)b0, a1 = *(const u32x4*)(b0 + 16), c0_ = *(const u32x4*)b1, c1 = *(const u32x4*)(b1 + 16);
+        const u32x4 d0 = *(const u32x4*)b2, d1 = *(const u32x4*)(b2 + 16), e0 = *(const u32x4*)b3, e1 = *(const u32x4*)(b3 + 16);
+        m[0] = pkmax(pkmax(m[0], a0.x), pkmax(c0_.x, pkmax(d0.x, e0.x)));
+        m[1] = pkmax(pkmax(m[1], a0.y), pkmax(c0_.y, pkmax(d0.y, e0.y)));
+        m[2] = pkmax(pkmax(m[2], a0.z), pkmax(c0_.z, pkmax(d0.z, e0.z)));
+        m[3] = pkmax(pkmax(m[3], a0.w), pkmax(c0_.w, pkmax(d0.w, e0.w)));
+        m[4] = pkmax(pkmax(m[4], a1.x), pkmax(c1.x, pkmax(d1.x, e1.x)));
+        m[5] = pkmax(pkmax(m[5], a1.y), pkmax(c1.y, pkmax(d1.y, e1.y)));
+        m[6] = pkmax(pkmax(m[6], a1.z), pkmax(c1.z, pkmax(d1.z, e1.z)));
+        m[7] = pkmax(pkmax(m[7], a1.w), pkmax(c1.w, pkmax(d1.w, e1.w)));
+      }
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t w2 = sortable(m[j]);
+        const int nt = j >> 1, r = (j & 1) * 2;
+        const float q0 = acc[f][nt][r], q1 = acc[f][nt][r + 1];
+        const float y0 = __uint_as_float(w2 << 16) + q0, y1 = __uint_as_float(w2 & 0xffff0000u) + q1;
+        v[2 * j] = y0 > 0.f ? y0 : y0 * p.slope;
+        v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
+      }
+      uint16_t* dst = (uint16_t*)p.out + ((size_t)b * EF_N + n) * p.out_cs + p.out_coff + s * 64 + q * 16;
+      *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
+      *(u32x4*)(dst + 8) = Vec16<BF16Tag>::pack(v + 8);
+    }
+    __syncthreads();                                        // every gather of this slice is done: the table may be rewritten
+  }
+}
+
+// [slice][half P/Q][chunk][tile][lane][8 bf16]; tile row r of tile nt = output channel 64 slice + (r >> 2) * 16 + 4 nt + (r & 3)
+// of wpq rows [0, Cout) (P half) / [Cout, 2 Cout) (Q half); element e of lane (r, q): input channel 32 chunk + 8 q + e.
+__global__ void pack_edgeconv_fused_kernel(const float* __restrict__ wpq, uint16_t* __restrict__ out, int Cin, int Cout, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int KC = Cin / 32;
+  const int e = (int)(i % 8);
+  const int lane = (int)((i / 8) % 64);
+  size_t blk = i / 512;
+  const int nt = (int)(blk % 4); blk /= 4;
+  const int kc = (int)(blk % KC); blk /= KC;
+  const int half = (int)(blk % 2);
+  const int s = (int)(blk / 2);
+  const int r = lane & 15, q = lane >> 4;
+  const int c = s * 64 + (r >> 2) * 16 + nt * 4 + (r & 3);
+  const int cin = kc * 32 + q * 8 + e;
+  out[i] = (uint16_t)f32_to_bf16_bits(wpq[((size_t)(half * Cout + c)) * Cin + cin]);
+}
+
+}  // namespace
+
+extern "C" int cp_edgeconv_fused_supported(int N, int K, int Cin, int Cout) {
+  return (N == EF_N && K > 0 && K <= EF_KMAX && K % 4 == 0 && (Cin == 64 || Cin == 256) && Cout >= 64 && Cout % 64 == 0 && Cout <= 256) ? 1 : 0;
+}
+
+extern "C" size_t cp_edgeconv_fused_weight_bytes(int Cin, int Cout) { return (size_t)2 * Cout * Cin * 2; }
+
+extern "C" int cp_pack_edgeconv_fused_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed) {
+  if (!wpq || !packed || !cp_edgeconv_fused_supported(EF_N, 4, Cin, Cout)) return CP_ERR_INVALID;
+  if (!cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const size_t total = (size_t)2 * Cout * Cin;
+  CP_LAUNCH(pack_edgeconv_fused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpq, (uint16_t*)packed, Cin, Cout, total);
+  return cp_check_launch();
+}
+
+extern "C" int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w,
+                                 const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
+                                 int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope) {
+  if (!x || !packed_w || !scale || !shift || !idx || !out || B <= 0 || G <= 0) return CP_ERR_INVALID;
+  if (!cp_edgeconv_fused_supported(N, K, Cin, Cout)) return CP_ERR_INVALID;
+  if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + Cout > out_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(x) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift) || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)edgeconv_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS) != hipSuccess)
+      return CP_ERR_HIP;
+    attr_done = true;
+  }
+  EdgeFusedParams p;
+  p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.idx = idx; p.gids = graph_ids; p.out = out;
+  p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.K = K; p.Cout = Cout; p.slope = slope;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64) CP_LAUNCH((edgeconv_fused_kernel<64>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
+  else CP_LAUNCH((edgeconv_fused_kernel<256>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
+  return cp_check_launch();
+}

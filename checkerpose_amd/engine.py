@@ -20,6 +20,8 @@ USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
+USE_EDGE_FUSED = os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED", "1") != "0"   # EdgeConv layer (node GEMM + gather-max) in one launch
+EDGE_FUSED_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED_MIN_BATCH", "16"))   # one workgroup per crop: needs crops to fill the chip
 CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "16"))   # below: per-conv launches (a crop's chain runs on ONE CU)
 NO_RECYCLE = os.environ.get("CHECKERPOSE_AMD_NO_RECYCLE", "0") == "1"   # debugging aid: every workspace tensor gets its own bytes
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
@@ -452,6 +454,36 @@ class Program:
         N = pq.W
         self._add(fn, lambda P: (self.dtype, P(pt), ip, gp, P(ot), pq.B, N, K, C_, G, out.cstride, out.coff, slope),
                   "edge_gather", [pt], [ot])
+        return out
+
+    def can_fuse_edgeconv(self, N, K, Cin, Cout):
+        return (USE_EDGE_FUSED and self.dtype == CP_BF16 and self.B >= EDGE_FUSED_MIN_BATCH
+                and bool(self.lib.cp_edgeconv_fused_supported(N, K, Cin, Cout)))
+
+    def edge_fused(self, x: Act, wkey, wpq, scale, shift, idx_t, gids_t, out: Act, K, G, slope):
+        """whole EdgeConv layer in one launch (cp_edgeconv_fused): wpq fp32 (2 C', C) = [W1 ; W2 - W1]"""
+        Co2, Cin = wpq.shape[0], wpq.shape[1]
+        ck = ("edge_fused", wkey)
+        if ck not in self.ws.cache:
+            buf = torch.empty(self.lib.cp_edgeconv_fused_weight_bytes(Cin, Co2 // 2), dtype=torch.uint8, device=self.device)
+            w2 = wpq.reshape(Co2, Cin).contiguous()
+            self.ws.keep.append(w2)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _abi.check(self.lib.cp_pack_edgeconv_fused_weight(st, w2.data_ptr(), Cin, Co2 // 2, buf.data_ptr()), "cp_pack_edgeconv_fused_weight")
+            self.ws.cache[ck] = (buf, scale.contiguous(), shift.contiguous())
+        buf, sc, sh = self.ws.cache[ck]
+        self.keep += [buf, sc, sh]
+        fn = self.lib.cp_edgeconv_fused
+        xt, ot = x.tbuf, out.tbuf
+        ip = idx_t.data_ptr()
+        gp = gids_t.data_ptr() if gids_t is not None else None
+        N = x.W
+        a = (buf.data_ptr(), sc.data_ptr(), sh.data_ptr(), ip, gp)
+        self._add(fn, lambda P: (P(xt), x.cstride, x.coff) + a + (P(ot), out.cstride, out.coff, self.B, N, K, Cin, Co2 // 2, G, slope),
+                  "edge_fused:" + wkey, [xt], [ot])
+        fl = 2 * self.B * N * Cin * Co2
+        self.flops += fl
+        self.conv_log.append((wkey, self.B * N, Co2, Cin, fl, "edge_fused", self.B * N * (Cin + Co2 // 2) * self.es + Co2 * Cin * self.es))
         return out
 
     def index2feat(self, patches: Act, xid_t, yid_t, mask_t, out: Act, N, E_ch, k):

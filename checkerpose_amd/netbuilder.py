@@ -362,9 +362,11 @@ class NetEmitter:
             self.ws.cache[ck] = (torch.cat([w1, w2 - w1], 0).reshape(2 * Co, Cc, 1, 1).contiguous(),
                                  torch.cat([s, s]), torch.cat([torch.zeros_like(t), t]))
         wpq, sc, sh = self.ws.cache[ck]
-        pq = self.p.conv(x, ck, wpq, sc, sh, 1, 1, 1, 0, 2 * Co)
         if out is None:
             out = self.p.act(1, x.W, Co)
+        if self.p.can_fuse_edgeconv(x.W, graph["K"], Cc, Co) and x.C == Cc:
+            return self.p.edge_fused(x, ck, wpq, sc, sh, graph["idx"], graph["gids"], out, graph["K"], graph["G"], slope)
+        pq = self.p.conv(x, ck, wpq, sc, sh, 1, 1, 1, 0, 2 * Co)
         return self.p.edge_gather(pq, graph["idx"], graph["gids"], out, graph["K"], Co, graph["G"], slope)
 
 

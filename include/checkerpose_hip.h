@@ -194,6 +194,21 @@ int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, int C, int H, in
 int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
                        const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out);
 
+/* EdgeConv layer in ONE launch for N = 512 keypoints (bf16): per-node GEMM [P' | Q'] = x . wpq^T on MFMA, P' table of one
+ * 64-channel slice in LDS, neighbour gather-max out of LDS, + Q', LeakyReLU (StaticGraph_module, init.py:54-68 ==
+ * pipeline.py:45-59; per-sample graphs `knn_idx[obj_ids-1]` of pipeline_lm.py:55-57 through graph_ids).
+ *   x (B, 512, in_cstride) channels [in_coff, in_coff + Cin);  wpq fp32 (2 Cout, Cin) = [W1 ; W2 - W1], packed by
+ *   cp_pack_edgeconv_fused_weight;  scale / shift fp32 [2 Cout] = [s | s], [0 | t] (folded BatchNorm);  idx int32 (G, 512, K);
+ *   out (B, 512, out_cstride) channels [out_coff, out_coff + Cout) = leaky(max_k (s W1 x)_{idx[k]} + s (W2 - W1) x + t).
+ * Supported: N = 512, K <= 20 and a multiple of 4, Cin in {64, 256}, Cout in {64, 128, 192, 256} (cp_edgeconv_fused_supported);
+ * other shapes (N = 4096) use cp_conv2d_igemm / cp_gemm_rows + cp_edgeconv_gather_max. */
+int cp_edgeconv_fused_supported(int N, int K, int Cin, int Cout);
+size_t cp_edgeconv_fused_weight_bytes(int Cin, int Cout);
+int cp_pack_edgeconv_fused_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed);
+int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w,
+                      const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
+                      int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope);
+
 /* Bit decode (pipeline.py:72-127, 367-369, 380-381) on the fp32 logit block `bits` (B, 13, N):
  * row 0 = roi, rows 1..6 = x bits (MSB first), rows 7..12 = y bits.
  *   stage < 0 : mask = bit(bits[0]) ; x_id = MSB-first int of rows 1..3 ; y_id of rows 7..9

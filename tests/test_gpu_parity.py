@@ -497,6 +497,50 @@ def test_edgeconv_factored_vs_reference_form(lib, dtype, Cc, pfx):
     close(got, ref, 1e-5 if dtype == CP_F32 else 4e-2)
 
 
+@pytest.mark.parametrize("Cc,pfx", [(64, "init_net.pre_query_block.0"), (256, "refine_net.1.pre_query_block.2")])
+def test_edgeconv_fused_vs_reference_form(lib, monkeypatch, Cc, pfx):
+    """cp_edgeconv_fused (node GEMM + LDS gather-max in one launch, N = 512, bf16) == the reference's per-edge
+    conv + BN + LeakyReLU + max (StaticGraph_module) on the real `ape` graph with mixed-sign BN gammas, a channel-sliced
+    output and per-sample LM graphs (graph ids), B not a multiple of anything."""
+    from checkerpose_amd import engine
+    from checkerpose_amd.engine import Program, WeightStore
+    from checkerpose_amd.netbuilder import NetEmitter
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    dtype = CP_BF16
+    net = build_net(seed=0)
+    sd_cpu = net.state_dict()
+    idx15 = O.knn(lm_p3d(512), 20)                                      # (15, N, K): per-sample graphs
+    obj = torch.tensor([3, 15, 1, 9, 9])
+    B, N = 5, 512
+    x = det_tensor("efx%d" % Cc, (B, Cc, N))
+    ref = torch.cat([_edge_ref(sd_cpu, pfx, rnd(x[i:i + 1], dtype), idx15[obj[i] - 1:obj[i]]) for i in range(B)], 0)
+    sd = {k: v.to(dev()) for k, v in sd_cpu.items() if k.startswith(pfx)}
+    ws = WeightStore(lib, sd, dtype, dev())
+    prog = Program(lib, ws, dtype, B, dev())
+    em = NetEmitter(prog, sd)
+    xin = prog.act(1, N, Cc)
+    wide = prog.act(1, N, Cc + 64)
+    idx_d = idx15.to(torch.int32).contiguous().to(dev())
+    gids = (obj - 1).to(torch.int32).to(dev())
+    out = em.edgeconv(pfx, xin, dict(idx=idx_d, gids=gids, K=20, G=15), 0.2, out=wide.slice(64, Cc))
+    assert prog.ops[-1][2].startswith("edge_fused")
+    prog._add(lambda *a: 0, lambda P: (), "keepalive", [xin.tbuf, wide.tbuf], [])
+    prog.finalize()
+
+    def tview(a):
+        n = a.B * a.H * a.W * a.cstride
+        return prog.workspace[a.tbuf.offset: a.tbuf.offset + n * 2].view(torch.bfloat16).view(a.B, a.W, a.cstride)
+
+    tview(xin).copy_(x.permute(0, 2, 1).to(torch.bfloat16))
+    tview(wide).fill_(7.0)
+    prog.run(st())
+    torch.cuda.synchronize()
+    got = tview(wide).float().cpu()
+    assert float((got[..., :64] - 7.0).abs().max()) == 0.0               # channels outside the slice untouched
+    close(got[..., 64:].permute(0, 2, 1), ref, 4e-2)
+    assert out.coff == 64
+
+
 def test_edgeconv_per_sample_graphs_lm(lib):
     """LM twin: each sample gathers along its own object's graph (pipeline_lm.py:55-57), 1-based obj_ids."""
     B, N, K, Cc = 4, 512, 20, 64
@@ -711,6 +755,7 @@ def test_e2e_bf16_accuracy_contract(lib, monkeypatch, chain):
     from checkerpose_amd.agreement import logit_agreement
     # both kernel selections of the HRNet branches: per-conv launches (small batches) / one LDS-resident chain launch each
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1 if chain else 1 << 30)
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if chain else 1 << 30)
     net = build_net(seed=1)
     img = det_image(4, seed=3)
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
@@ -771,6 +816,7 @@ def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     unsplit sequential replay; bf16 so the test is cheap on the CPU side (no oracle needed: pure scheduling check)."""
     from checkerpose_amd import engine
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)      # slices and the unsplit batch must pick the same kernels
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
     img = det_image(16, seed=3).to(dev())
     net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
     net.batch_splits = 2
@@ -850,6 +896,7 @@ def test_full_batch_size_property_batch_independence(lib, dt, monkeypatch):
     lanes).  256 crops = 4 distinct crops x 64 copies: every copy must equal, bit for bit, the B=4 forward -- which
     test_e2e_* pins to the oracle (fp32) and test_e2e_bf16_accuracy_contract bounds (bf16)."""
     from checkerpose_amd import engine
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)    # same kernel selection at B=4 and B=256 (below 16 crops the engine
     #                                                      would pick per-conv launches: other K order, other bf16 roundings)
     net = build_net(seed=1).to(dev()).set_compute_dtype(dt)
