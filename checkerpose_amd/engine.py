@@ -20,6 +20,8 @@ USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
+USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
+STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "16"))   # one persistent workgroup per crop
 USE_EDGE_FUSED = os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED", "1") != "0"   # EdgeConv layer (node GEMM + gather-max) in one launch
 EDGE_FUSED_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED_MIN_BATCH", "16"))   # one workgroup per crop: needs crops to fill the chip
 CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "16"))   # below: per-conv launches (a crop's chain runs on ONE CU)
@@ -339,6 +341,34 @@ class Program:
         nb = x.B * x.H * x.W * C_ * self.es
         self.flops += 2 * fl
         self.conv_log.append((k1, x.B * x.H * x.W, C_, 9 * C_, 2 * fl, "basicblock_fused", 2 * nb + 2 * 9 * C_ * C_ * self.es))
+        return out
+
+    def can_fuse_stem(self, size):
+        return USE_STEM and self.dtype == CP_BF16 and self.B >= STEM_MIN_BATCH and size % 64 == 0
+
+    def hr_stem(self, img_t, size, k1, w1, s1, t1, k2, w2, s2, t2):
+        """timm hrnet stem (conv1-bn1-relu-conv2-bn2-relu) from the NCHW fp32 image in one launch (cp_hr_stem)"""
+        ck = ("stem", k1)
+        if ck not in self.ws.cache:
+            p1 = torch.empty(self.lib.cp_hr_stem_weight_bytes(0), dtype=torch.uint8, device=self.device)
+            p2 = torch.empty(self.lib.cp_hr_stem_weight_bytes(1), dtype=torch.uint8, device=self.device)
+            w1c, w2c = w1.contiguous(), w2.contiguous()
+            self.ws.keep += [w1c, w2c]
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _abi.check(self.lib.cp_pack_hr_stem_weights(st, w1c.data_ptr(), w2c.data_ptr(), p1.data_ptr(), p2.data_ptr()), "cp_pack_hr_stem_weights")
+            self.ws.cache[ck] = (p1, p2)
+        p1, p2 = self.ws.cache[ck]
+        a1, a2 = self.ws.affine(k1 + "#0", s1, t1, 64), self.ws.affine(k2 + "#0", s2, t2, 64)
+        out = self.act(size // 4, size // 4, 64)
+        self.keep += [p1, p2, a1, a2]
+        fn = self.lib.cp_hr_stem
+        ip = img_t.data_ptr()
+        ot = out.tbuf
+        args = (p1.data_ptr(), a1[0].data_ptr(), a1[1].data_ptr(), p2.data_ptr(), a2[0].data_ptr(), a2[1].data_ptr())
+        self._add(fn, lambda P: (ip, self.B, size, size) + args + (P(ot),), "hr_stem:" + k1, [], [ot])
+        fl = 2 * self.B * ((size // 2) ** 2 * 64 * 27 + (size // 4) ** 2 * 64 * 576)
+        self.flops += fl
+        self.conv_log.append((k1, self.B * (size // 4) ** 2, 64, 576, fl, "hr_stem", self.B * (3 * size * size * 4 + (size // 4) ** 2 * 64 * 2)))
         return out
 
     def can_chain(self, C_, H, W):

@@ -262,9 +262,10 @@ class NetEmitter:
                 tp.fuse_sum_bwd(go, out, tp.grad_of(s_), sh, True)
         tp.tape.append(bwd)
 
-    def hrnet(self, pfx, x, feat_outs=None):
-        x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 3, 2, 1)
-        x = self.conv_bn(x, pfx + "conv2", pfx + "bn2", 3, 2, 1)
+    def hrnet(self, pfx, x, feat_outs=None, stem_done=False):
+        if not stem_done:
+            x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 3, 2, 1)
+            x = self.conv_bn(x, pfx + "conv2", pfx + "bn2", 3, 2, 1)
         for k in range(4):
             x = self.bottleneck("%slayer1.%d" % (pfx, k), x)
         if self.tp is None:                  # the two transition convs are independent: two lanes
@@ -374,15 +375,20 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
     """InitNet_GNN.forward init.py:109-128.  Returns (feats [Act], graph_feats Act)."""
     p = em.p
     N = cfg["npoint"]
-    if cfg.get("uint8_input"):     # raw uint8 HWC crops: ToTensor + Normalize on the device (row N3)
+    tp = em.tp
+    bb = pfx + "img_backbone."
+    fused_stem = (tp is None and cfg["backbone"] == "hrnet_w18" and not cfg.get("uint8_input") and p.can_fuse_stem(cfg["img_size"]))
+    if fused_stem:                 # layout change + conv1 + conv2 of the HRNet stem in one launch, straight from the NCHW image
+        s1, t1 = em.ws.bn_fold(bb + "bn1")
+        s2, t2 = em.ws.bn_fold(bb + "bn2")
+        x = p.hr_stem(io["img"], cfg["img_size"], bb + "conv1", em.W(bb + "conv1.weight"), s1, t1, bb + "conv2", em.W(bb + "conv2.weight"), s2, t2)
+    elif cfg.get("uint8_input"):   # raw uint8 HWC crops: ToTensor + Normalize on the device (row N3)
         x = p.u8_to_nhwc_norm(io["img"], cfg["img_size"], cfg["img_size"])
     else:
         x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
-    tp = em.tp
     if tp is not None:
         tp.nograd.add(id(x.tbuf))                           # the image needs no gradient
-    bb = pfx + "img_backbone."
-    feats = em.hrnet(bb, x) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
+    feats = em.hrnet(bb, x, stem_done=fused_stem) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
     f = feats[-1]                                           # (B, 8, 8, Cb)
     # conv1x1 Cb -> N, then `view(-1, N, 64).permute(0,2,1)` (init.py:112-114): keypoint n's 8x8 response map is its
     # 64-d feature -> written straight into the (B, N, 64) graph layout through the epilogue strides.

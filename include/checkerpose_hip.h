@@ -175,6 +175,16 @@ int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* patches, con
                          const int32_t* y_id, const float* mask, void* out, int B, int N, int Hp, int Wp,
                          int E, int k, int out_cstride, int out_coff);
 
+/* HRNet stem in one launch (bf16): NCHW fp32 image (B, 3, Hin, Win) -> conv1 3x3/s2 (3 -> 64) + BN + ReLU -> conv2 3x3/s2
+ * (64 -> 64) + BN + ReLU -> (B, Hin/4, Win/4, 64) bf16 channels-last (timm hrnet conv1/bn1/conv2/bn2 behind reference
+ * backbone.py:48-49); the 2 MB-per-crop intermediate never leaves LDS.  Hin % 32 == 0, Win % 64 == 0.  Weights: fp32
+ * (64, 3, 3, 3) and (64, 64, 3, 3) packed by cp_pack_hr_stem_weights into buffers of cp_hr_stem_weight_bytes(0 | 1) bytes;
+ * scale / shift = folded BatchNorm, 64 floats each. */
+size_t cp_hr_stem_weight_bytes(int which);
+int cp_pack_hr_stem_weights(cp_stream_t stream, const float* w1, const float* w2, void* packed1, void* packed2);
+int cp_hr_stem(cp_stream_t stream, const float* img_nchw, int B, int Hin, int Win, const void* packed1, const float* scale1,
+               const float* shift1, const void* packed2, const float* scale2, const float* shift2, void* out);
+
 /* ---------------------------------------------------------------------------------------------
  * One launch per HRNet branch chain (bf16): the four BasicBlocks of `HighResolutionModule.branches[j]` (inside
  * timm.create_model("hrnet_w18", features_only=True), reference backbone.py:48-49; restated oracle/checkerpose_oracle.py

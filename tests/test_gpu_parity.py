@@ -229,6 +229,35 @@ def test_basicblock_fused_vs_torch_cpu(lib, dtype, Cc, shape):
                                    pw2.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), xin.data_ptr()) == -1   # in-place refused
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 64), (2, 96, 128), (1, 256, 256)])
+def test_hr_stem_fused_vs_torch_cpu(lib, shape):
+    """cp_hr_stem (layout change + conv1/s2 + BN + ReLU + conv2/s2 + BN + ReLU in one launch, bf16) == torch CPU with the
+    image and the 64-channel intermediate rounded to bf16; image borders (zero padding of BOTH convs), several tiles."""
+    B, Hin, Win = shape
+    img = det_tensor("stimg%s" % (shape,), (B, 3, Hin, Win), 1.7)
+    w1 = det_tensor("stw1", (64, 3, 3, 3), (2.0 / 27) ** 0.5 * 1.7)
+    w2 = det_tensor("stw2", (64, 64, 3, 3), (2.0 / 576) ** 0.5 * 1.7)
+    s1, t1 = 1.0 + 0.3 * det_tensor("sts1", (64,)), 0.2 * det_tensor("stt1", (64,))
+    s2, t2 = 1.0 + 0.3 * det_tensor("sts2", (64,)), 0.2 * det_tensor("stt2", (64,))
+    v4 = lambda v: v.view(1, -1, 1, 1)   # noqa: E731
+    y1 = rnd(F.relu(F.conv2d(rnd(img, CP_BF16), rnd(w1, CP_BF16), None, 2, 1) * v4(s1) + v4(t1)), CP_BF16)
+    ref = F.relu(F.conv2d(y1, rnd(w2, CP_BF16), None, 2, 1) * v4(s2) + v4(t2))
+    d = dev()
+    p1 = torch.empty(lib.cp_hr_stem_weight_bytes(0), dtype=torch.uint8, device=d)
+    p2 = torch.empty(lib.cp_hr_stem_weight_bytes(1), dtype=torch.uint8, device=d)
+    w1d, w2d = w1.contiguous().to(d), w2.contiguous().to(d)
+    _abi.check(lib.cp_pack_hr_stem_weights(st(), w1d.data_ptr(), w2d.data_ptr(), p1.data_ptr(), p2.data_ptr()))
+    a = [v.contiguous().to(d) for v in (s1, t1, s2, t2)]
+    imgd = img.contiguous().to(d)
+    out = torch.full((B, Hin // 4, Win // 4, 64), float("nan"), dtype=torch.bfloat16, device=d)
+    _abi.check(lib.cp_hr_stem(st(), imgd.data_ptr(), B, Hin, Win, p1.data_ptr(), a[0].data_ptr(), a[1].data_ptr(), p2.data_ptr(),
+                              a[2].data_ptr(), a[3].data_ptr(), out.data_ptr()), "hr stem")
+    torch.cuda.synchronize()
+    close(from_cl(out, 64), ref, 3e-2)
+    assert lib.cp_hr_stem(st(), imgd.data_ptr(), B, Hin + 8, Win, p1.data_ptr(), a[0].data_ptr(), a[1].data_ptr(), p2.data_ptr(),
+                          a[2].data_ptr(), a[3].data_ptr(), out.data_ptr()) == -1                 # not a whole number of tiles
+
+
 @pytest.mark.parametrize("nsrc", [1, 3])
 @pytest.mark.parametrize("cfg", [(36, 32, 32, 3), (72, 16, 16, 5), (144, 8, 8, 3), (36, 32, 32, 1), (18, 64, 64, 3)])
 def test_hr_branch_chain_vs_torch_cpu(lib, cfg, nsrc):
@@ -754,6 +783,7 @@ def test_e2e_bf16_accuracy_contract(lib, monkeypatch, chain):
     from checkerpose_amd import engine
     from checkerpose_amd.agreement import logit_agreement
     # both kernel selections of the HRNet branches: per-conv launches (small batches) / one LDS-resident chain launch each
+    monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1 if chain else 1 << 30)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1 if chain else 1 << 30)
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if chain else 1 << 30)
     net = build_net(seed=1)
@@ -815,6 +845,7 @@ def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     """B=16 is run as two concurrent 8-crop slice graphs (CHECKERPOSE_AMD_SPLITS=2): identical, bit for bit, to the
     unsplit sequential replay; bf16 so the test is cheap on the CPU side (no oracle needed: pure scheduling check)."""
     from checkerpose_amd import engine
+    monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)      # slices and the unsplit batch must pick the same kernels
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
     img = det_image(16, seed=3).to(dev())
@@ -897,6 +928,7 @@ def test_full_batch_size_property_batch_independence(lib, dt, monkeypatch):
     test_e2e_* pins to the oracle (fp32) and test_e2e_bf16_accuracy_contract bounds (bf16)."""
     from checkerpose_amd import engine
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)    # same kernel selection at B=4 and B=256 (below 16 crops the engine
     #                                                      would pick per-conv launches: other K order, other bf16 roundings)
     net = build_net(seed=1).to(dev()).set_compute_dtype(dt)
