@@ -73,6 +73,10 @@ SIGNATURES = {
     "cp_edgeconv_fused_weight_bytes": (C.c_size_t, [_I, _I]),
     "cp_pack_edgeconv_fused_weight": (_I, [_P, _P, _I, _I, _P]),
     "cp_edgeconv_fused": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_index2feat_conv_supported": (_I, [_I, _I, _I]),
+    "cp_index2feat_conv_weight_bytes": (C.c_size_t, []),
+    "cp_pack_index2feat_conv_weight": (_I, [_P, _P, _P]),
+    "cp_index2feat_conv": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_bits_decode": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
     "cp_correspondences": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),

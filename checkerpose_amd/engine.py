@@ -20,6 +20,7 @@ USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
+USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
 #   crossover against the tiled launches (tools/batch_sweep.py, MI355X): chains win from 64 crops, stem + EdgeConv from 96
@@ -515,6 +516,32 @@ class Program:
         fl = 2 * self.B * N * Cin * Co2
         self.flops += fl
         self.conv_log.append((wkey, self.B * N, Co2, Cin, fl, "edge_fused", self.B * N * (Cin + Co2 // 2) * self.es + Co2 * Cin * self.es))
+        return out
+
+    def can_gather_patch(self, f: Act, N, E_ch, k):
+        """gathered patch conv: 4 N rows per crop instead of (H+1)(W+1) positions -- pays from 2 x 4 N < (H+1)(W+1)"""
+        return (USE_PATCH_GATHER and self.dtype == CP_BF16 and bool(self.lib.cp_index2feat_conv_supported(f.C, E_ch, k))
+                and 8 * N <= (f.H + 1) * (f.W + 1) and f.B * f.H * f.W * f.cstride * 2 < (1 << 31))
+
+    def index2feat_conv(self, f: Act, wkey, w, bias, xid_t, yid_t, mask_t, out: Act, N, k):
+        ck = ("patch_gather", wkey)
+        if ck not in self.ws.cache:
+            buf = torch.empty(self.lib.cp_index2feat_conv_weight_bytes(), dtype=torch.uint8, device=self.device)
+            wc = w.contiguous()
+            self.ws.keep.append(wc)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _abi.check(self.lib.cp_pack_index2feat_conv_weight(st, wc.data_ptr(), buf.data_ptr()), "cp_pack_index2feat_conv_weight")
+            self.ws.cache[ck] = (buf, bias.contiguous())
+        buf, bs = self.ws.cache[ck]
+        self.keep += [buf, bs]
+        fn = self.lib.cp_index2feat_conv
+        ft, ot = f.tbuf, out.tbuf
+        a = (buf.data_ptr(), bs.data_ptr(), xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())
+        self._add(fn, lambda P: (P(ft), f.cstride, f.coff) + a + (P(ot), f.B, N, f.H, f.W, k, out.cstride, out.coff),
+                  "patch_gather:" + wkey, [ft], [ot])
+        fl = 2 * f.B * 4 * N * 64 * 4 * f.C
+        self.flops += fl
+        self.conv_log.append((wkey, f.B * 4 * N, 64, 4 * f.C, fl, "patch_gather", f.B * 4 * N * (4 * f.C + 64) * self.es))
         return out
 
     def index2feat(self, patches: Act, xid_t, yid_t, mask_t, out: Act, N, E_ch, k):

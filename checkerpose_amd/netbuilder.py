@@ -563,11 +563,15 @@ def emit_posenet(em: NetEmitter, cfg, io):
         wpg = em.W(rp + ".local_feat_ext_block.patch_generator.weight")     # (E, nf, k, k)
         Ech = wpg.shape[0]
         pgk = rp + ".local_feat_ext_block.patch_generator"
-        if tp is None:
+        if tp is None and p.can_gather_patch(f, N, Ech, k):     # conv only where it is gathered (the 64x64 stage at N = 512)
+            p.index2feat_conv(f, rp + ".patch", wpg, em.W(pgk + ".bias"), io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, k)
+            patches = None
+        elif tp is None:
             patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(pgk + ".bias"), k, k, 1, k - 1, Ech)
         else:
             patches = p.conv(f, rp + ".patch", wpg, tp.const_vec(Ech, True), em._bias_vec(pgk, Ech), k, k, 1, k - 1, Ech)
-        p.index2feat(patches, io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, Ech, k)
+        if patches is not None:
+            p.index2feat(patches, io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, Ech, k)
         if tp is not None:
             # the decode ops advance io["xid"/"yid"] in place: keep this stage's gather positions for the backward
             ids_i = dict(mask=io["mask"])

@@ -219,6 +219,20 @@ int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_
                       const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
                       int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope);
 
+/* Index2Feat_module.forward + RoI mask in one launch (bf16): the patch_generator conv (Conv2d(256 -> 64, k = 2, pad = 1),
+ * pipeline.py:146-147) evaluated ONLY at the 4 gathered taps of every keypoint (pipeline.py:156-163), times mask (pipeline.py:280):
+ *   out[b, n, 64 t + c] = mask[b, n] * (bias[c] + sum_{dy, dx, ci} w[c, ci, dy, dx] * f[b, py - 1 + dy, px - 1 + dx, ci]),
+ *   (py, px) = (2 y_id + k [t & 1], 2 x_id + k [t >> 1]),  t = 0..3 in the reference's sf1..sf4 order.
+ * f (B, H, W, in_cstride) channels [in_coff, +256); w fp32 (64, 256, 2, 2) packed by cp_pack_index2feat_conv_weight into
+ * cp_index2feat_conv_weight_bytes() bytes; out (B, N, out_cstride) channels [out_coff, +256).  Used where it is cheaper than
+ * cp_conv2d_igemm + cp_index2feat_gather (the 64 x 64 stage at N = 512: half the FLOPs, no (H+1) x (W+1) x 64 tensor). */
+int cp_index2feat_conv_supported(int Cin, int E_ch, int k);
+size_t cp_index2feat_conv_weight_bytes(void);
+int cp_pack_index2feat_conv_weight(cp_stream_t stream, const float* w, void* packed);
+int cp_index2feat_conv(cp_stream_t stream, const void* f, int in_cstride, int in_coff, const void* packed_w, const float* bias,
+                       const int32_t* x_id, const int32_t* y_id, const float* mask, void* out, int B, int N, int H, int W, int k,
+                       int out_cstride, int out_coff);
+
 /* Bit decode (pipeline.py:72-127, 367-369, 380-381) on the fp32 logit block `bits` (B, 13, N):
  * row 0 = roi, rows 1..6 = x bits (MSB first), rows 7..12 = y bits.
  *   stage < 0 : mask = bit(bits[0]) ; x_id = MSB-first int of rows 1..3 ; y_id of rows 7..9

@@ -618,6 +618,39 @@ def test_index2feat_gather_vs_golden(lib, H):
     assert float(out.abs().max()) == 0.0
 
 
+def test_index2feat_conv_gathered_vs_golden(lib):
+    """cp_index2feat_conv (patch conv evaluated only at the gathered taps + RoI mask, bf16) against the REFERENCE
+    Index2Feat_module's golden output at the 64 x 64 stage incl. border ids (taps that read the conv's zero padding), a
+    channel-sliced output and a masked-out keypoint."""
+    H = 64
+    g = golden("blk_index2feat_h%d" % H)
+    net = build_net(seed=0)
+    sd = net.state_dict()
+    B, N = 2, 512
+    f = det_tensor("i2f%d" % H, (B, 256, H, H))
+    w = sd["refine_net.2.local_feat_ext_block.patch_generator.weight"]
+    bias = sd["refine_net.2.local_feat_ext_block.patch_generator.bias"]
+    assert lib.cp_index2feat_conv_supported(256, 64, 2) == 1
+    d = dev()
+    pw = torch.empty(lib.cp_index2feat_conv_weight_bytes(), dtype=torch.uint8, device=d)
+    wd = w.contiguous().to(d)
+    _abi.check(lib.cp_pack_index2feat_conv_weight(st(), wd.data_ptr(), pw.data_ptr()))
+    fin = to_cl(f, CP_BF16)
+    xid = torch.from_numpy(g["xid"].astype(np.int32)).to(d); yid = torch.from_numpy(g["yid"].astype(np.int32)).to(d)
+    mask = torch.ones(B, N, device=d); mask[1, 8] = 0.0
+    out = torch.full((B, N, 320), 5.0, dtype=torch.bfloat16, device=d)
+    bd = bias.contiguous().to(d)
+    _abi.check(lib.cp_index2feat_conv(st(), fin.data_ptr(), 256, 0, pw.data_ptr(), bd.data_ptr(), xid.data_ptr(), yid.data_ptr(),
+                                      mask.data_ptr(), out.data_ptr(), B, N, H, H, 2, 320, 64), "index2feat conv")
+    torch.cuda.synchronize()
+    got = out[..., 64:].float().cpu().permute(0, 2, 1)                     # (B, 256, N)
+    ref = torch.from_numpy(g["out"]).clone()                               # keypoints ::4 of the reference output
+    assert float(got[1, :, 8].abs().max()) == 0.0                          # RoI mask
+    ref[1, :, 2] = 0.0
+    close(got[:, :, ::4], ref, 3e-2)
+    assert float((out[..., :64].float() - 5.0).abs().max()) == 0.0         # channels outside the slice untouched
+
+
 def test_bits_decode_exact(lib):
     B, N = 3, 700
     bits = det_tensor("bits", (B, 13, N))
