@@ -28,7 +28,9 @@ constexpr int MPLANES = 8, OPLANES = 32;                         // 64 / 8, 256 
 constexpr int ST1_BYTES = MPLANES * PITCH_X, ST2_BYTES = MPLANES * PITCH_T, SO_BYTES = OPLANES * PITCH_T;
 // XCH = 64-byte chunks of the input row: 8 (256 channels, identity shortcut, output written in place over the x tile)
 // or 2 (64 channels, projection shortcut `downsample`, output tile in its own LDS region).
-constexpr int lds_bytes(int XCH, bool HAS_DS) { return XCH * 4 * PITCH_X + ST1_BYTES + ST2_BYTES + (HAS_DS ? SO_BYTES : 0); }   // 140 032 / 131 968
+constexpr int AFF_FLOATS = 4 * 64 + 4 * 256;                     // s1 t1 s2 t2 [64] | s3 t3 sd td [256]
+constexpr int lds_main(int XCH, bool HAS_DS) { return XCH * 4 * PITCH_X + ST1_BYTES + ST2_BYTES + (HAS_DS ? SO_BYTES : 0); }   // 140 032 / 131 968
+constexpr int lds_bytes(int XCH, bool HAS_DS) { return lds_main(XCH, HAS_DS) + AFF_FLOATS * 4; }
 
 struct BottleneckParams {
   const void* in; void* out;
@@ -59,6 +61,19 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
   const int x = lane & 15, q = lane >> 4;
   const int nt = wave & 3, half = wave >> 2;
+  // BN scale / shift vectors live in LDS: an epilogue that fetched them from global memory would have to wait (vmcnt is
+  // in-order) for the next tile's halo loads, which are in flight during conv3
+  float* const sAff = (float*)(smem + lds_main(XCH, HAS_DS));
+  {
+    const float* const v64[4] = {p.s1, p.t1, p.s2, p.t2};
+    const float* const v256[4] = {p.s3, p.t3, p.sd, p.td};
+    if (tid < 256) sAff[tid] = v64[tid >> 6][tid & 63];
+#pragma unroll
+    for (int k = 0; k < (HAS_DS ? 4 : 2); ++k)
+      if (tid < 256) sAff[256 + k * 256 + tid] = v256[k][tid];
+  }
+  const float* const a_s1 = sAff, * const a_t1 = sAff + 64, * const a_s2 = sAff + 128, * const a_t2 = sAff + 192;
+  const float* const a_s3 = sAff + 256, * const a_t3 = sAff + 512, * const a_sd = sAff + 768, * const a_td = sAff + 1024;
 
   // ---- block-resident weights (generic packing [tile][chunk][lane][16 B], see cp_pack_conv_weight)
   u32x4 W2[18], W3[2][2];
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
         for (int f = 0; f < 6; ++f) mma_bf16(W1[kc], *(const u32x4*)(base + f * 256), acc[f]);
       }
       const int c0 = nt * 16 + q * 4;
-      const f32x4 sc = *(const f32x4*)(p.s1 + c0), sh = *(const f32x4*)(p.t1 + c0);
+      const f32x4 sc = *(const f32x4*)(a_s1 + c0), sh = *(const f32x4*)(a_t1 + c0);
 #pragma unroll
       for (int f = 0; f < 6; ++f) {
         const int p1 = (half * 6 + f) * 16 + x;
@@ -178,6 +193,9 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
       }
     }
     __syncthreads();
+    // next tile's halo loads take off now (conv1's weight fragments are dead) and stay in registers until this tile's
+    // output has left the x planes: they are in flight under conv2, conv3 and the store phase
+    issue_loads(li + nbx, xv);
 
     // ---- conv2 (3x3 on t1): channel tile nt, rows 4*half .. 4*half+3
     {
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
         }
       }
       const int c0 = nt * 16 + q * 4;
-      const f32x4 sc = *(const f32x4*)(p.s2 + c0), sh = *(const f32x4*)(p.t2 + c0);
+      const f32x4 sc = *(const f32x4*)(a_s2 + c0), sh = *(const f32x4*)(a_t2 + c0);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         float v[4];
@@ -206,7 +224,6 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
       }
     }
     __syncthreads();
-
     // ---- conv3 (1x1, K = 64): channel tiles 2*wave, 2*wave+1, all 8 rows (two passes of 4: bounds the live
     // accumulators + operands); + residual (x tile in LDS), written back in place
     constexpr int RP = HAS_DS ? 2 : 4;                           // rows per pass (two accumulator sets with the shortcut)
@@ -247,9 +264,9 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int c0 = (2 * wave + t) * 16 + q * 4;
-        const f32x4 sc = *(const f32x4*)(p.s3 + c0), sh = *(const f32x4*)(p.t3 + c0);
+        const f32x4 sc = *(const f32x4*)(a_s3 + c0), sh = *(const f32x4*)(a_t3 + c0);
         if constexpr (HAS_DS) {
-          const f32x4 scd = *(const f32x4*)(p.sd + c0), shd = *(const f32x4*)(p.td + c0);
+          const f32x4 scd = *(const f32x4*)(a_sd + c0), shd = *(const f32x4*)(a_td + c0);
           unsigned char* col = sO + (c0 >> 3) * PITCH_T + (fh * RP * 16 + x) * 16 + (c0 & 7) * 2;
 #pragma unroll
           for (int f = 0; f < RP; ++f) {
@@ -278,8 +295,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     }
     __syncthreads();
 
-    // ---- next tile's halo loads take off now; this tile's output leaves LDS meanwhile
-    issue_loads(li + nbx, xv);
+    // ---- this tile's output leaves LDS (the next tile's halo loads have been in flight since conv1)
     {
       const int ox = x0 + scol;
       const unsigned char* src = HAS_DS ? sO + spc * PITCH_T + scol * 16 : sX + spc * PITCH_X + (BPW + 1 + scol) * 16;

@@ -49,6 +49,29 @@ template <> struct Vec16<BF16Tag> {
   }
 };
 
+// align_corners source coordinate of output index o (scale s = (n - 1) / (2 n - 1)): left neighbour, step to the right one, the
+// right one's weight.  `contract(off)`: hipcc's default -ffp-contract=fast may fuse s * o - i0 into one fma in one kernel and
+// not in another (__fmul_rn / __fsub_rn are plain * and - in HIP); with the pragma every kernel derives the same weights.
+__device__ __forceinline__ void cp_up_coord(float s, int o, int n, int& i0, int& step, float& l1) {
+#pragma clang fp contract(off)
+  const float f = s * (float)o;
+  i0 = (int)f;
+  step = i0 < n - 1 ? 1 : 0;
+  l1 = f - (float)i0;
+}
+__device__ __forceinline__ float cp_one_minus(float l1) {
+#pragma clang fp contract(off)
+  return 1.f - l1;
+}
+// bilinear sample from its four neighbours, ONE rounding sequence shared by the stand-alone x2 kernel (elementwise.hip) and
+// the conv loader that interpolates while staging (conv3x3_halo.hip): both give the same bits
+__device__ __forceinline__ float cp_bilerp(float a, float b, float c, float d, float lx0, float lx1, float ly0, float ly1) {
+#pragma clang fp contract(off)
+  const float t = __builtin_fmaf(lx1, b, lx0 * a);
+  const float u = __builtin_fmaf(lx1, d, lx0 * c);
+  return __builtin_fmaf(ly1, u, ly0 * t);
+}
+
 template <typename Tag> __device__ __forceinline__ float load_elem(const void* p, size_t i);
 template <> __device__ __forceinline__ float load_elem<F32Tag>(const void* p, size_t i) { return ((const float*)p)[i]; }
 template <> __device__ __forceinline__ float load_elem<BF16Tag>(const void* p, size_t i) {

@@ -28,10 +28,13 @@ struct HaloParams {
   int act; float slope;
   uint32_t in_bytes, w_bytes;
   long long o_base, o_sb, o_sy, o_sx;
+  int Hs, Ws; float up_sy, up_sx;     // fused bilinear x2 (halo4 UP variant): source size, align_corners scales
 };
 
 constexpr int HTH = 8, HTW = 16, HPW = HTW + 2, HPH = HTH + 2, HNPIX = 192;   // 180 halo pixels, plane padded to 192
 constexpr int HPLANE = HNPIX * 16, HBUF = 4 * HPLANE;                          // bytes
+// fused bilinear x2 (align_corners, scale < 1/2): the 10 x 18 halo of the upsampled map comes from at most 7 x 11 source pixels
+constexpr int USRH = 7, USRW = 11, USPIX = 80, USBUF = USPIX * 64;             // source tile: [pixel][16-byte piece 0..3]
 
 template <typename Tag> struct MmaH;
 template <> struct MmaH<F32Tag> {
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
   // label, consecutive slots) so the halo they all stage is an L2 hit after the first.
   const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int nblk = slot % p.NB;
-  const int t = (slot / p.NB) * 8 + label;
+  const int t = label * ((p.total_tiles + 7) >> 3) + slot / p.NB;   // an XCD owns a contiguous run of tiles: halo overlaps hit its L2
   if (t >= p.total_tiles) return;                      // whole block, before any barrier
   const int tpi = p.tiles_x * p.tiles_y;
   const int b = t / tpi;
@@ -259,16 +262,22 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
 // registers leave room for only half-tap operand sets, so the halo rows are pipelined in two halves (rows 0-3 /
 // 4-7): each half's ds_reads are issued under the other half's 16 MFMAs.  Rows are permuted so lane q ends with
 // channels 16q..16q+15 of its 64-channel group: two 16-byte stores per pixel, 128 contiguous bytes across q.
-template <typename Tag, bool HAS_RES>
+//
+// UP = true: the conv's input is bilinear_x2(align_corners)(p.in) and the upsampled tensor never exists (pipeline.py:199-200,
+// up_net[1..2] conv1): per channel chunk the block loads the <= 7 x 11 SOURCE pixels under its halo (2 loads per thread
+// instead of 3) two chunks ahead, parks them in a small LDS tile, and interpolates the next chunk's 10 x 18 halo from it
+// LDS -> LDS between the taps of the current chunk (same arithmetic, cp_bilerp, as the stand-alone kernel: same bits).
+template <typename Tag, bool HAS_RES, bool UP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams p) {
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
   constexpr int ES = 16 / E;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * HBUF
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * HBUF (+ 2 * USBUF)
+  unsigned char* const sSrc = smem + 2 * HBUF;
 
   const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int nblk = slot % p.NB;                       // 256-channel block
-  const int t = (slot / p.NB) * 8 + label;
+  const int t = label * ((p.total_tiles + 7) >> 3) + slot / p.NB;   // an XCD owns a contiguous run of tiles: halo overlaps hit its L2
   if (t >= p.total_tiles) return;
   const int tpi = p.tiles_x * p.tiles_y;
   const int b = t / tpi;
@@ -311,6 +320,72 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams 
     for (int k = 0; k < 3; ++k) *(u32x4*)(smem + buf * HBUF + s_lds[k]) = v[k];
   };
 
+  // ---- UP: source-tile loads (piece i = tid + 256 k -> source pixel i >> 2, 16-byte piece i & 3) and, per halo piece this
+  // thread produces, its 4 neighbours' place in the source tile + the two lerp weights
+  uint32_t u_goff[2], m_off[3];
+  float m_lx[3], m_ly[3];
+  if constexpr (UP) {
+    int sy0, sx0, st_; float fr_;                              // source tile origin = left / top neighbour of the first in-image halo pixel
+    cp_up_coord(p.up_sy, y0 > 0 ? y0 - 1 : 0, p.Hs, sy0, st_, fr_);
+    cp_up_coord(p.up_sx, x0 > 0 ? x0 - 1 : 0, p.Ws, sx0, st_, fr_);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k;
+      const int sp = i >> 2, pq = i & 3;
+      const int ry = sp / USRW, rx = sp - ry * USRW;
+      const int yy = sy0 + ry, xx = sx0 + rx;
+      const bool ok = (sp < USRH * USRW) & (yy < p.Hs) & (xx < p.Ws);
+      u_goff[k] = ok ? (uint32_t)(((b * p.Hs + yy) * p.Ws + xx) * p.in_cs + p.in_coff + pq * E) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = tid + 256 * k;
+      const int hp = i >> 2, pq = i & 3;
+      const int py = hp / HPW, px = hp - py * HPW;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = (hp < HPH * HPW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+      int iy0, ix0, my, mx;
+      cp_up_coord(p.up_sy, gy, p.Hs, iy0, my, m_ly[k]);
+      cp_up_coord(p.up_sx, gx, p.Ws, ix0, mx, m_lx[k]);
+      m_off[k] = ok ? (uint32_t)((((iy0 - sy0) * USRW + (ix0 - sx0)) * 4 + pq) * 16) | (uint32_t)(mx | (my << 1) | 4) : 0u;
+    }
+  }
+  auto src_load = [&](u32x4* v, int c) {
+    const int c0 = c * KCH;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool ok = (u_goff[k] != 0xFFFFFFFFu) & (c0 + (tid & 3) * E < p.Cin);
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (u_goff[k] + (uint32_t)c0) * ES : 0x80000000u, 0, 0));
+    }
+  };
+  auto src_write = [&](const u32x4* v, int sb) {
+    *(u32x4*)(sSrc + sb * USBUF + tid * 16) = v[0];
+    if (tid < USPIX * 4 - 256) *(u32x4*)(sSrc + sb * USBUF + (tid + 256) * 16) = v[1];
+  };
+  auto interp = [&](int k, int sb, int hb) {          // halo piece tid + 256 k of buffer hb from source tile sb
+    const uint32_t mo = m_off[k];
+    const unsigned char* s00 = sSrc + sb * USBUF + (mo & ~15u);
+    const uint32_t dx = (mo & 1u) ? 64u : 0u, dy = (mo & 2u) ? (uint32_t)(USRW * 64) : 0u;
+    const float lx1 = m_lx[k], lx0 = cp_one_minus(lx1), ly1 = m_ly[k], ly0 = cp_one_minus(ly1);
+    const bool in_img = (mo & 4u) != 0u;              // outside the upsampled image: the conv's zero padding
+    unsigned char* dst = smem + hb * HBUF + s_lds[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                      // one dword at a time: a handful of live registers beside the 128 accumulators
+      const uint32_t r00 = *(const uint32_t*)(s00 + 4 * j), r01 = *(const uint32_t*)(s00 + dx + 4 * j);
+      const uint32_t r10 = *(const uint32_t*)(s00 + dy + 4 * j), r11 = *(const uint32_t*)(s00 + dy + dx + 4 * j);
+      uint32_t o;
+      if constexpr (E == 4) {
+        o = __float_as_uint(cp_bilerp(__uint_as_float(r00), __uint_as_float(r01), __uint_as_float(r10), __uint_as_float(r11), lx0, lx1, ly0, ly1));
+      } else {
+        const float lo = cp_bilerp(__uint_as_float(r00 << 16), __uint_as_float(r01 << 16), __uint_as_float(r10 << 16), __uint_as_float(r11 << 16), lx0, lx1, ly0, ly1);
+        const float hi = cp_bilerp(__uint_as_float(r00 & 0xffff0000u), __uint_as_float(r01 & 0xffff0000u), __uint_as_float(r10 & 0xffff0000u),
+                                   __uint_as_float(r11 & 0xffff0000u), lx0, lx1, ly0, ly1);
+        o = pack_bf16x2(lo, hi);
+      }
+      *(uint32_t*)(dst + 4 * j) = in_img ? o : 0u;
+    }
+  };
+
   f32x4 acc[HTH][4];
 #pragma unroll
   for (int mt = 0; mt < HTH; ++mt)
@@ -339,10 +414,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams 
   };
 
   u32x4 sv[3];
-  stage_load(sv, 0);
   u32x4 wA[4], wB[4], a0[4], a1[4];
-  w_load(wA, 0, 0);
-  stage_write(sv, 0);
+  if constexpr (UP) {
+    src_load(sv, 0);
+    w_load(wA, 0, 0);
+    src_write(sv, 0);
+    src_load(sv, 1);
+    __syncthreads();
+    interp(0, 0, 0); interp(1, 0, 0); interp(2, 0, 0);
+    src_write(sv, 1);
+  } else {
+    stage_load(sv, 0);
+    w_load(wA, 0, 0);
+    stage_write(sv, 0);
+  }
   __syncthreads();
 
   // weights one tap (32 MFMAs, ~512 cycles) ahead in two sets; a third set (two taps ahead) measured no faster
@@ -354,20 +439,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams 
   mma(a1, WCUR, 1); __builtin_amdgcn_sched_barrier(0);
   for (int c = 0; c < p.nchunk; ++c) {
     const int buf = c & 1;
-    stage_load(sv, c + 1);
+    if constexpr (UP) src_load(sv, c + 2); else stage_load(sv, c + 1);
     a_load(a0, buf, 0, 0);
     CP_TAP4(0, wA, wB, c, 1)
     CP_TAP4(1, wB, wA, c, 2)
+    if constexpr (UP) { __builtin_amdgcn_sched_barrier(0); interp(0, buf ^ 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }    // chunk c+1's halo from ITS source tile
     CP_TAP4(2, wA, wB, c, 3)
     CP_TAP4(3, wB, wA, c, 4)
     CP_TAP4(4, wA, wB, c, 5)
+    if constexpr (UP) { __builtin_amdgcn_sched_barrier(0); interp(1, buf ^ 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
     CP_TAP4(5, wB, wA, c, 6)
     CP_TAP4(6, wA, wB, c, 7)
     CP_TAP4(7, wB, wA, c, 8)
+    if constexpr (UP) { __builtin_amdgcn_sched_barrier(0); interp(2, buf ^ 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
     CP_TAP4(8, wA, wB, c + 1, 0)          // next chunk's tap 0 (out of range past the end -> zeros)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) wA[nt] = wB[nt];
-    stage_write(sv, buf ^ 1);
+    if constexpr (UP) src_write(sv, buf); else stage_write(sv, buf ^ 1);   // UP: chunk c+2's source tile (tile c's is spent)
     __syncthreads();
   }
 #undef CP_TAP4
@@ -1120,6 +1208,7 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   HaloParams p;
   p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.Hs = p.Ws = 0; p.up_sy = p.up_sx = 0.f;
   p.nchunk = (d->Cin + 4 * E - 1) / (4 * E);
   p.Cout = d->Cout; p.ngroups = (d->Cout + 31) / 32; p.NB = (p.ngroups + 3) / 4;
   p.tiles_x = (d->W + HTW - 1) / HTW; p.tiles_y = (d->H + HTH - 1) / HTH;
@@ -1171,6 +1260,48 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
     if (residual) CP_LAUNCH((conv3x3_halo_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * HBUF, st, p);
     else CP_LAUNCH((conv3x3_halo_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * HBUF, st, p);
   }
+  return cp_check_launch();
+}
+
+// ---- conv3x3( bilinear_x2(in) ): the decoder's upsample + first conv (pipeline.py:199-200) without the upsampled tensor
+extern "C" int cp_conv3x3_halo_up2x_supported(int dtype, int Cout) {
+  return (dtype == CP_F32 || dtype == CP_BF16) && halo_wide(Cout) ? 1 : 0;
+}
+
+extern "C" int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                                    const float* scale, const float* shift, void* out) {
+  if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
+  if (!cp_conv3x3_halo_up2x_supported(d->dtype, d->Cout)) return CP_ERR_INVALID;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
+    return CP_ERR_INVALID;
+  if (d->B <= 0 || d->H < 2 || d->W < 2 || (d->H & 1) || (d->W & 1)) return CP_ERR_INVALID;   // d->H, d->W: the UPSAMPLED size
+  const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
+  if (d->Cin <= 0 || d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift)) return CP_ERR_ALIGN;
+  if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4) || ((uintptr_t)out % (4 * es))) return CP_ERR_ALIGN;
+  HaloParams p;
+  p.Hs = d->H / 2; p.Ws = d->W / 2;
+  const long long in_bytes = (long long)d->B * p.Hs * p.Ws * d->in_cstride * es;
+  if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
+  p.up_sy = p.Hs > 1 ? (float)(p.Hs - 1) / (float)(d->H - 1) : 0.f;       // the stand-alone kernel's scales (elementwise.hip)
+  p.up_sx = p.Ws > 1 ? (float)(p.Ws - 1) / (float)(d->W - 1) : 0.f;
+  p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = nullptr; p.out = out;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.nchunk = (d->Cin + 4 * E - 1) / (4 * E);
+  p.Cout = d->Cout; p.ngroups = (d->Cout + 31) / 32; p.NB = d->Cout / 256;
+  p.tiles_x = (d->W + HTW - 1) / HTW; p.tiles_y = (d->H + HTH - 1) / HTH;
+  const long long tt = (long long)d->B * p.tiles_x * p.tiles_y;
+  if (tt >= (1LL << 28)) return CP_ERR_RANGE;
+  p.total_tiles = (int)tt;
+  p.act = d->act; p.slope = d->slope;
+  p.in_bytes = (uint32_t)in_bytes;
+  const size_t wb = cp_packed_halo_weight_bytes(d->dtype, d->Cout, d->Cin);
+  if (wb >= (1ull << 31)) return CP_ERR_RANGE;
+  p.w_bytes = (uint32_t)wb;
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
+  if (d->dtype == CP_F32) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false, true>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
+  else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false, true>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
   return cp_check_launch();
 }
 

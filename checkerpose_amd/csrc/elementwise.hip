@@ -21,35 +21,36 @@ __global__ void upsample2x_bilinear_kernel(const void* __restrict__ in, void* __
   if (row >= rows) return;
   const int oy = (int)(row % (unsigned)(2 * H));
   const size_t b = row / (unsigned)(2 * H);
-  const float fy = sy * oy;
-  const int y0 = (int)fy;
-  const int y1 = y0 + (y0 < H - 1);
-  const float ly1 = fy - y0, ly0 = 1.f - ly1;
+  int y0, ystep; float ly1;
+  cp_up_coord(sy, oy, H, y0, ystep, ly1);
+  const int y1 = y0 + ystep;
+  const float ly0 = cp_one_minus(ly1);
   const u32x4* src = (const u32x4*)in;
   const size_t r0 = ((b * H + y0) * W) * in_cs + in_coff + (size_t)g * E, r1 = ((b * H + y1) * W) * in_cs + in_coff + (size_t)g * E;
   const int oxa = 2 * j, oxb = 2 * j + 1;
-  const float fxa = sx * oxa, fxb = sx * oxb;
-  const int xa0 = (int)fxa, xb0 = (int)fxb;
-  const int xa1 = xa0 + (xa0 < W - 1), xb1 = xb0 + (xb0 < W - 1);
+  int xa0, xb0, xas, xbs; float lxa1, lxb1;
+  cp_up_coord(sx, oxa, W, xa0, xas, lxa1);
+  cp_up_coord(sx, oxb, W, xb0, xbs, lxb1);
+  const int xa1 = xa0 + xas, xb1 = xb0 + xbs;
   // distinct source columns: xa0 <= xb0 <= xa0 + 1, so {xa0, xa1, xb1} covers all four (xb0 is xa0 or xa1)
   u32x4 t0 = src[(r0 + (size_t)xa0 * in_cs) / E], t1 = src[(r0 + (size_t)xa1 * in_cs) / E], t2 = src[(r0 + (size_t)xb1 * in_cs) / E];
   u32x4 u0 = src[(r1 + (size_t)xa0 * in_cs) / E], u1 = src[(r1 + (size_t)xa1 * in_cs) / E], u2 = src[(r1 + (size_t)xb1 * in_cs) / E];
   float a[E], bb[E], c[E], d[E], o[E];
   {
-    const float lx1 = fxa - xa0, lx0 = 1.f - lx1;
+    const float lx1 = lxa1, lx0 = cp_one_minus(lx1);
     Vec16<Tag>::unpack(t0, a); Vec16<Tag>::unpack(t1, bb); Vec16<Tag>::unpack(u0, c); Vec16<Tag>::unpack(u1, d);
 #pragma unroll
-    for (int e = 0; e < E; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+    for (int e = 0; e < E; ++e) o[e] = cp_bilerp(a[e], bb[e], c[e], d[e], lx0, lx1, ly0, ly1);
     const size_t oe = ((b * 2 * H + oy) * 2 * W + oxa) * out_cs + out_coff + (size_t)g * E;
     ((u32x4*)out)[oe / E] = Vec16<Tag>::pack(o);
   }
   {
-    const float lx1 = fxb - xb0, lx0 = 1.f - lx1;
+    const float lx1 = lxb1, lx0 = cp_one_minus(lx1);
     const bool same = xb0 == xa0;                                  // left column of the second pixel: xa0 or xa1
     Vec16<Tag>::unpack(same ? t0 : t1, a); Vec16<Tag>::unpack(same ? t1 : t2, bb);
     Vec16<Tag>::unpack(same ? u0 : u1, c); Vec16<Tag>::unpack(same ? u1 : u2, d);
 #pragma unroll
-    for (int e = 0; e < E; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+    for (int e = 0; e < E; ++e) o[e] = cp_bilerp(a[e], bb[e], c[e], d[e], lx0, lx1, ly0, ly1);
     const size_t oe = ((b * 2 * H + oy) * 2 * W + oxb) * out_cs + out_coff + (size_t)g * E;
     ((u32x4*)out)[oe / E] = Vec16<Tag>::pack(o);
   }

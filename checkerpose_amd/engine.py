@@ -20,6 +20,7 @@ USE_FUSED_BN = os.environ.get("CHECKERPOSE_AMD_FUSED_BN", "1") != "0"   # fused 
 USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused BasicBlock kernel (C <= 32)
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
+USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decoder: bilinear x2 interpolated inside the conv's halo loader
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
@@ -314,6 +315,41 @@ class Program:
         nbytes = (x.B * x.H * x.W * wCin * self.es + x.B * Ho * Wo * wCout * oes * (2 if residual is not None else 1)
                   + R * S * wCin * wCout * self.es)          # algorithmic: input + output (+ residual) + weights, unpadded
         self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl, fam, nbytes))
+        return out
+
+    def can_conv_up2x(self, H, W, Cout):
+        """(H, W): the low-resolution input; the conv runs at (2H, 2W), which must tile like the plain halo kernel's maps"""
+        return (USE_UP_FUSED and 2 * H >= 8 and 2 * W >= 16 and
+                bool(self.lib.cp_conv3x3_halo_up2x_supported(self.dtype, _rup(Cout, self.E))))
+
+    def conv_up2x(self, x: Act, wkey, w, scale, shift, act=ACT_NONE, slope=0.0, out: Act = None):
+        """conv3x3(bilinear_x2(x)) in one launch (cp_conv3x3_halo_up2x): x is the LOW-resolution input, possibly a channel
+        slice; the upsampled tensor never exists."""
+        wCout, wCin = w.shape[0], w.shape[1]
+        if wCin != x.C:
+            raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
+        packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
+        sc, sh = self.ws.affine(wkey + "#0", scale, shift, wCout)
+        Ho, Wo = 2 * x.H, 2 * x.W
+        if out is None:
+            out = self.act(Ho, Wo, wCout)
+        d = CpConvDesc()
+        d.dtype, d.out_f32 = self.dtype, 0
+        d.B, d.H, d.W = x.B, Ho, Wo
+        d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 3, 3, 1, 1, Ho, Wo
+        d.act, d.slope, d.Cout = act, slope, out.Cphys
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
+        self.keep += [d, packed, sc, sh]
+        fn = self.lib.cp_conv3x3_halo_up2x
+        dref = C.byref(d)
+        pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        xtb, otb = x.tbuf, out.tbuf
+        self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(otb)), "conv3x3_halo4:" + wkey, [xtb], [otb])
+        fl = 2 * x.B * Ho * Wo * 9 * wCin * wCout
+        self.flops += fl
+        nbytes = x.B * x.H * x.W * wCin * self.es + x.B * Ho * Wo * wCout * self.es + 9 * wCin * wCout * self.es
+        self.conv_log.append((wkey, x.B * Ho * Wo, wCout, 9 * wCin, fl, "conv3x3_halo4", nbytes))
         return out
 
     def can_fuse_basicblock(self, x: Act, C_):

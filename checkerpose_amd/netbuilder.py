@@ -371,7 +371,7 @@ class NetEmitter:
         return self.p.edge_gather(pq, graph["idx"], graph["gids"], out, graph["K"], Co, graph["G"], slope)
 
 
-def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
+def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_outs=None):
     """InitNet_GNN.forward init.py:109-128.  Returns (feats [Act], graph_feats Act)."""
     p = em.p
     N = cfg["npoint"]
@@ -388,7 +388,7 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None):
         x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
     if tp is not None:
         tp.nograd.add(id(x.tbuf))                           # the image needs no gradient
-    feats = em.hrnet(bb, x, stem_done=fused_stem) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
+    feats = em.hrnet(bb, x, feat_outs=feat_outs, stem_done=fused_stem) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
     f = feats[-1]                                           # (B, 8, 8, Cb)
     # conv1x1 Cb -> N, then `view(-1, N, 64).permute(0,2,1)` (init.py:112-114): keypoint n's 8x8 response map is its
     # 64-d feature -> written straight into the (B, N, 64) graph layout through the epilogue strides.
@@ -502,7 +502,21 @@ def emit_posenet(em: NetEmitter, cfg, io):
         return p.act(1, N, qd[0] + gdim)       # [local 4*E | previous graph feature]
 
     L = local_buf(0) if active > 0 else None
-    feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None)
+    # eval: up_net[i >= 1] = conv(bilinear_x2(cat[img_feat, skip])) runs as ONE launch that interpolates inside its halo loader
+    # (engine.conv_up2x); its input is the LOW-resolution concat buffer, filled in place by its two producers -- the previous
+    # stage's last conv (channels [0, nf)) and the backbone's incre module (the skip feature, channels [nf, ..))
+    lowcats, feat_outs = {}, None
+    if tp is None and cfg["backbone"] == "hrnet_w18":
+        feat_outs = [None] * 4
+        for i in range(1, active):
+            j = 3 - i
+            Cs = em.W("init_net.img_backbone.incre_modules.%d.0.conv3.weight" % j).shape[0]
+            Hs = cfg["img_size"] // (4 << j)
+            if p.can_conv_up2x(Hs, Hs, nf):
+                lowcats[i] = p.act(Hs, Hs, nf + Cs)
+                feat_outs[j] = lowcats[i].slice(_rup(nf, p.E), Cs)
+    feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None,
+                             feat_outs=feat_outs)
     dbits = io.get("decode_bits", io["bits"])      # teacher forcing (tests only): decode from supplied logits
     p.decode(dbits, -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
     f = feats[-1]
@@ -515,6 +529,8 @@ def emit_posenet(em: NetEmitter, cfg, io):
     cats = {}
     if tp is None:
         for i in range(1, active):
+            if i in lowcats:
+                continue
             sk = feats[-i - 1]
             cats[i] = p.act(2 * sk.H, 2 * sk.W, nf + sk.C)
             p.set_lane(2)
@@ -542,7 +558,11 @@ def emit_posenet(em: NetEmitter, cfg, io):
             if tp is not None:
                 o = _convt_train_tail(em, up, wt, f, o, nf)
             f = em.conv_bn(o, up + ".3", up + ".4", 3, 1, 1)
-            f = em.conv_bn(f, up + ".6", up + ".7", 3, 1, 1)
+            f = em.conv_bn(f, up + ".6", up + ".7", 3, 1, 1, out=lowcats[1].slice(0, nf) if 1 in lowcats else None)
+        elif i in lowcats:   # the same, upsample fused into conv1's loader
+            s1, t1 = em.ws.bn_fold(up + ".2")
+            f = p.conv_up2x(lowcats[i], up + ".1", em.W(up + ".1.weight"), s1, t1, ACT_RELU)
+            f = em.conv_bn(f, up + ".4", up + ".5", 3, 1, 1, out=lowcats[i + 1].slice(0, nf) if (i + 1) in lowcats else None)
         else:        # cat[img_feat, img_feats[-i-1]] -> bilinear x2 (align_corners) -> 2x conv3x3+BN+ReLU
             sk = feats[-i - 1]
             cat = cats[i] if i in cats else p.act(2 * f.H, 2 * f.W, f.C + sk.C)

@@ -108,6 +108,15 @@ int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const float* w, i
 int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                     const float* scale, const float* shift, const void* residual, void* out);
 
+/* conv3x3( UpsamplingBilinear2d(scale_factor=2)(in) ) without the upsampled tensor: the decoder's `up_net[1..2]` upsample + first
+ * conv (pipeline.py:199-200, get_gdrn_upsample_module).  Descriptor as cp_conv3x3_halo, except that d->H, d->W (= Ho, Wo, both
+ * even) are the UPSAMPLED size and `in` is the (B, H/2, W/2, in_cstride) source; Cout a multiple of 256 (the wide kernel), no
+ * residual.  Each halo pixel is interpolated (align_corners=True, the arithmetic of cp_upsample2x_bilinear_ac bit for bit) while
+ * the tile is staged.  Weights: cp_pack_conv3x3_halo_weight. */
+int cp_conv3x3_halo_up2x_supported(int dtype, int Cout);
+int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                         const float* scale, const float* shift, void* out);
+
 /* Fused timm BasicBlock of the HRNet branches (C -> C channels, C <= 32 and one 64-byte chunk, stride 1):
  *   out = relu( conv3x3(relu(conv3x3(x)*s1+t1))*s2+t2 + x )     -- intermediate and residual never leave LDS.
  * packed_w1: cp_pack_conv3x3_rows_weight (unpermuted rows); packed_w2: cp_pack_conv3x3_halo_weight.

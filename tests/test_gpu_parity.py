@@ -184,6 +184,61 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
     assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
 
 
+UP_CASES = [  # (B, Cin, cin_total, coff, Hs, Ws, Cout, act): low-resolution source (Hs, Ws), conv at (2 Hs, 2 Ws)
+    (2, 64, 64, 0, 16, 16, 256, ACT_RELU),       # exact tiles
+    (1, 96, 160, 64, 12, 20, 256, ACT_RELU),     # channel slice of a wider buffer, tile rows / cols ragged (24 x 40)
+    (2, 40, 40, 0, 4, 8, 512, ACT_LEAKY),        # one tile per crop, two 256-channel blocks, partial chunk
+    (1, 256, 256, 0, 32, 32, 256, ACT_RELU),     # decoder shape class (many tiles per crop, interior tiles)
+    (1, 32, 32, 0, 5, 9, 256, ACT_NONE),         # odd source size
+]
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv3x3_halo_up2x_bit_identical_to_unfused(lib, dtype, case):
+    """cp_conv3x3_halo_up2x (bilinear x2 interpolated inside the conv's halo loader, pipeline.py:199-200) gives the SAME BITS as
+    cp_upsample2x_bilinear_ac followed by cp_conv3x3_halo, and both match torch (interpolate align_corners + conv)."""
+    B, Cin, ctot, coff, Hs, Ws, Cout, act = case
+    H, W = 2 * Hs, 2 * Ws
+    xall = det_tensor("ux%s" % (case,), (B, ctot, Hs, Ws))
+    w = det_tensor("uw%s" % (case,), (Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("us%s" % (case,), (Cout,))
+    shift = 0.2 * det_tensor("ut%s" % (case,), (Cout,))
+    xs = rnd(xall[:, coff:coff + Cin], dtype)
+    up = F.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = F.conv2d(rnd(up, dtype), rnd(w, dtype), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.01) if act == ACT_LEAKY else ref)
+    xin = to_cl(xall, dtype)                                   # (B, Hs, Ws, ctot)
+    assert xin.shape[-1] == ctot
+    pw = torch.empty(lib.cp_packed_halo_weight_bytes(dtype, Cout, Cin), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv3x3_halo_weight(st(), dtype, wd.data_ptr(), Cout, Cin, Cin, pw.data_ptr()))
+    sc, sh = scale.to(dev()).contiguous(), shift.to(dev()).contiguous()
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 1, 1, H, W, Cout, act, 0.01
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * Cout, W * Cout, Cout, 1
+    # unfused pair
+    upb = torch.full((B, H, W, Cin), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_upsample2x_bilinear_ac(st(), dtype, xin.data_ptr(), upb.data_ptr(), B, Hs, Ws, Cin, ctot, coff, Cin, 0))
+    d.Cin, d.in_cstride, d.in_coff = Cin, Cin, 0
+    out_a = torch.full((B, H, W, Cout), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_conv3x3_halo(st(), C.byref(d), upb.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out_a.data_ptr()))
+    # fused
+    d.Cin, d.in_cstride, d.in_coff = Cin, ctot, coff
+    out_b = torch.full((B, H, W, Cout), float("nan"), dtype=DT[dtype], device=dev())
+    assert lib.cp_conv3x3_halo_up2x_supported(dtype, Cout) == 1
+    _abi.check(lib.cp_conv3x3_halo_up2x(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), out_b.data_ptr()),
+               "fused upsample conv")
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.view(torch.int16 if dtype == CP_BF16 else torch.int32), out_b.view(torch.int16 if dtype == CP_BF16 else torch.int32)), \
+        "fused and unfused paths must agree bit for bit"
+    close(from_cl(out_b, Cout), ref, TOL[dtype])
+    d.H = H + 1                                                # odd upsampled size -> loud error
+    assert lib.cp_conv3x3_halo_up2x(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), out_b.data_ptr()) == -1
+    assert lib.cp_conv3x3_halo_up2x_supported(dtype, 128) == 0
+
+
 @pytest.mark.parametrize("dtype,Cc", [(CP_BF16, 18), (CP_BF16, 32), (CP_BF16, 8), (CP_F32, 16), (CP_F32, 10)])
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 13, 21), (3, 8, 16)])
 def test_basicblock_fused_vs_torch_cpu(lib, dtype, Cc, shape):
