@@ -25,6 +25,11 @@ class CpConvDesc(C.Structure):
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 
+class CpFuseConv(C.Structure):
+    _fields_ = [("packed_w", C.c_void_p), ("affine", C.c_void_p), ("out", C.c_void_p),
+                ("kind", C.c_int32), ("Cout", C.c_int32), ("out_cphys", C.c_int32), ("relu", C.c_int32)]
+
+
 class CpPackItem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("a", C.c_int32 * 9), ("src", C.c_void_p), ("dst", C.c_void_p), ("row_map", C.c_void_p),
                 ("total", C.c_uint64)]
@@ -71,6 +76,11 @@ SIGNATURES = {
     "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_maxpool3x3s2": (_I, [_P, _I, _P, _P, _I, _I, _I, _I]),
     "cp_edgeconv_gather_max": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_hr_fuse_out_supported": (_I, [_I, _I, _I]),
+    "cp_hr_fuse_out_weight_bytes": (C.c_size_t, [_I, _I, _I]),
+    "cp_hr_fuse_out_affine_floats": (_I, [_I]),
+    "cp_pack_hr_fuse_out_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "cp_hr_fuse_out": (_I, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(CpFuseConv)]),
     "cp_edgeconv_fused_supported": (_I, [_I, _I, _I, _I]),
     "cp_edgeconv_fused_weight_bytes": (C.c_size_t, [_I, _I]),
     "cp_pack_edgeconv_fused_weight": (_I, [_P, _P, _I, _I, _P]),

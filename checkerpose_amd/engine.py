@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc, CpFuseConv
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
@@ -21,6 +21,7 @@ USE_FUSED_BB = os.environ.get("CHECKERPOSE_AMD_FUSED_BB", "1") != "0"   # fused 
 USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1 / Linear kernel
 USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
 USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decoder: bilinear x2 interpolated inside the conv's halo loader
+USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
@@ -439,6 +440,57 @@ class Program:
         nb = self.B * H * W * C_ * self.es
         self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es))
         return out
+
+    def can_fuse_out(self, x: Act):
+        return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= CHAIN_MIN_BATCH and x.coff == 0 and x.cstride == x.Cphys
+                and bool(self.lib.cp_hr_fuse_out_supported(x.H, x.W, x.Cphys)))
+
+    def hr_fuse_out(self, x: Act, convs):
+        """Every first-level fuse-layer conv fed by one branch output `x` in ONE launch (cp_hr_fuse_out).  convs: list of
+        (wkey, w fp32 (Cout, Cin, k, k), scale, shift, k in (1, 3), relu): k = 1 -> 1x1 at x's resolution, k = 3 -> 3x3 / stride 2.
+        Returns the output Acts."""
+        assert 1 <= len(convs) <= 4
+        arr = (CpFuseConv * len(convs))()
+        outs, keep, fl, nbytes = [], [], 0, x.B * x.H * x.W * x.C * self.es
+        for i, (wkey, w, scale, shift, k, relu) in enumerate(convs):
+            kind = 1 if k == 3 else 0
+            Cout, Cin = w.shape[0], w.shape[1]
+            assert Cin == x.C and w.shape[2] == k
+            out = self.act(x.H >> kind, x.W >> kind, Cout)
+            ck = ("fuse_out", wkey)
+            if ck not in self.ws.cache:
+                buf = torch.empty(self.lib.cp_hr_fuse_out_weight_bytes(x.Cphys, out.Cphys, kind), dtype=torch.uint8, device=self.device)
+                wc = w.contiguous()
+                self.ws.keep.append(wc)
+                st = torch.cuda.current_stream(self.device).cuda_stream
+                _abi.check(self.lib.cp_pack_hr_fuse_out_weight(st, wc.data_ptr(), Cout, Cin, x.Cphys, out.Cphys, kind, buf.data_ptr()),
+                           "cp_pack_hr_fuse_out_weight")
+                n = self.lib.cp_hr_fuse_out_affine_floats(out.Cphys)
+                aff = torch.zeros(2, n, dtype=torch.float32, device=self.device)
+                aff[0, :Cout] = scale
+                aff[1, :Cout] = shift
+                self.ws.cache[ck] = (buf, aff)
+            buf, aff = self.ws.cache[ck]
+            keep += [buf, aff]
+            arr[i].packed_w, arr[i].affine = buf.data_ptr(), aff.data_ptr()
+            arr[i].kind, arr[i].Cout, arr[i].out_cphys, arr[i].relu = kind, Cout, out.Cphys, 1 if relu else 0
+            outs.append(out)
+            fl += 2 * x.B * out.H * out.W * k * k * Cin * Cout
+            nbytes += x.B * out.H * out.W * Cout * self.es + k * k * Cin * Cout * self.es
+        self.keep += keep + [arr]
+        fn = self.lib.cp_hr_fuse_out
+        xt, ots = x.tbuf, [o.tbuf for o in outs]
+
+        def argb(P):
+            for i, t in enumerate(ots):
+                arr[i].out = P(t)
+            return (P(xt), x.B, x.H, x.W, x.Cphys, len(convs), arr)
+
+        name = convs[0][0]
+        self._add(fn, argb, "hr_fuse_out:" + name, [xt], ots)
+        self.flops += fl
+        self.conv_log.append((name, x.B * x.H * x.W, sum(c[1].shape[0] for c in convs), x.C, fl, "hr_fuse_out", nbytes))
+        return outs
 
     def can_fuse_bottleneck(self, x: Act, planes, cout, has_ds):
         cin = 64 if has_ds else 256

@@ -190,6 +190,7 @@ class NetEmitter:
         # source branch j): the long stride-2 chains fed by the 64x64 branch -- the module's critical path -- then run beside
         # each other on the lanes whose own (low-resolution) branch finished early, not one after the other behind branch 0
         terms = [[None] * nb for _ in range(nb)]
+        first = {}                           # (i, j) -> output of fuse chain j -> i's first conv, from the grouped launch
         p.par_begin(nb)
         for j in range(nb):
             p.set_lane(j)
@@ -204,6 +205,20 @@ class NetEmitter:
                 ws = [self.W("%s.%d.conv%d.weight" % (bp, k, c)) for k in range(4) for c in (1, 2)]
                 affs = [self.ws.bn_fold("%s.%d.bn%d" % (bp, k, c)) for k in range(4) for c in (1, 2)]
                 xs[j] = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W)
+                if nb > 1 and p.can_fuse_out(xs[j]):
+                    # the same lane goes on with ONE launch for every first-level fuse conv that reads branch j (its map staged
+                    # in LDS once); the second region keeps only the 2nd / 3rd convs of the long stride-2 chains
+                    lst = []
+                    for i in range(nb):
+                        q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+                        if j > i:
+                            lst.append((i, q + ".0", q + ".1", 1, False))
+                        elif j < i:
+                            lst.append((i, q + ".0.0", q + ".0.1", 3, i - j > 1))
+                    outs = p.hr_fuse_out(xs[j], [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (k, relu)
+                                                 for (_, ck, bk, k, relu) in lst])
+                    for (i, _, _, _, _), o in zip(lst, outs):
+                        first[(i, j)] = o
             else:
                 xs[j] = self._materialize(xs[j])
                 for k in range(4):
@@ -215,20 +230,30 @@ class NetEmitter:
             # stride-2 chains fed by the 64x64 branch used to queue up behind it on ONE lane: the module's critical path).
             # (Cross-lane event edges inside one region would express this without the join, but a capture in which two
             # streams wait on each other's events crashes hipStreamEndCapture on ROCm 7.2.)
-            p.par_end()
-            p.par_begin(nb)
+            def cost_of(i, j):               # launches still to run for term (i, j)
+                if (i, j) in first:
+                    return max(i - j - 1, 0)
+                return (i - j) if j < i else 0.3
             load = [0.0] * nb
             sched = []
-            for cost, i, j in sorted([((i - j) if j < i else 0.3, i, j) for i in range(nb) for j in range(nb) if i != j], reverse=True):
-                ln = min(range(nb), key=lambda k: load[k])
+            for cost, i, j in sorted([(cost_of(i, j), i, j) for i in range(nb) for j in range(nb) if i != j], reverse=True):
+                ln = min(range(nb), key=lambda k: load[k]) if cost > 0 else 0
                 load[ln] += cost
                 sched.append((ln, i, j))
+            second = any(c > 0 for c in load)
+            if second:
+                p.par_end()
+                p.par_begin(nb)
         for i in range(nb):
             terms[i][i] = xs[i]
         for ln, i, j in sched:
             p.set_lane(ln)
             q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
-            if j > i:
+            if (i, j) in first:
+                t = first[(i, j)]
+                for k in range(1, i - j):
+                    t = self.conv_bn(t, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), 3, 2, 1, relu=(k != i - j - 1))
+            elif j > i:
                 t = self.conv_bn(xs[j], q + ".0", q + ".1", 1, 1, 0, relu=False)
             else:
                 t = xs[j]

@@ -213,6 +213,27 @@ int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, int C, int H, in
 int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
                        const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out);
 
+/* The first-level fuse-layer convs of a timm HighResolutionModule that read ONE branch's output `src` (B, H, W, cin_phys) bf16
+ * (timm HighResolutionModule.fuse_layers inside backbone.py:35): up to 4 convs per launch, each
+ *   kind 0: 1x1 conv + folded BN at the source resolution (the term towards a higher-resolution branch, before its nearest
+ *           upsample), or
+ *   kind 1: 3x3 / stride 2 / pad 1 conv + folded BN (+ ReLU when `relu`: a chain that goes on) at half the resolution,
+ * out_i = act(conv_i(src) * scale + shift) as (B, Ho, Wo, out_cphys) bf16, channels [Cout, out_cphys) exactly zero.  A
+ * workgroup stages a band of src in LDS once and runs every conv off it.  packed_w: cp_pack_hr_fuse_out_weight of the fp32
+ * (Cout, Cin, k, k) weight; affine: fp32 [2][cp_hr_fuse_out_affine_floats(out_cphys)] = scale then shift, zero beyond Cout. */
+typedef struct CpFuseConv {
+  const void* packed_w;
+  const float* affine;
+  void* out;
+  int32_t kind, Cout, out_cphys, relu;
+} CpFuseConv;
+int cp_hr_fuse_out_supported(int H, int W, int cin_phys);
+size_t cp_hr_fuse_out_weight_bytes(int cin_phys, int out_cphys, int kind);
+int cp_hr_fuse_out_affine_floats(int out_cphys);
+int cp_pack_hr_fuse_out_weight(cp_stream_t stream, const float* w, int Cout, int Cin, int cin_phys, int out_cphys, int kind,
+                               void* packed);
+int cp_hr_fuse_out(cp_stream_t stream, const void* src, int B, int H, int W, int cin_phys, int nconv, const CpFuseConv* convs);
+
 /* EdgeConv layer in ONE launch for N = 512 keypoints (bf16): per-node GEMM [P' | Q'] = x . wpq^T on MFMA, P' table of one
  * 64-channel slice in LDS, neighbour gather-max out of LDS, + Q', LeakyReLU (StaticGraph_module, init.py:54-68 ==
  * pipeline.py:45-59; per-sample graphs `knn_idx[obj_ids-1]` of pipeline_lm.py:55-57 through graph_ids).

@@ -313,6 +313,61 @@ def test_hr_stem_fused_vs_torch_cpu(lib, shape):
                           a[2].data_ptr(), a[3].data_ptr(), out.data_ptr()) == -1                 # not a whole number of tiles
 
 
+FUSE_OUT_CASES = [  # (B, C, H, W, [(Cout, k, relu), ...]): the convs of an HRNet-W18 stage-4 fuse layer, by source branch
+    (3, 18, 64, 64, [(36, 3, False), (18, 3, True), (18, 3, True)]),       # 4 bands per crop
+    (2, 36, 32, 32, [(18, 1, False), (72, 3, False), (36, 3, True)]),      # 2 bands
+    (2, 72, 16, 16, [(18, 1, False), (36, 1, False), (144, 3, False)]),    # output rows of 8 pixels: a 16-pixel tile spans 2 rows
+    (3, 144, 8, 8, [(18, 1, False), (36, 1, False), (72, 1, False)]),      # 1x1 only, 18 channel groups
+    (1, 18, 64, 64, [(36, 3, False)]),                                     # stage 2: one conv per source
+    (2, 40, 12, 20, [(24, 3, True), (50, 1, True), (7, 3, False), (16, 1, False)]),   # odd sizes: ragged tiles, 4 convs, Cout 7 / 50
+]
+
+
+@pytest.mark.parametrize("case", FUSE_OUT_CASES)
+def test_hr_fuse_out_vs_torch_cpu(lib, case):
+    """cp_hr_fuse_out (every first-level fuse conv of one source branch in one launch) == the per-conv torch reference."""
+    from checkerpose_amd._abi import CpFuseConv
+    B, Cc, H, W, convs = case
+    dtype = CP_BF16
+    x = det_tensor("fo_x%s" % (case[:4],), (B, Cc, H, W))
+    xin = to_cl(x, dtype)
+    cp = xin.shape[-1]
+    assert lib.cp_hr_fuse_out_supported(H, W, cp) == 1
+    arr = (CpFuseConv * len(convs))()
+    keep, outs, refs = [], [], []
+    for i, (Cout, k, relu) in enumerate(convs):
+        w = det_tensor("fo_w%d%s" % (i, case[:4]), (Cout, Cc, k, k), (2.0 / (Cc * k * k)) ** 0.5 * 1.7)
+        scale = 1.0 + 0.3 * det_tensor("fo_s%d%s" % (i, case[:4]), (Cout,))
+        shift = 0.2 * det_tensor("fo_t%d%s" % (i, case[:4]), (Cout,))
+        r = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, 2 if k == 3 else 1, 1 if k == 3 else 0)
+        r = r * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        refs.append(F.relu(r) if relu else r)
+        kind = 1 if k == 3 else 0
+        ocp = rup(Cout, 8)
+        pw = torch.empty(lib.cp_hr_fuse_out_weight_bytes(cp, ocp, kind), dtype=torch.uint8, device=dev())
+        wd = w.contiguous().to(dev())
+        _abi.check(lib.cp_pack_hr_fuse_out_weight(st(), wd.data_ptr(), Cout, Cc, cp, ocp, kind, pw.data_ptr()))
+        n = lib.cp_hr_fuse_out_affine_floats(ocp)
+        aff = torch.zeros(2, n)
+        aff[0, :Cout] = scale
+        aff[1, :Cout] = shift
+        aff = aff.to(dev())
+        out = torch.full((B, H >> kind, W >> kind, ocp), float("nan"), dtype=DT[dtype], device=dev())
+        arr[i].packed_w, arr[i].affine, arr[i].out = pw.data_ptr(), aff.data_ptr(), out.data_ptr()
+        arr[i].kind, arr[i].Cout, arr[i].out_cphys, arr[i].relu = kind, Cout, ocp, 1 if relu else 0
+        keep += [pw, aff, wd]
+        outs.append(out)
+    _abi.check(lib.cp_hr_fuse_out(st(), xin.data_ptr(), B, H, W, cp, len(convs), arr), "cp_hr_fuse_out")
+    torch.cuda.synchronize()
+    for (Cout, k, relu), out, ref in zip(convs, outs, refs):
+        assert not torch.isnan(out.float()).any(), "every output element must be written"
+        if out.shape[-1] > Cout:
+            assert float(out[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+        close(from_cl(out, Cout), ref, TOL[dtype])
+    assert lib.cp_hr_fuse_out(st(), xin.data_ptr(), B, H + 1, W, cp, len(convs), arr) == -1       # odd size: loud error
+    assert lib.cp_hr_fuse_out(st(), xin.data_ptr(), B, H, W, cp, 5, arr) == -1                    # more than 4 convs
+
+
 @pytest.mark.parametrize("nsrc", [1, 3])
 @pytest.mark.parametrize("cfg", [(36, 32, 32, 3), (72, 16, 16, 5), (144, 8, 8, 3), (36, 32, 32, 1), (18, 64, 64, 3)])
 def test_hr_branch_chain_vs_torch_cpu(lib, cfg, nsrc):
