@@ -3,6 +3,8 @@ InitNet_GNN.forward (reference checkerpose/model/init.py:109-128) and PoseNet_GN
 (model/pipeline.py:351-384; LM twin model/pipeline_lm.py:392-425).  No arithmetic happens here: every step
 appends a C-ABI launch.  Layout: channels-last activations, graph features (B, N, C).
 """
+import os
+
 import torch
 
 from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU
@@ -10,6 +12,9 @@ from .engine import Act, Program, _rup
 
 HR_STAGES = (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144)))
 IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024]}   # pipeline.py:6-15
+
+
+FUSE_OUT_DEEP = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_DEEP", "1") != "0"   # A/B: 2nd / 3rd convs of the stride-2 fuse chains through cp_hr_fuse_out
 
 
 class NetEmitter:
@@ -252,7 +257,11 @@ class NetEmitter:
             if (i, j) in first:
                 t = first[(i, j)]
                 for k in range(1, i - j):
-                    t = self.conv_bn(t, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), 3, 2, 1, relu=(k != i - j - 1))
+                    ck, bk, relu = "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), k != i - j - 1
+                    if FUSE_OUT_DEEP and p.can_fuse_out(t):        # the rest of a long stride-2 chain: same kernel, one conv per launch
+                        t = p.hr_fuse_out(t, [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (3, relu)])[0]
+                    else:
+                        t = self.conv_bn(t, ck, bk, 3, 2, 1, relu=relu)
             elif j > i:
                 t = self.conv_bn(xs[j], q + ".0", q + ".1", 1, 1, 0, relu=False)
             else:
