@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int ZH = 64, ZW = 64, ZC = 18, ZCP = 24, ZWP = 66, ZHP = 66;
+constexpr int ZH = 64, ZW = 64, ZC = 18, ZWP = 66, ZHP = 66;
 constexpr int ZPLPX = (ZHP * ZWP + 15) / 16 * 16;        // 4368 ring pixels per plane (padded)
 constexpr int ZPL16 = ZPLPX * 16, ZPL4 = ZPLPX * 4;
 constexpr int ZAFF = 32;                                 // floats per scale / shift vector
