@@ -20,6 +20,7 @@ struct GemmParams {
   int act; float slope;
   uint32_t in_bytes, w_bytes;
   long long o_base, o_sb, o_sy, o_sx;
+  int dense;                  // o_sy == Wo * o_sx and o_sb == HoWo * o_sx: output row m starts at o_base + m * o_sx
 };
 
 constexpr int GROWS = 128, GSUP = 4;                       // rows per block, chunks per super-chunk
@@ -318,11 +319,15 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_ws_kernel(const GemmParams p
       for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + mh * 32 + mt * 16 + x;
         if (m >= p.M) continue;
-        const int b = m / p.HoWo;
-        const int rem = m - b * p.HoWo;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        uint16_t* op = (uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+        uint16_t* op;
+        if (p.dense) op = (uint16_t*)p.out + p.o_base + (long long)m * p.o_sx + ch;   // row-major output: no (b, y, x) split (2 integer divisions per fragment)
+        else {
+          const int b = m / p.HoWo;
+          const int rem = m - b * p.HoWo;
+          const int oy = rem / p.Wo;
+          const int ox = rem - oy * p.Wo;
+          op = (uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + ch;
+        }
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = acc[mt][2 * h][j] * s0[j] + t0[j]; v[4 + j] = acc[mt][2 * h + 1][j] * s1[j] + t1[j]; }
@@ -431,6 +436,7 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
   if (wb >= (1ull << 31)) return CP_ERR_RANGE;
   p.w_bytes = (uint32_t)wb;
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  p.dense = (d->o_sy == (long long)d->Wo * d->o_sx && d->o_sb == (long long)d->Ho * d->Wo * d->o_sx) ? 1 : 0;
   const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_BF16 && !residual && p.nchunk <= WS_NCH && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {

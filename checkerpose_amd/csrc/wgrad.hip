@@ -218,9 +218,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReducePara
     stride = (size_t)p.GY * 9 * 4096;
   }
   off += (size_t)(co & 63) * 64 + (ci & 63);
+  // 8 slices' loads in flight per lane (one dependent load per iteration made the kernel a chain of memory latencies: 16
+  // round trips at 256 slices); the additions stay in slice order, so the sum does not depend on the unroll factor
   float acc = 0.f;
-  if (ok)
-    for (int sl = sl0; sl < p.S; sl += 16) acc += p.ws[off + (size_t)sl * stride];
+  if (ok) {
+    int sl = sl0;
+    for (; sl + 7 * 16 < p.S; sl += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p.ws[off + (size_t)(sl + 16 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sl < p.S; sl += 16) acc += p.ws[off + (size_t)sl * stride];
+  }
   red[sl0][e] = acc;
   __syncthreads();
   if (sl0 == 0 && ok) {
