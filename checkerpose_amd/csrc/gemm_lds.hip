@@ -231,12 +231,22 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmParams p) {
 // while its block walks row tiles of 64: per tile only the 32 KB of activation rows are loaded (double-buffered LDS,
 // next tile's loads in flight during the MFMAs, one barrier per tile) and every fragment read feeds 4 MFMAs.
 // Column-group blocks of one row stream share a blockIdx % 8 label: the rows they both read are an L2 hit.
-constexpr int WS_ROWS = 64, WS_NCH = 8;
+// Two shapes: K <= 256: 4 waves, a wave owns 64 channels (2 groups, 4 tiles), two blocks per CU; 256 < K <= 512: 8 waves, a
+// wave owns 32 channels (1 group, 2 tiles: the same 128 weight VGPRs), one block per CU -- both cover 256 channels per block.
+constexpr int WS_ROWS = 64;
 constexpr int WS_PITCH = WS_ROWS * 16 + 16;                 // plane [row][16 B]; +16: consecutive planes shift one slot
-constexpr int WS_BUF = WS_NCH * 4 * WS_PITCH;               // 33 280 B
+constexpr int ws_buf(int NCH) { return NCH * 4 * WS_PITCH; }   // 33 280 B (K <= 256) / 66 560 B (K <= 512)
 
-__global__ __launch_bounds__(256, 2) void gemm_rows_ws_kernel(const GemmParams p, const int ncg, const int n_rt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * WS_BUF
+template <int NCH, int NG>                                   // K chunks resident per wave, 32-channel groups per wave
+__global__ __launch_bounds__(512 / NG, NG) void gemm_rows_ws_kernel(const GemmParams p, const int ncg, const int n_rt) {
+  constexpr int NT = 2 * NG;                                 // MFMA tiles per wave
+  constexpr int NWAVE = 8 / NG, THREADS = 64 * NWAVE;
+  constexpr int PPR = NCH * 4;                               // 16-byte pieces per row
+  constexpr int RPP = THREADS / PPR;                         // rows staged per pass (8)
+  constexpr int MTP = 4 / NG;                                // 16-row fragments per accumulator pass (2 or 4)
+  constexpr int BUF = ws_buf(NCH);
+  static_assert(RPP * 8 == WS_ROWS, "8 staging loads per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,37 +254,36 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_ws_kernel(const GemmParams p
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int cg = slot % ncg, stream = slot / ncg;
   const int nstreams = (gridDim.x >> 3) / ncg;               // row streams per XCD
-  const int g0 = (cg * 4 + wave) * 2;                        // first of this wave's two 32-channel groups
-  const bool act0 = g0 < p.ngroups, act1 = g0 + 1 < p.ngroups;
+  const int g0 = (cg * NWAVE + wave) * NG;                   // first of this wave's NG 32-channel groups
 
   // ---- resident weights: [group][chunk][nt][lane][16 B]; chunks >= nchunk and groups past the end stay zero
-  u32x4 W[WS_NCH][4];
+  u32x4 W[NCH][NT];
 #pragma unroll
-  for (int kc = 0; kc < WS_NCH; ++kc)
+  for (int kc = 0; kc < NCH; ++kc)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int g = g0 + (t >> 1);
       W[kc][t] = u32x4{0u, 0u, 0u, 0u};
       if (kc < p.nchunk && g < p.ngroups) W[kc][t] = ((const u32x4*)p.w)[((size_t)(g * p.nchunk + kc) * 2 + (t & 1)) * 64 + lane];
     }
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  // staging: piece i = tid + 256 k (k = 0..7): row = i >> 5, piece-in-row pr = i & 31 (= chunk * 4 + q)
-  const int s_pr = tid & 31, s_row = tid >> 5;               // rows s_row + 8 k
+  // staging: piece i = tid + THREADS k (k = 0..7): row = i / PPR, piece-in-row pr = i % PPR (= chunk * 4 + q)
+  const int s_pr = tid % PPR, s_row = tid / PPR;             // rows s_row + RPP k
   auto stage_load = [&](u32x4* v, int rt) {
     const int m0 = rt * WS_ROWS;
     const bool pok = (rt < n_rt) & (s_pr * 8 < p.Cin);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int m = m0 + s_row + 8 * k;
+      const int m = m0 + s_row + RPP * k;
       const uint32_t off = (pok & (m < p.M)) ? (uint32_t)(m * p.in_cs + p.in_coff + s_pr * 8) * 2u : 0x80000000u;
       v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
     }
   };
   auto stage_write = [&](const u32x4* v, int buf) {
-    unsigned char* dst = smem + buf * WS_BUF + s_pr * WS_PITCH + s_row * 16;
+    unsigned char* dst = smem + buf * BUF + s_pr * WS_PITCH + s_row * 16;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) *(u32x4*)(dst + k * 8 * 16) = v[k];
+    for (int k = 0; k < 8; ++k) *(u32x4*)(dst + k * RPP * 16) = v[k];
   };
 
   const int rt_step = nstreams * 8;
@@ -288,36 +297,36 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_ws_kernel(const GemmParams p
     stage_load(sv, rt + rt_step);                            // past the end: zeros, never consumed
     const int m0 = rt * WS_ROWS;
 #pragma unroll 1
-    for (int mh = 0; mh < 2; ++mh) {                         // two passes of 32 rows: bounds the live accumulators
-    f32x4 acc[2][4];
+    for (int mh = 0; mh < 4 / MTP; ++mh) {                   // passes of 16 MTP rows: bounds the live accumulators (32 VGPRs)
+    f32x4 acc[MTP][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* ab = smem + buf * WS_BUF + q * WS_PITCH + (mh * 32 + x) * 16;
+      for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* ab = smem + buf * BUF + q * WS_PITCH + (mh * MTP * 16 + x) * 16;
 #pragma unroll
-    for (int kc = 0; kc < WS_NCH; ++kc) {
+    for (int kc = 0; kc < NCH; ++kc) {
       if (kc < p.nchunk) {                                   // block-uniform
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MTP; ++mt) {
           const u32x4 a = *(const u32x4*)(ab + kc * 4 * WS_PITCH + mt * 256);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) MmaG<BF16Tag>::run(W[kc][t], a, acc[mt][t]);
+          for (int t = 0; t < NT; ++t) MmaG<BF16Tag>::run(W[kc][t], a, acc[mt][t]);
         }
       }
     }
-    // ---- epilogue: lane (x, q): row m0 + 16 mt + x, channels (g0 + h) * 32 + 8 q + {0..7}  (h = 0, 1)
+    // ---- epilogue: lane (x, q): row m0 + 16 MTP mh + 16 mt + x, channels (g0 + h) * 32 + 8 q + {0..7}
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (!(h ? act1 : act0)) continue;
+    for (int h = 0; h < NG; ++h) {
+      if (g0 + h >= p.ngroups) continue;
       const int ch = (g0 + h) * 32 + q * 8;
       if (ch >= p.Cout) continue;
       const bool hi_ok = ch + 4 < p.Cout;
       const f32x4 s0 = *(const f32x4*)(p.scale + ch), t0 = *(const f32x4*)(p.shift + ch);
       const f32x4 s1 = *(const f32x4*)(p.scale + ch + 4), t1 = *(const f32x4*)(p.shift + ch + 4);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + mh * 32 + mt * 16 + x;
+      for (int mt = 0; mt < MTP; ++mt) {
+        const int m = m0 + mh * MTP * 16 + mt * 16 + x;
         if (m >= p.M) continue;
         uint16_t* op;
         if (p.dense) op = (uint16_t*)p.out + p.o_base + (long long)m * p.o_sx + ch;   // row-major output: no (b, y, x) split (2 integer divisions per fragment)
@@ -439,22 +448,26 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
   p.dense = (d->o_sy == (long long)d->Wo * d->o_sx && d->o_sb == (long long)d->Ho * d->Wo * d->o_sx) ? 1 : 0;
   const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CP_BF16 && !residual && p.nchunk <= WS_NCH && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {
+  if (d->dtype == CP_BF16 && !residual && p.nchunk <= 16 && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {
     static int n_cu = 0;
     if (!n_cu) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      int dev = 0, ncu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return CP_ERR_HIP;
-      if (hipFuncSetAttribute((const void*)gemm_rows_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_BUF) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)gemm_rows_ws_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_buf(8)) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_rows_ws_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_buf(16)) != hipSuccess)
         return CP_ERR_HIP;
+      n_cu = ncu;
     }
+    const bool deep = p.nchunk > 8;                           // 256 < K <= 512: 8-wave blocks, one per CU
     const int ncg = (p.ngroups + 7) / 8;                      // column groups of 256 channels
     const int n_rt = (int)((M + WS_ROWS - 1) / WS_ROWS);
-    int per_xcd = 2 * n_cu / 8;                               // resident blocks per XCD (2 per CU)
+    int per_xcd = (deep ? 1 : 2) * n_cu / 8;                  // resident blocks per XCD
     int nstreams = per_xcd / ncg > 0 ? per_xcd / ncg : 1;
     const int need = (n_rt + 7) / 8;                          // row tiles one XCD label owns
     if (nstreams > need) nstreams = need;
-    CP_LAUNCH(gemm_rows_ws_kernel, dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * WS_BUF, st, p, ncg, n_rt);
+    if (deep) CP_LAUNCH((gemm_rows_ws_kernel<16, 1>), dim3((unsigned)(8 * nstreams * ncg)), dim3(512), 2 * ws_buf(16), st, p, ncg, n_rt);
+    else CP_LAUNCH((gemm_rows_ws_kernel<8, 2>), dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * ws_buf(8), st, p, ncg, n_rt);
     return cp_check_launch();
   }
   if (d->dtype == CP_F32) {

@@ -489,6 +489,9 @@ GEMM_CASES = [  # (B, H, W, Cin, Cout, act, residual)
     (33, 1, 512, 256, 512, ACT_NONE, False),    # EdgeConv node GEMM at full N: two column groups, M = 16896 (264 row tiles)
     (4, 1, 4133, 160, 136, ACT_LEAKY, False),   # ragged M (16532 = 258.3 tiles), K = 160 (5 chunks), partial last group
     (2, 96, 96, 72, 256, ACT_RELU, False),      # image-shaped rows (H, W strides), K = 72 (ragged chunk)
+    # ... 256 < K <= 512: its 8-wave variant (a wave owns 32 channels)
+    (33, 1, 512, 512, 256, ACT_LEAKY, False),   # refinement pre_graph MLP: M = 16896
+    (4, 1, 4133, 320, 296, ACT_LEAKY, False),   # stage-0 pre_graph MLP K = 320 (10 chunks), ragged M, two column groups, partial last group
 ]
 
 
