@@ -33,6 +33,18 @@ NO_RECYCLE = os.environ.get("CHECKERPOSE_AMD_NO_RECYCLE", "0") == "1"   # debugg
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
 
+class _ConvLog(list):
+    """conv_log entries remember which launch they describe (dead-launch elimination drops both together)"""
+
+    def __init__(self, prog):
+        super().__init__()
+        self.prog, self.op_index = prog, []
+
+    def append(self, e):
+        super().append(e)
+        self.op_index.append(len(self.prog.ops) - 1)
+
+
 def _rup(x, m):
     return (x + m - 1) // m * m
 
@@ -186,7 +198,8 @@ class Program:
         self.regions = []      # [start_op, end_op] of fork/join regions (buffer lifetimes are extended over them)
         self._open = None
         self.flops = 0         # dense MACs*2 issued through cp_conv2d_igemm (algorithmic, unpadded)
-        self.conv_log = []     # (name, M, Cout, K, flops) per conv launch -- bench roofline uses it
+        self.conv_log = _ConvLog(self)     # (name, M, Cout, K, flops, family, bytes) per MFMA launch -- bench roofline uses it
+        self._rw = {}          # op index -> (reads, writes): dead-launch elimination in finalize(dce=True)
 
     # ---- tensors
     def tensor(self, nelem, es=None):
@@ -213,6 +226,7 @@ class Program:
             if t.first is None:
                 t.first = i
             t.last = i
+        self._rw[i] = ([t for t in reads if t is not None], [t for t in writes if t is not None])
         self.ops.append((fn, argb, name, self.lane))
 
     # ---- structured concurrency: independent sub-chains (HRNet branches, decoder vs GNN refinement) are launched on
@@ -672,10 +686,45 @@ class Program:
         self._add(fn, lambda P: (self.dtype, P(xt), op, x.B, x.C, x.H, x.W, x.cstride, x.coff), "to_nchw", [xt], [])
 
     # ---- memory plan + argument binding
-    def finalize(self):
+    def _drop_dead_launches(self):
+        """A launch whose outputs nobody reads is not run: walking the list backwards, a launch is live if it writes a caller-
+        visible (fixed) tensor, declares no outputs (decode / export ops working on raw pointers), or writes a workspace tensor a
+        later live launch reads.  In the reference the highest-resolution `incre_modules[0]` feature is computed by timm and
+        never used by PoseNet_GNNskip (pipeline.py:354-358 reads img_feats[-1..-3]); with return_img_feats it stays live."""
+        needed, dead = set(), set()
+        for i in range(len(self.ops) - 1, -1, -1):
+            if i not in self._rw:
+                continue
+            reads, writes = self._rw[i]
+            if (not writes) or any(w.fixed is not None or id(w) in needed for w in writes):
+                needed.update(id(r) for r in reads)
+            else:
+                dead.add(i)
+        if not dead:
+            return 0
+        for i in dead:
+            self.ops[i] = ("__dead__",)
+        for t in self.tbufs:
+            t.first = t.last = None
+        for i, (reads, writes) in sorted(self._rw.items()):
+            if i in dead:
+                continue
+            for t in reads + writes:
+                if t.fixed is None:
+                    if t.first is None:
+                        t.first = i
+                    t.last = i
+        live = [(e, k) for e, k in zip(list(self.conv_log), self.conv_log.op_index) if k not in dead]
+        self.conv_log[:] = [e for e, _ in live]
+        self.conv_log.op_index = [k for _, k in live]
+        self.flops = sum(e[4] for e in self.conv_log)
+        return len(dead)
+
+    def finalize(self, dce=False):
         """Linear-scan placement of every workspace tensor by liveness (outputs are placed before the op's dead
         inputs are released, so an op never aliases its own operands)."""
         assert self._open is None
+        self.dropped = self._drop_dead_launches() if dce else 0
         for t in self.tbufs:                      # inside a fork/join region nothing may be recycled: another lane
             if t.fixed is None and t.first is not None:   # can still be reading (or not yet have written) it
                 for rs, re in self.regions:
@@ -735,6 +784,8 @@ class Program:
                 self.sched.append(("mark", op[1], op[2]))
             elif op[0] == "__wait__":
                 self.sched.append(("wait", op[1], op[2]))
+            elif op[0] == "__dead__":
+                continue
             else:
                 fn, argb, name, lane = op
                 self.sched.append(("op", len(self.calls), lane))

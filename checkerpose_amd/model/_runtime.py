@@ -221,7 +221,7 @@ class HipForwardMixin:
                 if "graph_feats" not in io:
                     io["graph_feats"] = torch.empty(B, g.C, N, dtype=torch.float32, device=device)
                 prog.to_nchw_f32(g, io["graph_feats"][sl])
-            prog.finalize()
+            prog.finalize(dce=os.environ.get("CHECKERPOSE_AMD_DCE", "1") != "0")       # e.g. timm's highest-resolution incre feature: computed by the reference, read by nobody
             progs.append(prog)
         prog = ProgramGroup(progs)
         torch.cuda.current_stream(device).synchronize()      # weight packing done before temporaries die
