@@ -846,6 +846,13 @@ def test_e2e_fp32_vs_golden_hrnet_and_oracle(lib):
     o3, feats, gf = net.init_net(img.to(dev()), return_graph_feats=True)
     assert [tuple(f.shape[1:]) for f in feats] == [(128, 64, 64), (256, 32, 32), (512, 16, 16), (1024, 8, 8)]
     assert tuple(gf.shape) == (1, 64, 512) and torch.equal(o3, init_out)
+    # the returned features themselves (all four incre modules are live when they are asked for; without return_img_feats the
+    # launch program drops the highest-resolution one, which nothing reads)
+    sdi = {k[len("init_net."):]: v for k, v in net.state_dict().items() if k.startswith("init_net.")}
+    _, rfeats, rg = O.init_net_forward({k: v.cpu() for k, v in sdi.items()}, "", img, net.init_net.knn_idx.cpu(), 512)
+    for f, r in zip(feats, rfeats):
+        close(f.cpu(), r, 1e-4)
+    close(gf.cpu(), rg, 1e-4)
 
 
 def test_e2e_fp32_batch_ragged_and_stage_truncation(lib):
