@@ -144,11 +144,10 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     const int y0 = ty * BTH, x0 = tx * BTW;
 
-    // conv1's weight fragments are re-fetched per tile (8 KB per wave from L2, in flight during the staging):
-    // keeping them resident too does not fit 256 VGPRs next to conv2's 18 and conv3's 4 fragments
-    u32x4 W1[XCH];
-#pragma unroll
-    for (int kc = 0; kc < XCH; ++kc) W1[kc] = ((const u32x4*)p.w1)[(nt * XCH + kc) * 64 + lane];
+    // conv1: wave w owns channel tiles 2 (w & 1), 2 (w & 1) + 1 and halo fragments 3 (w >> 1) .. + 2: every x fragment read
+    // from LDS feeds two MFMAs (one tile per wave and six fragments read each fragment four times: LDS-port bound)
+    const int nt1 = 2 * (wave & 1), fr1 = 3 * (wave >> 1);
+    u32x4 W1[2][XCH];
     // ---- stage: registers -> LDS planes
     if constexpr (XCH == 8) {
       unsigned char* dst = sX + spc * PITCH_X + scol * 16;
@@ -164,32 +163,45 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
         *(u32x4*)(sX + (i % XPLANES) * PITCH_X + (i / XPLANES) * 16) = xv[it];
       }
     }
+    // (16 KB per wave from L2, issued once the staged registers are free: resident next to conv2's 18 and conv3's 4
+    // fragments they do not fit 256 VGPRs)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kc = 0; kc < XCH; ++kc) W1[t][kc] = ((const u32x4*)p.w1)[((nt1 + t) * XCH + kc) * 64 + lane];
     __syncthreads();
 
-    // ---- conv1 (1x1, K = 256): channel tile nt, fragments 6*half .. 6*half+5 of the halo
+    // ---- conv1 (1x1, K = 256): channel tiles nt1, nt1 + 1, fragments fr1 .. fr1 + 2 of the halo
     {
-      f32x4 acc[6];
+      f32x4 acc[3][2];
 #pragma unroll
-      for (int f = 0; f < 6; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int f = 0; f < 3; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int kc = 0; kc < XCH; ++kc) {
-        const unsigned char* base = sX + (kc * 4 + q) * PITCH_X + ((half * 6) * 16 + x) * 16;
+        const unsigned char* base = sX + (kc * 4 + q) * PITCH_X + (fr1 * 16 + x) * 16;
 #pragma unroll
-        for (int f = 0; f < 6; ++f) mma_bf16(W1[kc], *(const u32x4*)(base + f * 256), acc[f]);
+        for (int f = 0; f < 3; ++f) {
+          const u32x4 a = *(const u32x4*)(base + f * 256);
+          mma_bf16(W1[0][kc], a, acc[f][0]);
+          mma_bf16(W1[1][kc], a, acc[f][1]);
+        }
       }
-      const int c0 = nt * 16 + q * 4;
-      const f32x4 sc = *(const f32x4*)(a_s1 + c0), sh = *(const f32x4*)(a_t1 + c0);
 #pragma unroll
-      for (int f = 0; f < 6; ++f) {
-        const int p1 = (half * 6 + f) * 16 + x;
-        const int py = p1 / BPW, px = p1 - py * BPW;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool inimg = (p1 < BNPIX) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-        float v[4];
+      for (int t = 0; t < 2; ++t) {
+        const int c0 = (nt1 + t) * 16 + q * 4;
+        const f32x4 sc = *(const f32x4*)(a_s1 + c0), sh = *(const f32x4*)(a_t1 + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[f][e] * sc[e] + sh[e], 0.f) : 0.f;
-        u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-        *(u32x2*)(sT1 + (c0 >> 3) * PITCH_X + p1 * 16 + (c0 & 7) * 2) = pk;
+        for (int f = 0; f < 3; ++f) {
+          const int p1 = (fr1 + f) * 16 + x;
+          const int py = p1 / BPW, px = p1 - py * BPW;
+          const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+          const bool inimg = (p1 < BNPIX) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[f][t][e] * sc[e] + sh[e], 0.f) : 0.f;
+          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(sT1 + (c0 >> 3) * PITCH_X + p1 * 16 + (c0 & 7) * 2) = pk;
+        }
       }
     }
     __syncthreads();
@@ -202,14 +214,21 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
       f32x4 acc[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // per (column shift, channel half): the 6 t1 rows this wave's 4 output rows touch are read ONCE and feed the three
+      // row taps (12 MFMAs per 6 fragment reads; tap-major order read every fragment up to three times -- the LDS port,
+      // not the matrix pipe, bounds this phase)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int r3 = tap / 3, s3 = tap - 3 * r3;
+      for (int s3 = 0; s3 < 3; ++s3) {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
-          const unsigned char* base = sT1 + (c2 * 4 + q) * PITCH_X + ((half * 4 + r3) * BPW + x + s3) * 16;
+          const unsigned char* base = sT1 + (c2 * 4 + q) * PITCH_X + ((half * 4) * BPW + x + s3) * 16;
+          u32x4 rowf[6];
 #pragma unroll
-          for (int f = 0; f < 4; ++f) mma_bf16(W2[tap * 2 + c2], *(const u32x4*)(base + f * BPW * 16), acc[f]);
+          for (int rr = 0; rr < 6; ++rr) rowf[rr] = *(const u32x4*)(base + rr * BPW * 16);
+#pragma unroll
+          for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) mma_bf16(W2[(r3 * 3 + s3) * 2 + c2], rowf[r3 + f], acc[f]);
         }
       }
       const int c0 = nt * 16 + q * 4;
