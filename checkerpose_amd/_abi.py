@@ -70,7 +70,7 @@ SIGNATURES = {
     "cp_hr_chain_supported": (_I, [_I, _I, _I]),
     "cp_hr_chain_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "cp_hr_chain_affine_floats": (_I, [_I, _I, _I]),
-    "cp_pack_hr_chain_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cp_pack_hr_chain_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cp_hr_branch_chain": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P]),
     "cp_upsample2x_bilinear_ac": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I]),

@@ -5,7 +5,7 @@
 
 #include "common.h"
 
-extern "C" int cp_version(void) { return 200; }   // 0.2.0
+extern "C" int cp_version(void) { return 201; }   // 0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale
 
 static thread_local char g_last_kernel[128] = "";
 void cp_mark_kernel(const char* fmt, ...) {

@@ -20,6 +20,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }
 
+// relu of two packed bf16 values: the sign bit is the int16 sign bit, so max(int16, 0) per half (-0.0 -> +0.0 as fmaxf does)
+typedef short cp_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cp_s16x2, v), cp_s16x2{0, 0}));
+}
+
 // element type tags
 struct F32Tag { using elem = float; static constexpr int E = 4; static constexpr int dtype = CP_F32; };
 struct BF16Tag { using elem = uint16_t; static constexpr int E = 8; static constexpr int dtype = CP_BF16; };

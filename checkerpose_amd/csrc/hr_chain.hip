@@ -28,7 +28,7 @@
 // the 64x64x18 branch has its own kernel (hr_chain0.hip: banded in-place update, residual through HBM)
 size_t cp_chain0_conv_bytes();
 int cp_chain0_aff();
-int cp_chain0_pack(hipStream_t st, const float* w, int conv_index, void* blob);
+int cp_chain0_pack(hipStream_t st, const float* w, const float* scale, int conv_index, void* blob);
 int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
                      const void* packed_w, const float* affine, void* out);
 
@@ -247,10 +247,26 @@ __global__ __launch_bounds__(Cfg::NTHR) void hr_chain_kernel(const ChainParams p
     static_assert(2 * AFF <= NTHR, "one affine float per thread");
     float affv = 0.f;
     if (cv + 1 < 8 && tid < 2 * AFF) affv = p.aff[(cv + 1) * 2 * AFF + tid];
+    // the accumulators start at the folded-BN shift (the scale sits in the packed weights) -- plus, in a block's second
+    // conv, the residual: the epilogue is ReLU + pack only (its VALU instructions, 4 issue cycles each, ran 1:1 with the MFMAs)
+    {
+      const float* const sh = sAff + (cv & 1) * 2 * AFF + AFF;
 #pragma unroll
-    for (int f = 0; f < MT; ++f)
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int c0 = q * 4 * NT_ALL + (nt0 + nt) * 4;
+        f32x4 t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has(nt) && c0 < CPHYS) t4 = *(const f32x4*)(sh + c0);
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < MT; ++f) {
+          acc[f][nt] = t4;
+          if (cv & 1) {
+            const u32x2 r = f < RL ? resL[(f * NTW + nt) * 64] : res[f - RL < 0 ? 0 : f - RL][nt];
+            acc[f][nt][0] += __uint_as_float(r.x << 16); acc[f][nt][1] += __uint_as_float(r.x & 0xffff0000u);
+            acc[f][nt][2] += __uint_as_float(r.y << 16); acc[f][nt][3] += __uint_as_float(r.y & 0xffff0000u);
+          }
+        }
+      }
+    }
 
 #pragma unroll 1
     for (int s = 0; s < NS; ++s, ++gs) {
@@ -302,28 +318,17 @@ __global__ __launch_bounds__(Cfg::NTHR) void hr_chain_kernel(const ChainParams p
     if (tid < 2 * AFF) sAff[((cv + 1) & 1) * 2 * AFF + tid] = affv;   // read by conv cv+1's epilogue, many barriers from here
     // ---- epilogue in registers, then back over the map (every wave is past its last read of the old map)
     {
-      const float* const sc = sAff + (cv & 1) * 2 * AFF;
-      const float* const sh = sc + AFF;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const int c0 = q * 4 * NT_ALL + (nt0 + nt) * 4;
         if (has(nt) && c0 < CPHYS) {
-          const f32x4 s4 = *(const f32x4*)(sc + c0), t4 = *(const f32x4*)(sh + c0);
           uint32_t co = c_off(c0);
           asm volatile("" : "+v"(co));
 #pragma unroll
           for (int f = 0; f < MT; ++f) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[f][nt][j] * s4[j] + t4[j];
-            if (cv & 1) {
-              const u32x2 r = f < RL ? resL[(f * NTW + nt) * 64] : res[f - RL < 0 ? 0 : f - RL][nt];
-              v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-              v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-            u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            u32x2 pk;                                                  // ReLU on the rounded pair: bf16 keeps the sign bit, so max(int16, 0)
+            pk.x = relu_bf16x2(pack_bf16x2(acc[f][nt][0], acc[f][nt][1]));
+            pk.y = relu_bf16x2(pack_bf16x2(acc[f][nt][2], acc[f][nt][3]));
             *(u32x2*)(sMap + base[f] + co) = pk;
           }
         }
@@ -352,7 +357,8 @@ __global__ __launch_bounds__(Cfg::NTHR) void hr_chain_kernel(const ChainParams p
 // packing: [chunk kc][tile nt][lane][16 B]; lane (row = lane & 15, q = lane >> 4), element e: K group G = 4 kc + q ->
 // tap G / CG, input channel 8 (G % CG) + e; tile row `row` of tile nt is output channel (row >> 2) * 4 NT_ALL + 4 nt + (row & 3)
 // (lane q of the MFMA result then holds 4 NT_ALL consecutive channels of its pixel).
-__global__ void pack_chain_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int C, int CG, int NT_ALL, size_t total) {
+__global__ void pack_chain_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, uint16_t* __restrict__ out, int C,
+                                         int CG, int NT_ALL, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int e = (int)(i % 8);
@@ -365,7 +371,7 @@ __global__ void pack_chain_weight_kernel(const float* __restrict__ w, uint16_t* 
   const int tap = G / CG, cin = (G % CG) * 8 + e;
   const int n = (row >> 2) * 4 * NT_ALL + nt * 4 + (row & 3);
   float v = 0.f;
-  if (tap < 9 && cin < C && n < C) v = w[((size_t)n * C + cin) * 9 + tap];
+  if (tap < 9 && cin < C && n < C) v = w[((size_t)n * C + cin) * 9 + tap] * (scale ? scale[n] : 1.f);   // folded BN scale
   out[i] = (uint16_t)f32_to_bf16_bits(v);
 }
 
@@ -408,14 +414,15 @@ extern "C" int cp_hr_chain_affine_floats(int C, int H, int W) {
   return chain_info(C, H, W, &ci) ? ci.AFF : 0;
 }
 
-extern "C" int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, int C, int H, int W, int conv_index, void* blob) {
+extern "C" int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, const float* scale, int C, int H, int W, int conv_index,
+                                       void* blob) {
   ChainInfo ci;
   if (!w || !blob || conv_index < 0 || conv_index > 7 || !chain_info(C, H, W, &ci)) return CP_ERR_INVALID;
   if (!cp_aligned16(blob)) return CP_ERR_ALIGN;
-  if (C == 18) return cp_chain0_pack((hipStream_t)stream, w, conv_index, blob);
+  if (C == 18) return cp_chain0_pack((hipStream_t)stream, w, scale, conv_index, blob);
   const size_t total = ci.conv_w / 2;
   uint16_t* dst = (uint16_t*)((unsigned char*)blob + (size_t)conv_index * ci.conv_w);
-  CP_LAUNCH(pack_chain_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, dst, C, ci.CG, ci.NT_ALL, total);
+  CP_LAUNCH(pack_chain_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale, dst, C, ci.CG, ci.NT_ALL, total);
   return cp_check_launch();
 }
 

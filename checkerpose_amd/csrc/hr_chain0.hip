@@ -163,8 +163,7 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
   for (int cv = 0; cv < 8; ++cv) {
     float affv = 0.f;
     if (cv + 1 < 8 && tid < 2 * ZAFF) affv = p.aff[(cv + 1) * 2 * ZAFF + tid];
-    const float* const sc = sAff + (cv & 1) * 2 * ZAFF + q * 8;
-    const float* const sh = sc + ZAFF;
+    const float* const sh = sAff + (cv & 1) * 2 * ZAFF + ZAFF + q * 8;
     const bool second = cv & 1;
 #pragma unroll 1
     for (int band = 0; band < 8; ++band) {
@@ -175,9 +174,12 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) rres[f] = ((const u32x4*)p.out)[(gpix0 + row * ZW + f * 16 + x) * 3 + q];
       }
-      f32x4 acc[4][2];
+      f32x4 acc[4][2];                 // start at the folded-BN shift (the scale sits in the packed weights)
+      {
+        const f32x4 t0 = *(const f32x4*)(sh), t1 = *(const f32x4*)(sh + 4);
 #pragma unroll
-      for (int f = 0; f < 4; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int f = 0; f < 4; ++f) { acc[f][0] = t0; acc[f][1] = t1; }
+      }
       u32x4 af[2][4];
       load_frags(af[0], 0, pb);
 #pragma unroll
@@ -197,22 +199,21 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
       }
       // ---- epilogue: lane (x, q) holds channels 8q .. 8q+7 of pixel (row, 16 f + x)
       u32x4 v[4];
-      if (q < 3) {
-        const f32x4 s0 = *(const f32x4*)(sc), s1 = *(const f32x4*)(sc + 4), t0 = *(const f32x4*)(sh), t1 = *(const f32x4*)(sh + 4);
+      if (q < 3) {                     // (+ residual), round, ReLU on the packed pairs (bf16 keeps the sign bit: max(int16, 0))
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           float e[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j] * s0[j] + t0[j]; e[4 + j] = acc[f][1][j] * s1[j] + t1[j]; }
+          for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j]; e[4 + j] = acc[f][1][j]; }
           if (second) {
             float r8[8];
             Vec16<BF16Tag>::unpack(rres[f], r8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] += r8[j];
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = fmaxf(e[j], 0.f);
-          v[f] = Vec16<BF16Tag>::pack(e);
+          u32x4 pk = Vec16<BF16Tag>::pack(e);
+          pk.x = relu_bf16x2(pk.x); pk.y = relu_bf16x2(pk.y); pk.z = relu_bf16x2(pk.z); pk.w = relu_bf16x2(pk.w);
+          v[f] = pk;
           if (second) ((u32x4*)p.out)[(gpix0 + row * ZW + f * 16 + x) * 3 + q] = v[f];
         }
       }
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
 // [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
 //   G < 18: tap G >> 1, input channel 8 (G & 1) + e;   18 <= G < 27: tap G - 18, input channel 16 + e (e < 2);   else zero.
 // tile row `row` of tile nt is output channel (row >> 2) * 8 + 4 nt + (row & 3).
-__global__ void pack_chain0_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, size_t total) {
+__global__ void pack_chain0_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, uint16_t* __restrict__ out, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int e = (int)(i % 8);
@@ -258,7 +259,7 @@ __global__ void pack_chain0_weight_kernel(const float* __restrict__ w, uint16_t*
   else if (G < 27 && e < 2) { tap = G - 18; cin = 16 + e; }
   const int n = (row >> 2) * 8 + nt * 4 + (row & 3);
   float v = 0.f;
-  if (tap >= 0 && n < ZC && cin < ZC) v = w[((size_t)n * ZC + cin) * 9 + tap];
+  if (tap >= 0 && n < ZC && cin < ZC) v = w[((size_t)n * ZC + cin) * 9 + tap] * (scale ? scale[n] : 1.f);   // folded BN scale
   out[i] = (uint16_t)f32_to_bf16_bits(v);
 }
 
@@ -268,10 +269,10 @@ __global__ void pack_chain0_weight_kernel(const float* __restrict__ w, uint16_t*
 size_t cp_chain0_conv_bytes() { return ZCONV_W; }
 int cp_chain0_aff() { return ZAFF; }
 
-int cp_chain0_pack(hipStream_t st, const float* w, int conv_index, void* blob) {
+int cp_chain0_pack(hipStream_t st, const float* w, const float* scale, int conv_index, void* blob) {
   const size_t total = ZCONV_W / 2;
   uint16_t* dst = (uint16_t*)((unsigned char*)blob + (size_t)conv_index * ZCONV_W);
-  CP_LAUNCH(pack_chain0_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, dst, total);
+  CP_LAUNCH(pack_chain0_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, scale, dst, total);
   return cp_check_launch();
 }
 

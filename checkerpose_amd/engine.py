@@ -145,7 +145,8 @@ class WeightStore:
         return out
 
     def pack_chain(self, name, ws, affs, C_, H, W):
-        """the 8 convs of an HRNet branch chain: one packed weight blob + one [8][2][AFF] fp32 affine tensor"""
+        """the 8 convs of an HRNet branch chain: one packed weight blob (BN scale folded in) + one [8][2][AFF] fp32 affine tensor
+        (row 0: the scale, informational -- the kernel reads row 1, the shift)"""
         ck = ("chain", name)
         if ck in self.cache:
             return self.cache[ck]
@@ -153,8 +154,10 @@ class WeightStore:
         st = torch.cuda.current_stream(self.device).cuda_stream
         for i, w in enumerate(ws):
             w = w.contiguous()
-            self.keep.append(w)
-            _abi.check(self.lib.cp_pack_hr_chain_weight(st, w.data_ptr(), C_, H, W, i, blob.data_ptr()), "cp_pack_hr_chain_weight(%s)" % name)
+            sc = affs[i][0].to(device=self.device, dtype=torch.float32).contiguous()      # folded-BN scale goes INTO the packed weights
+            self.keep += [w, sc]
+            _abi.check(self.lib.cp_pack_hr_chain_weight(st, w.data_ptr(), sc.data_ptr(), C_, H, W, i, blob.data_ptr()),
+                       "cp_pack_hr_chain_weight(%s)" % name)
         n = self.lib.cp_hr_chain_affine_floats(C_, H, W)
         aff = torch.zeros(8, 2, n, dtype=torch.float32, device=self.device)
         for i, (s_, t_) in enumerate(affs):

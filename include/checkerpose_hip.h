@@ -204,12 +204,14 @@ int cp_hr_stem(cp_stream_t stream, const float* img_nchw, int B, int Hin, int Wi
  * Supported (C, H, W): (18, 64, 64), (36, 32, 32), (72, 16, 16), (144, 8, 8) -- the four HRNet-W18 branches of a 256 x 256
  * crop (cp_hr_chain_supported).  The 64 x 64 branch keeps its BasicBlock residuals in `out` between blocks (its map alone fills
  * the LDS), the others keep them on chip.  Weights: cp_pack_hr_chain_weight() packs conv `conv_index` (0..7 = block.conv1, block.conv2, ...)
- * of fp32 (C, C, 3, 3) weights into the caller-owned blob of cp_hr_chain_weight_bytes() bytes; `affine` = fp32
- * [8][2][cp_hr_chain_affine_floats()] folded-BN (scale, shift) per conv, zero beyond C.  out must not alias a source. */
+ * of fp32 (C, C, 3, 3) weights TIMES the folded-BN `scale` of their output channel (fp32 [C]; NULL = 1) into the caller-owned
+ * blob of cp_hr_chain_weight_bytes() bytes; `affine` = fp32 [8][2][cp_hr_chain_affine_floats()] per conv, zero beyond C: row 1
+ * is the folded-BN shift the accumulators start from, row 0 is NOT read (the scale lives in the weights: a block's epilogue
+ * is residual + ReLU + rounding only).  out must not alias a source. */
 int cp_hr_chain_supported(int C, int H, int W);
 size_t cp_hr_chain_weight_bytes(int C, int H, int W);
 int cp_hr_chain_affine_floats(int C, int H, int W);
-int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, int C, int H, int W, int conv_index, void* blob);
+int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, const float* scale, int C, int H, int W, int conv_index, void* blob);
 int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
                        const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out);
 

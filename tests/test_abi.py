@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_strerror_align(lib):
-    assert lib.cp_version() >= 200
+    assert lib.cp_version() >= 201
     assert lib.cp_strerror(0) == b"ok"
     assert b"invalid" in lib.cp_strerror(-1)
     assert lib.cp_chan_align(_abi.CP_F32) == 4 and lib.cp_chan_align(_abi.CP_BF16) == 8

@@ -402,7 +402,8 @@ def test_hr_branch_chain_vs_torch_cpu(lib, cfg, nsrc):
     blob = torch.empty(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev())
     for i, w in enumerate(ws):
         wd = w.contiguous().to(dev())
-        _abi.check(lib.cp_pack_hr_chain_weight(st(), wd.data_ptr(), Cc, H, W, i, blob.data_ptr()))
+        sd_ = affs[i][0].contiguous().to(dev())               # the folded-BN scale goes into the packed weights
+        _abi.check(lib.cp_pack_hr_chain_weight(st(), wd.data_ptr(), sd_.data_ptr(), Cc, H, W, i, blob.data_ptr()))
         torch.cuda.synchronize()
     n = lib.cp_hr_chain_affine_floats(Cc, H, W)
     aff = torch.zeros(8, 2, n)

@@ -14,7 +14,12 @@ for (Cc, H, W) in ((18, 64, 64), (36, 32, 32), (72, 16, 16), (144, 8, 8)):
         blob = torch.zeros(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev)
         w = (torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05).contiguous()
         for i in range(8):
-            _abi.check(lib.cp_pack_hr_chain_weight(torch.cuda.current_stream().cuda_stream, w.data_ptr(), Cc, H, W, i, blob.data_ptr()))
+            if lib.cp_version() >= 201:
+                _abi.check(lib.cp_pack_hr_chain_weight(torch.cuda.current_stream().cuda_stream, w.data_ptr(), None, Cc, H, W, i, blob.data_ptr()))
+            else:       # A/B against an older build (CHECKERPOSE_AMD_LIB): the pack call had no scale argument
+                import ctypes
+                lib.cp_pack_hr_chain_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+                _abi.check(lib.cp_pack_hr_chain_weight(torch.cuda.current_stream().cuda_stream, w.data_ptr(), Cc, H, W, i, blob.data_ptr()))
         n = lib.cp_hr_chain_affine_floats(Cc, H, W)
         aff = torch.zeros(8, 2, n, device=dev); aff[:, 0, :Cc] = 0.5
         out = torch.empty(B, H, W, cp, device=dev, dtype=torch.bfloat16)
