@@ -252,6 +252,7 @@ def test_workspace_planner_never_aliases_live_tensors():
     prog.lib, prog.ws, prog.dtype, prog.B, prog.device = _Lib(), _WS(), 0, 2, "cpu"
     prog.E, prog.es, prog.ops, prog.tbufs, prog.keep = 4, 4, [], [], []
     prog.lane, prog.nlanes, prog.regions, prog._open, prog.flops, prog.conv_log = 0, 1, [], None, 0, []
+    prog._rw = {}
     import random
     rnd = random.Random(0)
     live = []
@@ -277,6 +278,48 @@ def test_workspace_planner_never_aliases_live_tensors():
     rs, re = prog.regions[0]
     assert all(t.last >= re for t in placed if t.first <= re and t.last >= rs)   # pinned until the join
     assert prog.workspace_bytes <= sum(t.nbytes for t in placed)
+
+
+def test_dead_launch_elimination_keeps_exactly_what_is_read():
+    """engine.Program.finalize(dce=True): a launch is kept iff it writes a caller-visible (fixed) tensor, declares no outputs,
+    or feeds a kept launch; dropped launches take their conv_log entry and their workspace with them (host logic only)."""
+    import torch
+    from checkerpose_amd.engine import Program, _ConvLog
+
+    class _Lib:
+        def cp_chan_align(self, dt):
+            return 4
+
+    prog = Program.__new__(Program)
+    prog.lib, prog.ws, prog.dtype, prog.B, prog.device = _Lib(), object(), 0, 2, "cpu"
+    prog.E, prog.es, prog.ops, prog.tbufs, prog.keep = 4, 4, [], [], []
+    prog.lane, prog.nlanes, prog.regions, prog._open, prog.flops = 0, 1, [], None, 0
+    prog.conv_log, prog._rw = _ConvLog(prog), {}
+    out = prog.fixed(torch.zeros(4))                       # caller-visible
+    a, b, c, d, e = (prog.tensor(256) for _ in range(5))
+    calls = []
+
+    def add(name, reads, writes, flops=0):
+        prog._add(lambda *x: 0, lambda P: (), name, reads, writes)
+        if flops:
+            prog.flops += flops
+            prog.conv_log.append((name, 1, 1, 1, flops, "conv_igemm", 1))
+        calls.append(name)
+
+    add("in->a", [], [a], 10)
+    add("a->b", [a], [b], 20)
+    add("a->c (dead branch)", [a], [c], 40)
+    add("c->d (dead branch)", [c], [d], 80)
+    add("b->out", [b], [out], 160)
+    add("side effect, no declared outputs", [b], [])
+    add("writes e, never read", [], [e], 320)
+    prog.finalize(dce=True)
+    assert prog.dropped == 3
+    assert [n for _, _, n in prog.calls] == ["in->a", "a->b", "b->out", "side effect, no declared outputs"]
+    assert [r[0] for r in prog.conv_log] == ["in->a", "a->b", "b->out"] and prog.flops == 190
+    assert c.first is None and d.first is None and e.first is None        # dead tensors get no workspace
+    assert a.first == 0 and a.last == 1 and b.last == 5
+
 
 
 def test_pretrained_backbone_is_never_silent(tmp_path, monkeypatch):
