@@ -17,6 +17,9 @@ IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 
 FUSE_OUT_DEEP = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_DEEP", "1") != "0"   # A/B: 2nd / 3rd convs of the stride-2 fuse chains through cp_hr_fuse_out
 
 
+FUSE_SAME_LANE = os.environ.get("CHECKERPOSE_AMD_FUSE_SAME_LANE", "1") != "0"   # A/B: a fuse chain's later convs on its source's lane (no second region)
+
+
 class NetEmitter:
     def __init__(self, prog: Program, sd):
         self.p, self.ws, self.sd = prog, prog.ws, sd
@@ -241,11 +244,15 @@ class NetEmitter:
                 return (i - j) if j < i else 0.3
             load = [0.0] * nb
             sched = []
+            same_lane = FUSE_SAME_LANE and len(first) == nb * (nb - 1)      # every chain starts in a grouped launch:
             for cost, i, j in sorted([(cost_of(i, j), i, j) for i in range(nb) for j in range(nb) if i != j], reverse=True):
-                ln = min(range(nb), key=lambda k: load[k]) if cost > 0 else 0
+                if same_lane:                # its later convs follow on their SOURCE's lane -- one fork/join region per module
+                    ln = j
+                else:
+                    ln = min(range(nb), key=lambda k: load[k]) if cost > 0 else 0
                 load[ln] += cost
                 sched.append((ln, i, j))
-            second = any(c > 0 for c in load)
+            second = any(c > 0 for c in load) and not same_lane
             if second:
                 p.par_end()
                 p.par_begin(nb)
