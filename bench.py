@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 MFMA_KERNELS = {"conv_igemm": "conv_igemm_kernel", "conv3x3_halo": "conv3x3_halo_kernel", "conv3x3_halo4": "conv3x3_halo4_kernel",
-                "conv3x3_halo_s": "conv3x3_halo_s_kernel", "gemm_rows": "gemm_rows_kernel|gemm_rows_ws_kernel",
+                "conv3x3_halo_s": "conv3x3_halo_s_kernel", "conv3x3_s2_small": "conv3x3_s2_small_kernel", "gemm_rows": "gemm_rows_kernel|gemm_rows_ws_kernel",
                 "basicblock_fused": "basicblock_fused_kernel|basicblock_persist_kernel", "bottleneck_fused": "bottleneck_fused_kernel",
                 "hr_chain": "hr_chain_kernel|hr_chain0_kernel", "hr_fuse_out": "hr_fuse_out_kernel", "edge_fused": "edgeconv_fused_kernel", "hr_stem": "hr_stem_kernel", "patch_gather": "patch_gather_kernel"}
 

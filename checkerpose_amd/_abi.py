@@ -56,6 +56,10 @@ SIGNATURES = {
     "cp_packed_halo_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "cp_pack_conv3x3_halo_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_conv3x3_halo": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
+    "cp_conv3x3_s2_small_supported": (_I, [_I, _I, _I, _I]),
+    "cp_conv3x3_s2_small_weight_bytes": (C.c_size_t, [_I, _I]),
+    "cp_pack_conv3x3_s2_small_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cp_conv3x3_s2_small": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P]),
     "cp_conv3x3_halo_up2x_supported": (_I, [_I, _I]),
     "cp_conv3x3_halo_up2x": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P]),
     "cp_pack_conv3x3_rows_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),

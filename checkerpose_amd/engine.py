@@ -22,6 +22,7 @@ USE_GEMM = os.environ.get("CHECKERPOSE_AMD_GEMM", "1") != "0"   # LDS-staged 1x1
 USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch per HRNet branch chain (bf16, map resident in LDS)
 USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decoder: bilinear x2 interpolated inside the conv's halo loader
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
+USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
@@ -288,7 +289,22 @@ class Program:
             halo = _rup(x.Cphys, 16) <= 1.15 * x.Cphys
         gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
                 and not transposed and row_map is None and wCout >= 96 and x.Cphys >= 16 * self.E)
-        if halo:
+        s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
+                   and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= 16
+                   and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
+        if s2small:
+            ck = ("s2small", wkey, x.Cphys)
+            if ck not in self.ws.cache:
+                buf = torch.empty(self.lib.cp_conv3x3_s2_small_weight_bytes(x.Cphys, _rup(wCout, self.E)), dtype=torch.uint8, device=self.device)
+                wc = w.contiguous()
+                self.ws.keep.append(wc)
+                st_ = torch.cuda.current_stream(self.device).cuda_stream
+                _abi.check(self.lib.cp_pack_conv3x3_s2_small_weight(st_, wc.data_ptr(), wCout, wCin, x.Cphys, _rup(wCout, self.E), buf.data_ptr()),
+                           "cp_pack_conv3x3_s2_small_weight(%s)" % wkey)
+                self.ws.cache[ck] = buf
+            packed = self.ws.cache[ck]
+            halo = gemm = False
+        elif halo:
             packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
         elif gemm:
             packed = self.ws.pack_gemm(wkey, w, wCout, wCin, x.Cphys)
@@ -325,8 +341,12 @@ class Program:
             fam = "conv3x3_halo_s" if wCout <= 80 else ("conv3x3_halo4" if wCout % 256 == 0 else "conv3x3_halo")
         else:
             fam = "gemm_rows" if gemm else "conv_igemm"
-        self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(rtb) if rtb is not None else None, P(otb)),
-                  fam + ":" + wkey, [xtb, rtb], [otb])
+        if s2small:
+            fam = "conv3x3_s2_small"
+            self._add(self.lib.cp_conv3x3_s2_small, lambda P: (dref, P(xtb), pw, ps, pt, P(otb)), fam + ":" + wkey, [xtb], [otb])
+        else:
+            self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(rtb) if rtb is not None else None, P(otb)),
+                      fam + ":" + wkey, [xtb, rtb], [otb])
         fl = 2 * x.B * Ho * Wo * R * S * wCin * wCout
         self.flops += fl
         oes = 4 if out_f32 else self.es

@@ -117,6 +117,17 @@ int cp_conv3x3_halo_up2x_supported(int dtype, int Cout);
 int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                          const float* scale, const float* shift, void* out);
 
+/* 3x3 / stride 2 / pad 1 convolution with a wide input and at most 48 output channels (bf16): HRNet `transition1[1]`
+ * (256 -> 36 at 64 x 64 -> 32 x 32; timm HighResolutionNet.transition1 inside backbone.py:48-49).  Descriptor as
+ * cp_conv2d_igemm with R = S = 3, stride 2, pad 1, Ho = H / 2, Wo = W / 2; H a multiple of 8, W in {32, 64}, Cin a multiple of
+ * 32, d->Cout = physical output channels (multiple of 8, <= 48), scale / shift padded to a multiple of 16 floats.  A
+ * workgroup stages 8 input rows of one 32-channel chunk in LDS (every input byte is fetched 9/8 times instead of 2.4). */
+int cp_conv3x3_s2_small_supported(int H, int W, int cin_phys, int out_cphys);
+size_t cp_conv3x3_s2_small_weight_bytes(int cin_phys, int out_cphys);
+int cp_pack_conv3x3_s2_small_weight(cp_stream_t stream, const float* w, int Cout, int Cin, int cin_phys, int out_cphys, void* packed);
+int cp_conv3x3_s2_small(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
+                        const float* shift, void* out);
+
 /* Fused timm BasicBlock of the HRNet branches (C -> C channels, C <= 32 and one 64-byte chunk, stride 1):
  *   out = relu( conv3x3(relu(conv3x3(x)*s1+t1))*s2+t2 + x )     -- intermediate and residual never leave LDS.
  * packed_w1: cp_pack_conv3x3_rows_weight (unpermuted rows); packed_w2: cp_pack_conv3x3_halo_weight.

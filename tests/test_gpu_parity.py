@@ -184,6 +184,52 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
     assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
 
 
+S2_CASES = [  # (B, Cin, ctot, coff, H, W, Cout, act)
+    (2, 256, 256, 0, 64, 64, 36, ACT_RELU),      # HRNet transition1[1]
+    (3, 64, 96, 32, 16, 32, 48, ACT_LEAKY),      # channel slice of a wider buffer, W = 32 (2 tiles per wave), 3 full M tiles
+    (1, 32, 32, 0, 8, 64, 8, ACT_NONE),          # one band, one chunk, one partial M tile
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv3x3_s2_small_vs_torch_cpu(lib, case):
+    """cp_conv3x3_s2_small (3x3 / stride 2 with the input chunk staged in LDS) == torch conv2d(stride 2, pad 1) + affine + act."""
+    B, Cin, ctot, coff, H, W, Cout, act = case
+    dtype = CP_BF16
+    xall = det_tensor("s2x%s" % (case,), (B, ctot, H, W))
+    w = det_tensor("s2w%s" % (case,), (Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("s2s%s" % (case,), (Cout,))
+    shift = 0.2 * det_tensor("s2t%s" % (case,), (Cout,))
+    ref = F.conv2d(rnd(xall[:, coff:coff + Cin], dtype), rnd(w, dtype), None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.01) if act == ACT_LEAKY else ref)
+    xin = to_cl(xall, dtype)
+    ocp = rup(Cout, 8)
+    assert lib.cp_conv3x3_s2_small_supported(H, W, Cin, ocp) == 1
+    pw = torch.empty(lib.cp_conv3x3_s2_small_weight_bytes(Cin, ocp), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv3x3_s2_small_weight(st(), wd.data_ptr(), Cout, Cin, Cin, ocp, pw.data_ptr()))
+    n16 = rup(Cout, 16)
+    sc = torch.zeros(n16); sc[:Cout] = scale
+    sh = torch.zeros(n16); sh[:Cout] = shift
+    sc, sh = sc.to(dev()), sh.to(dev())
+    Ho, Wo = H // 2, W // 2
+    out = torch.full((B, Ho, Wo, ocp), float("nan"), dtype=DT[dtype], device=dev())
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = Cin, ctot, coff
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 2, 1, Ho, Wo, ocp, act, 0.01
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, Ho * Wo * ocp, Wo * ocp, ocp, 1
+    _abi.check(lib.cp_conv3x3_s2_small(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr()), "s2 conv")
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any()
+    if ocp > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+    close(from_cl(out, Cout), ref, TOL[dtype])
+    d.stride = 1                                        # not this kernel's shape -> loud error
+    assert lib.cp_conv3x3_s2_small(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr()) == -1
+    assert lib.cp_conv3x3_s2_small_supported(H, 48, Cin, ocp) == 0 and lib.cp_conv3x3_s2_small_supported(H, W, Cin, 56) == 0
+
+
 UP_CASES = [  # (B, Cin, cin_total, coff, Hs, Ws, Cout, act): low-resolution source (Hs, Ws), conv at (2 Hs, 2 Ws)
     (2, 64, 64, 0, 16, 16, 256, ACT_RELU),       # exact tiles
     (1, 96, 160, 64, 12, 20, 256, ACT_RELU),     # channel slice of a wider buffer, tile rows / cols ragged (24 x 40)
