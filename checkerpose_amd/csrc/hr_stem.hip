@@ -68,32 +68,50 @@ __global__ __launch_bounds__(512) void hr_stem_kernel(const StemParams p) {
     ko[e] = k < 27 ? (uint32_t)((dr * ST_ICP + dc) * 8 + c * 2) : 0u;
   }
 
-  // image patch staging: piece i = tid + 512 k over 35 x 67 pixels, 3 planes each
-  constexpr int IPX = ST_IR * ST_IC;                  // 2345
-  constexpr int IIT = (IPX + 511) / 512;              // 5
-  const float* const img = p.img + (size_t)b * 3 * p.Hin * p.Win;
+  // image patch staging: piece i = tid + 512 k = (patch row, ALIGNED group of 4 image columns 64 tx - 4 + 4 g): three 16-byte
+  // loads (one per colour plane; a row is contiguous in NCHW) -> four [c0 c1 c2 0] bf16 pixels.  The image width is a multiple
+  // of 4, so a group lies entirely inside or entirely outside the row; outside (or past the last tile) it reads through an
+  // out-of-range buffer offset -> zeros: no branch, and the loop keeps counted vmcnt waits.  (One 4-byte load per pixel and
+  // plane cost 144 of the kernel's 301 us.)
+  constexpr int IGR = 18;                             // columns c0 - 1 .. c0 + 70 cover the patch's c0 .. c0 + 66
+  constexpr int IPC = ST_IR * IGR;                    // 630 pieces
+  constexpr int IIT = (IPC + 511) / 512;              // 2
   const size_t plane = (size_t)p.Hin * p.Win;
-  float iv[IIT][3];
+  const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img + (size_t)b * 3 * plane), 0,
+                                                                          (uint32_t)(3 * plane * 4), 0x00020000);
+  u32x4 iv[IIT][3];
   auto img_load = [&](int t) {
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int r0 = 4 * ty * ST_TH - 3, c0 = 4 * tx * ST_TW - 3;
 #pragma unroll
     for (int k = 0; k < IIT; ++k) {
       const int i = tid + 512 * k;
-      const int pr = i / ST_IC, pc = i - pr * ST_IC;
-      const int gy = r0 + pr, gx = c0 + pc;
-      const bool ok = (i < IPX) & (t < ntiles) & ((unsigned)gy < (unsigned)p.Hin) & ((unsigned)gx < (unsigned)p.Win);
-      const size_t o = (size_t)gy * p.Win + gx;
+      const int pr = i / IGR, pg = i - pr * IGR;
+      const int gy = r0 + pr, gx = c0 - 1 + 4 * pg;
+      const bool ok = (i < IPC) & (t < ntiles) & ((unsigned)gy < (unsigned)p.Hin) & ((unsigned)gx < (unsigned)p.Win);
+      const uint32_t off = ok ? (uint32_t)((gy * p.Win + gx) * 4) : 0x80000000u;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) iv[k][c] = ok ? img[c * plane + o] : 0.f;
+      for (int c = 0; c < 3; ++c)
+        iv[k][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off + (uint32_t)(c * plane * 4), 0, 0));
     }
   };
   auto img_write = [&]() {
 #pragma unroll
     for (int k = 0; k < IIT; ++k) {
       const int i = tid + 512 * k;
-      const int pr = i / ST_IC, pc = i - pr * ST_IC;
-      if (i < IPX) *(u32x2*)(sImg + (pr * ST_ICP + pc) * 8) = u32x2{pack_bf16x2(iv[k][0], iv[k][1]), pack_bf16x2(iv[k][2], 0.f)};
+      const int pr = i / IGR, pg = i - pr * IGR;
+      if (i < IPC) {
+        const uint32_t c0v[4] = {iv[k][0].x, iv[k][0].y, iv[k][0].z, iv[k][0].w};
+        const uint32_t c1v[4] = {iv[k][1].x, iv[k][1].y, iv[k][1].z, iv[k][1].w};
+        const uint32_t c2v[4] = {iv[k][2].x, iv[k][2].y, iv[k][2].z, iv[k][2].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pc = 4 * pg + e - 1;              // patch column of image column gx + e
+          if (pc >= 0 && pc < ST_IC)
+            *(u32x2*)(sImg + (pr * ST_ICP + pc) * 8) = u32x2{pack_bf16x2(__uint_as_float(c0v[e]), __uint_as_float(c1v[e])),
+                                                              pack_bf16x2(__uint_as_float(c2v[e]), 0.f)};
+        }
+      }
     }
   };
   // the pad column (pixel 67 of every row) and nothing else is ever read uninitialised: zero the patch once
@@ -146,17 +164,25 @@ __global__ __launch_bounds__(512) void hr_stem_kernel(const StemParams p) {
     f32x4 acc2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < 18; ++kc) {
+    // fragments one K chunk ahead, pinned (left alone hipcc sinks each ds_read to its MFMA: one LDS latency per MFMA)
+    auto c2_load = [&](u32x4* af, int kc) {
       const int tap = kc >> 1, ch = kc & 1;
       const int dr = tap / 3, dc = tap - 3 * dr;
       const int jb = dc == 1 ? 17 : (dc == 2 ? 1 : 0);           // de-interleaved column of ring column 2 x + dc
       const unsigned char* base = sT1 + (ch * 4 + q) * ST_PLANE + ((2 * 4 * half + dr) * ST_C1 + jb + x) * 16;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const u32x4 af = *(const u32x4*)(base + (2 * m) * ST_C1 * 16);
-        acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W2f[kc]), __builtin_bit_cast(bf16x8, af), acc2[m], 0, 0, 0);
-      }
+      for (int m = 0; m < 4; ++m) af[m] = *(const u32x4*)(base + (2 * m) * ST_C1 * 16);
+    };
+    u32x4 af2[2][4];
+    c2_load(af2[0], 0);
+#pragma unroll
+    for (int kc = 0; kc < 18; ++kc) {
+      if (kc + 1 < 18) c2_load(af2[(kc + 1) & 1], kc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W2f[kc]), __builtin_bit_cast(bf16x8, af2[kc & 1][m]), acc2[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     {
       uint16_t* const ob = (uint16_t*)p.out + (((size_t)b * H2 + oy0 + 4 * half) * W2 + ox0 + x) * 64 + 16 * nt2 + 4 * q;
