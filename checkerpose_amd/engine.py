@@ -290,7 +290,7 @@ class Program:
         gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
                 and not transposed and row_map is None and wCout >= 96 and x.Cphys >= 16 * self.E)
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
-                   and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= 16
+                   and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= CHAIN_MIN_BATCH
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
         if s2small:
             ck = ("s2small", wkey, x.Cphys)
