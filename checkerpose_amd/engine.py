@@ -23,6 +23,7 @@ USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch p
 USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decoder: bilinear x2 interpolated inside the conv's halo loader
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
+GEMM_WS_SMALL_K = os.environ.get("CHECKERPOSE_AMD_GEMM_WS_SMALL_K", "1") != "0"   # A/B: weight-stationary GEMM from K = 64
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
@@ -287,8 +288,11 @@ class Program:
             # small-Cout variant pads Cin to 64-byte chunks PER TAP: in fp32 (MFMA-bound) that only pays when the
             # padding waste is small (measured: 18/36-channel convs are faster on the generic kernel in fp32)
             halo = _rup(x.Cphys, 16) <= 1.15 * x.Cphys
+        # K >= 4 chunks; from 16384 rows the bf16 weight-stationary variant runs (weights in registers, rows streamed once), which
+        # also pays at K = 64 .. 127 (incre conv3 + shortcut of the 32^2 branch: 98 -> 72 us)
+        kmin = 16 * self.E if not (self.dtype == CP_BF16 and residual is None and x.B * x.H * x.W >= 16384 and GEMM_WS_SMALL_K) else 64
         gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
-                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= 16 * self.E)
+                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= kmin)
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
                    and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= CHAIN_MIN_BATCH
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
