@@ -17,7 +17,7 @@ class CpConvDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("out_f32", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cin", C.c_int32), ("in_cstride", C.c_int32), ("in_coff", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("ksplit", C.c_int32),
                 ("o_base", C.c_int64), ("o_sb", C.c_int64), ("o_sy", C.c_int64), ("o_sx", C.c_int64),
                 ("o_sc", C.c_int64)]
 
@@ -53,6 +53,7 @@ SIGNATURES = {
     "cp_packed_weight_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "cp_pack_conv_weight": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "cp_conv2d_igemm": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
+    "cp_conv2d_igemm_splitk": (_I, [_I, C.c_longlong, _I, _I]),
     "cp_packed_halo_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "cp_pack_conv3x3_halo_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_conv3x3_halo": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
@@ -142,6 +143,8 @@ SIGNATURES = {
     "cp_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),
     "cp_graph_begin_capture": (_I, [_P]),
     "cp_graph_end_capture": (_I, [_P, C.POINTER(_P)]),
+    "cp_graph_capture_set_deps": (_I, [_P, C.POINTER(_P), _I]),
+    "cp_graph_capture_tail": (_I, [_P, C.POINTER(_P), _I, C.POINTER(_I)]),
     "cp_graph_launch": (_I, [_P, _P]),
     "cp_graph_destroy": (_I, [_P]),
 }

@@ -5,7 +5,7 @@
 
 #include "common.h"
 
-extern "C" int cp_version(void) { return 201; }   // 0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale
+extern "C" int cp_version(void) { return 202; }   // 0.2.2: cp_graph_capture_set_deps / _tail (0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale)
 
 static thread_local char g_last_kernel[128] = "";
 void cp_mark_kernel(const char* fmt, ...) {
@@ -49,6 +49,30 @@ extern "C" int cp_graph_end_capture(cp_stream_t stream, void** graph_exec_out) {
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess) return CP_ERR_HIP;
   *graph_exec_out = (void*)exec;
+  return CP_OK;
+}
+
+// Dataflow capture: ONE capturing stream, and before each launch the caller names the graph nodes it depends on (the
+// producers of its operands) instead of inheriting "everything so far on this stream".  The captured graph is then the
+// program's true dependency DAG -- no fork/join barriers, and no cross-stream event pairs (which crash
+// hipStreamEndCapture on ROCm 7.2 when two streams wait on each other).
+extern "C" int cp_graph_capture_set_deps(cp_stream_t stream, void* const* nodes, int n) {
+  if (n < 0 || (n > 0 && !nodes)) return CP_ERR_INVALID;
+  return hipStreamUpdateCaptureDependencies((hipStream_t)stream, (hipGraphNode_t*)nodes, (size_t)n, hipStreamSetCaptureDependencies) == hipSuccess
+             ? CP_OK : CP_ERR_HIP;
+}
+
+// the capturing stream's current dependency set = the node(s) the next launch would wait for (after a launch: that launch)
+extern "C" int cp_graph_capture_tail(cp_stream_t stream, void** nodes_out, int cap, int* n_out) {
+  if (!nodes_out || !n_out || cap < 1) return CP_ERR_INVALID;
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  const hipGraphNode_t* deps = nullptr;
+  size_t n = 0;
+  if (hipStreamGetCaptureInfo_v2((hipStream_t)stream, &status, nullptr, nullptr, &deps, &n) != hipSuccess) return CP_ERR_HIP;
+  if (status != hipStreamCaptureStatusActive) return CP_ERR_INVALID;
+  if ((int)n > cap) return CP_ERR_RANGE;
+  for (size_t i = 0; i < n; ++i) nodes_out[i] = (void*)deps[i];
+  *n_out = (int)n;
   return CP_OK;
 }
 

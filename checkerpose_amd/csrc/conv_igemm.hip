@@ -334,7 +334,187 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ split-K variant
+// Small-batch regime (the reference's own inference batch is 1, test.py:198): a 3x3 conv on an 8x8x144 map is 64 pixels x
+// 144 channels x K = 1296 -- two or three workgroups of the tiled kernel above, each walking 41 K chunks one dependent
+// L2 round trip after the other (13 us for 0.02 GFLOP).  Here the KS waves of a workgroup share ONE 32-pixel x NT*16-
+// channel tile and split its K chunks between them (wave w: chunks w, w + KS, ...), with all of a wave's operand loads
+// in flight at once; the partial accumulators meet in LDS and the (pixel, 4-channel) items of the tile are finished by
+// the whole workgroup, one item per thread.  Same packed weights, same K order per chunk, same epilogue arithmetic as
+// the tiled kernel; the fp32 partial sums are added in a different order (wave-major), so results agree with it to
+// fp32 rounding of the accumulator, not bit for bit.
+template <typename Tag, int NT, int KS>
+__global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvParams p) {
+  constexpr int E = Tag::E, KCH = 4 * E, ES = 16 / E, MT = 2, T = MT * NT;
+  constexpr int U = NT == 1 ? 8 : 6;                        // chunks of one wave in flight together
+  __shared__ __attribute__((aligned(16))) float red[KS * T * 64 * 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int nblk = blockIdx.x % p.n_blocks, mblk = blockIdx.x / p.n_blocks;
+  const int m0 = mblk * (MT * 16), nt0 = nblk * NT;
+
+  int iy0[MT], ix0[MT], rowbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + x;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / p.HoWo;
+    const int rem = mm - b * p.HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    iy0[mt] = ok ? oy * p.stride - p.pad : -(1 << 28);
+    ix0[mt] = ox * p.stride - p.pad;
+    rowbase[mt] = ((b * p.H + (ok ? iy0[mt] : 0)) * p.W + ix0[mt]) * p.in_cs + p.in_coff;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  uint32_t woff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int t = nt0 + nt;
+    t = t < p.n_tiles ? t : p.n_tiles - 1;
+    woff[nt] = ((uint32_t)t * p.KC * 64 + lane) * 16u;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc0 = wave; kc0 < p.KC; kc0 += KS * U) {
+    u32x4 a[U][MT], w[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kc = kc0 + u * KS;                          // past the last chunk: tap >= R*S and the weight offset is out of range -> zeros
+      const int kk = kc * KCH + q * E;
+      const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+      const int r = tap / p.S, s_ = tap - r * p.S;
+      const int tapoff = (r * p.W + s_) * p.in_cs + c;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool ok = (r < p.R) & ((unsigned)(iy0[mt] + r) < (unsigned)p.H) & ((unsigned)(ix0[mt] + s_) < (unsigned)p.W);
+        const uint32_t off = ok ? (uint32_t)(rowbase[mt] + tapoff) * ES : 0x80000000u;
+        a[u][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t off = kc < p.KC ? woff[nt] + (uint32_t)kc * 1024u : 0x80000000u;
+        w[u][nt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Mma<Tag>::run(w[u][nt], a[u][mt], acc[mt][nt]);
+  }
+
+  // ---- partial sums meet in LDS: [wave][tile][lane] f32x4
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *(f32x4*)(red + ((wave * T + mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+  __syncthreads();
+
+  // ---- one (pixel, 4 channels) item per thread: sum the KS partials in wave order, then the tiled kernel's epilogue
+  const bool f32io = p.out_f32 || E == 4;
+  for (int it = threadIdx.x; it < T * 64; it += KS * 64) {
+    const int t = it >> 6, l = it & 63;
+    const int mt = t / NT, nt = t - mt * NT;
+    f32x4 sum = *(const f32x4*)(red + (t * 64 + l) * 4);
+#pragma unroll
+    for (int wv = 1; wv < KS; ++wv) {
+      const f32x4 v = *(const f32x4*)(red + ((wv * T + t) * 64 + l) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum[j] += v[j];
+    }
+    const int m = m0 + mt * 16 + (l & 15);
+    const int n = (nt0 + nt) * 16 + (l >> 4) * 4;
+    if (m >= p.M || nt0 + nt >= p.n_tiles || n >= p.Cout) continue;
+    const int b = m / p.HoWo;
+    const int rem = m - b * p.HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    const long long pix = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx;
+    const f32x4 sc = *(const f32x4*)(p.scale + n);
+    const f32x4 sh = *(const f32x4*)(p.shift + n);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sum[j] * sc[j] + sh[j];
+    if (p.o_sc == 1) {
+      const long long o = pix + n;
+      if (p.res) {
+        if (f32io) {
+          const f32x4 r4 = *(const f32x4*)((const float*)p.res + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += r4[j];
+        } else {
+          const u32x2 r2 = *(const u32x2*)((const uint16_t*)p.res + o);
+          v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+          v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      }
+      if (f32io) {
+        *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)((uint16_t*)p.out + o) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (n + j >= p.Cout) continue;
+        const long long o = pix + (long long)(n + j) * p.o_sc;
+        float y = v[j];
+        if (p.res) y += f32io ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
+        if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == CP_ACT_LEAKY) y = y > 0.f ? y : y * p.slope;
+        if (f32io) ((float*)p.out)[o] = y;
+        else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
+// split-K plan: bf16, a K walk worth splitting, and a tiled grid that would leave most CUs idle (then 32 pixels x 16
+// channels per workgroup is at most a few workgroups per CU)
+static int splitk_plan(int dtype, long long M, int KC, int n_tiles) {
+  if (dtype != CP_BF16 || KC < 6 || cp_knob("CP_NO_SPLITK")) return 0;
+  int NT = 1, best = 1 << 30;
+  for (int nt = 5; nt >= 1; --nt) {
+    const int padded = (n_tiles + nt - 1) / nt * nt;
+    if (padded < best) { best = padded; NT = nt; }
+  }
+  const long long blocks2 = ((M + 127) / 128) * ((n_tiles + NT - 1) / NT);     // the tiled kernel's grid at MT = 2
+  if (blocks2 > 96) return 0;
+  return KC >= 24 ? 8 : 4;
+}
+
+template <int NT, int KS>
+static void launch_splitk(ConvParams p, hipStream_t st) {
+  p.m_blocks = (p.M + 31) / 32;
+  p.n_blocks = (p.n_tiles + NT - 1) / NT;
+  cp_mark_kernel("conv_igemm_splitk_kernel<BF16Tag, %d, %d>", NT, KS);
+  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BF16Tag, NT, KS>), dim3((unsigned)(p.m_blocks * p.n_blocks)), dim3(KS * 64), 0, st, p);
+}
+
+// 0, or the number of waves the K walk of this conv would be split over (the engine then routes 3x3 / 1x1 convs that have
+// faster large-batch kernels to cp_conv2d_igemm with the generic weight pack)
+extern "C" int cp_conv2d_igemm_splitk(int dtype, long long M, int K, int Cout) {
+  if (M <= 0 || K <= 0 || Cout <= 0 || (dtype != CP_F32 && dtype != CP_BF16)) return 0;
+  const int KCH = 4 * cp_chan_align(dtype);
+  return splitk_plan(dtype, M, (K + KCH - 1) / KCH, (Cout + 15) / 16);
+}
+
 template <typename Tag, int MT, int NT>
 static void launch(ConvParams p, hipStream_t st) {
   p.m_blocks = (p.M + 4 * MT * 16 - 1) / (4 * MT * 16);
@@ -391,6 +571,11 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   p.w_bytes = (uint32_t)((size_t)p.n_tiles * p.KC * 1024);
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx; p.o_sc = d->o_sc;
 
+  if (const int ks = d->ksplit == -1 ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles)) {
+    if (ks == 8) launch_splitk<1, 8>(p, (hipStream_t)stream);
+    else launch_splitk<1, 4>(p, (hipStream_t)stream);
+    return cp_check_launch();
+  }
   // tile choice: NT minimises padded channel tiles (ties -> wider), MT=4 (256 pixels/block) unless the
   // grid would leave most of the 256 CUs idle.
   int NT = 1, best = 1 << 30;

@@ -23,6 +23,7 @@ USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch p
 USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decoder: bilinear x2 interpolated inside the conv's halo loader
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
+USE_SPLITK = os.environ.get("CHECKERPOSE_AMD_SPLITK", "1") != "0"     # small-batch split-K routing (cp_conv2d_igemm_splitk)
 GEMM_WS_SMALL_K = os.environ.get("CHECKERPOSE_AMD_GEMM_WS_SMALL_K", "1") != "0"   # A/B: weight-stationary GEMM from K = 64
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
@@ -204,7 +205,8 @@ class Program:
         self._open = None
         self.flops = 0         # dense MACs*2 issued through cp_conv2d_igemm (algorithmic, unpadded)
         self.conv_log = _ConvLog(self)     # (name, M, Cout, K, flops, family, bytes) per MFMA launch -- bench roofline uses it
-        self._rw = {}          # op index -> (reads, writes): dead-launch elimination in finalize(dce=True)
+        self._rw = {}          # op index -> (reads, writes): dead-launch elimination in finalize(dce=True), hazards of run_dag
+        self._raw = {}         # (ptr, nbytes) -> TBuf of a raw-pointer operand (see raw())
 
     # ---- tensors
     def tensor(self, nelem, es=None):
@@ -222,6 +224,17 @@ class Program:
         t.fixed = torch_tensor
         self.keep.append(torch_tensor)
         return t
+
+    def raw(self, torch_tensor):
+        """The TBuf standing for a caller-owned tensor an op touches through a raw pointer (index / mask / logits buffers):
+        listed in the op's reads / writes so the dataflow capture (run_dag) orders its producer and consumers."""
+        key = (torch_tensor.data_ptr(), torch_tensor.numel() * torch_tensor.element_size())
+        if key not in self._raw:
+            t = TBuf(key[1])
+            t.nbytes = key[1]
+            t.fixed = torch_tensor
+            self._raw[key] = t
+        return self._raw[key]
 
     def _add(self, fn, argb, name, reads, writes):
         i = len(self.ops)
@@ -296,6 +309,10 @@ class Program:
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
                    and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= CHAIN_MIN_BATCH
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
+        if (USE_SPLITK and not transposed and row_map is None and (halo or gemm or s2small)
+                and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
+                                                    R * S * x.Cphys, _rup(wCout, self.E))):
+            halo = gemm = s2small = False      # small batch: the generic kernel's split-K variant beats the tiled specialists
         if s2small:
             ck = ("s2small", wkey, x.Cphys)
             if ck not in self.ws.cache:
@@ -322,6 +339,7 @@ class Program:
         d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
         d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = R, S, stride, pad, Ho, Wo
         d.act, d.slope = act, slope
+        d.ksplit = 0 if USE_SPLITK else -1
         if ostr is None:
             if out is None:
                 out = self.act(Ho, Wo, Cout)
@@ -667,7 +685,7 @@ class Program:
         ft, ot = f.tbuf, out.tbuf
         a = (buf.data_ptr(), bs.data_ptr(), xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())
         self._add(fn, lambda P: (P(ft), f.cstride, f.coff) + a + (P(ot), f.B, N, f.H, f.W, k, out.cstride, out.coff),
-                  "patch_gather:" + wkey, [ft], [ot])
+                  "patch_gather:" + wkey, [ft, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
         fl = 2 * f.B * 4 * N * 64 * 4 * f.C
         self.flops += fl
         self.conv_log.append((wkey, f.B * 4 * N, 64, 4 * f.C, fl, "patch_gather", f.B * 4 * N * (4 * f.C + 64) * self.es))
@@ -678,14 +696,15 @@ class Program:
         pt, ot = patches.tbuf, out.tbuf
         args = (xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())
         tail = (patches.B, N, patches.H, patches.W, E_ch, k, out.cstride, out.coff)
-        self._add(fn, lambda P: (self.dtype, P(pt)) + args + (P(ot),) + tail, "index2feat", [pt], [ot])
+        self._add(fn, lambda P: (self.dtype, P(pt)) + args + (P(ot),) + tail, "index2feat", [pt, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
         return out
 
     def decode(self, bits_t, stage, mask_t, xid_t, yid_t, x64_t, y64_t, N):
         fn = self.lib.cp_bits_decode
         a = (bits_t.data_ptr(), stage, mask_t.data_ptr(), xid_t.data_ptr(), yid_t.data_ptr(), x64_t.data_ptr(),
              y64_t.data_ptr(), self.B, N)
-        self._add(fn, lambda P: a, "decode", [], [])
+        self._add(fn, lambda P: a, "decode", [self.raw(bits_t), self.raw(mask_t), self.raw(xid_t), self.raw(yid_t)],
+                  [self.raw(mask_t), self.raw(xid_t), self.raw(yid_t), self.raw(x64_t), self.raw(y64_t)])
 
     def nchw_to_nhwc(self, img_t, Cc, H, W):
         out = self.act(H, W, Cc)
@@ -710,7 +729,7 @@ class Program:
         fn = self.lib.cp_nhwc_to_nchw_f32
         xt = x.tbuf
         op = out_t.data_ptr()
-        self._add(fn, lambda P: (self.dtype, P(xt), op, x.B, x.C, x.H, x.W, x.cstride, x.coff), "to_nchw", [xt], [])
+        self._add(fn, lambda P: (self.dtype, P(xt), op, x.B, x.C, x.H, x.W, x.cstride, x.coff), "to_nchw", [xt], [self.raw(out_t)])
 
     # ---- memory plan + argument binding
     def _drop_dead_launches(self):
@@ -800,6 +819,12 @@ class Program:
 
         self.calls = []       # kernel launches only: (fn, (None, args...), name)
         self.sched = []       # launches + fork/sync/join markers: ("op", call_index, lane) | ("fork", n) | ...
+        acc = []              # per launch: (reads, writes) as (lo, hi, tbuf id) byte intervals -- hazards of run_dag
+        for oi, op in enumerate(self.ops):
+            if op[0] not in ("__fork__", "__sync__", "__join__", "__mark__", "__wait__", "__dead__"):
+                rd, wr = self._rw.get(oi, ([], []))
+                acc.append(tuple([(P(t), P(t) + t.nbytes, id(t)) for t in lst] for lst in (rd, wr)))
+        self.dag = self._hazards(acc)
         for op in self.ops:
             if op[0] == "__fork__":
                 self.sched.append(("fork", op[1]))
@@ -818,6 +843,57 @@ class Program:
                 self.sched.append(("op", len(self.calls), lane))
                 self.calls.append((fn, (None,) + tuple(argb(P)), name))
         return self
+
+    @staticmethod
+    def _hazards(acc):
+        """Per launch, the earlier launches it must wait for (transitively reduced): read-after-write, write-after-read and
+        write-after-write on overlapping BYTES (the planner recycles workspace bytes, so two tensors can share them) --
+        except that two launches writing the SAME tensor do not order each other: they fill disjoint channel slices of a
+        concatenation buffer (an in-place update lists the tensor in its reads and is ordered by that)."""
+        def hit(a, b, same_ok):
+            for lo, hi, ia in a:
+                for lo2, hi2, ib in b:
+                    if lo < hi2 and lo2 < hi and not (same_ok and ia == ib):
+                        return True
+            return False
+        deps, anc = [], []
+        for k, (rd, wr) in enumerate(acc):
+            d = set()
+            for j in range(k - 1, -1, -1):
+                rj, wj = acc[j]
+                if hit(wj, rd, False) or hit(rj, wr, False) or hit(wj, wr, True):
+                    d.add(j)
+            a = set(d)
+            for j in d:
+                a |= anc[j]
+            anc.append(a)
+            deps.append(sorted(j for j in d if not any(j in anc[i] for i in d if i != j)))
+        return deps
+
+    def run_dag(self, stream_ptr):
+        """Replay on ONE stream that is being captured into a hipGraph, each launch depending on exactly the launches
+        whose bytes it reads or overwrites (self.dag) -- the graph is the dataflow DAG of the program: a branch of the next
+        HRNet module starts as soon as ITS fuse terms are there, the tail of the slow stride-2 fuse chains runs under it."""
+        lib = self.lib
+        tails = []                                   # per launch: its last graph node
+        cap = 8
+        buf, n = (C.c_void_p * cap)(), C.c_int(0)
+        used = set()
+        for k, (fn, args, name) in enumerate(self.calls):
+            nodes = [tails[j] for j in self.dag[k]]
+            used.update(self.dag[k])
+            arr = (C.c_void_p * max(len(nodes), 1))(*nodes)
+            _abi.check(lib.cp_graph_capture_set_deps(stream_ptr, arr, len(nodes)), "capture deps")
+            rc = fn(stream_ptr, *args[1:])
+            if rc != 0:
+                _abi.check(rc, name)
+            _abi.check(lib.cp_graph_capture_tail(stream_ptr, buf, cap, C.byref(n)), "capture tail")
+            if n.value != 1:
+                raise RuntimeError("checkerpose_amd: launch %s left %d capture tail nodes (expected 1)" % (name, n.value))
+            tails.append(buf[0])
+        sinks = [tails[k] for k in range(len(tails)) if k not in used]
+        arr = (C.c_void_p * max(len(sinks), 1))(*sinks)
+        _abi.check(lib.cp_graph_capture_set_deps(stream_ptr, arr, len(sinks)), "capture deps")   # join: the capture ends on every sink
 
     def run(self, stream_ptr):
         """Sequential replay on one stream (program order)."""

@@ -112,6 +112,7 @@ class HipForwardMixin:
         self.compute_dtype = os.environ.get("CHECKERPOSE_AMD_DTYPE", "fp32")
         self.use_graph = os.environ.get("CHECKERPOSE_AMD_GRAPH", "1") != "0"
         self.use_lanes = os.environ.get("CHECKERPOSE_AMD_LANES", "1") != "0"   # parallel graph branches
+        self.use_dag = os.environ.get("CHECKERPOSE_AMD_DAG", "0") == "1"       # dataflow capture (Program.run_dag) instead of fork/join lanes
         self.batch_splits = int(os.environ.get("CHECKERPOSE_AMD_SPLITS", "1"))   # concurrent batch slices per forward (measured: 1 is fastest; 2 and 4 lose 8 % / 30 % at B=128)
         self.clone_outputs = True
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
@@ -398,11 +399,13 @@ class HipForwardMixin:
                     # launched concurrently on separate streams, forked from / joined to the caller's stream
                     graphs, keep = [], []
                     for sub in prog.progs:
-                        lanes = [torch.cuda.Stream(device) for _ in range(sub.nlanes if self.use_lanes else 1)]
+                        lanes = [torch.cuda.Stream(device) for _ in range(sub.nlanes if self.use_lanes and not self.use_dag else 1)]
                         lanes[0].wait_stream(cur)
                         _abi.check(lib.cp_graph_begin_capture(lanes[0].cuda_stream), "graph capture begin")
                         try:
-                            if len(lanes) > 1:
+                            if self.use_dag:
+                                sub.run_dag(lanes[0].cuda_stream)
+                            elif len(lanes) > 1:
                                 keep.append(sub.run_lanes(lanes))
                             else:
                                 sub.run(lanes[0].cuda_stream)

@@ -90,11 +90,19 @@ typedef struct CpConvDesc {
   int32_t Cout;           /* channels stored (physical) ; weights were packed with cout_rows >= Cout */
   int32_t act;            /* CP_ACT_* */
   float slope;            /* LeakyReLU negative slope */
+  int32_t ksplit;         /* cp_conv2d_igemm: -1 = never use the split-K variant (results then do not depend on the batch
+                             size, bit for bit); anything else = the library decides by shape (cp_conv2d_igemm_splitk).
+                             Sits in what was alignment padding: the struct's size and offsets are unchanged. */
   int64_t o_base, o_sb, o_sy, o_sx, o_sc;   /* output (and residual) element strides */
 } CpConvDesc;
 
 int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                     const float* scale, const float* shift, const void* residual, void* out);
+/* Small-batch routing query: 0, or the number of waves cp_conv2d_igemm would split this conv's K walk over (bf16, long K,
+ * a grid that would leave most CUs idle: the split-K variant of the kernel).  M = B*Ho*Wo output pixels, K = R*S*Cin with
+ * Cin the PHYSICAL input channels, Cout the physical output channels.  A host that has a specialised large-batch kernel
+ * for the layer (halo / row-GEMM) asks this first and, if non-zero, packs the generic weight image instead. */
+int cp_conv2d_igemm_splitk(int dtype, long long M, int K, int Cout);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 specialisation with an LDS-staged input halo tile (decoder convs pipeline.py:183-211,
@@ -501,6 +509,10 @@ int cp_u8hwc_to_nhwc_norm(cp_stream_t stream, int dtype, const uint8_t* in, void
  * ------------------------------------------------------------------------------------------- */
 int cp_graph_begin_capture(cp_stream_t stream);
 int cp_graph_end_capture(cp_stream_t stream, void** graph_exec_out);
+/* Dataflow capture on ONE stream: name the graph nodes the next launch depends on (n = 0: none, a root of the graph), and
+ * read back the node(s) the stream's next launch would wait for (after a launch: that launch's last kernel node). */
+int cp_graph_capture_set_deps(cp_stream_t stream, void* const* nodes, int n);
+int cp_graph_capture_tail(cp_stream_t stream, void** nodes_out, int cap, int* n_out);
 int cp_graph_launch(void* graph_exec, cp_stream_t stream);
 int cp_graph_destroy(void* graph_exec);
 

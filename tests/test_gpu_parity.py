@@ -70,7 +70,7 @@ def pack(lib, dtype, w, cin_phys, R, S, rows=None, transposed=0, phase=0):
     return buf
 
 
-def run_conv(lib, dtype, x, w, scale, shift, stride, pad, act=ACT_NONE, slope=0.0, residual=None):
+def run_conv(lib, dtype, x, w, scale, shift, stride, pad, act=ACT_NONE, slope=0.0, residual=None, ksplit=0):
     """x NCHW fp32 (CPU), w (Cout,Cin,R,S).  Returns NCHW fp32 (CPU) from the channels-last HIP conv."""
     B, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
@@ -90,6 +90,7 @@ def run_conv(lib, dtype, x, w, scale, shift, stride, pad, act=ACT_NONE, slope=0.
     d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
     d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = R, S, stride, pad, Ho, Wo, cop, act, slope
     d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, Ho * Wo * cop, Wo * cop, cop, 1
+    d.ksplit = ksplit
     _abi.check(lib.cp_conv2d_igemm(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                    res.data_ptr() if res is not None else None, out.data_ptr()), "conv")
     torch.cuda.synchronize()
@@ -108,13 +109,23 @@ CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, act, residual)
     (2, 256, 16, 16, 64, 2, 1, 1, ACT_NONE, False),    # patch_generator k=2 pad=1 -> (H+1, W+1)
     (3, 64, 1, 100, 128, 1, 1, 0, ACT_LEAKY, False),   # linear over keypoints, M not a tile multiple
     (1, 16, 40, 40, 10, 7, 2, 3, ACT_RELU, False),     # 7x7 stride 2 (resnet stem shape class)
+    (1, 144, 8, 8, 144, 3, 1, 1, ACT_RELU, True),      # B = 1 HRNet 8x8 branch: 41 K chunks over 8 waves (split-K), residual
+    (3, 72, 16, 16, 72, 3, 1, 1, ACT_RELU, False),     # 21 chunks over 4 waves, ragged channel tiles (72 = 4.5 tiles)
+    (1, 72, 16, 16, 144, 3, 2, 1, ACT_NONE, False),    # stride-2 fuse conv, 64 output pixels
+    (2, 320, 1, 77, 256, 1, 1, 0, ACT_LEAKY, False),   # refinement MLP rows at small batch: K = 320, M = 154 (ragged pixel tile)
 ]
 
 
+@pytest.mark.parametrize("ksplit", [0, -1])
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_igemm_vs_torch_cpu(lib, dtype, case):
+def test_conv_igemm_vs_torch_cpu(lib, dtype, case, ksplit):
+    """ksplit = 0: the library picks the split-K variant where its plan says so (bf16, long K, small grid: most of these
+    shapes); -1: always the tiled kernel."""
     B, Cin, H, W, Cout, k, stride, pad, act, has_res = case
+    if ksplit == -1 and not lib.cp_conv2d_igemm_splitk(dtype, B * ((H + 2 * pad - k) // stride + 1) * ((W + 2 * pad - k) // stride + 1),
+                                                        k * k * rup(Cin, 8 if dtype == CP_BF16 else 4), rup(Cout, 8)):
+        pytest.skip("same kernel as ksplit = 0")
     x = det_tensor("cx%s" % (case,), (B, Cin, H, W))
     w = det_tensor("cw%s" % (case,), (Cout, Cin, k, k), (2.0 / (Cin * k * k)) ** 0.5 * 1.7)
     scale = 1.0 + 0.3 * det_tensor("cs%s" % (case,), (Cout,))
@@ -125,7 +136,7 @@ def test_conv_igemm_vs_torch_cpu(lib, dtype, case):
         res = det_tensor("cr%s" % (case,), tuple(ref.shape))
         ref = ref + rnd(res, dtype)
     ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.01) if act == ACT_LEAKY else ref)
-    got = run_conv(lib, dtype, x, w, scale, shift, stride, pad, act, 0.01, res)
+    got = run_conv(lib, dtype, x, w, scale, shift, stride, pad, act, 0.01, res, ksplit)
     close(got, ref, TOL[dtype])
 
 
@@ -1047,6 +1058,7 @@ def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     from checkerpose_amd import engine
     monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)      # slices and the unsplit batch must pick the same kernels
+    monkeypatch.setattr(engine, "USE_SPLITK", False)       # (the split-K conv variant is chosen by output pixels = batch size)
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
     img = det_image(16, seed=3).to(dev())
     net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
@@ -1060,6 +1072,31 @@ def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     for a, b, c, d in zip(o1, o2, o3, o4):
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     assert len(net.program_for(16).progs) == 2 and len(ref.program_for(16).progs) == 1
+
+
+def test_dataflow_graph_capture_bitwise(lib, monkeypatch):
+    """The forward captured as its dataflow DAG (Program.run_dag: every launch depends on exactly the launches whose bytes
+    it reads or overwrites) == the sequential eager replay, bit for bit, over repeated replays; chain / stem / fused-edge
+    kernels forced on so the B=16 program has the same launch mix as the B=256 one."""
+    from checkerpose_amd import engine
+    monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    img = det_image(16, seed=3).to(dev())
+    net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    net.use_dag = True
+    o1 = [t.clone() for t in net(img, None)]            # eager (sequential) warm pass
+    prog = net.program_for(16).progs[0]
+    assert any(len(d) > 1 for d in prog.dag) and sum(1 for d in prog.dag if not d) >= 1
+    for _ in range(4):                                   # replays of the captured DAG
+        o = net(img, None)
+        for a, b in zip(o1, o):
+            assert torch.equal(a, b)
+    img2 = det_image(16, seed=4).to(dev())              # and on fresh inputs against a graph-free twin
+    ref = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    ref.use_graph = False
+    for a, b in zip(net(img2, None), ref(img2, None)):
+        assert torch.equal(a, b)
 
 
 def test_postprocess_correspondences_on_device(lib):
@@ -1129,6 +1166,7 @@ def test_full_batch_size_property_batch_independence(lib, dt, monkeypatch):
     from checkerpose_amd import engine
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "USE_SPLITK", False)     # ... and no batch-size-dependent split-K conv variant
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)    # same kernel selection at B=4 and B=256 (below 16 crops the engine
     #                                                      would pick per-conv launches: other K order, other bf16 roundings)
     net = build_net(seed=1).to(dev()).set_compute_dtype(dt)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# timeline of one captured-graph replay at batch $1 (default 1): bash tools/b1_timeline.sh [B]
+B=${1:-1}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/tl
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --batch $B --steps 6 --no-extras --no-cpu-baseline --no-breakdown > gpurun_out/tl.log 2>&1
+N=$(python3 -c "
+import json
+d=json.loads([l for l in open('gpurun_out/tl.log') if l.startswith('{')][-1]); print(d['config']['launch'].split()[3])")
+python3 tools/timeline.py gpurun_out/tl $N > gpurun_out/timeline_b$B.txt
+rm -rf gpurun_out/tl
+head -2 gpurun_out/timeline_b$B.txt; tail -1 gpurun_out/tl.log | cut -c1-200
