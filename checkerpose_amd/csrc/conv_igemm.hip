@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 template <typename Tag, int NT, int KS>
 __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvParams p) {
   constexpr int E = Tag::E, KCH = 4 * E, ES = 16 / E, MT = 2, T = MT * NT;
-  constexpr int U = NT == 1 ? 8 : 6;                        // chunks of one wave in flight together
+  constexpr int U = NT == 1 ? 8 : (NT == 2 ? 6 : 4);        // chunks of one wave in flight together
   __shared__ __attribute__((aligned(16))) float red[KS * T * 64 * 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
 }
 
 // ------------------------------------------------------------------------------------------------ host
-// split-K plan: bf16, a K walk worth splitting, and a tiled grid that would leave most CUs idle (then 32 pixels x 16
-// channels per workgroup is at most a few workgroups per CU)
-static int splitk_plan(int dtype, long long M, int KC, int n_tiles) {
+// split-K plan: bf16, a K walk worth splitting, and a tiled grid that would leave most CUs idle.  Channel tiles per
+// workgroup: as many (<= 3: the pixel fragments are then read once for 48 channels) as still leave a workgroup per CU.
+static int splitk_plan(int dtype, long long M, int KC, int n_tiles, int* NTs) {
   if (dtype != CP_BF16 || KC < 6 || cp_knob("CP_NO_SPLITK")) return 0;
   int NT = 1, best = 1 << 30;
   for (int nt = 5; nt >= 1; --nt) {
@@ -496,6 +496,10 @@ static int splitk_plan(int dtype, long long M, int KC, int n_tiles) {
   }
   const long long blocks2 = ((M + 127) / 128) * ((n_tiles + NT - 1) / NT);     // the tiled kernel's grid at MT = 2
   if (blocks2 > 96) return 0;
+  const long long m32 = (M + 31) / 32;
+  *NTs = 1;
+  for (int nt = 3; nt >= 2; --nt)
+    if (m32 * ((n_tiles + nt - 1) / nt) >= 256) { *NTs = nt; break; }
   return KC >= 24 ? 8 : 4;
 }
 
@@ -512,7 +516,8 @@ static void launch_splitk(ConvParams p, hipStream_t st) {
 extern "C" int cp_conv2d_igemm_splitk(int dtype, long long M, int K, int Cout) {
   if (M <= 0 || K <= 0 || Cout <= 0 || (dtype != CP_F32 && dtype != CP_BF16)) return 0;
   const int KCH = 4 * cp_chan_align(dtype);
-  return splitk_plan(dtype, M, (K + KCH - 1) / KCH, (Cout + 15) / 16);
+  int nts = 1;
+  return splitk_plan(dtype, M, (K + KCH - 1) / KCH, (Cout + 15) / 16, &nts);
 }
 
 template <typename Tag, int MT, int NT>
@@ -571,9 +576,11 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   p.w_bytes = (uint32_t)((size_t)p.n_tiles * p.KC * 1024);
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx; p.o_sc = d->o_sc;
 
-  if (const int ks = d->ksplit == -1 ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles)) {
-    if (ks == 8) launch_splitk<1, 8>(p, (hipStream_t)stream);
-    else launch_splitk<1, 4>(p, (hipStream_t)stream);
+  int nts = 1;
+  if (const int ks = d->ksplit == -1 ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles, &nts)) {
+    hipStream_t st_ = (hipStream_t)stream;
+    if (ks == 8) { if (nts == 3) launch_splitk<3, 8>(p, st_); else if (nts == 2) launch_splitk<2, 8>(p, st_); else launch_splitk<1, 8>(p, st_); }
+    else         { if (nts == 3) launch_splitk<3, 4>(p, st_); else if (nts == 2) launch_splitk<2, 4>(p, st_); else launch_splitk<1, 4>(p, st_); }
     return cp_check_launch();
   }
   // tile choice: NT minimises padded channel tiles (ties -> wider), MT=4 (256 pixels/block) unless the

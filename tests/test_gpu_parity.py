@@ -113,6 +113,8 @@ CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, act, residual)
     (3, 72, 16, 16, 72, 3, 1, 1, ACT_RELU, False),     # 21 chunks over 4 waves, ragged channel tiles (72 = 4.5 tiles)
     (1, 72, 16, 16, 144, 3, 2, 1, ACT_NONE, False),    # stride-2 fuse conv, 64 output pixels
     (2, 320, 1, 77, 256, 1, 1, 0, ACT_LEAKY, False),   # refinement MLP rows at small batch: K = 320, M = 154 (ragged pixel tile)
+    (32, 144, 8, 8, 144, 3, 1, 1, ACT_RELU, True),     # B = 32: 3 channel tiles per workgroup (64 x 3 workgroups), 8 waves
+    (16, 72, 16, 16, 72, 3, 1, 1, ACT_RELU, False),    # 2 channel tiles per workgroup (5 tiles: one workgroup's second tile absent), 4 waves
 ]
 
 
