@@ -31,7 +31,7 @@ STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   #
 #   crossover against the tiled launches (tools/batch_sweep.py, MI355X): chains win from 64 crops, stem + EdgeConv from 96
 USE_EDGE_FUSED = os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED", "1") != "0"   # EdgeConv layer (node GEMM + gather-max) in one launch
 EDGE_FUSED_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED_MIN_BATCH", "96"))   # one workgroup per crop: needs crops to fill the chip
-CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "64"))   # below: per-conv launches (a crop's chain runs on ONE CU)
+CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "40"))   # below: per-conv launches (a crop's chain runs on ONE CU)
 NO_RECYCLE = os.environ.get("CHECKERPOSE_AMD_NO_RECYCLE", "0") == "1"   # debugging aid: every workspace tensor gets its own bytes
 DTYPES = {"fp32": CP_F32, "f32": CP_F32, "float32": CP_F32, "bf16": CP_BF16, "bfloat16": CP_BF16}
 
