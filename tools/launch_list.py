@@ -1,4 +1,4 @@
-"""every launch of the default forward with its eager device time (HIP events), slowest first"""
+"""every launch of the default forward with its eager device time (HIP events), slowest first (argv[2] = "order": program order)"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -25,7 +25,9 @@ for it in range(4):
     if it:
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1) / 3
-rows = sorted([(acc[i] * 1e3, prog.calls[i][2]) for i in range(len(acc))], reverse=True)
+rows = [(acc[i] * 1e3, prog.calls[i][2]) for i in range(len(acc))]
+if not (len(sys.argv) > 2 and sys.argv[2] == "order"):
+    rows.sort(reverse=True)
 print("%d launches, %.2f ms sequential" % (len(rows), sum(r[0] for r in rows) / 1e3))
 for us, name in rows:
     print("%8.1f us  %s" % (us, name))
