@@ -63,6 +63,8 @@ SIGNATURES = {
     "cp_conv3x3_s2_small": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P]),
     "cp_conv3x3_halo_up2x_supported": (_I, [_I, _I]),
     "cp_conv3x3_halo_up2x": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P]),
+    "cp_conv3x3_halo_seg_supported": (_I, [_I, _I, _I]),
+    "cp_conv3x3_halo_seg": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cp_pack_conv3x3_rows_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_basicblock_fused": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "cp_bottleneck_fused": (_I, [_P, C.POINTER(CpConvDesc)] + [_P] * 14),

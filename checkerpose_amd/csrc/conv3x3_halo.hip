@@ -29,6 +29,7 @@ struct HaloParams {
   uint32_t in_bytes, w_bytes;
   long long o_base, o_sb, o_sy, o_sx;
   int Hs, Ws; float up_sy, up_sx;     // fused bilinear x2 (halo4 UP variant): source size, align_corners scales
+  const float* seg_w; const float* seg_b; float* seg_out; int seg_S;   // fused 1x1 head (halo4 SEG variant): [S][Cout] weights, NCHW fp32 out
 };
 
 constexpr int HTH = 8, HTW = 16, HPW = HTW + 2, HPH = HTH + 2, HNPIX = 192;   // 180 halo pixels, plane padded to 192
@@ -267,7 +268,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
 // up_net[1..2] conv1): per channel chunk the block loads the <= 7 x 11 SOURCE pixels under its halo (2 loads per thread
 // instead of 3) two chunks ahead, parks them in a small LDS tile, and interpolates the next chunk's 10 x 18 halo from it
 // LDS -> LDS between the taps of the current chunk (same arithmetic, cp_bilerp, as the stand-alone kernel: same bits).
-template <typename Tag, bool HAS_RES, bool UP = false>
+//
+// SEG = true (Cout == 256, one channel block): the 1x1 conv head that reads this conv's output (seg_block, pipeline.py:349,383:
+// Conv2d(256 -> 2) + bias on the last decoder map, NCHW fp32 out) rides in the epilogue -- every lane dots the 16 activated,
+// storage-rounded channels of its pixel with the head's weights, the four lane groups of a pixel meet by shuffle, the four
+// waves (64 channels each) through LDS: the 537 MB re-read of the map by a separate launch disappears.
+template <typename Tag, bool HAS_RES, bool UP = false, bool SEG = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams p) {
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
@@ -463,7 +469,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams 
   // ---- epilogue: lane (x, q): pixel (y0+mt, x0+x), channels g*64 + 16q + 4nt + {0..3}
   const int ch = g * 64 + q * 16;
   const int ox = x0 + x;
-  if (ox >= p.W) return;
+  if constexpr (!SEG) { if (ox >= p.W) return; }
+  const bool xok = SEG ? ox < p.W : true;              // SEG: every lane stays for the shuffles and the barrier
+  constexpr int SMAX = 2;
+  float segw[SEG ? SMAX : 1][16], segp[SEG ? 8 : 1][SEG ? SMAX : 1];
+  if constexpr (SEG) {
+#pragma unroll
+    for (int s_ = 0; s_ < SMAX; ++s_) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 w4 = s_ < p.seg_S ? *(const f32x4*)(p.seg_w + (size_t)s_ * p.Cout + ch + 4 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) segw[s_][4 * k + j] = w4[j];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) segp[mt][s_] = 0.f;
+    }
+  }
   float sc[16], sh[16];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -520,12 +542,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams 
         else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
       }
       if (E == 4) {
+        if (xok) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *(f32x4*)((float*)p.out + o + 4 * k) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+          for (int k = 0; k < 4; ++k) *(f32x4*)((float*)p.out + o + 4 * k) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        }
       } else {
-        *(u32x4*)((uint16_t*)p.out + o) = Vec16<BF16Tag>::pack(v);
-        *(u32x4*)((uint16_t*)p.out + o + 8) = Vec16<BF16Tag>::pack(v + 8);
+        const u32x4 pk0 = Vec16<BF16Tag>::pack(v), pk1 = Vec16<BF16Tag>::pack(v + 8);
+        if (xok) {
+          *(u32x4*)((uint16_t*)p.out + o) = pk0;
+          *(u32x4*)((uint16_t*)p.out + o + 8) = pk1;
+        }
+        if constexpr (SEG) { Vec16<BF16Tag>::unpack(pk0, v); Vec16<BF16Tag>::unpack(pk1, v + 8); }   // the head reads the STORED values
       }
+      if constexpr (SEG) {
+#pragma unroll
+        for (int s_ = 0; s_ < SMAX; ++s_) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) a += v[j] * segw[s_][j];
+          segp[mt][s_] = a;
+        }
+      }
+    }
+  }
+  if constexpr (SEG) {
+    float* const red = (float*)smem;                    // [wave][row][x][s]: the halo buffers are spent (last barrier of the loop)
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int s_ = 0; s_ < SMAX; ++s_) {
+        float a = segp[mt][s_];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        if (q == 0) red[((wave * 8 + mt) * 16 + x) * SMAX + s_] = a;
+      }
+    __syncthreads();
+    const int s_ = tid & 1, px = tid >> 1;              // 128 pixels x 2 outputs = 256 threads
+    const int mt = px >> 4, xx = px & 15;
+    const int oy = y0 + mt, oxx = x0 + xx;
+    if (s_ < p.seg_S && oy < p.H && oxx < p.W) {
+      float a = p.seg_b[s_];
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) a += red[((wv * 8 + mt) * 16 + xx) * SMAX + s_];
+      p.seg_out[(((size_t)b * p.seg_S + s_) * p.H + oy) * p.W + oxx] = a;
     }
   }
 }
@@ -1209,6 +1268,7 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
   p.Hs = p.Ws = 0; p.up_sy = p.up_sx = 0.f;
+  p.seg_w = p.seg_b = nullptr; p.seg_out = nullptr; p.seg_S = 0;
   p.nchunk = (d->Cin + 4 * E - 1) / (4 * E);
   p.Cout = d->Cout; p.ngroups = (d->Cout + 31) / 32; p.NB = (p.ngroups + 3) / 4;
   p.tiles_x = (d->W + HTW - 1) / HTW; p.tiles_y = (d->H + HTH - 1) / HTH;
@@ -1280,6 +1340,7 @@ extern "C" int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, con
   if (!cp_aligned16(in) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift)) return CP_ERR_ALIGN;
   if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4) || ((uintptr_t)out % (4 * es))) return CP_ERR_ALIGN;
   HaloParams p;
+  p.seg_w = p.seg_b = nullptr; p.seg_out = nullptr; p.seg_S = 0;
   p.Hs = d->H / 2; p.Ws = d->W / 2;
   const long long in_bytes = (long long)d->B * p.Hs * p.Ws * d->in_cstride * es;
   if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
@@ -1302,6 +1363,47 @@ extern "C" int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, con
   const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
   if (d->dtype == CP_F32) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false, true>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
   else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false, true>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
+  return cp_check_launch();
+}
+
+// ---- conv3x3 + folded BN + act with the 1x1 head that reads its output fused into the epilogue (decoder's last conv + seg_block)
+extern "C" int cp_conv3x3_halo_seg_supported(int dtype, int Cout, int S) {
+  return (dtype == CP_F32 || dtype == CP_BF16) && Cout == 256 && halo_wide(Cout) && S >= 1 && S <= 2 ? 1 : 0;
+}
+
+extern "C" int cp_conv3x3_halo_seg(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
+                                   const float* shift, void* out, const float* seg_w, const float* seg_b, int S, float* seg_out) {
+  if (!d || !in || !packed_w || !scale || !shift || !out || !seg_w || !seg_b || !seg_out) return CP_ERR_INVALID;
+  if (!cp_conv3x3_halo_seg_supported(d->dtype, d->Cout, S)) return CP_ERR_INVALID;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
+    return CP_ERR_INVALID;
+  const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0) return CP_ERR_INVALID;
+  if (d->Cin <= 0 || d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift) || !cp_aligned16(seg_w)) return CP_ERR_ALIGN;
+  if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4) || ((uintptr_t)out % (4 * es))) return CP_ERR_ALIGN;
+  const long long in_bytes = (long long)d->B * d->H * d->W * d->in_cstride * es;
+  if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
+  HaloParams p;
+  p.in = in; p.w = packed_w; p.scale = scale; p.shift = shift; p.res = nullptr; p.out = out;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.in_coff = d->in_coff;
+  p.Hs = p.Ws = 0; p.up_sy = p.up_sx = 0.f;
+  p.nchunk = (d->Cin + 4 * E - 1) / (4 * E);
+  p.Cout = d->Cout; p.ngroups = (d->Cout + 31) / 32; p.NB = 1;
+  p.tiles_x = (d->W + HTW - 1) / HTW; p.tiles_y = (d->H + HTH - 1) / HTH;
+  const long long tt = (long long)d->B * p.tiles_x * p.tiles_y;
+  if (tt >= (1LL << 28)) return CP_ERR_RANGE;
+  p.total_tiles = (int)tt;
+  p.act = d->act; p.slope = d->slope;
+  p.in_bytes = (uint32_t)in_bytes;
+  const size_t wb = cp_packed_halo_weight_bytes(d->dtype, d->Cout, d->Cin);
+  if (wb >= (1ull << 31)) return CP_ERR_RANGE;
+  p.w_bytes = (uint32_t)wb;
+  p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  p.seg_w = seg_w; p.seg_b = seg_b; p.seg_out = seg_out; p.seg_S = S;
+  const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8);
+  if (d->dtype == CP_F32) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false, false, true>), dim3(grid4), dim3(256), 2 * HBUF, (hipStream_t)stream, p);
+  else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false, false, true>), dim3(grid4), dim3(256), 2 * HBUF, (hipStream_t)stream, p);
   return cp_check_launch();
 }
 

@@ -23,6 +23,7 @@ USE_CHAIN = os.environ.get("CHECKERPOSE_AMD_CHAIN", "1") != "0"   # one launch p
 USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decoder: bilinear x2 interpolated inside the conv's halo loader
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
+USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
 USE_SPLITK = os.environ.get("CHECKERPOSE_AMD_SPLITK", "1") != "0"     # small-batch split-K routing (cp_conv2d_igemm_splitk)
 GEMM_WS_SMALL_K = os.environ.get("CHECKERPOSE_AMD_GEMM_WS_SMALL_K", "1") != "0"   # A/B: weight-stationary GEMM from K = 64
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
@@ -410,6 +411,46 @@ class Program:
         self.flops += fl
         nbytes = x.B * x.H * x.W * wCin * self.es + x.B * Ho * Wo * wCout * self.es + 9 * wCin * wCout * self.es
         self.conv_log.append((wkey, x.B * Ho * Wo, wCout, 9 * wCin, fl, "conv3x3_halo4", nbytes))
+        return out
+
+    def can_conv_halo_seg(self, x: Act, Cout, S):
+        """3x3/s1/p1 conv + the 1x1 head on its output in one launch (cp_conv3x3_halo_seg): Cout == 256, S <= 2 head outputs"""
+        return (USE_SEG_FUSED and USE_HALO and x.W >= 16 and x.H >= 8 and
+                bool(self.lib.cp_conv3x3_halo_seg_supported(self.dtype, _rup(Cout, self.E), S)))
+
+    def conv_halo_seg(self, x: Act, wkey, w, scale, shift, act, seg_key, seg_w, seg_b, seg_tbuf, slope=0.0):
+        """act(bn(conv3x3(x))) -> Act, and seg = Conv2d(Cout -> S, 1x1)(that) + bias into the caller's (B, S, H, W) fp32 tensor"""
+        wCout, wCin = w.shape[0], w.shape[1]
+        if wCin != x.C:
+            raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
+        packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
+        sc, sh = self.ws.affine(wkey + "#0", scale, shift, wCout)
+        S = seg_w.shape[0]
+        ck = ("seg_head", seg_key, self.dtype)
+        if ck not in self.ws.cache:
+            w2 = seg_w.reshape(S, wCout).float()
+            if self.dtype == CP_BF16:
+                w2 = w2.to(torch.bfloat16).float()          # what the packed bf16 weights of the stand-alone head conv hold
+            self.ws.cache[ck] = (w2.contiguous().to(self.device), seg_b.float().contiguous().to(self.device))
+        sw, sb = self.ws.cache[ck]
+        out = self.act(x.H, x.W, wCout)
+        d = CpConvDesc()
+        d.dtype, d.out_f32 = self.dtype, 0
+        d.B, d.H, d.W = x.B, x.H, x.W
+        d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 3, 3, 1, 1, x.H, x.W
+        d.act, d.slope, d.Cout = act, slope, out.Cphys
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
+        self.keep += [d, packed, sc, sh, sw, sb]
+        fn = self.lib.cp_conv3x3_halo_seg
+        dref = C.byref(d)
+        pw, ps, pt, psw, psb = packed.data_ptr(), sc.data_ptr(), sh.data_ptr(), sw.data_ptr(), sb.data_ptr()
+        xtb, otb = x.tbuf, out.tbuf
+        self._add(fn, lambda P: (dref, P(xtb), pw, ps, pt, P(otb), psw, psb, S, P(seg_tbuf)), "conv3x3_halo4:" + wkey, [xtb], [otb, seg_tbuf])
+        fl = 2 * x.B * x.H * x.W * 9 * wCin * wCout
+        self.flops += fl
+        nbytes = x.B * x.H * x.W * (wCin + wCout) * self.es + 9 * wCin * wCout * self.es
+        self.conv_log.append((wkey, x.B * x.H * x.W, wCout, 9 * wCin, fl, "conv3x3_halo4", nbytes))
         return out
 
     def can_fuse_basicblock(self, x: Act, C_):

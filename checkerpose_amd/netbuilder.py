@@ -576,9 +576,21 @@ def emit_posenet(em: NetEmitter, cfg, io):
             cats[i] = p.act(2 * sk.H, 2 * sk.W, nf + sk.C)
             p.set_lane(2)
             p.upsample2x(sk, cats[i].slice(_rup(nf, p.E), sk.C))
+    wseg = em.W("seg_block.weight")
+    seg_fused = [False]
+
+    def tail_conv(x, ck, bk, last, out=None):
+        """a decoder stage's last conv3x3+BN+ReLU; on the LAST active stage (eval) the seg_block head rides in its epilogue"""
+        if last and tp is None and out is None and p.can_conv_halo_seg(x, em.W(ck + ".weight").shape[0], wseg.shape[0]):
+            s_, t_ = em.ws.bn_fold(bk)
+            seg_fused[0] = True
+            return p.conv_halo_seg(x, ck, em.W(ck + ".weight"), s_, t_, ACT_RELU, "seg_block", wseg, em.W("seg_block.bias"), io["seg_tb"])
+        return em.conv_bn(x, ck, bk, 3, 1, 1, out=out)
+
     for i in range(active):
         p.set_lane(0)
         up = "up_net.%d" % i
+        last = i == active - 1
         if i == 0:   # ConvTranspose2d(k3,s2,p1,op1)+BN+ReLU as 4 sub-pixel phase convs, then 2x conv3x3+BN+ReLU
             wt = em.W(up + ".0.weight")                     # (Cin, Cout, 3, 3)
             s, t = em.ws.bn_fold(up + ".1") if tp is None else (None, None)
@@ -599,11 +611,11 @@ def emit_posenet(em: NetEmitter, cfg, io):
             if tp is not None:
                 o = _convt_train_tail(em, up, wt, f, o, nf)
             f = em.conv_bn(o, up + ".3", up + ".4", 3, 1, 1)
-            f = em.conv_bn(f, up + ".6", up + ".7", 3, 1, 1, out=lowcats[1].slice(0, nf) if 1 in lowcats else None)
+            f = tail_conv(f, up + ".6", up + ".7", last, out=lowcats[1].slice(0, nf) if 1 in lowcats else None)
         elif i in lowcats:   # the same, upsample fused into conv1's loader
             s1, t1 = em.ws.bn_fold(up + ".2")
             f = p.conv_up2x(lowcats[i], up + ".1", em.W(up + ".1.weight"), s1, t1, ACT_RELU)
-            f = em.conv_bn(f, up + ".4", up + ".5", 3, 1, 1, out=lowcats[i + 1].slice(0, nf) if (i + 1) in lowcats else None)
+            f = tail_conv(f, up + ".4", up + ".5", last, out=lowcats[i + 1].slice(0, nf) if (i + 1) in lowcats else None)
         else:        # cat[img_feat, img_feats[-i-1]] -> bilinear x2 (align_corners) -> 2x conv3x3+BN+ReLU
             sk = feats[-i - 1]
             cat = cats[i] if i in cats else p.act(2 * f.H, 2 * f.W, f.C + sk.C)
@@ -616,7 +628,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
                 _upsample_tape(tp, f, cat.slice(0, f.C))
                 _upsample_tape(tp, sk, cat.slice(f.Cphys, sk.C))
             f = em.conv_bn(cat, up + ".1", up + ".2", 3, 1, 1)
-            f = em.conv_bn(f, up + ".4", up + ".5", 3, 1, 1)
+            f = tail_conv(f, up + ".4", up + ".5", last)
         # ---- Refine_moduleGNN.forward pipeline.py:262-298
         p.sync(0, 1)
         p.set_lane(1)
@@ -666,9 +678,10 @@ def emit_posenet(em: NetEmitter, cfg, io):
     # seg_block Conv2d(nf -> seg_dim, 1x1) on the last feature map, NCHW fp32 out (pipeline.py:349,383)
     if active > 0:
         p.set_lane(0)
-    wseg = em.W("seg_block.weight")
     sd_ = wseg.shape[0]
-    if tp is None:
+    if seg_fused[0]:
+        pass                                  # written by the last decoder conv's epilogue (engine.conv_halo_seg)
+    elif tp is None:
         p.conv(f, "seg_block", wseg, em._unit(sd_), em.W("seg_block.bias"), 1, 1, 1, 0, sd_, out_f32=True,
                ostr=(0, sd_ * f.H * f.W, f.W, 1, f.H * f.W), out_tbuf=io["seg_tb"])
     else:

@@ -125,6 +125,14 @@ int cp_conv3x3_halo_up2x_supported(int dtype, int Cout);
 int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                          const float* scale, const float* shift, void* out);
 
+/* conv3x3/s1/p1 + folded BN + act (Cout == 256) WITH the 1x1 head that reads its output fused into the epilogue: the decoder's
+ * last conv + `seg_block` (pipeline.py:349,383: Conv2d(256 -> S) + bias on the last feature map).  `out` is written as by
+ * cp_conv3x3_halo; seg_out (B, S, H, W) fp32 NCHW = seg_b[s] + sum_c seg_w[s][c] * out[b, y, x, c] (the stored, i.e.
+ * dtype-rounded, activations; seg_w = [S][256] fp32, pre-rounded to `dtype` by the caller).  S <= 2. */
+int cp_conv3x3_halo_seg_supported(int dtype, int Cout, int S);
+int cp_conv3x3_halo_seg(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
+                        const float* shift, void* out, const float* seg_w, const float* seg_b, int S, float* seg_out);
+
 /* 3x3 / stride 2 / pad 1 convolution with a wide input and at most 48 output channels (bf16): HRNet `transition1[1]`
  * (256 -> 36 at 64 x 64 -> 32 x 32; timm HighResolutionNet.transition1 inside backbone.py:48-49).  Descriptor as
  * cp_conv2d_igemm with R = S = 3, stride 2, pad 1, Ho = H / 2, Wo = W / 2; H a multiple of 8, W in {32, 64}, Cin a multiple of

@@ -194,6 +194,53 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
     assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
 
 
+SEG_CASES = [  # (B, Cin, H, W, S)
+    (2, 256, 16, 32, 2),     # exact tiles
+    (1, 64, 13, 21, 2),      # ragged tile rows / cols (masked stores, lanes past the image still shuffle)
+    (3, 40, 8, 16, 1),       # one head output, partial K chunk
+]
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", SEG_CASES)
+def test_conv3x3_halo_seg_vs_torch_cpu(lib, dtype, case):
+    """cp_conv3x3_halo_seg: relu(bn(conv3x3(x))) as cp_conv3x3_halo writes it, AND the 1x1 head (seg_block, pipeline.py:349,383)
+    on the STORED activations in the same launch: both against torch CPU; the feature map bit-identical to the plain kernel."""
+    B, Cin, H, W, S = case
+    Cout = 256
+    x = det_tensor("sgx%s" % (case,), (B, Cin, H, W))
+    w = det_tensor("sgw%s" % (case,), (Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("sgs%s" % (case,), (Cout,))
+    shift = 0.2 * det_tensor("sgt%s" % (case,), (Cout,))
+    wseg = det_tensor("sgh%s" % (case,), (S, Cout), 0.1)
+    bseg = det_tensor("sgb%s" % (case,), (S,), 0.5)
+    feat = F.relu(F.conv2d(rnd(x, dtype), rnd(w, dtype), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    xin = to_cl(x, dtype)
+    out = torch.full((B, H, W, Cout), float("nan"), dtype=DT[dtype], device=dev())
+    out2 = torch.full((B, H, W, Cout), float("nan"), dtype=DT[dtype], device=dev())
+    seg = torch.full((B, S, H, W), float("nan"), dtype=torch.float32, device=dev())
+    pw = torch.empty(lib.cp_packed_halo_weight_bytes(dtype, Cout, xin.shape[-1]), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv3x3_halo_weight(st(), dtype, wd.data_ptr(), Cout, Cin, xin.shape[-1], pw.data_ptr()))
+    sc, sh = scale.to(dev()), shift.to(dev())
+    sw, sb = rnd(wseg, dtype).contiguous().to(dev()), bseg.to(dev())
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 1, 1, H, W, Cout, ACT_RELU, 0.0
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * Cout, W * Cout, Cout, 1
+    assert lib.cp_conv3x3_halo_seg_supported(dtype, Cout, S) == 1 and lib.cp_conv3x3_halo_seg_supported(dtype, 512, S) == 0
+    _abi.check(lib.cp_conv3x3_halo_seg(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr(),
+                                       sw.data_ptr(), sb.data_ptr(), S, seg.data_ptr()), "halo_seg")
+    _abi.check(lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out2.data_ptr()), "halo")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)                                           # same main loop, same stores
+    close(from_cl(out, Cout), feat, TOL[dtype])
+    stored = out.float().cpu().permute(0, 3, 1, 2)                          # the head reads what was stored
+    ref = F.conv2d(stored, rnd(wseg, dtype).view(S, Cout, 1, 1), bseg)
+    assert float((seg.cpu() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 S2_CASES = [  # (B, Cin, ctot, coff, H, W, Cout, act)
     (2, 256, 256, 0, 64, 64, 36, ACT_RELU),      # HRNet transition1[1]
     (3, 64, 96, 32, 16, 32, 48, ACT_LEAKY),      # channel slice of a wider buffer, W = 32 (2 tiles per wave), 3 full M tiles
