@@ -1302,11 +1302,11 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
     const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
     hipStream_t st4 = (hipStream_t)stream;
     if (d->dtype == CP_F32) {
-      if (residual) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
-      else CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      if (residual) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, true, false, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      else CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false, false, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
     } else {
-      if (residual) CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, true>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
-      else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      if (residual) CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, true, false, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
+      else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false, false, false>), dim3(grid4), dim3(256), 2 * HBUF, st4, p);
     }
     return cp_check_launch();
   }
@@ -1361,8 +1361,8 @@ extern "C" int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, con
   p.w_bytes = (uint32_t)wb;
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
   const unsigned grid4 = (unsigned)(((tt + 7) / 8) * 8 * p.NB);
-  if (d->dtype == CP_F32) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false, true>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
-  else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false, true>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
+  if (d->dtype == CP_F32) CP_LAUNCH((conv3x3_halo4_kernel<F32Tag, false, true, false>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
+  else CP_LAUNCH((conv3x3_halo4_kernel<BF16Tag, false, true, false>), dim3(grid4), dim3(256), 2 * HBUF + 2 * USBUF, (hipStream_t)stream, p);
   return cp_check_launch();
 }
 
