@@ -143,10 +143,11 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
     for (int f = 0; f < 4; ++f) {
       const uint32_t px = pb + f * 16;
       if (kc < 4) a[f] = *(const u32x4*)(smem + o16[kc] + px * 16);
-      else if (kc == 4) {
-        const u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
+      else if (kc == 4) {              // lanes q = 2, 3: K slots 1..7 of their group meet zero weights -- any finite data does (one select)
+        u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
         const uint32_t sm = *(const uint32_t*)(smem + o4[0] + px * 4);
-        a[f] = small4 ? u32x4{sm, 0u, 0u, 0u} : big;
+        big.x = small4 ? sm : big.x;
+        a[f] = big;
       } else {
         const uint32_t sm = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);
         a[f] = u32x4{sm, 0u, 0u, 0u};
@@ -174,12 +175,8 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) rres[f] = ((const u32x4*)p.out)[(gpix0 + row * ZW + f * 16 + x) * 3 + q];
       }
-      f32x4 acc[4][2];                 // start at the folded-BN shift (the scale sits in the packed weights)
-      {
-        const f32x4 t0 = *(const f32x4*)(sh), t1 = *(const f32x4*)(sh + 4);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) { acc[f][0] = t0; acc[f][1] = t1; }
-      }
+      f32x4 acc[4][2];                 // start at the folded-BN shift (the scale sits in the packed weights): the first chunk's
+      const f32x4 t0 = *(const f32x4*)(sh), t1 = *(const f32x4*)(sh + 4);       // MFMAs take it as their C operand (no copies)
       u32x4 af[2][4];
       load_frags(af[0], 0, pb);
 #pragma unroll
@@ -188,8 +185,13 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          mma16z(Wf[kc][0], af[kc & 1][f], acc[f][0]);
-          mma16z(Wf[kc][1], af[kc & 1][f], acc[f][1]);
+          if (kc == 0) {
+            acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][0]), __builtin_bit_cast(bf16x8, af[0][f]), t0, 0, 0, 0);
+            acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][1]), __builtin_bit_cast(bf16x8, af[0][f]), t1, 0, 0, 0);
+          } else {
+            mma16z(Wf[kc][0], af[kc & 1][f], acc[f][0]);
+            mma16z(Wf[kc][1], af[kc & 1][f], acc[f][1]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (band == 7 && cv + 1 < 8) {                             // next conv's fragments behind the last use of this conv's
