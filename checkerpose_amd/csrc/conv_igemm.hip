@@ -495,7 +495,7 @@ static int splitk_plan(int dtype, long long M, int KC, int n_tiles, int* NTs) {
     if (padded < best) { best = padded; NT = nt; }
   }
   const long long blocks2 = ((M + 127) / 128) * ((n_tiles + NT - 1) / NT);     // the tiled kernel's grid at MT = 2
-  if (blocks2 > 96) return 0;
+  if (blocks2 > (KC >= 64 ? 192 : 96)) return 0;                               // a long K walk (decoder convs at batch 1-2) pays a little longer
   const long long m32 = (M + 31) / 32;
   *NTs = 1;
   for (int nt = 3; nt >= 2; --nt)

@@ -378,6 +378,10 @@ class Program:
         self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl, fam, nbytes))
         return out
 
+    def would_splitk(self, M, K, Cout):
+        """small-batch regime: cp_conv2d_igemm would run this conv as its split-K variant (M output pixels, K = R*S*Cin physical)"""
+        return bool(USE_SPLITK and self.lib.cp_conv2d_igemm_splitk(self.dtype, M, K, _rup(Cout, self.E)))
+
     def can_conv_up2x(self, H, W, Cout):
         """(H, W): the low-resolution input; the conv runs at (2H, 2W), which must tile like the plain halo kernel's maps"""
         return (USE_UP_FUSED and 2 * H >= 8 and 2 * W >= 16 and

@@ -553,7 +553,8 @@ def emit_posenet(em: NetEmitter, cfg, io):
             j = 3 - i
             Cs = em.W("init_net.img_backbone.incre_modules.%d.0.conv3.weight" % j).shape[0]
             Hs = cfg["img_size"] // (4 << j)
-            if p.can_conv_up2x(Hs, Hs, nf):
+            # (at batch 1-2 the split-K conv on a materialised upsample beats the fused loader's 8-32 workgroups)
+            if p.can_conv_up2x(Hs, Hs, nf) and not p.would_splitk(p.B * 4 * Hs * Hs, 9 * (_rup(nf, p.E) + _rup(Cs, p.E)), nf):
                 lowcats[i] = p.act(Hs, Hs, nf + Cs)
                 feat_outs[j] = lowcats[i].slice(_rup(nf, p.E), Cs)
     feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None,
@@ -581,7 +582,8 @@ def emit_posenet(em: NetEmitter, cfg, io):
 
     def tail_conv(x, ck, bk, last, out=None):
         """a decoder stage's last conv3x3+BN+ReLU; on the LAST active stage (eval) the seg_block head rides in its epilogue"""
-        if last and tp is None and out is None and p.can_conv_halo_seg(x, em.W(ck + ".weight").shape[0], wseg.shape[0]):
+        if (last and tp is None and out is None and p.can_conv_halo_seg(x, em.W(ck + ".weight").shape[0], wseg.shape[0])
+                and not p.would_splitk(x.B * x.H * x.W, 9 * x.Cphys, em.W(ck + ".weight").shape[0])):
             s_, t_ = em.ws.bn_fold(bk)
             seg_fused[0] = True
             return p.conv_halo_seg(x, ck, em.W(ck + ".weight"), s_, t_, ACT_RELU, "seg_block", wseg, em.W("seg_block.bias"), io["seg_tb"])
@@ -628,7 +630,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
                 _upsample_tape(tp, f, cat.slice(0, f.C))
                 _upsample_tape(tp, sk, cat.slice(f.Cphys, sk.C))
             f = em.conv_bn(cat, up + ".1", up + ".2", 3, 1, 1)
-            f = tail_conv(f, up + ".4", up + ".5", last)
+            f = tail_conv(f, up + ".4", up + ".5", last, out=lowcats[i + 1].slice(0, nf) if (i + 1) in lowcats else None)
         # ---- Refine_moduleGNN.forward pipeline.py:262-298
         p.sync(0, 1)
         p.set_lane(1)
