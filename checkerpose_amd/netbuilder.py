@@ -17,6 +17,7 @@ IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 
 FUSE_OUT_DEEP = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_DEEP", "1") != "0"   # A/B: 2nd / 3rd convs of the stride-2 fuse chains through cp_hr_fuse_out
 
 
+HEAD_ON_REFINE_LANE = os.environ.get("CHECKERPOSE_AMD_HEAD_LANE", "1") != "0"   # A/B: InitNet head beside up_net[0]
 FUSE_SAME_LANE = os.environ.get("CHECKERPOSE_AMD_FUSE_SAME_LANE", "1") != "0"   # A/B: a fuse chain's later convs on its source's lane (no second region)
 
 
@@ -412,8 +413,10 @@ class NetEmitter:
         return self.p.edge_gather(pq, graph["idx"], graph["gids"], out, graph["K"], Co, graph["G"], slope)
 
 
-def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_outs=None):
-    """InitNet_GNN.forward init.py:109-128.  Returns (feats [Act], graph_feats Act)."""
+def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_outs=None, defer_head=False):
+    """InitNet_GNN.forward init.py:109-128.  Returns (feats [Act], graph_feats Act).  defer_head: only the backbone is emitted
+    now and the second return value is a callable that emits the head (conv1x1 -> EdgeConv layers -> Linear) and returns the
+    graph features -- PoseNet runs it on the refinement lane, beside the decoder's first stage (which needs the backbone only)."""
     p = em.p
     N = cfg["npoint"]
     tp = em.tp
@@ -430,6 +433,13 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_o
     if tp is not None:
         tp.nograd.add(id(x.tbuf))                           # the image needs no gradient
     feats = em.hrnet(bb, x, feat_outs=feat_outs, stem_done=fused_stem) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
+    if defer_head:
+        return feats, (lambda: _emit_init_head(em, cfg, io, pfx, graph_out, feats))
+    return feats, _emit_init_head(em, cfg, io, pfx, graph_out, feats)
+
+
+def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
+    p, tp, N = em.p, em.tp, cfg["npoint"]
     f = feats[-1]                                           # (B, 8, 8, Cb)
     # conv1x1 Cb -> N, then `view(-1, N, 64).permute(0,2,1)` (init.py:112-114): keypoint n's 8x8 response map is its
     # 64-d feature -> written straight into the (B, N, 64) graph layout through the epilogue strides.
@@ -474,7 +484,7 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_o
            ostr=(0, 13 * N, 0, 1, N), out_tbuf=io["bits_tb"])
     if tp is not None:       # incoming gradient: rows [roi, x2 x1 x0, y2 y1 y0] gathered by the autograd hook into (B,7,N)
         em._out_layer_bwd(pfx + "mlp", wl.view(7, 64, 1, 1), g, 7, io["dinit"], 0, 7 * N, 1, N)
-    return feats, g
+    return g
 
 
 def _convt_train_tail(em, up, wt, f, o, nf):
@@ -557,15 +567,22 @@ def emit_posenet(em: NetEmitter, cfg, io):
             if p.can_conv_up2x(Hs, Hs, nf) and not p.would_splitk(p.B * 4 * Hs * Hs, 9 * (_rup(nf, p.E) + _rup(Cs, p.E)), nf):
                 lowcats[i] = p.act(Hs, Hs, nf + Cs)
                 feat_outs[j] = lowcats[i].slice(_rup(nf, p.E), Cs)
+    head_later = tp is None and active > 0 and HEAD_ON_REFINE_LANE
     feats, g = emit_init_net(em, cfg, io, "init_net.", graph_out=L.slice(qd[0], 64) if L is not None else None,
-                             feat_outs=feat_outs)
+                             feat_outs=feat_outs, defer_head=head_later)
     dbits = io.get("decode_bits", io["bits"])      # teacher forcing (tests only): decode from supplied logits
-    p.decode(dbits, -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
+    if not head_later:
+        p.decode(dbits, -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
     f = feats[-1]
     # lane 0: decoder chain up_net[0..2] -> seg (MFMA-bound) ; lane 1: refine stages (latency-bound graph kernels).
     # refine[i] needs up_net[i]'s output (sync 0 -> 1) and refine[i-1]; up_net[i+1] needs only up_net[i].
     if active > 0:
         p.par_begin(6 if tp is None else 2)      # 0 decoder, 1 refinement, 2 skip upsamples, 3-5 transposed-conv phases
+    if head_later:     # InitNet's head needs only the backbone's last feature, like up_net[0]: it runs on the refinement lane beside it
+        p.set_lane(1)
+        g = g()
+        p.decode(dbits, -1, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
+        p.set_lane(0)
     # the skip features' bilinear x2 halves of the decoder's concat buffers do not depend on the decoder: they run on a lane
     # of their own right away (lane 2 never waits for anybody) instead of on the decoder's critical path
     cats = {}
