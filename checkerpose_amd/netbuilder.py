@@ -17,6 +17,7 @@ IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 
 FUSE_OUT_DEEP = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_DEEP", "1") != "0"   # A/B: 2nd / 3rd convs of the stride-2 fuse chains through cp_hr_fuse_out
 
 
+DECODER_SPLITK = os.environ.get("CHECKERPOSE_AMD_DECODER_SPLITK", "1") != "0"   # A/B: decoder convs as split-K convs at batch 1-4
 HEAD_ON_REFINE_LANE = os.environ.get("CHECKERPOSE_AMD_HEAD_LANE", "1") != "0"   # A/B: InitNet head beside up_net[0]
 FUSE_SAME_LANE = os.environ.get("CHECKERPOSE_AMD_FUSE_SAME_LANE", "1") != "0"   # A/B: a fuse chain's later convs on its source's lane (no second region)
 
@@ -564,7 +565,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
             Cs = em.W("init_net.img_backbone.incre_modules.%d.0.conv3.weight" % j).shape[0]
             Hs = cfg["img_size"] // (4 << j)
             # (at batch 1-2 the split-K conv on a materialised upsample beats the fused loader's 8-32 workgroups)
-            if p.can_conv_up2x(Hs, Hs, nf) and not p.would_splitk(p.B * 4 * Hs * Hs, 9 * (_rup(nf, p.E) + _rup(Cs, p.E)), nf):
+            if p.can_conv_up2x(Hs, Hs, nf) and not (DECODER_SPLITK and p.would_splitk(p.B * 4 * Hs * Hs, 9 * (_rup(nf, p.E) + _rup(Cs, p.E)), nf)):
                 lowcats[i] = p.act(Hs, Hs, nf + Cs)
                 feat_outs[j] = lowcats[i].slice(_rup(nf, p.E), Cs)
     head_later = tp is None and active > 0 and HEAD_ON_REFINE_LANE
@@ -600,7 +601,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
     def tail_conv(x, ck, bk, last, out=None):
         """a decoder stage's last conv3x3+BN+ReLU; on the LAST active stage (eval) the seg_block head rides in its epilogue"""
         if (last and tp is None and out is None and p.can_conv_halo_seg(x, em.W(ck + ".weight").shape[0], wseg.shape[0])
-                and not p.would_splitk(x.B * x.H * x.W, 9 * x.Cphys, em.W(ck + ".weight").shape[0])):
+                and not (DECODER_SPLITK and p.would_splitk(x.B * x.H * x.W, 9 * x.Cphys, em.W(ck + ".weight").shape[0]))):
             s_, t_ = em.ws.bn_fold(bk)
             seg_fused[0] = True
             return p.conv_halo_seg(x, ck, em.W(ck + ".weight"), s_, t_, ACT_RELU, "seg_block", wseg, em.W("seg_block.bias"), io["seg_tb"])
