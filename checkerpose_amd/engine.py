@@ -869,7 +869,7 @@ class Program:
             if op[0] not in ("__fork__", "__sync__", "__join__", "__mark__", "__wait__", "__dead__"):
                 rd, wr = self._rw.get(oi, ([], []))
                 acc.append(tuple([(P(t), P(t) + t.nbytes, id(t)) for t in lst] for lst in (rd, wr)))
-        self.dag = self._hazards(acc)
+        self._acc, self._dag = acc, None      # hazards are derived on first use (dag property): quadratic in the launch count
         for op in self.ops:
             if op[0] == "__fork__":
                 self.sched.append(("fork", op[1]))
@@ -888,6 +888,12 @@ class Program:
                 self.sched.append(("op", len(self.calls), lane))
                 self.calls.append((fn, (None,) + tuple(argb(P)), name))
         return self
+
+    @property
+    def dag(self):
+        if self._dag is None:
+            self._dag = self._hazards(self._acc)
+        return self._dag
 
     @staticmethod
     def _hazards(acc):
