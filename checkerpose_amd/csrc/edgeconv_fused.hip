@@ -11,20 +11,23 @@
 //     under the other half's MFMAs; P' = s * (W1 x) is written to the LDS table as ORDER-PRESERVING int16 keys of its bf16
 //     value (so the K-way max is v_pk_max_i16, two channels per instruction), Q' = s * ((W2 - W1) x) + t stays in the fp32
 //     accumulators;
-//   * gather: a lane owns 16 channels of a keypoint: 2 ds_read_b128 per neighbour row (row pitch 144 B = 9 slots), index
-//     lists staged once per layer as int16; out = leaky(max_k P'_j(k) + Q'_i) leaves as 32 B per lane.
+//   * gather: a lane owns 16 channels of a keypoint: 2 ds_read_b128 per neighbour row.  The table is [8-channel plane][row][16 B]:
+//     the 16 lanes of a ds_read_b128 group are 16 different keypoints reading 16 different rows, bank slot = row mod 16, and the
+//     host hands in every keypoint's list ORDERED so that the rows of a step have different residues (graph_sched.py: the max
+//     does not care; bank-conflict share of the kernel's LDS cycles 54 % -> 23 %).  Index lists staged once per layer as int16;
+//     out = leaky(max_k P'_j(k) + Q'_i) leaves as 32 B per lane.
 // Two barriers per slice.  Numerics: P' rounded to bf16 as before, Q' no longer rounded to bf16 (one rounding less).
 #include "common.h"
 
 namespace {
 
 constexpr int EF_N = 512, EF_KMAX = 20;
-constexpr int EF_PITCH = 144;                               // bytes per P' row (64 channels + 16 B pad: odd number of slots)
-constexpr int EF_TABLE = EF_N * EF_PITCH;                   // 73 728
+constexpr int EF_PLANE = EF_N * 16;                         // P' table: one plane per 8 channels, [plane][row][16 B] -> bank slot = row mod 16
+constexpr int EF_TABLE = 8 * EF_PLANE;                      // 65 536
 constexpr int EF_WBUF = 32 * 1024;                          // one (slice, half) of weights at Cin = 256
 constexpr int EF_IDX = EF_N * EF_KMAX * 2;                  // 20 480
 constexpr int EF_AFF = 2 * 512 * 4;                         // scale | shift of the 2 C' <= 512 GEMM rows
-constexpr int EF_LDS = EF_TABLE + 2 * EF_WBUF + EF_IDX + EF_AFF;     // 163 840 = all 160 KiB of the CU
+constexpr int EF_LDS = EF_TABLE + 2 * EF_WBUF + EF_IDX + EF_AFF;     // 155 648
 
 struct EdgeFusedParams {
   const void* x; const void* w; const float* scale; const float* shift;
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
           hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
           hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
           hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
-          unsigned char* dst = sP + (wave * 64 + f * 16 + x) * EF_PITCH + q * 32;
+          unsigned char* dst = sP + (2 * q) * EF_PLANE + (wave * 64 + f * 16 + x) * 16;       // 16 consecutive rows: 16 slots
           *(u32x4*)dst = lo;
-          *(u32x4*)(dst + 16) = hi;
+          *(u32x4*)(dst + EF_PLANE) = hi;
         }
         __syncthreads();                                    // table complete; the Q half of the weights has landed
       } else {                                              // Q' stays in the accumulators (fp32)
@@ -168,12 +171,14 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
       for (int k = 0; k < p.K; k += 4) {                     // K is a multiple of 4 (20)
         const u32x2 i4 = *(const u32x2*)(my + k);
         const int r0 = (int)(i4.x & 0xffffu), r1 = (int)(i4.x >> 16), r2 = (int)(i4.y & 0xffffu), r3 = (int)(i4.y >> 16);
-        const unsigned char* b0 = sP + r0 * EF_PITCH + q * 32;
-        const unsigned char* b1 = sP + r1 * EF_PITCH + q * 32;
-        const unsigned char* b2 = sP + r2 * EF_PITCH + q * 32;
-        const unsigned char* b3 = sP + r3 * EF_PITCH + q * 32;
-        const u32x4 a0 = *(const u32x4*)b0, a1 = *(const u32x4*)(b0 + 16), c0_ = *(const u32x4*)b1, c1 = *(const u32x4*)(b1 + 16);
-        const u32x4 d0 = *(const u32x4*)b2, d1 = *(const u32x4*)(b2 + 16), e0 = *(const u32x4*)b3, e1 = *(const u32x4*)(b3 + 16);
+        // a ds_read_b128 lane group = the 16 keypoints of this fragment, each reading ITS k-th neighbour's row: slot = row mod 16.
+        // The host orders every keypoint's list so that the 16 rows of a step have different residues (graph_sched.py).
+        const unsigned char* b0 = sP + (2 * q) * EF_PLANE + r0 * 16;
+        const unsigned char* b1 = sP + (2 * q) * EF_PLANE + r1 * 16;
+        const unsigned char* b2 = sP + (2 * q) * EF_PLANE + r2 * 16;
+        const unsigned char* b3 = sP + (2 * q) * EF_PLANE + r3 * 16;
+        const u32x4 a0 = *(const u32x4*)b0, a1 = *(const u32x4*)(b0 + EF_PLANE), c0_ = *(const u32x4*)b1, c1 = *(const u32x4*)(b1 + EF_PLANE);
+        const u32x4 d0 = *(const u32x4*)b2, d1 = *(const u32x4*)(b2 + EF_PLANE), e0 = *(const u32x4*)b3, e1 = *(const u32x4*)(b3 + EF_PLANE);
         m[0] = pkmax(pkmax(m[0], a0.x), pkmax(c0_.x, pkmax(d0.x, e0.x)));
         m[1] = pkmax(pkmax(m[1], a0.y), pkmax(c0_.y, pkmax(d0.y, e0.y)));
         m[2] = pkmax(pkmax(m[2], a0.z), pkmax(c0_.z, pkmax(d0.z, e0.z)));

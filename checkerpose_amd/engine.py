@@ -24,6 +24,7 @@ USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decode
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
+EDGE_SCHED = os.environ.get("CHECKERPOSE_AMD_EDGE_SCHED", "1") != "0"   # A/B: bank-conflict-aware neighbour order for edge_fused
 USE_SPLITK = os.environ.get("CHECKERPOSE_AMD_SPLITK", "1") != "0"     # small-batch split-K routing (cp_conv2d_igemm_splitk)
 GEMM_WS_SMALL_K = os.environ.get("CHECKERPOSE_AMD_GEMM_WS_SMALL_K", "1") != "0"   # A/B: weight-stationary GEMM from K = 64
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
@@ -699,6 +700,14 @@ class Program:
         self.keep += [buf, sc, sh]
         fn = self.lib.cp_edgeconv_fused
         xt, ot = x.tbuf, out.tbuf
+        sk = ("edge_sched", idx_t.data_ptr(), tuple(idx_t.shape))
+        if EDGE_SCHED and sk not in self.ws.cache:      # the same graph, every keypoint's list reordered against LDS bank conflicts
+            from .graph_sched import schedule_neighbours
+            i3 = idx_t.detach().cpu().numpy().reshape(-1, x.W, K)
+            self.ws.cache[sk] = torch.from_numpy(schedule_neighbours(i3)[0]).reshape(tuple(idx_t.shape)).to(self.device).contiguous()
+        if EDGE_SCHED:
+            idx_t = self.ws.cache[sk]
+            self.keep.append(idx_t)
         ip = idx_t.data_ptr()
         gp = gids_t.data_ptr() if gids_t is not None else None
         N = x.W

@@ -1145,6 +1145,21 @@ def test_dataflow_graph_capture_bitwise(lib, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_edge_neighbour_schedule_bitwise(lib, monkeypatch):
+    """The bank-conflict-aware neighbour order handed to cp_edgeconv_fused (graph_sched.py) changes nothing: forward with the
+    scheduled lists == forward with the kNN order, bit for bit (the max over a keypoint's neighbours ignores their order)."""
+    from checkerpose_amd import engine
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    img = det_image(4, seed=3).to(dev())
+    a = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    o1 = [t.clone() for t in a(img, None)]
+    assert any(k[0] == "edge_sched" for k in a._stores[list(a._stores)[0]].cache if isinstance(k, tuple))
+    monkeypatch.setattr(engine, "EDGE_SCHED", False)
+    b = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    for x, y in zip(o1, b(img, None)):
+        assert torch.equal(x, y)
+
+
 def test_postprocess_correspondences_on_device(lib):
     """Next-row N2: device-side correspondence list == the reference's host-side extraction (oracle restatement of
     test.py:294-329 + from_id_to_pose :50-59), bit exact, on real forward outputs."""

@@ -1,4 +1,5 @@
 """micro-benchmark of cp_edgeconv_fused (one EdgeConv layer, N = 512, K = 20, 256 -> 256)"""
+import os
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -15,6 +16,11 @@ for Cin, Cout in ((256, 256), (64, 64)):
     _abi.check(lib.cp_pack_edgeconv_fused_weight(st, wpq.data_ptr(), Cin, Cout, pw.data_ptr()))
     sc = torch.ones(2 * Cout, device=dev); sh = torch.zeros(2 * Cout, device=dev)
     idx = torch.randint(0, N, (1, N, K), device=dev, dtype=torch.int32)
+    if os.environ.get("EDGE_BENCH_SCHED", "1") != "0":      # the order the engine hands in (graph_sched.py); 0: as drawn
+        from checkerpose_amd.graph_sched import schedule_neighbours
+        o, before, after = schedule_neighbours(idx.cpu().numpy())
+        print("scheduled neighbour lists: residue clashes %d -> %d of %d reads" % (before, after, o.size))
+        idx = torch.from_numpy(o).to(dev)
     out = torch.empty(B, N, Cout, device=dev, dtype=torch.bfloat16)
     run = lambda: _abi.check(lib.cp_edgeconv_fused(st, x.data_ptr(), Cin, 0, pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), idx.data_ptr(), None,
                                                   out.data_ptr(), Cout, 0, B, N, K, Cin, Cout, 1, 0.2))
