@@ -86,23 +86,58 @@ def cpu_baseline(npoint, seconds=12.0):
             "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
 
 
-def pmc_traffic_mb(kernel_prefix, dtype, B):
-    """HBM bytes per launch (MB) of a kernel family from the committed rocprofv3 PMC summary of this same bench command
-    (profiles/r*_<dtype>_b<B>_kernel_summary.csv: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied
-    by profiles/summarize.py).  None when no summary for this dtype is committed."""
+def profile_tag(workload, dtype, B):
+    return ("%s_b%d" % (dtype, B)) if workload == "lmo_ape" else ("%s_%s_b%d" % (workload, dtype, B))
+
+
+def committed_profile(kernel_prefix, tag):
+    """What the committed rocprofv3 evidence of this same bench command says about one kernel symbol
+    (profiles/r*_<tag>_kernel_summary.csv, made by profiles/summarize.py from a `--kernel-trace --stats` run and two separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes with the gfx950 corrections): HBM MB per launch, rocprofv3's average launch
+    duration in us, and the file.  (None, None, None) when no summary for this workload / dtype / batch is committed.  These
+    figures are NOT re-measured by this run: they go stale when the kernel changes, hence the file name beside them."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_b%d_kernel_summary.csv" % (dtype, B))))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_summary.csv" % tag)))
     if not files:
-        return None, None
-    tot, calls = 0.0, 0
+        return None, None, None
+    tot, calls, dur, dcalls = 0.0, 0, 0.0, 0
     for r in csv.DictReader(open(files[-1])):
-        hit = r["kernel"] == kernel_prefix
-        if hit and r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
-            n = int(r["calls"])
+        if r["kernel"] != kernel_prefix:
+            continue
+        n = int(r["calls"])
+        dur += n * float(r["avg_us"])
+        dcalls += n
+        if r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
             tot += n * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"]))
             calls += n
-    return (round(tot / calls, 2) if calls else None), os.path.relpath(files[-1], ROOT)
+    return ((round(tot / calls, 2) if calls else None), (round(dur / dcalls, 2) if dcalls else None),
+            os.path.relpath(files[-1], ROOT))
+
+
+def _profile_prefix_mb_per_step(prefix, tag):
+    """sum over the rows of the committed summary whose kernel name starts with `prefix` (template instances): HBM MB per STEP"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_summary.csv" % tag)))
+    if not files:
+        return None, None
+    rows = [r for r in csv.DictReader(open(files[-1])) if r["kernel"].startswith(prefix) and r["avg_hbm_read_MB(FETCH_SIZE*2)"]]
+    if not rows:
+        return None, None
+    steps = _profile_steps(files[-1])
+    mb = sum(int(r["calls"]) * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"])) for r in rows)
+    return round(mb / steps, 1), os.path.relpath(files[-1], ROOT)
+
+
+def _profile_steps(path):
+    """forwards covered by a committed kernel summary: the stats run is `bench.py --steps 5` = 5 timed + 3 warm-up + 1 program
+    build forward = 9 (every decoder launch appears exactly twice per forward: calls of the dominant kernel / 2)"""
+    import csv
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith("conv3x3_halo4_kernel<BF16Tag, false, true"):
+            return max(int(r["calls"]) // 2, 1)
+    return 9
 
 
 def timed_steps(step, steps, warmup):
@@ -389,33 +424,67 @@ def main():
                                    "algorithmic_gflop_per_launch_avg": round(sv["flops"] / n / 1e9, 3),
                                    "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
             out["kernel_symbols"] = dict(sorted(ksym.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8])
-            if a.workload == "lmo_ape":   # a committed PMC summary of this exact command (same dtype and batch), if any
-                tr, src = pmc_traffic_mb(dom, a.dtype, B)
-                if tr is not None:
-                    out["roofline"]["traffic"] = tr
-                    out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch"
-                    out["roofline"]["traffic_source"] = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                                         "this command; not re-measured by this run)" % src)
+            out["roofline"]["timing"] = ("HIP events on the launch stream around every launch of an eager replay of the same launch "
+                                         "program, mean over %d steps (bench.py:kernel_breakdown)" % min(a.steps, 5))
+            short = dom.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+            tr, us_prof, src = committed_profile(short, profile_tag(a.workload, a.dtype, B))
+            if src is not None:      # committed rocprofv3 evidence of this exact command (same workload, dtype and batch), if any
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch"
+                out["roofline"]["traffic_source"] = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                     "this command; not re-measured by this run)" % src)
+                if us_prof:          # the same fraction priced with rocprofv3's own average duration of that kernel
+                    per_launch = (sv["bytes"] / n / 1e3 / us_prof / PEAK_HBM_GBS) if out["roofline"]["bound"] == "hbm" else \
+                                 (sv["flops"] / n / 1e6 / us_prof / PEAK_TFLOPS[a.dtype])
+                    out["roofline"]["rocprofv3_avg_launch_us"] = us_prof
+                    out["roofline"]["frac_rocprofv3"] = round(per_launch, 4)
             tot_s = sum(v["ms_per_step"] for v in mf.values()) * 1e-3
             out["mfma_kernels"] = per
             out["mfma_all"] = {"achieved": round(prog.flops / tot_s / 1e12, 2), "unit": "TFLOP/s",
                                "frac": round(prog.flops / tot_s / 1e12 / PEAK_TFLOPS[a.dtype], 4)}
-            # memory-bound neighbour-gather kernel: algorithmic bytes = N*K*C*e + 2*N*C*e + N*K*4 per layer
-            eg = fam.get("edge_gather")
-            if eg:
-                e = 2 if a.dtype == "bf16" else 4
-                N, K = a.npoint, 20
-                by = B * sum(N * K * c * e + 2 * N * c * e + N * K * 4 for c in (64, 64) + (256,) * 9)
-                gbs = by / (eg["ms_per_step"] * 1e-3) / 1e9
-                hbm_by = B * sum(2 * N * c * e for c in (64, 64) + (256,) * 9)       # compulsory: read P'|Q' once, write out
-                out["roofline_gather"] = {"bound": "l2", "kernel": "edgeconv_gather_max_kernel (11 launches)",
-                                          "achieved": round(gbs, 1), "peak": 34500.0, "unit": "GB/s",
-                                          "frac": round(gbs / 34500.0, 4), "traffic": None,
-                                          "algorithmic_mb_per_step": round(by / 1e6, 1),
-                                          "compulsory_hbm_gbs": round(hbm_by / (eg["ms_per_step"] * 1e-3) / 1e9, 1),
-                                          "note": "algorithmic bytes = K=20 neighbour rows + centre + write + idx (SURVEY.md 8d); the "
-                                                  "neighbour rows are served by the XCD L2 (a crop's P' table is 256-512 KiB, all its "
-                                                  "blocks share one XCD), so the roof is the ~34.5 TB/s aggregate L2, not HBM"}
+            # the GNN gather (north_star: "achieved GB/s on the GNN gather"): algorithmic bytes per layer =
+            # N*K*C*e neighbour rows + N*C*e centre + N*C*e write + N*K*4 index, all 11 EdgeConv layers.  Three kernels can carry
+            # it: edgeconv_fused (N = 512: table in LDS), edgeconv_tiled (N = 4096: neighbour window in LDS), and the L2 gather.
+            e = 2 if a.dtype == "bf16" else 4
+            N, K = a.npoint, 20
+            LDS_PEAK = 256 * 256 * 2.4          # B/clk/CU x CUs x GHz = GB/s (MI355X_MICROARCH.md: ds_read_b128 256 B/clk/CU)
+            layers = {}                          # family -> [C' per launch]
+            for (fn_, args_, name_) in prog.calls:
+                f_ = name_.split(":")[0]
+                if f_ in ("edge_fused", "edge_tiled"):
+                    layers.setdefault(f_, []).append(64 if name_.split(":")[1].startswith("init_net.") else 256)
+                elif f_ == "edge_gather":
+                    layers.setdefault(f_, []).append(int(name_.split(":")[1]))
+            rg = {}
+            for f_, cs in layers.items():
+                t_ = fam[f_]["ms_per_step"] * 1e-3
+                by = B * sum(N * K * c * e + 2 * N * c * e + N * K * 4 for c in cs)
+                hbm_by = B * sum(2 * N * c * e for c in cs)            # compulsory: the layer's input rows in, its output out
+                lds = f_ != "edge_gather"
+                peak = LDS_PEAK if lds else 34500.0
+                sym_ = {"edge_fused": "edgeconv_fused_kernel", "edge_tiled": "edgeconv_tiled_kernel", "edge_gather": "edgeconv_gather_max_kernel"}[f_]
+                r_ = {"bound": "lds" if lds else "l2", "kernel": "%s (%d launches per step)" % (sym_, len(cs)),
+                      "achieved": round(by / t_ / 1e9, 1), "peak": round(peak, 0), "unit": "GB/s", "frac": round(by / t_ / 1e9 / peak, 4),
+                      "algorithmic_mb_per_step": round(by / 1e6, 1), "ms_per_step": round(t_ * 1e3, 3),
+                      "compulsory_hbm_mb_per_step": round(hbm_by / 1e6, 1), "compulsory_hbm_gbs": round(hbm_by / t_ / 1e9, 1),
+                      "traffic": None,
+                      "note": ("gather bytes = K=20 neighbour rows + centre + write + idx (SURVEY.md 8d) over the WHOLE launch time; "
+                               + ("the launch also runs the layer's node GEMM on the MFMA pipe, so this is a lower bound of the gather "
+                                  "rate; the neighbour rows are read from the LDS table (ds_read_b128: %.0f TB/s aggregate)" % (LDS_PEAK / 1e3)
+                                  if lds else "the neighbour rows are served by the XCD L2 (~34.5 TB/s aggregate), not HBM"))}
+                tr, src = _profile_prefix_mb_per_step(sym_, profile_tag(a.workload, a.dtype, B))      # template instances: by prefix
+                if tr is not None:
+                    r_["traffic"] = tr
+                    r_["traffic_unit"] = "MB of HBM read+write per step, all launches of this kernel (PMC)"
+                    r_["traffic_source"] = "from_committed_profile: %s" % src
+                    r_["compulsory_hbm_fraction"] = round(hbm_by / 1e6 / tr, 3)
+                rg[f_] = r_
+            if rg:
+                main_f = max(rg, key=lambda k_: rg[k_]["ms_per_step"])
+                out["roofline_gather"] = rg[main_f]
+                for k_, v_ in rg.items():
+                    if k_ != main_f:
+                        out["roofline_gather_" + k_] = v_
             out["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             out["dense_gflop_per_crop"] = round(prog.flops / B / 1e9, 2)
             out["workspace_mb"] = round(prog.workspace_bytes / 2 ** 20, 1)

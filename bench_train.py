@@ -179,8 +179,8 @@ def main():
             ms = sum(t for _, t in w3)
             fl = sum(prog.wgrad_flops[i] for i, _ in w3)
             big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
-            from bench import pmc_traffic_mb
-            tr = [pmc_traffic_mb(k, a.dtype, B)[0] for k in ("wgrad3x3_kernel", "wgrad_reduce_kernel")]
+            from bench import committed_profile
+            tr = [committed_profile(k, "train_%s_b%d" % (a.dtype, B))[0] for k in ("wgrad3x3_kernel", "wgrad_reduce_kernel")]
             out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel + wgrad_reduce_kernel (%d launches per step)" % len(w3),
                                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),

@@ -105,6 +105,7 @@ SIGNATURES = {
     "cp_loss_workspace_bytes": (C.c_size_t, []),
     "cp_code_loss": (_I, [_P, _I, _P, _L, _P, _L, _P, _I, _I, _I, _P, _P, _L, _P]),
     "cp_mask_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
+    "cp_masked_ce_loss": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "cp_conv2d_wgrad": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P]),
     "cp_conv2d_wgrad_ws": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t]),
     "cp_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -319,6 +319,69 @@ extern "C" int cp_code_loss(cp_stream_t stream, int loss_type, const float* pred
   return cp_check_launch();
 }
 
+// MaskedCodeLoss(loss_type="CE") (losses/code_loss.py:36-37,47-61): nn.CrossEntropyLoss(reduction="none") over the class axis
+// of pred (B, C, N) against class ids gt (B, N) (ids handed over as fp32: exact up to 2^24), times the mask, summed and divided by
+// clamp(mask.sum(), 1) (num_bits = 1 for CE).  One thread per (b, n): max-shifted log-sum-exp in fp32, value summed in fp64.
+struct CeLossArgs {
+  const float* pred; const float* gt; const float* mask; float* dpred;
+  long long pred_bs, dpred_bs;
+  int B, C, N;
+};
+
+__global__ __launch_bounds__(256) void ce_loss_kernel(const CeLossArgs a, LossWs* ws, float* loss) {
+  const long long total = (long long)a.B * a.N;
+  double s0 = 0.0, s1 = 0.0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long b = e / a.N;
+    const int n = (int)(e - b * a.N);
+    const float* p = a.pred + b * a.pred_bs + n;
+    float mx = p[0];
+    for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, p[(long long)c * a.N]);
+    float se = 0.f;
+    for (int c = 0; c < a.C; ++c) se += expf(p[(long long)c * a.N] - mx);
+    const int y = (int)a.gt[e];
+    const float m = a.mask[e];
+    s0 += (double)((mx + logf(se) - p[(long long)y * a.N]) * m);
+    s1 += m;
+  }
+  loss_block_reduce(s0, s1, ws, loss, 1, (double)total, 1);
+}
+
+__global__ __launch_bounds__(256) void ce_loss_grad_kernel(const CeLossArgs a, const LossWs* ws) {
+  const long long total = (long long)a.B * a.N;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / a.N;
+  const int n = (int)(e - b * a.N);
+  const float* p = a.pred + b * a.pred_bs + n;
+  float* d = a.dpred + b * a.dpred_bs + n;
+  float mx = p[0];
+  for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, p[(long long)c * a.N]);
+  float se = 0.f;
+  for (int c = 0; c < a.C; ++c) se += expf(p[(long long)c * a.N] - mx);
+  const int y = (int)a.gt[e];
+  const float w = a.mask[e] / ws->denom, inv = 1.f / se;
+  for (int c = 0; c < a.C; ++c) d[(long long)c * a.N] = (expf(p[(long long)c * a.N] - mx) * inv - (c == y ? 1.f : 0.f)) * w;
+}
+
+extern "C" int cp_masked_ce_loss(cp_stream_t stream, const float* pred, long long pred_bstride, const float* gt_class,
+                                 const float* mask, int B, int C, int N, float* loss, float* dpred, long long dpred_bstride,
+                                 void* workspace) {
+  if (!pred || !gt_class || !mask || !loss || !workspace || B <= 0 || C <= 0 || N <= 0) return CP_ERR_INVALID;
+  const long long per = (long long)C * N;
+  if (pred_bstride < per || (dpred && dpred_bstride < per)) return CP_ERR_INVALID;
+  if (!cp_aligned16(workspace)) return CP_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  LossWs* ws = (LossWs*)workspace;
+  if (hipMemsetAsync(&ws->ticket, 0, sizeof(uint32_t), st) != hipSuccess) return CP_ERR_HIP;
+  CeLossArgs a{pred, gt_class, mask, dpred, pred_bstride, dpred_bstride, B, C, N};
+  const long long total = (long long)B * N;
+  const int blocks = (int)((total + 255) / 256 < LOSS_BLOCKS ? (total + 255) / 256 : LOSS_BLOCKS);
+  CP_LAUNCH(ce_loss_kernel, dim3(blocks), dim3(256), 0, st, a, ws, loss);
+  if (dpred) CP_LAUNCH(ce_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, ws);
+  return cp_check_launch();
+}
+
 // F.interpolate(mode="nearest") source index (mask_loss.py:14): min(floor(dst * in/out), in - 1), scale in fp32
 __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
   const float scale = (float)in / (float)out;

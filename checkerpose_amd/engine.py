@@ -678,7 +678,7 @@ class Program:
         gp = gids_t.data_ptr() if gids_t is not None else None
         N = pq.W
         self._add(fn, lambda P: (self.dtype, P(pt), ip, gp, P(ot), pq.B, N, K, C_, G, out.cstride, out.coff, slope),
-                  "edge_gather", [pt], [ot])
+                  "edge_gather:%d" % C_, [pt], [ot])
         return out
 
     def can_fuse_edgeconv(self, N, K, Cin, Cout):
@@ -742,7 +742,10 @@ class Program:
                   "patch_gather:" + wkey, [ft, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
         fl = 2 * f.B * 4 * N * 64 * 4 * f.C
         self.flops += fl
-        self.conv_log.append((wkey, f.B * 4 * N, 64, 4 * f.C, fl, "patch_gather", f.B * 4 * N * (4 * f.C + 64) * self.es))
+        # algorithmic HBM bytes: the gathered 2x2 patches overlap and repeat, so at most the feature map itself is read once
+        # (PMC: far less -- only pixels some keypoint points at are touched), + the (B, N, 4*64) output + weights
+        nby = (f.B * min(f.H * f.W * f.C, 4 * N * 4 * f.C) + f.B * N * 4 * 64 + 64 * 4 * f.C) * self.es
+        self.conv_log.append((wkey, f.B * 4 * N, 64, 4 * f.C, fl, "patch_gather", nby))
         return out
 
     def index2feat(self, patches: Act, xid_t, yid_t, mask_t, out: Act, N, E_ch, k):

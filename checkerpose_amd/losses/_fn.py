@@ -60,6 +60,34 @@ class _CodeLossFn(torch.autograd.Function):
         return (ctx.dp * gl if ctx.dp is not None else None), None, None, None
 
 
+class _CeLossFn(torch.autograd.Function):
+    """MaskedCodeLoss("CE"): pred (B, C, N) class logits, gt (B, 1, N) class ids, mask (B, 1, N) (code_loss.py:47-61)"""
+
+    @staticmethod
+    def forward(ctx, pred, gt, mask):
+        _require_cuda(pred, gt, mask)
+        lib = _abi.load()
+        B, Cc, N = pred.shape
+        if tuple(gt.shape) != (B, 1, N) or tuple(mask.shape) != (B, 1, N):
+            raise ValueError("CE: gt_code and gt_mask must be (B, 1, #keypoints)")
+        p, pbs = _batch_view(pred.detach(), Cc * N)
+        g = gt[:, 0, :].float().contiguous()
+        m = mask.float().contiguous()
+        need = pred.requires_grad
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        dp = torch.empty(B, Cc, N, dtype=torch.float32, device=pred.device) if need else None
+        ws = _workspace(pred.device)
+        st = torch.cuda.current_stream(pred.device).cuda_stream
+        _abi.check(lib.cp_masked_ce_loss(st, p.data_ptr(), pbs, g.data_ptr(), m.data_ptr(), B, Cc, N, loss.data_ptr(),
+                                         dp.data_ptr() if need else None, Cc * N, ws.data_ptr()), "cp_masked_ce_loss")
+        ctx.dp = dp
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        return (ctx.dp * gl if ctx.dp is not None else None), None, None
+
+
 class _MaskLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt):

@@ -3,7 +3,7 @@ constructor argument, forward signature and value; value + gradient come from on
 import torch.nn as nn
 
 from .._abi import LOSS_BCE, LOSS_L1
-from ._fn import _CodeLossFn
+from ._fn import _CeLossFn, _CodeLossFn
 
 _TYPES = {"BCE": LOSS_BCE, "L1": LOSS_L1}
 
@@ -23,12 +23,13 @@ class UnmaskedCodeLoss(nn.Module):
 class MaskedCodeLoss(nn.Module):
     def __init__(self, loss_type="BCE"):
         super().__init__()
-        if loss_type == "CE":
-            raise ValueError("loss_type CE (multi-class) is not used by train.py/pretrain.py and is not built")
-        if loss_type not in _TYPES:
+        if loss_type != "CE" and loss_type not in _TYPES:     # "CE": multi-class (code_loss.py:36-37), cp_masked_ce_loss
             raise ValueError("loss_type {} not supported in MaskedCodeLoss".format(loss_type))
         self.loss_type = loss_type
 
     def forward(self, pred_code_prob, gt_code, gt_mask):
-        """pred_code_prob, gt_code: (batch, #bits, #keypoints); gt_mask: (batch, 1, #keypoints)"""
+        """pred_code_prob, gt_code: (batch, #bits, #keypoints) -- gt_code (batch, 1, #keypoints) class ids for "CE";
+        gt_mask: (batch, 1, #keypoints)"""
+        if self.loss_type == "CE":
+            return _CeLossFn.apply(pred_code_prob, gt_code, gt_mask)
         return _CodeLossFn.apply(pred_code_prob, gt_code, gt_mask, _TYPES[self.loss_type])

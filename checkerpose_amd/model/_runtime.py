@@ -47,6 +47,17 @@ def _replay_half(mod, pr, which, lo, hi, device):
     _abi.check(lib.cp_graph_launch(g, cur.cuda_stream), "graph launch")
 
 
+def batch_bucket(B):
+    """Eval programs (launch list + workspace + hipGraph) are built per batch size; a ragged last batch or a varying number of
+    detections would rebuild one per distinct size.  Sizes are therefore rounded up to the next of 1, 2, 3, 4, 6, 8, 12, 16, 24,
+    32, 48, 64, ... (2^k and 3*2^(k-1): at most 33 % padding): the B crops run in the first rows of the bucket's program (crops
+    are independent -- eval BatchNorm has no cross-sample term, every kernel is per crop), the outputs are sliced back."""
+    if B <= 4:
+        return B
+    k = 1 << (B - 1).bit_length()          # next power of two >= B
+    return 3 * k // 4 if 3 * k // 4 >= B else k
+
+
 class _TrainFn(torch.autograd.Function):
     """autograd hook of the training program (trainer.TrainProgram): forward() replays the forward half of the launch
     list (train-mode BatchNorm, activations saved in the program's workspace), backward() copies the incoming logit /
@@ -72,7 +83,8 @@ class _TrainFn(torch.autograd.Function):
             raise RuntimeError("checkerpose_amd: backward() of a train-mode forward whose saved activations were overwritten "
                                "by a later forward of the same batch size (one backward per forward)")
         io["dbits"].copy_(dbits)
-        io["dinit"].copy_(torch.cat([dbits[:, 0:4], dbits[:, 7:10]], dim=1))
+        nbi = io["dinit"].shape[1]        # 7: rows [roi | x2 x1 x0] + [y2 y1 y0] of the logit block; else an InitNet alone, packed rows
+        io["dinit"].copy_(torch.cat([dbits[:, 0:4], dbits[:, 7:10]], dim=1) if nbi == 7 else dbits[:, :nbi])
         if "dseg" in io:
             io["dseg"].copy_(dseg)
         pg = pr["pgrad"]
@@ -115,6 +127,9 @@ class HipForwardMixin:
         self.use_dag = os.environ.get("CHECKERPOSE_AMD_DAG", "0") == "1"       # dataflow capture (Program.run_dag) instead of fork/join lanes
         self.batch_splits = int(os.environ.get("CHECKERPOSE_AMD_SPLITS", "1"))   # concurrent batch slices per forward (measured: 1 is fastest; 2 and 4 lose 8 % / 30 % at B=128)
         self.clone_outputs = True
+        self.batch_buckets = os.environ.get("CHECKERPOSE_AMD_BUCKETS", "1") != "0"   # eval: pad ragged batches to a cached size
+        self.check_weight_versions = os.environ.get("CHECKERPOSE_AMD_CHECK_VERSIONS", "1") != "0"   # eval: detect in-place weight edits
+        self._sig_tensors = None
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
     # ---- cache control
@@ -131,6 +146,7 @@ class HipForwardMixin:
                     lib.cp_graph_destroy(g)
         self._programs, self._stores, self._idx_dev = {}, {}, None
         self._train_programs = {}
+        self._sig_tensors = None
         # the owning PoseNet folded this init net's weights into ITS programs, and vice versa: drop those too
         for other in (getattr(self, "_owner", None), getattr(self, "init_net", None)):
             other = other() if callable(other) and not isinstance(other, torch.nn.Module) else other
@@ -151,12 +167,13 @@ class HipForwardMixin:
         return self
 
     # ---- program construction
-    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False, u8=False):
+    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False, u8=False, inject=False):
         dtype = DTYPES[self.compute_dtype]
         cfg = self._net_cfg()
         cfg["img_size"] = size
         cfg["stage"] = stage
         cfg["uint8_input"] = u8
+        cfg["inject_feats"] = inject
         N = cfg["npoint"]
         sd = self.state_dict()
         if dtype not in self._stores:
@@ -180,6 +197,10 @@ class HipForwardMixin:
         )
         if teacher:   # teacher forcing (tests): the discrete feedback is decoded from THESE logits, not the computed ones
             io["decode_bits"] = torch.zeros(B, 13, N, dtype=torch.float32, device=device)
+        if inject:    # injected backbone features (tests): NCHW fp32, the layout the reference's backbone returns them in
+            from ..netbuilder import IMG_FEATS_DIMS as _FD
+            io["inject"] = [torch.zeros(B, c, size >> (2 + i), size >> (2 + i), dtype=torch.float32, device=device)
+                            for i, c in enumerate(_FD[cfg["backbone"]])]
         # batch slices: independent sub-programs that the captured graph runs concurrently (see ProgramGroup)
         nsplit = self.batch_splits if (B >= 8 * self.batch_splits and B % self.batch_splits == 0) else 1
         # the kernels address every tensor through 32-bit buffer descriptors (< 2 GiB): the widest one is the last decoder
@@ -202,7 +223,7 @@ class HipForwardMixin:
         progs = []
         for si in range(nsplit):
             sl = slice(si * Bs, (si + 1) * Bs)
-            sio = {k: (v[sl] if torch.is_tensor(v) else v) for k, v in io.items()}
+            sio = {k: (v[sl] if torch.is_tensor(v) else ([t[sl] for t in v] if isinstance(v, list) else v)) for k, v in io.items()}
             prog = Program(lib, ws, dtype, Bs, device)
             sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
             sio["bits_tb"] = prog.fixed(sio["bits"])
@@ -255,7 +276,7 @@ class HipForwardMixin:
         z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)   # noqa: E731
         io = dict(img=(z(B, size, size, 3, dt=torch.uint8) if u8 else z(B, 3, size, size)), bits=z(B, 13, N), mask=z(B, N), xid=z(B, N, dt=torch.int32), yid=z(B, N, dt=torch.int32),
                   x64=z(B, N, dt=torch.int64), y64=z(B, N, dt=torch.int64), gids=z(B, dt=torch.int32) if self.LM else None,
-                  dbits=z(B, 13, N), dinit=z(B, 7, N))
+                  dbits=z(B, 13, N), dinit=z(B, 1 + 2 * cfg.get("init_res_log2", 3), N))
         if cfg["kind"] != "init":
             nref = cfg["res_log2"] - 3
             fs = (size // 32) << (stage if stage is not None else nref)
@@ -346,19 +367,23 @@ class HipForwardMixin:
     def train(self, mode=True):
         r = super().train(mode)
         if not mode and getattr(self, "_stale_eval", False):     # eval programs fold BatchNorm / pack weights at build time
-            lib = _abi._lib
-            for pr in self._programs.values():
-                if pr.get("graph") and lib is not None:
-                    for g in pr["graph"]:
-                        lib.cp_graph_destroy(g)
-            self._programs, self._stores = {}, {}
-            self._stale_eval = False
+            self._drop_eval_programs()
         return r
 
+    def _drop_eval_programs(self):
+        """the eval programs (folded BatchNorm, packed weights, graphs) are stale; the training programs read live weights"""
+        lib = _abi._lib
+        for pr in self._programs.values():
+            if pr.get("graph") and lib is not None:
+                for g in pr["graph"]:
+                    lib.cp_graph_destroy(g)
+        self._programs, self._stores = {}, {}
+        self._stale_eval = False
+
     # ---- one forward
-    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False, teacher_bits=None):
+    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False, teacher_bits=None, inject_feats=None):
         if self.training:
-            if want_feats or want_graph or teacher_bits is not None:
+            if want_feats or want_graph or teacher_bits is not None or inject_feats is not None:
                 raise RuntimeError("checkerpose_amd: return_img_feats / return_graph_feats / teacher forcing are eval-mode only")
             return self._run_train(img, obj_ids, stage=stage)
         if not (torch.is_tensor(img) and img.is_cuda):
@@ -375,23 +400,37 @@ class HipForwardMixin:
         p0 = next(self.parameters())
         if p0.device != device:
             raise RuntimeError("module parameters are on %s but the input is on %s" % (p0.device, device))
-        B, size = img.shape[0], img.shape[2]
-        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None, u8)
+        Bu, size = img.shape[0], img.shape[2]                 # the caller's batch; B: the (possibly larger) cached program size
+        B = batch_bucket(Bu) if self.batch_buckets else Bu
+        if self.check_weight_versions:
+            # eval programs fold BatchNorm and pack weights at build time: an in-place edit of any parameter / buffer since then
+            # (optimizer step, EMA swap, `p.data.copy_`, a child's load_state_dict) bumps its version counter -> rebuild
+            if self._sig_tensors is None:
+                self._sig_tensors = list(self.parameters()) + list(self.buffers())
+            sig = sum(t._version for t in self._sig_tensors) + len(self._sig_tensors)
+            if self._programs and sig != getattr(self, "_eval_sig", None):
+                self._drop_eval_programs()
+            self._eval_sig = sig
+        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None, u8, inject_feats is not None)
         pr = self._programs.get(key)
         if pr is None:
             with torch.cuda.device(device):
-                pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None, u8)
+                pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None, u8,
+                                 inject_feats is not None)
             self._programs[key] = pr
         io, prog = pr["io"], pr["prog"]
         with torch.cuda.device(device):
             if img.data_ptr() != io["img"].data_ptr():        # zero-copy when the caller filled input_buffer(B)
-                io["img"].copy_(img)                          # boundary: stage the caller's NCHW fp32 batch
+                io["img"][:Bu].copy_(img)                     # boundary: stage the caller's NCHW fp32 batch
             if teacher_bits is not None:
-                io["decode_bits"].copy_(teacher_bits)
+                io["decode_bits"][:Bu].copy_(teacher_bits)
+            if inject_feats is not None:
+                for dst, src in zip(io["inject"], inject_feats):
+                    dst[:Bu].copy_(src)
             if self.LM:
                 if obj_ids is None:
                     raise ValueError("obj_ids is required for the LM networks")
-                io["gids"].copy_((obj_ids.to(device) - 1).to(torch.int32))   # obj_ids start from 1 (init_lm.py:65)
+                io["gids"][:Bu].copy_((obj_ids.to(device) - 1).to(torch.int32))   # obj_ids start from 1 (init_lm.py:65)
             cur = torch.cuda.current_stream(device)
             if self.use_graph and pr["warm"]:
                 if pr["graph"] is None:
@@ -432,6 +471,8 @@ class HipForwardMixin:
                 prog.run(cur.cuda_stream)
                 pr["warm"] = True
         out = {k: io[k] for k in ("bits", "seg", "x64", "y64", "img_feats", "graph_feats") if k in io}
+        if Bu != B:
+            out = {k: ([t[:Bu] for t in v] if isinstance(v, list) else v[:Bu]) for k, v in out.items()}
         if self.clone_outputs:
             out = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in out.items()}
         return out
@@ -439,14 +480,16 @@ class HipForwardMixin:
     def input_buffer(self, B, stage=None):
         """The persistent (B,3,256,256) fp32 device tensor the launch program reads.  A producer (data loader, bench)
         that writes crops into it and passes it to forward() skips the staging copy.  Needs one prior forward at B."""
+        Bp = batch_bucket(B) if self.batch_buckets else B
         for k, pr in self._programs.items():
-            if k[0] == B and k[2] == stage and k[3] == self.compute_dtype:
-                return pr["io"]["img"]
+            if k[0] == Bp and k[2] == stage and k[3] == self.compute_dtype and not k[7]:
+                return pr["io"]["img"][:B]
         raise RuntimeError("no program for batch %d yet: run one forward first" % B)
 
     def program_for(self, B, stage=None):
         """Introspection for bench / tests: the cached Program of batch size B (after at least one forward)."""
+        Bp = batch_bucket(B) if self.batch_buckets else B
         for k, pr in self._programs.items():
-            if k[0] == B and k[2] == stage and k[3] == self.compute_dtype:
+            if k[0] == Bp and k[2] == stage and k[3] == self.compute_dtype:
                 return pr["prog"]
         return None

@@ -42,17 +42,23 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
     def __init__(self, npoint, p3d_normed, res_log2=3, backbone_name="resnet34", pretrain_backbone=True,
                  num_conv1x1=1, max_batch_size=64, num_graph_module=2, graph_k=20, graph_leaky_slope=0.2):
         super().__init__()
-        if res_log2 != 3:
-            raise ValueError("InitNet_GNN: res_log2 != 3 is not in scope of the HIP program (SURVEY.md 8a: no BASELINE config "
-                             "uses it; the reference accepts it, init.py:85-95)")
-        if num_conv1x1 != 1:
-            raise ValueError("InitNet_GNN: num_conv1x1 != 1 is not in scope of the HIP program (SURVEY.md 8a: no BASELINE config "
-                             "uses it; the reference accepts it, init.py:85-95)")
+        if not 1 <= res_log2 <= 6:
+            raise ValueError("InitNet_GNN: res_log2 must be in 1..6 (1 + 2*res_log2 <= 13 output rows)")
+        if num_conv1x1 < 1:
+            raise ValueError("InitNet_GNN: num_conv1x1 must be >= 1")
         self.num_out_bits = 1 + 2 * res_log2
         self.npoint = npoint
         self.backbone_name = backbone_name
         self.img_backbone = get_timm_backbone(model_name=backbone_name, concat_decoder=True, pretrained=pretrain_backbone)
-        self.conv1x1 = nn.Conv2d(CONV1X1_IN_CHANS[backbone_name], npoint, kernel_size=1, stride=1, padding=0)
+        if num_conv1x1 == 1:
+            self.conv1x1 = nn.Conv2d(CONV1X1_IN_CHANS[backbone_name], npoint, kernel_size=1, stride=1, padding=0)
+        else:                                               # init.py:87-95: same Sequential layout -> keys conv1x1.{0,2,..}
+            layers = [nn.Conv2d(CONV1X1_IN_CHANS[backbone_name], npoint, kernel_size=1, stride=1, padding=0)]
+            for _ in range(num_conv1x1 - 1):
+                layers += [nn.LeakyReLU(negative_slope=0.01), nn.Conv2d(npoint, npoint, kernel_size=1, stride=1, padding=0)]
+            self.conv1x1 = nn.Sequential(*layers)
+        self.num_conv1x1 = num_conv1x1
+        self.res_log2 = res_log2
         self.pre_query_block = nn.ModuleList()
         self.knn_idx = knn(p3d_normed, graph_k)             # (G, N, K) int64, G = 1 or #objects (LM)
         self.graph_k = graph_k
@@ -67,7 +73,7 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
     def _net_cfg(self):
         return dict(kind="init", npoint=self.npoint, backbone=self.backbone_name, img_size=None,
                     init_num_graph_module=len(self.pre_query_block), init_graph_slope=self.graph_leaky_slope,
-                    graph_k=self.graph_k)
+                    graph_k=self.graph_k, init_res_log2=self.res_log2, num_conv1x1=self.num_conv1x1)
 
     def _knn_table(self):
         return self.knn_idx
@@ -76,7 +82,8 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
         """init.py:109-128: returns out (B,7,N) | (out, img_feats) | (out, img_feats, graph_feats)."""
         res = self._run(img, None, want_feats=return_img_feats or return_graph_feats, want_graph=return_graph_feats)
         bits = res["bits"]
-        out = torch.cat([bits[:, 0:4], bits[:, 7:10]], dim=1)
+        r = self.res_log2          # rows of the (B,13,N) logit block: [roi | x bits at 1.. | y bits at 7..]; res_log2 > 3: packed
+        out = torch.cat([bits[:, 0:4], bits[:, 7:10]], dim=1) if r == 3 else bits[:, :1 + 2 * r]
         if return_img_feats:
             return out, res["img_feats"]
         if return_graph_feats:

@@ -95,6 +95,8 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
         self.num_refine_steps = res_log2 - 3
         if not 0 <= self.num_refine_steps <= 3:
             raise ValueError("PoseNet_GNNskip: res_log2 must be in 3..6")
+        if getattr(init_net, "res_log2", 3) != 3:
+            raise ValueError("PoseNet_GNNskip: the init net must predict 1 + 3 + 3 bits (pipeline.py:363-365 splits them so)")
         if graph_k != init_net.graph_k:
             raise ValueError("PoseNet_GNNskip: graph_k must equal the init net's (one shared kNN table)")
         self.cfg = dict(res_log2=res_log2, num_filters=num_filters, query_dims=tuple(query_dims) if query_dims else None,
@@ -124,7 +126,7 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
         c = dict(self.cfg)
         c.update(kind="pose", npoint=self.npoint, backbone=self.init_net.backbone_name,
                  init_num_graph_module=len(self.init_net.pre_query_block),
-                 init_graph_slope=self.init_net.graph_leaky_slope)
+                 init_graph_slope=self.init_net.graph_leaky_slope, num_conv1x1=getattr(self.init_net, "num_conv1x1", 1))
         return c
 
     def _knn_table(self):
@@ -144,6 +146,13 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
         so one flipped bit cannot mask or fake agreement downstream.  Returns the 6-tuple; ids are the teacher's."""
         active = stage if stage is not None else self.num_refine_steps
         return self._outputs(self._run(img, obj_ids, stage=stage, teacher_bits=teacher_bits), active)
+
+    def forward_injected_feats(self, img, feats, stage=None, obj_ids=None, teacher_bits=None):
+        """Test hook: the forward with the backbone's four features GIVEN (NCHW fp32 list, as `img_backbone` returns them in the
+        reference, init.py:111) -- exactly how the reference-made `*_injected` goldens were produced (a timm stub returning preset
+        features), so the whole head is compared with the reference's own outputs directly.  `img` only supplies B and the size."""
+        active = stage if stage is not None else self.num_refine_steps
+        return self._outputs(self._run(img, obj_ids, stage=stage, teacher_bits=teacher_bits, inject_feats=feats), active)
 
     def forward(self, img, p3d_normed, stage=None):
         """pipeline.py:351-384.  `p3d_normed` is accepted for signature parity; it has no numeric effect in the

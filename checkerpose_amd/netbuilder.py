@@ -422,6 +422,21 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_o
     N = cfg["npoint"]
     tp = em.tp
     bb = pfx + "img_backbone."
+    if cfg.get("inject_feats"):
+        # test hook (HipForwardMixin._run(inject_feats=...)): the backbone's four features are GIVEN as NCHW fp32 tensors --
+        # what the reference-made `*_injected` goldens do through their timm stub -- so the head (everything the reference's
+        # own code pins) is compared with the reference directly; a feature the decoder expects inside a concat buffer is
+        # copied into its channel slice (a one-term, no-ReLU cp_fuse_sum_act)
+        assert tp is None
+        feats = []
+        for i, t in enumerate(io["inject"]):
+            a = p.nchw_to_nhwc(t, t.shape[1], t.shape[2], t.shape[3])
+            if feat_outs and feat_outs[i] is not None:
+                a = p.fuse_sum([a], [0], feat_outs[i], relu=False)
+            feats.append(a)
+        if defer_head:
+            return feats, (lambda: _emit_init_head(em, cfg, io, pfx, graph_out, feats))
+        return feats, _emit_init_head(em, cfg, io, pfx, graph_out, feats)
     fused_stem = (tp is None and cfg["backbone"] == "hrnet_w18" and not cfg.get("uint8_input") and p.can_fuse_stem(cfg["img_size"]))
     if fused_stem:                 # layout change + conv1 + conv2 of the HRNet stem in one launch, straight from the NCHW image
         s1, t1 = em.ws.bn_fold(bb + "bn1")
@@ -444,25 +459,30 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
     f = feats[-1]                                           # (B, 8, 8, Cb)
     # conv1x1 Cb -> N, then `view(-1, N, 64).permute(0,2,1)` (init.py:112-114): keypoint n's 8x8 response map is its
     # 64-d feature -> written straight into the (B, N, 64) graph layout through the epilogue strides.
-    w = em.W(pfx + "conv1x1.weight")
+    nc1 = cfg.get("num_conv1x1", 1)
+    c1key = pfx + ("conv1x1" if nc1 == 1 else "conv1x1.%d" % (2 * (nc1 - 1)))
+    for j in range(nc1 - 1):     # init.py:87-95: Conv2d -> [LeakyReLU(0.01) -> Conv2d(N -> N)]*: the activation rides in the producer
+        f = em.linear(f, pfx + "conv1x1.%d" % (2 * j), ACT_LEAKY, 0.01)
+    w = em.W(c1key + ".weight")
     g0 = p.act(1, N, 64)
     npix = f.H * f.W
     if tp is None:
-        p.conv(f, pfx + "conv1x1", w, em._unit(N), em.W(pfx + "conv1x1.bias"), 1, 1, 1, 0, N,
+        p.conv(f, c1key, w, em._unit(N), em.W(c1key + ".bias"), 1, 1, 1, 0, N,
                ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
     else:
-        p.conv(f, pfx + "conv1x1", w, tp.const_vec(N, True), em._bias_vec(pfx + "conv1x1", N), 1, 1, 1, 0, N,
+        p.conv(f, c1key, w, tp.const_vec(N, True), em._bias_vec(c1key, N), 1, 1, 1, 0, N,
                ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+        f_in = f
 
         def bwd_conv1x1():
             if g0.tbuf not in tp.grads:
                 return
             gg = tp.grad_of(g0)                              # (B, N, 64): gy[b, pix, n] = gg[b, n, pix]
-            gy = tp.act(f.H, f.W, N)
+            gy = tp.act(f_in.H, f_in.W, N)
             ggt = gg.tbuf
             tp.strided_to_act(lambda P: P(ggt), tp.dtype, gg.coff, N * gg.cstride, 1, gg.cstride, gy, N, reads=[ggt])
-            tp.bn_bwd(gy, None, None, None, ACT_NONE, 0.0, None, None, tp.pg_ptr(pfx + "conv1x1.bias"))
-            tp.conv_backward(pfx + "conv1x1", w, f, gy, 1, 1, 1, 0)
+            tp.bn_bwd(gy, None, None, None, ACT_NONE, 0.0, None, None, tp.pg_ptr(c1key + ".bias"))
+            tp.conv_backward(c1key, w, f_in, gy, 1, 1, 1, 0)
         tp.tape.append(bwd_conv1x1)
     g = g0
     ng = cfg["init_num_graph_module"]
@@ -472,19 +492,25 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
                         out=graph_out if (last and graph_out is not None) else None)
     if ng == 0 and graph_out is not None:
         raise RuntimeError("init_network_num_graph_module == 0 is not supported by the fused program")
-    # Linear(64 -> 7) (init.py:107,120-122) into the (B,13,N) logit block: rows [roi | x2 x1 x0 | . . . | y2 y1 y0]
+    # Linear(64 -> 1 + 2r) (init.py:107,120-122) into the (B,13,N) logit block: r = 3 -> rows [roi | x2 x1 x0 | . . . | y2 y1 y0]
+    # (the layout PoseNet appends its refinement bits to); an InitNet used alone with another res_log2 writes rows [0, 1 + 2r)
     wl = em.W(pfx + "mlp.weight")
+    nbits = wl.shape[0]
+    r3 = nbits == 7
+    rows = 10 if r3 else nbits
+    rmap = [0, 1, 2, 3, -1, -1, -1, 4, 5, 6] if r3 else None
+    bl = em.W(pfx + "mlp.bias")
     if tp is None:
-        sc10 = em._unit(10)
-        sh10 = torch.cat([em.W(pfx + "mlp.bias")[:4], torch.zeros(3, device=p.device), em.W(pfx + "mlp.bias")[4:]])
+        scv = em._unit(rows)
+        shv = torch.cat([bl[:4], torch.zeros(3, device=p.device), bl[4:]]) if r3 else bl
     else:
-        bl = em.W(pfx + "mlp.bias")
-        sc10, sh10 = tp.const_vec(10, True), tp.live_vec(10, [(0, bl, 0, 4), (7, bl, 4, 3)])
-    p.conv(g, pfx + "mlp", wl.view(7, 64, 1, 1), sc10, sh10,
-           1, 1, 1, 0, 10, row_map=[0, 1, 2, 3, -1, -1, -1, 4, 5, 6], cout_rows=10, out_f32=True,
+        scv = tp.const_vec(rows, True)
+        shv = tp.live_vec(10, [(0, bl, 0, 4), (7, bl, 4, 3)]) if r3 else tp.live_vec(rows, [(0, bl, 0, rows)])
+    p.conv(g, pfx + "mlp", wl.view(nbits, 64, 1, 1), scv, shv,
+           1, 1, 1, 0, rows, row_map=rmap, cout_rows=rows, out_f32=True,
            ostr=(0, 13 * N, 0, 1, N), out_tbuf=io["bits_tb"])
-    if tp is not None:       # incoming gradient: rows [roi, x2 x1 x0, y2 y1 y0] gathered by the autograd hook into (B,7,N)
-        em._out_layer_bwd(pfx + "mlp", wl.view(7, 64, 1, 1), g, 7, io["dinit"], 0, 7 * N, 1, N)
+    if tp is not None:       # incoming gradient: rows [roi, x.., y..] gathered by the autograd hook into (B, 1 + 2r, N)
+        em._out_layer_bwd(pfx + "mlp", wl.view(nbits, 64, 1, 1), g, nbits, io["dinit"], 0, nbits * N, 1, N)
     return g
 
 

@@ -31,7 +31,7 @@ typedef void* cp_stream_t;
 
 enum { CP_F32 = 0, CP_BF16 = 1 };
 enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_LEAKY = 2 };
-enum { CP_LOSS_BCE = 0, CP_LOSS_L1 = 1 };   /* loss_type of losses/code_loss.py ("CE" is not used by train.py:87-88) */
+enum { CP_LOSS_BCE = 0, CP_LOSS_L1 = 1 };   /* loss_type of losses/code_loss.py ("CE": cp_masked_ce_loss) */
 enum {
   CP_OK = 0,
   CP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
@@ -348,6 +348,13 @@ size_t cp_loss_workspace_bytes(void);
 int cp_code_loss(cp_stream_t stream, int loss_type, const float* pred, long long pred_bstride, const float* gt,
                  long long gt_bstride, const float* mask, int B, int nbits, int N, float* loss, float* dpred,
                  long long dpred_bstride, void* workspace);
+
+/* MaskedCodeLoss(loss_type="CE") (losses/code_loss.py:36-37,47-61; not used by train.py:87-88, kept for the class contract):
+ * pred (B,C,N) fp32 class logits (batch stride pred_bstride), gt_class (B,N) class ids as fp32, mask (B,N):
+ * loss = sum_bn mask * (logsumexp_c pred - pred[gt]) / clamp(sum mask, 1); dpred (optional) = d loss / d pred. */
+int cp_masked_ce_loss(cp_stream_t stream, const float* pred, long long pred_bstride, const float* gt_class,
+                      const float* mask, int B, int C, int N, float* loss, float* dpred, long long dpred_bstride,
+                      void* workspace);
 
 /* MaskLoss_interpolate (losses/mask_loss.py:6-17): mean | sigmoid(pred[b,0]) - nearest_resize(gt[b]) |.
  * pred points at channel 0 of the slice the caller passes (train.py:315-316: pred_seg[:, 0:1] / [:, 1:2]), (h,w)

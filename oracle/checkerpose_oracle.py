@@ -279,11 +279,19 @@ BACKBONES = {"hrnet_w18": hrnet_features, "resnet34": resnet34_features}
 # --------------------------------------------------------------------------- the two nets
 def init_net_forward(sd, p, img, knn_idx, npoint, backbone="hrnet_w18", n_graph=2, graph_slope=0.2,
                      img_feats=None):
-    """InitNet_GNN.forward init.py:109-128 (num_conv1x1 == 1).  `img_feats` may be injected to test the
-    head independently of the (unpinned) backbone.  Returns (out (B,7,N), img_feats, graph_feats (B,64,N))."""
+    """InitNet_GNN.forward init.py:109-128.  `img_feats` may be injected to test the head independently of the (unpinned)
+    backbone.  num_conv1x1 > 1 (init.py:87-95: Conv2d, then LeakyReLU(0.01) + Conv2d(N -> N) pairs) is recognised by its
+    state-dict keys `conv1x1.{0,2,..}`; res_log2 by the rows of `mlp.weight`.
+    Returns (out (B,1+2*res_log2,N), img_feats, graph_feats (B,64,N))."""
     if img_feats is None:
         img_feats = BACKBONES[backbone](sd, p + "img_backbone.", img)
-    out = _conv(sd, p + "conv1x1", img_feats[-1])
+    if (p + "conv1x1.weight") in sd:
+        out = _conv(sd, p + "conv1x1", img_feats[-1])
+    else:
+        out, j = _conv(sd, p + "conv1x1.0", img_feats[-1]), 2
+        while (p + "conv1x1.%d.weight" % j) in sd:
+            out = _conv(sd, p + "conv1x1.%d" % j, F.leaky_relu(out, 0.01))
+            j += 2
     g = out.reshape(-1, npoint, 64).permute(0, 2, 1)
     for i in range(n_graph):
         g = static_graph_module(sd, "%spre_query_block.%d" % (p, i), g, knn_idx, graph_slope)

@@ -37,6 +37,23 @@ def code_loss(pred, gt, mask=None, loss_type="BCE"):
     return (raw * m).sum() / denom, d * m / denom
 
 
+def masked_ce_loss(pred, gt_class, mask):
+    """MaskedCodeLoss(loss_type="CE").forward (losses/code_loss.py:36-37,47-61): nn.CrossEntropyLoss(reduction="none") over the
+    class axis of pred (B,C,N) against class ids gt_class (B,1,N), times mask (B,1,N), / clamp(mask.sum(), 1) (num_bits = 1).
+    Returns (loss, d loss / d pred) in float64."""
+    z = pred.astype(np.float64)
+    y = gt_class[:, 0, :].astype(np.int64)
+    m = mask[:, 0, :].astype(np.float64)
+    zs = z - z.max(axis=1, keepdims=True)
+    lse = np.log(np.exp(zs).sum(axis=1))
+    sm = np.exp(zs - lse[:, None, :])
+    picked = np.take_along_axis(zs, y[:, None, :], axis=1)[:, 0, :]
+    denom = max(m.sum(), 1.0)
+    onehot = np.zeros_like(z)
+    np.put_along_axis(onehot, y[:, None, :], 1.0, axis=1)
+    return ((lse - picked) * m).sum() / denom, (sm - onehot) * m[:, None, :] / denom
+
+
 def nearest_index(out_size, in_size):
     """F.interpolate(mode='nearest') source indices (mask_loss.py:14): min(floor(dst * fp32(in/out)), in-1)."""
     scale = np.float32(in_size) / np.float32(out_size)

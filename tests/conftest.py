@@ -16,3 +16,38 @@ def pytest_configure(config):
 def lib():
     from checkerpose_amd import _abi
     return _abi.load()
+
+
+def pytest_sessionstart(session):
+    """`-m gpu` sessions on a GPU box: start the 2-rank data-parallel child job of tests/test_gpu_dp.py NOW, before anything in
+    this process touches the GPU (torch.cuda.device_count() does not initialise it on this image)."""
+    import subprocess
+    import tempfile
+    cfg = session.config
+    cfg._dp_child = None
+    mexpr = cfg.getoption("-m") or ""
+    if "gpu" not in mexpr or "not gpu" in mexpr or cfg.getoption("collectonly", False):
+        return
+    kexpr = cfg.getoption("-k") or ""
+    if kexpr and "dp" not in kexpr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    log = tempfile.NamedTemporaryFile(prefix="dp_child_", suffix=".log", delete=False)
+    env = dict(os.environ, CHECKERPOSE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_step_child.py")],
+                            stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    cfg._dp_child = (proc, log.name)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    job = getattr(session.config, "_dp_child", None)
+    if job is not None and job[0].poll() is None:
+        job[0].kill()

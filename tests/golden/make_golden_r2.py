@@ -2,7 +2,7 @@
 """Round-2 golden vectors, made by running the REFERENCE's own code in the build container (needs /root/reference;
 nothing of the reference travels, only the small outputs of this script are committed):
 
-  python tests/golden/make_golden_r2.py [lm4096] [n2] [sigmoid] [keys]
+  python tests/golden/make_golden_r2.py [lm4096] [n2] [sigmoid] [keys] [ycbv]
 
   lm4096   BASELINE config #5: LM 13-object shared estimator at npt=4096.  Keypoint data (15 x 4096 x 3, from the
            reference's fps pickles) -> checkerpose_amd/data/; `knn` (init.py:27) tables -> knn_lm4096.npz (3 objects in
@@ -14,6 +14,7 @@ nothing of the reference travels, only the small outputs of this script are comm
   sigmoid  from_mask_prob_to_mask / from_code_prob_to_id / from_bit_prob_to_id (pipeline.py:84-127) swept over the
            logits around the largest fp32 z with sigmoid(z) == 0.5 -> sigmoid_threshold.npz
   keys     state-dict key/shape list of the reference module tree (head; backbone = stub) -> head_state_dict_keys.json
+  ycbv     BASELINE config #4: reference `knn` tables of the 21 YCB-V objects at 512 keypoints -> knn_ycbv512.npz
 """
 import json
 import os
@@ -147,6 +148,18 @@ def do_sigmoid():
          ids3=ids3.numpy().astype(np.int16), bit=bit.numpy().astype(np.uint8))
 
 
+def do_ycbv():
+    """BASELINE config #4: the reference's `knn` (init.py:27) on the first 512 FPS keypoints of each of the 21 YCB-V objects
+    (datasets/BOP_DATASETS/ycbv/fps_202212/obj_0000NN.pkl): 3 objects in full + an order-sensitive checksum for all 21."""
+    tabs = []
+    for o in range(1, 22):
+        idx = R_init.knn(p3d(load_fps("ycbv", o), 512), 20)[0].numpy()
+        assert (idx[:, 0] == np.arange(512)).all()
+        tabs.append(idx)
+    save("knn_ycbv512", objs=np.array([1, 11, 21]), idx=np.stack([tabs[0], tabs[10], tabs[20]]).astype(np.int16),
+         checksum=np.array([knn_checksum(t) for t in tabs], dtype=np.int64))
+
+
 def do_keys():
     P512 = p3d(load_fps("lmo", 1), 512)
     _STUB["feats"] = inject_feats(1)
@@ -159,6 +172,6 @@ def do_keys():
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    what = sys.argv[1:] or ["lm4096", "n2", "sigmoid", "keys"]
+    what = sys.argv[1:] or ["lm4096", "n2", "sigmoid", "keys", "ycbv"]
     for w in what:
-        {"lm4096": do_lm4096, "n2": do_n2, "sigmoid": do_sigmoid, "keys": do_keys}[w]()
+        {"lm4096": do_lm4096, "n2": do_n2, "sigmoid": do_sigmoid, "keys": do_keys, "ycbv": do_ycbv}[w]()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Round-3 golden vectors, made by running the REFERENCE's own code in the build container (needs /root/reference; only the
+small outputs are committed):
+
+  python tests/golden/make_golden_r3.py [ce] [init_variants]
+
+  ce             MaskedCodeLoss(loss_type="CE") (losses/code_loss.py:36-37,47-61): value and d/dlogits on seeded class logits
+                 (B, C, N), class ids (B, 1, N), a mixed and an all-zero mask -> ce_loss.npz
+  init_variants  InitNet_GNN with res_log2 = 4 and with num_conv1x1 = 2 (init.py:78,83-95), backbone features injected through the
+                 timm stub -> initnet_variants.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import make_golden as MG  # noqa: E402,F401  (installs the timm stub, puts the reference on sys.path)
+from make_golden import R_init, _STUB, inject_feats, load_fps, p3d, save  # noqa: E402
+from checkerpose_amd.detweights import det_tensor, fill_state_dict_  # noqa: E402
+
+
+def ce_inputs(B, C, N, seed, empty=False):
+    pred = det_tensor("ce_pred", (B, C, N), 3.0, seed)
+    gt = (det_tensor("ce_gt", (B, 1, N), 1.0, seed).abs() * 1e4).long() % C
+    mask = torch.zeros(B, 1, N) if empty else (det_tensor("ce_mask", (B, 1, N), 1.0, seed) > -0.2).float()
+    return pred, gt, mask
+
+
+def do_ce():
+    from losses.code_loss import MaskedCodeLoss
+    out = {}
+    for name, (B, C, N, seed, empty) in {"c8": (3, 8, 40, 31, False), "c64": (2, 64, 24, 32, False), "empty": (2, 5, 16, 33, True)}.items():
+        pred, gt, mask = ce_inputs(B, C, N, seed, empty)
+        with torch.enable_grad():
+            p = pred.clone().requires_grad_(True)
+            loss = MaskedCodeLoss("CE")(p, gt, mask)
+            loss.backward()
+        out[name + "_loss"], out[name + "_grad"] = loss.detach().numpy(), p.grad.numpy()
+        out[name + "_shape"] = np.array([B, C, N, seed, int(empty)])
+    save("ce_loss", **out)
+
+
+def do_init_variants():
+    P512 = p3d(load_fps("lmo", 1), 512)
+    _STUB["mode"], _STUB["feats"] = "inject", inject_feats(2, seed=4)
+    out = {}
+    for name, kw in (("res4", dict(res_log2=4)), ("conv2", dict(num_conv1x1=2))):
+        net = R_init.InitNet_GNN(npoint=512, p3d_normed=P512, backbone_name="hrnet_w18", pretrain_backbone=False, max_batch_size=8,
+                                 num_graph_module=2, graph_k=20, graph_leaky_slope=0.2, **dict(dict(res_log2=3), **kw))
+        fill_state_dict_(net.state_dict(), seed=5)
+        net.eval()
+        o = net(torch.zeros(2, 3, 256, 256))
+        out[name + "_out"] = o.numpy()
+        out[name + "_keys"] = np.array(sorted(net.state_dict().keys()))
+        print(name, tuple(o.shape), float(o.abs().max()))
+    save("initnet_variants", **out)
+
+
+if __name__ == "__main__":
+    torch.set_grad_enabled(False)
+    for w in (sys.argv[1:] or ["ce", "init_variants"]):
+        {"ce": do_ce, "init_variants": do_init_variants}[w]()

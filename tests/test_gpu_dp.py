@@ -1,0 +1,23 @@
+"""GPU: the data-parallel TRAINING step as the driver will launch it -- `python -m torch.distributed.run`, one process per rank,
+real HIP training programs and hipGraph segments with the bucketed asynchronous all-reduce between them -- on the one GPU of
+the test box (two ranks share it; backend gloo, since RCCL needs a device per rank).  The children are started by
+tests/conftest.py at session start, BEFORE this process initialises the GPU (a process that has must not fork+exec on this
+pool), and run beside the other GPU tests; this test only joins them.  What is checked lives in tests/dp_step_child.py."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_dp_training_step_on_one_gpu(request):
+    job = getattr(request.config, "_dp_child", None)
+    if job is None:
+        pytest.skip("the 2-rank child job is only started for `-m gpu` sessions on a box with a GPU")
+    proc, log = job
+    try:
+        rc = proc.wait(timeout=900)
+    except Exception:
+        proc.kill()
+        raise
+    out = open(log).read()
+    assert rc == 0, out[-4000:]
+    assert "DP_STEP_OK world=2" in out, out[-4000:]

@@ -61,6 +61,22 @@ def test_code_loss_slices_of_logit_block_and_weighting():
     np.testing.assert_allclose(bits.grad.cpu().numpy(), ref_bits.grad.numpy(), rtol=2e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", list(TC.CE_CASES))
+def test_masked_ce_loss(name):
+    """MaskedCodeLoss("CE") (code_loss.py:36-37,47-61; cp_masked_ce_loss) vs the reference-made ce_loss.npz and the oracle"""
+    from checkerpose_amd.losses import MaskedCodeLoss
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ce_loss.npz"))
+    pred, gt, mask = TC.ce_inputs(*TC.CE_CASES[name])
+    p = pred.to(DEV).requires_grad_(True)
+    loss = MaskedCodeLoss("CE")(p, gt.to(DEV), mask.to(DEV))
+    (loss * 1.0).backward()
+    np.testing.assert_allclose(loss.item(), g[name + "_loss"], rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g[name + "_grad"], rtol=2e-5, atol=1e-8)
+    ol, og = TO.masked_ce_loss(pred.numpy(), gt.numpy(), mask.numpy())
+    np.testing.assert_allclose(loss.item(), ol, rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), og, rtol=2e-5, atol=1e-8)
+
+
 @pytest.mark.parametrize("name", list(TC.MASK_CASES))
 def test_mask_loss(name):
     from checkerpose_amd.losses import MaskLoss_interpolate

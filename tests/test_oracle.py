@@ -140,6 +140,47 @@ def test_knn_lm4096_matches_reference():
     assert [_knn_checksum(idx[o]) for o in range(15)] == g["checksum"].tolist()
 
 
+def test_knn_ycbv512_matches_reference():
+    """BASELINE config #4: one kNN graph per YCB-V object (the reference trains one network per object, train.py:384,396).
+    Objects 1 / 11 / 21 against the reference's tables in full (membership), all 21 through the order-sensitive checksum;
+    the PRODUCT's knn (model/init.py) must give the same tables, since those are what the device kernels gather through."""
+    from checkerpose_amd.model.init import knn
+    from tests.common import ycbv_p3d
+    g = golden("knn_ycbv512")
+    tabs = [O.knn(ycbv_p3d(o, 512), 20)[0].numpy() for o in range(1, 22)]
+    for k, o in enumerate(g["objs"]):
+        assert (np.sort(tabs[o - 1], 1) == np.sort(g["idx"][k].astype(np.int64), 1)).all()
+    assert [_knn_checksum(t) for t in tabs] == g["checksum"].tolist()
+    for o in (1, 7, 21):
+        assert torch.equal(knn(ycbv_p3d(o, 512), 20)[0], torch.from_numpy(tabs[o - 1]))
+
+
+INIT_VARIANTS = {"res4": dict(res_log2=4), "conv2": dict(num_conv1x1=2)}
+
+
+def build_init_variant(name):
+    from checkerpose_amd.detweights import fill_state_dict_
+    from checkerpose_amd.model.init import InitNet_GNN
+    kw = dict(dict(res_log2=3), **INIT_VARIANTS[name])
+    net = InitNet_GNN(npoint=512, p3d_normed=ape_p3d(512), backbone_name="hrnet_w18", pretrain_backbone=False, max_batch_size=8,
+                      num_graph_module=2, graph_k=20, graph_leaky_slope=0.2, **kw)
+    fill_state_dict_(net.state_dict(), seed=5)
+    return net.eval()
+
+
+def test_initnet_variants_match_reference():
+    """InitNet_GNN(res_log2=4) and InitNet_GNN(num_conv1x1=2) (init.py:78,83-95): the drop-in's head state-dict keys equal the
+    reference module's, and the oracle reproduces the reference's output on injected features (initnet_variants.npz)."""
+    g = golden("initnet_variants")
+    for name in INIT_VARIANTS:
+        net = build_init_variant(name)
+        sd = net.state_dict()
+        assert sorted(k for k in sd if not k.startswith("img_backbone.")) == list(g[name + "_keys"])
+        out, _, _ = O.init_net_forward(sd, "", None, net.knn_idx, 512, img_feats=inject_feats(2, seed=4))
+        assert np.abs(out.numpy() - g[name + "_out"]).max() <= 1e-4
+        assert net.num_out_bits == out.shape[1]
+
+
 def test_e2e_lm4096_matches_reference():
     """config #5 end to end: the reference's pipeline_lm.PoseNet_GNNskip at npt=4096 with per-sample graphs."""
     g = golden("e2e_lm4096_injected")

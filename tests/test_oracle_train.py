@@ -21,6 +21,17 @@ def test_code_loss_matches_reference(name):
     np.testing.assert_allclose(grad, G["code_%s_grad" % name], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("name", list(TC.CE_CASES))
+def test_masked_ce_loss_matches_reference(name):
+    """MaskedCodeLoss("CE") (code_loss.py:36-37,47-61), pinned by tests/golden/ce_loss.npz (make_golden_r3.py)"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ce_loss.npz"))
+    pred, gt, mask = TC.ce_inputs(*TC.CE_CASES[name])
+    assert list(g[name + "_shape"]) == [int(v) for v in TC.CE_CASES[name]]
+    loss, grad = TO.masked_ce_loss(pred.numpy(), gt.numpy(), mask.numpy())
+    np.testing.assert_allclose(loss, g[name + "_loss"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(grad, g[name + "_grad"], rtol=1e-5, atol=1e-8)
+
+
 @pytest.mark.parametrize("name", list(TC.MASK_CASES))
 def test_mask_loss_matches_reference(name):
     c = TC.MASK_CASES[name]

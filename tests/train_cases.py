@@ -106,3 +106,17 @@ def trainstep_targets(c):
     m_vis = _binary((B, 128, 128), 54)
     m_full = (det_tensor((B, 128, 128), 55) > -0.3).float()
     return roi_gt, x_gt, y_gt, m_vis, m_full
+
+
+# MaskedCodeLoss("CE") cases of tests/golden/make_golden_r3.py: name -> (B, C, N, seed, empty mask)
+CE_CASES = {"c8": (3, 8, 40, 31, False), "c64": (2, 64, 24, 32, False), "empty": (2, 5, 16, 33, True)}
+
+
+def ce_inputs(B, C, N, seed, empty=False):
+    """same closed form as make_golden_r3.py:ce_inputs"""
+    import torch
+    from checkerpose_amd.detweights import det_tensor as _dt
+    pred = _dt("ce_pred", (B, C, N), 3.0, seed)
+    gt = (_dt("ce_gt", (B, 1, N), 1.0, seed).abs() * 1e4).long() % C
+    mask = torch.zeros(B, 1, N) if empty else (_dt("ce_mask", (B, 1, N), 1.0, seed) > -0.2).float()
+    return pred, gt, mask
