@@ -92,6 +92,13 @@ SIGNATURES = {
     "cp_edgeconv_fused_weight_bytes": (C.c_size_t, [_I, _I]),
     "cp_pack_edgeconv_fused_weight": (_I, [_P, _P, _I, _I, _P]),
     "cp_edgeconv_fused": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_edgeconv_tiled_supported": (_I, [_I, _I, _I, _I, _I]),
+    "cp_edgeconv_tiled_weight_bytes": (C.c_size_t, [_I, _I]),
+    "cp_edgeconv_tiled_table_bytes": (C.c_size_t, [_I, _I, _I]),
+    "cp_pack_edgeconv_tiled_weight": (_I, [_P, _P, _I, _I, _P]),
+    "cp_edgeconv_tiled": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_permute_rows": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
+    "cp_permute_cols": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "cp_index2feat_conv_supported": (_I, [_I, _I, _I]),
     "cp_index2feat_conv_weight_bytes": (C.c_size_t, []),
     "cp_pack_index2feat_conv_weight": (_I, [_P, _P, _P]),

@@ -1,0 +1,401 @@
+// EdgeConv (StaticGraph_module: reference init.py:54-68 == pipeline.py:45-59, LM twin pipeline_lm.py:55-57) for LARGE graphs
+// (N = 1024 .. 4096 keypoints; BASELINE config #5 "npt=4096 dense keypoints, stress GNN gather / LDS"): the LDS-staged gather of
+// edgeconv_fused.hip, tiled.  A crop's P' table no longer fits in one CU's LDS (4096 rows x 256 ch x 2 B = 2 MB), but kNN
+// neighbourhoods are spatially local: the host renumbers the keypoints into compact patches of 512 (graph_sched.tile_schedule),
+// and a patch's neighbour rows are its own 512 rows plus a thin rim ("halo", 170-370 rows on the LM objects).  Two launches per
+// layer, both one 8-wave workgroup per (crop, patch) with the patch's 512 x rows in REGISTERS (the MFMA B operand):
+//
+//   edgeconv_ptable_kernel   P' = s * (W1 x) for every row, exactly once, written as ORDER-PRESERVING int16 keys of its bf16 value
+//                            in plane-major order [crop][8-channel plane][row][16 B] (the LDS table's own layout, so staging a
+//                            patch's rows is a stream of full 1 KB segments and staging its halo rows 16-byte pieces);
+//   edgeconv_tiled_kernel    per 32-channel slice: the table (512 own + HPAD halo rows, 4 planes) arrives by LDS-DMA with per-lane
+//                            source rows (no registers, no VALU); gather-max over the K neighbours out of LDS (one ds_read_b128 per
+//                            neighbour and lane, v_pk_max_i16, neighbour lists as table SLOTS, scheduled against bank conflicts);
+//                            Q' = s * ((W2 - W1) x) + t on the MFMA pipe from the register-resident rows while the NEXT slice's
+//                            table streams in; out = leaky(max_k P'_j(k) + Q'_i), 16 B per lane.
+// HBM / Infinity-Cache traffic per crop and layer at N = 4096, C = C' = 256: x 2 x 2 MB in, keys 2 MB out + 2.8 MB back in, out 2 MB
+// (the round-1 path: [P'|Q'] 4 MB out and K = 20 row reads per keypoint = 42 MB through the L2).
+#include "common.h"
+
+namespace {
+
+constexpr int ET_BLK = 512, ET_KMAX = 20;
+constexpr int ET_IDX = ET_BLK * ET_KMAX * 2;                // 20 480: neighbour slots, int16
+constexpr int ET_AFF = 2 * 256 * 4;                         // scale | shift of the C' <= 256 Q rows
+
+struct EdgeTiledParams {
+  const void* x; const void* w; const float* scale; const float* shift;
+  const int32_t* halo; const int16_t* nbr; const int32_t* gids; void* ptab; void* out;
+  int in_cs, in_coff, out_cs, out_coff, B, N, NB, K, Cout, HPAD;
+  float slope;
+};
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sortable(uint32_t w) {         // two bf16 -> two int16 keys, monotone in the float value
+  return w ^ (((w >> 15) & 0x00010001u) * 0x7fffu);                // (involution: the same call maps keys back)
+}
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+
+// blockIdx -> (crop, patch): all patches of a crop on ONE XCD (blockIdx % 8), so the halo pieces they share are hits in its L2
+__device__ __forceinline__ void crop_patch(int NB, int B, int& b, int& t) {
+  const int label = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  b = label + 8 * (jb / NB);
+  t = jb % NB;
+}
+
+// ------------------------------------------------------------------------------------------------ launch 1: the key table
+// weights: the P halves of cp_pack_edgeconv_fused_weight's image ([64-channel slice][half][32-deep chunk][tile][lane][8 bf16])
+template <int CIN>
+__global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledParams p) {
+  constexpr int KC = CIN / 32;
+  constexpr int HALF = KC * 4 * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sW = smem;                                   // 2 x HALF
+  float* const sScale = (float*)(smem + 2 * HALF);                  // [Cout]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  int b, t;
+  crop_patch(p.NB, p.B, b, t);
+  if (b >= p.B) return;                                             // whole workgroup, before any barrier
+  const int nslice = p.Cout / 64;
+  const u32x4* const wg = (const u32x4*)p.w;
+  auto w_issue = [&](int s) {
+    constexpr int PIECES = HALF / 16;
+#pragma unroll
+    for (int k = 0; k < (PIECES + 511) / 512; ++k) {
+      const int i0 = wave * 64 + 512 * k;
+      if (i0 < PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)(2 * s) * PIECES + i0 + lane),
+                                         (__attribute__((address_space(3))) void*)(sW + (s & 1) * HALF + i0 * 16), 16, 0, 0);
+    }
+  };
+  w_issue(0);
+  for (int i = tid; i < p.Cout; i += 512) sScale[i] = p.scale[i];
+  u32x4 xa[4][KC];
+  const size_t row0 = (size_t)b * p.N + (size_t)t * ET_BLK + wave * 64;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
+  __syncthreads();
+  unsigned char* const tab = (unsigned char*)p.ptab + (size_t)b * (p.Cout / 8) * p.N * 16;
+  for (int s = 0; s < nslice; ++s) {
+    if (s + 1 < nslice) w_issue(s + 1);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* const wb = sW + (s & 1) * HALF + lane * 16;
+    u32x4 wf[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *(const u32x4*)(wb + nt * 1024);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if (kc + 1 < KC) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[(kc + 1) & 1][nt] = *(const u32x4*)(wb + ((kc + 1) * 4 + nt) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
+                                                               acc[f][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane (x, q): keypoint row0 + 16 f + x, channels 64 s + 16 q + 4 nt + reg = planes 8 s + 2 q, 8 s + 2 q + 1
+    const int c0 = s * 64 + q * 16;
+    float sc[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 s4 = *(const f32x4*)(sScale + c0 + 4 * nt);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sc[4 * nt + j] = s4[j];
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      u32x4 lo, hi;
+      lo.x = sortable(pack_bf16x2(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+      lo.y = sortable(pack_bf16x2(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+      lo.z = sortable(pack_bf16x2(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+      lo.w = sortable(pack_bf16x2(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+      hi.x = sortable(pack_bf16x2(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+      hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+      hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+      hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+      const size_t r = (size_t)t * ET_BLK + wave * 64 + f * 16 + x;
+      unsigned char* dst = tab + ((size_t)(8 * s + 2 * q) * p.N + r) * 16;
+      *(u32x4*)dst = lo;
+      *(u32x4*)(dst + (size_t)p.N * 16) = hi;
+    }
+    __syncthreads();                                                // next slice's weights have landed, this buffer is free
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launch 2: gather + Q'
+// weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt = output channel
+// 32 slice + (r >> 2) * 8 + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels 32 s + 8 q + 4 nt + reg
+template <int CIN>
+__global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledParams p) {
+  constexpr int KC = CIN / 32;
+  constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int T = ET_BLK + p.HPAD;
+  const int PLANE = T * 16;                                         // a multiple of 256 B: bank slot = row mod 16
+  unsigned char* const sP = smem;                                   // [4 planes][T rows][16 B]
+  unsigned char* const sW = smem + 4 * PLANE;                       // 2 x WQ
+  int16_t* const sIdx = (int16_t*)(sW + 2 * WQ);
+  float* const sScale = (float*)((unsigned char*)sIdx + ET_IDX);    // [Cout] then shift [Cout] at + 256
+  float* const sShift = sScale + 256;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  int b, t;
+  crop_patch(p.NB, p.B, b, t);
+  if (b >= p.B) return;
+  const int nslice = p.Cout / 32;
+  const int g = p.gids ? p.gids[b] : 0;
+  const int32_t* const halo = p.halo + ((size_t)g * p.NB + t) * p.HPAD;
+  const unsigned char* const tab = (const unsigned char*)p.ptab + (size_t)b * (p.Cout / 8) * p.N * 16;
+
+  // table of slice s: plane pl <- global plane 4 s + pl; 64-row chunks: own rows are one contiguous 1 KB segment, halo rows
+  // 16-byte pieces at per-lane rows.  (4 planes x (8 + HPAD / 64) chunks, dealt round-robin to the 8 waves.)
+  const int nchunk = 8 + p.HPAD / 64;
+  auto table_issue = [&](int s) {
+    for (int c = wave; c < 4 * nchunk; c += 8) {
+      const int pl = c / nchunk, ch = c - pl * nchunk;
+      const int slot = ch * 64 + lane;
+      const int row = ch < 8 ? t * ET_BLK + slot : halo[slot - ET_BLK];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(4 * s + pl) * p.N + row) * 16),
+                                       (__attribute__((address_space(3))) void*)(sP + pl * PLANE + ch * 1024), 16, 0, 0);
+    }
+  };
+  const u32x4* const wg = (const u32x4*)p.w;
+  auto w_issue = [&](int s) {
+    constexpr int PIECES = WQ / 16;
+#pragma unroll
+    for (int k = 0; k < (PIECES + 511) / 512; ++k) {
+      const int i0 = wave * 64 + 512 * k;
+      if (i0 < PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)s * PIECES + i0 + lane),
+                                         (__attribute__((address_space(3))) void*)(sW + (s & 1) * WQ + i0 * 16), 16, 0, 0);
+    }
+  };
+  table_issue(0);
+  w_issue(0);
+  {
+    const int16_t* gi = p.nbr + ((size_t)g * p.NB + t) * ET_BLK * p.K;
+    for (int i = tid; i < ET_BLK * p.K; i += 512) sIdx[(i / p.K) * ET_KMAX + (i % p.K)] = gi[i];
+  }
+  for (int i = tid; i < p.Cout; i += 512) { sScale[i] = p.scale[p.Cout + i]; sShift[i] = p.shift[p.Cout + i]; }
+  u32x4 xa[4][KC];
+  const size_t row0 = (size_t)b * p.N + (size_t)t * ET_BLK + wave * 64;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
+  __syncthreads();                                                  // table(0), weights(0), lists, affine: all landed
+
+  for (int s = 0; s < nslice; ++s) {
+    if (s + 1 < nslice) w_issue(s + 1);                             // other buffer: its readers (Q phase s - 1) passed the last barrier
+    // ---- gather-max over the K neighbours out of the LDS table: lane (x, q) = keypoint x of fragment f, plane q
+    uint32_t m[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int16_t* my = sIdx + (wave * 64 + f * 16 + x) * ET_KMAX;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[f][j] = 0x80008000u;             // int16 minimum
+      const unsigned char* const pq = sP + q * PLANE;
+      for (int k = 0; k < p.K; k += 4) {                             // K is a multiple of 4 (20)
+        const u32x2 i4 = *(const u32x2*)(my + k);
+        const u32x4 a = *(const u32x4*)(pq + (i4.x & 0xffffu) * 16), c = *(const u32x4*)(pq + (i4.x >> 16) * 16);
+        const u32x4 d = *(const u32x4*)(pq + (i4.y & 0xffffu) * 16), e = *(const u32x4*)(pq + (i4.y >> 16) * 16);
+        m[f][0] = pkmax(pkmax(m[f][0], a.x), pkmax(c.x, pkmax(d.x, e.x)));
+        m[f][1] = pkmax(pkmax(m[f][1], a.y), pkmax(c.y, pkmax(d.y, e.y)));
+        m[f][2] = pkmax(pkmax(m[f][2], a.z), pkmax(c.z, pkmax(d.z, e.z)));
+        m[f][3] = pkmax(pkmax(m[f][3], a.w), pkmax(c.w, pkmax(d.w, e.w)));
+      }
+    }
+    __syncthreads();                                                // every gather of this slice is done: the table is free
+    if (s + 1 < nslice) table_issue(s + 1);                         // ... and streams in under the Q' GEMM below
+    // ---- Q' = s * ((W2 - W1) x) + t for this slice's 32 channels, from the register-resident rows
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const unsigned char* const wb = sW + (s & 1) * WQ + lane * 16;
+    u32x4 wf[2][2];
+    wf[0][0] = *(const u32x4*)wb; wf[0][1] = *(const u32x4*)(wb + 1024);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if (kc + 1 < KC) {
+        wf[(kc + 1) & 1][0] = *(const u32x4*)(wb + ((kc + 1) * 2) * 1024);
+        wf[(kc + 1) & 1][1] = *(const u32x4*)(wb + ((kc + 1) * 2 + 1) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
+                                                               acc[f][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int c0 = s * 32 + q * 8;
+    const f32x4 s0 = *(const f32x4*)(sScale + c0), s1 = *(const f32x4*)(sScale + c0 + 4);
+    const f32x4 t0 = *(const f32x4*)(sShift + c0), t1 = *(const f32x4*)(sShift + c0 + 4);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w2 = sortable(m[f][j]);                       // channels 2 j, 2 j + 1 of this lane's 8
+        const int nt = j >> 1, r = (j & 1) * 2;
+        const float sa = nt ? s1[r] : s0[r], sb = nt ? s1[r + 1] : s0[r + 1];
+        const float ta = nt ? t1[r] : t0[r], tb = nt ? t1[r + 1] : t0[r + 1];
+        const float y0 = __uint_as_float(w2 << 16) + (acc[f][nt][r] * sa + ta);
+        const float y1 = __uint_as_float(w2 & 0xffff0000u) + (acc[f][nt][r + 1] * sb + tb);
+        v[2 * j] = y0 > 0.f ? y0 : y0 * p.slope;
+        v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
+      }
+      uint16_t* dst = (uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0;
+      *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
+    }
+    __syncthreads();                                                // table(s + 1) and weights(s + 1) landed; weights(s) free
+  }
+}
+
+// Q halves, 32-channel slices (see the kernel's header comment)
+__global__ void pack_edgeconv_tiled_q_kernel(const float* __restrict__ wpq, uint16_t* __restrict__ out, int Cin, int Cout, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int KC = Cin / 32;
+  const int e = (int)(i % 8);
+  const int lane = (int)((i / 8) % 64);
+  size_t blk = i / 512;
+  const int nt = (int)(blk % 2); blk /= 2;
+  const int kc = (int)(blk % KC);
+  const int s = (int)(blk / KC);
+  const int r = lane & 15, q = lane >> 4;
+  const int c = s * 32 + (r >> 2) * 8 + nt * 4 + (r & 3);
+  const int cin = kc * 32 + q * 8 + e;
+  out[i] = (uint16_t)f32_to_bf16_bits(wpq[((size_t)(Cout + c)) * Cin + cin]);
+}
+
+// keypoint renumbering at the program's boundary.  rows: out[b, i, :] = in[b, perm[g, i], :] (row_bytes a multiple of 16)
+__global__ __launch_bounds__(256) void permute_rows_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ gids, int B, int N, int pieces) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * N * pieces) return;
+  const int pc = (int)(i % pieces);
+  const size_t r = i / pieces;
+  const int n = (int)(r % N), b = (int)(r / N);
+  const int g = gids ? gids[b] : 0;
+  out[i] = in[((size_t)b * N + perm[(size_t)g * N + n]) * pieces + pc];
+}
+// columns of (B, R, N) arrays of 4- or 8-byte elements: scatter = 1: out[b, r, perm[g, i]] = in[b, r, i] (internal -> original order),
+// scatter = 0: out[b, r, i] = in[b, r, perm[g, i]] (original -> internal)
+template <typename T>
+__global__ __launch_bounds__(256) void permute_cols_kernel(const T* __restrict__ in, T* __restrict__ out, const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ gids, int B, int R, int N, int scatter) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * R * N) return;
+  const int n = (int)(i % N);
+  const size_t br = i / N;
+  const int b = (int)(br / R);
+  const int g = gids ? gids[b] : 0;
+  const int pn = perm[(size_t)g * N + n];
+  if (scatter) out[br * N + pn] = in[i];
+  else out[i] = in[br * N + pn];
+}
+
+size_t tiled_lds(int Cin, int HPAD) { return (size_t)4 * (ET_BLK + HPAD) * 16 + (size_t)2 * (Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF; }
+
+}  // namespace
+
+extern "C" int cp_edgeconv_tiled_supported(int N, int K, int Cin, int Cout, int HPAD) {
+  return (N > ET_BLK && N % ET_BLK == 0 && N <= 32768 && K > 0 && K <= ET_KMAX && K % 4 == 0 && (Cin == 64 || Cin == 256) && Cout >= 64 &&
+          Cout % 64 == 0 && Cout <= 256 && HPAD >= 64 && HPAD % 64 == 0 && tiled_lds(Cin, HPAD) <= 160 * 1024) ? 1 : 0;
+}
+
+extern "C" size_t cp_edgeconv_tiled_weight_bytes(int Cin, int Cout) { return (size_t)Cout * Cin * 2; }
+extern "C" size_t cp_edgeconv_tiled_table_bytes(int B, int N, int Cout) { return (size_t)B * N * Cout * 2; }
+
+extern "C" int cp_pack_edgeconv_tiled_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed) {
+  if (!wpq || !packed || !cp_edgeconv_tiled_supported(2 * ET_BLK, 4, Cin, Cout, 64)) return CP_ERR_INVALID;
+  if (!cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const size_t total = (size_t)Cout * Cin;
+  CP_LAUNCH(pack_edgeconv_tiled_q_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpq, (uint16_t*)packed, Cin, Cout, total);
+  return cp_check_launch();
+}
+
+extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w_fused,
+                                 const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo,
+                                 const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
+                                 int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope) {
+  if (!x || !packed_w_fused || !packed_w_q || !scale || !shift || !halo || !nbr || !key_table || !out || B <= 0 || G <= 0) return CP_ERR_INVALID;
+  if (!cp_edgeconv_tiled_supported(N, K, Cin, Cout, HPAD)) return CP_ERR_INVALID;
+  if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + Cout > out_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(x) || !cp_aligned16(packed_w_fused) || !cp_aligned16(packed_w_q) || !cp_aligned16(scale) || !cp_aligned16(shift) ||
+      !cp_aligned16(out) || !cp_aligned16(key_table) || !cp_aligned16(nbr))
+    return CP_ERR_ALIGN;
+  const size_t lds1[2] = {(size_t)2 * 2 * 4 * 1024 + 1024, (size_t)2 * 8 * 4 * 1024 + 1024};      // Cin = 64 / 256
+  const size_t lds2 = tiled_lds(Cin, HPAD);
+  static size_t attr1 = 0, attr2 = 0;                       // largest dynamic-LDS size the kernels were allowed so far
+  if (attr1 < lds1[1]) {
+    if (hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[0]) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[1]) != hipSuccess)
+      return CP_ERR_HIP;
+    attr1 = lds1[1];
+  }
+  if (attr2 < lds2) {
+    const int want = (int)tiled_lds(256, (int)((160 * 1024 - tiled_lds(256, 0)) / 64 / 64) * 64);    // the largest supported table
+    if (hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
+      return CP_ERR_HIP;
+    attr2 = (size_t)want;
+  }
+  EdgeTiledParams p;
+  p.x = x; p.scale = scale; p.shift = shift; p.halo = halo; p.nbr = nbr; p.gids = graph_ids; p.ptab = key_table; p.out = out;
+  p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.N = N; p.NB = N / ET_BLK; p.K = K;
+  p.Cout = Cout; p.HPAD = HPAD; p.slope = slope;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(((B + 7) / 8) * p.NB * 8);
+  p.w = packed_w_fused;
+  if (Cin == 64) CP_LAUNCH((edgeconv_ptable_kernel<64>), dim3(grid), dim3(512), lds1[0], st, p);
+  else CP_LAUNCH((edgeconv_ptable_kernel<256>), dim3(grid), dim3(512), lds1[1], st, p);
+  p.w = packed_w_q;
+  if (Cin == 64) CP_LAUNCH((edgeconv_tiled_kernel<64>), dim3(grid), dim3(512), lds2, st, p);
+  else CP_LAUNCH((edgeconv_tiled_kernel<256>), dim3(grid), dim3(512), lds2, st, p);
+  return cp_check_launch();
+}
+
+extern "C" int cp_permute_rows(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids,
+                               int B, int N, int row_bytes) {
+  if (!in || !out || !perm || B <= 0 || N <= 0 || row_bytes <= 0 || row_bytes % 16) return CP_ERR_INVALID;
+  if (!cp_aligned16(in) || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  const size_t total = (size_t)B * N * (row_bytes / 16);
+  CP_LAUNCH(permute_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)in, (u32x4*)out,
+            perm, graph_ids, B, N, row_bytes / 16);
+  return cp_check_launch();
+}
+
+extern "C" int cp_permute_cols(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids,
+                               int B, int R, int N, int elem_bytes, int scatter) {
+  if (!in || !out || !perm || B <= 0 || R <= 0 || N <= 0 || (elem_bytes != 4 && elem_bytes != 8)) return CP_ERR_INVALID;
+  const size_t total = (size_t)B * R * N;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (elem_bytes == 4)
+    CP_LAUNCH(permute_cols_kernel<uint32_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)in, (uint32_t*)out, perm, graph_ids, B, R, N, scatter);
+  else
+    CP_LAUNCH(permute_cols_kernel<uint64_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint64_t*)in, (uint64_t*)out, perm, graph_ids, B, R, N, scatter);
+  return cp_check_launch();
+}

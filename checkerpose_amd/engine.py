@@ -32,6 +32,7 @@ USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet st
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
 #   crossover against the tiled launches (tools/batch_sweep.py, MI355X): chains win from 64 crops, stem + EdgeConv from 96
 USE_EDGE_FUSED = os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED", "1") != "0"   # EdgeConv layer (node GEMM + gather-max) in one launch
+USE_EDGE_TILED = os.environ.get("CHECKERPOSE_AMD_EDGE_TILED", "1") != "0"   # N > 512: patches of 512 keypoints, table slices in LDS (cp_edgeconv_tiled)
 EDGE_FUSED_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED_MIN_BATCH", "96"))   # one workgroup per crop: needs crops to fill the chip
 CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "40"))   # below: per-conv launches (a crop's chain runs on ONE CU)
 NO_RECYCLE = os.environ.get("CHECKERPOSE_AMD_NO_RECYCLE", "0") == "1"   # debugging aid: every workspace tensor gets its own bytes
@@ -718,6 +719,65 @@ class Program:
         self.flops += fl
         self.conv_log.append((wkey, self.B * N, Co2, Cin, fl, "edge_fused", self.B * N * (Cin + Co2 // 2) * self.es + Co2 * Cin * self.es))
         return out
+
+    def can_tile_edgeconv(self, N, K, Cin, Cout, HPAD):
+        """large graphs: one workgroup per (crop, patch of 512 keypoints) -- needs B * N / 512 workgroups to fill the chip"""
+        return (USE_EDGE_TILED and self.dtype == CP_BF16 and N > 512 and N % 512 == 0 and self.B * (N // 512) >= EDGE_FUSED_MIN_BATCH
+                and bool(self.lib.cp_edgeconv_tiled_supported(N, K, Cin, Cout, HPAD)))
+
+    def edge_tiled(self, x: Act, wkey, wpq, scale, shift, tiled, gids_t, out: Act, K, G, slope):
+        """whole EdgeConv layer at N > 512 (cp_edgeconv_tiled: key-table launch + LDS-staged gather launch); x / out rows are in
+        the INTERNAL keypoint order of `tiled` (graph_sched.tile_schedule, device tensors)"""
+        Co2, Cin = wpq.shape[0], wpq.shape[1]
+        Co, N = Co2 // 2, x.W
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        ck = ("edge_fused", wkey)
+        if ck not in self.ws.cache:
+            buf = torch.empty(self.lib.cp_edgeconv_fused_weight_bytes(Cin, Co), dtype=torch.uint8, device=self.device)
+            w2 = wpq.reshape(Co2, Cin).contiguous()
+            self.ws.keep.append(w2)
+            _abi.check(self.lib.cp_pack_edgeconv_fused_weight(st, w2.data_ptr(), Cin, Co, buf.data_ptr()), "cp_pack_edgeconv_fused_weight")
+            self.ws.cache[ck] = (buf, scale.contiguous(), shift.contiguous())
+        buf, sc, sh = self.ws.cache[ck]
+        cq = ("edge_tiled_q", wkey)
+        if cq not in self.ws.cache:
+            bq = torch.empty(self.lib.cp_edgeconv_tiled_weight_bytes(Cin, Co), dtype=torch.uint8, device=self.device)
+            w2 = wpq.reshape(Co2, Cin).contiguous()
+            self.ws.keep.append(w2)
+            _abi.check(self.lib.cp_pack_edgeconv_tiled_weight(st, w2.data_ptr(), Cin, Co, bq.data_ptr()), "cp_pack_edgeconv_tiled_weight")
+            self.ws.cache[cq] = bq
+        bq = self.ws.cache[cq]
+        ktab = self.tensor(self.lib.cp_edgeconv_tiled_table_bytes(self.B, N, Co), es=1)
+        self.keep += [buf, sc, sh, bq, tiled["halo"], tiled["nbr"]]
+        fn = self.lib.cp_edgeconv_tiled
+        xt, ot = x.tbuf, out.tbuf
+        gp = gids_t.data_ptr() if gids_t is not None else None
+        a = (buf.data_ptr(), bq.data_ptr(), sc.data_ptr(), sh.data_ptr(), tiled["halo"].data_ptr(), tiled["nbr"].data_ptr(), gp)
+        HPAD = tiled["HPAD"]
+        self._add(fn, lambda P: (P(xt), x.cstride, x.coff) + a + (P(ktab), P(ot), out.cstride, out.coff, self.B, N, K, Cin, Co, G, HPAD, slope),
+                  "edge_tiled:" + wkey, [xt], [ot, ktab])
+        fl = 2 * self.B * N * Cin * Co2
+        self.flops += fl
+        self.conv_log.append((wkey, self.B * N, Co2, Cin, fl, "edge_tiled", self.B * N * (Cin + Co) * self.es + Co2 * Cin * self.es))
+        return out
+
+    def permute_rows(self, x: Act, out: Act, perm_t, gids_t):
+        """out[b, i, :] = x[b, perm[g_b, i], :] over whole (B, N, cstride) rows (cp_permute_rows)"""
+        assert x.coff == 0 and out.coff == 0 and x.cstride == out.cstride and (x.cstride * self.es) % 16 == 0
+        fn = self.lib.cp_permute_rows
+        xt, ot = x.tbuf, out.tbuf
+        gp = gids_t.data_ptr() if gids_t is not None else None
+        self.keep.append(perm_t)
+        self._add(fn, lambda P: (P(xt), P(ot), perm_t.data_ptr(), gp, x.B, x.W, x.cstride * self.es), "permute_rows", [xt], [ot])
+        return out
+
+    def permute_cols(self, in_t, out_t, perm_t, gids_t, R, N, scatter):
+        """(B, R, N) caller-owned arrays: scatter: out[b, r, perm[i]] = in[b, r, i]; else out[b, r, i] = in[b, r, perm[i]]"""
+        fn = self.lib.cp_permute_cols
+        gp = gids_t.data_ptr() if gids_t is not None else None
+        self.keep += [perm_t, in_t, out_t]
+        a = (in_t.data_ptr(), out_t.data_ptr(), perm_t.data_ptr(), gp, self.B, R, N, in_t.element_size(), 1 if scatter else 0)
+        self._add(fn, lambda P: a, "permute_cols", [self.raw(in_t)], [self.raw(out_t)])
 
     def can_gather_patch(self, f: Act, N, E_ch, k):
         """gathered patch conv: 4 N rows per crop instead of (H+1)(W+1) positions -- pays from 2 x 4 N < (H+1)(W+1)"""

@@ -147,6 +147,7 @@ class HipForwardMixin:
         self._programs, self._stores, self._idx_dev = {}, {}, None
         self._train_programs = {}
         self._sig_tensors = None
+        self._tiled = None
         # the owning PoseNet folded this init net's weights into ITS programs, and vice versa: drop those too
         for other in (getattr(self, "_owner", None), getattr(self, "init_net", None)):
             other = other() if callable(other) and not isinstance(other, torch.nn.Module) else other
@@ -184,6 +185,7 @@ class HipForwardMixin:
             self._idx_dev = self._knn_table().to(torch.int32).contiguous().to(device)
         idx = self._idx_dev
         G = idx.shape[0]
+        tiled = self._tile_tables(lib, B, N, idx, device) if (dtype == DTYPES["bf16"] and not want_graph) else None
         io = dict(
             img=(torch.empty(B, size, size, 3, dtype=torch.uint8, device=device) if u8
                  else torch.empty(B, 3, size, size, dtype=torch.float32, device=device)),
@@ -226,6 +228,18 @@ class HipForwardMixin:
             sio = {k: (v[sl] if torch.is_tensor(v) else ([t[sl] for t in v] if isinstance(v, list) else v)) for k, v in io.items()}
             prog = Program(lib, ws, dtype, Bs, device)
             sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
+            ext = None
+            if tiled is not None and prog.can_tile_edgeconv(N, idx.shape[2], 64, 64, tiled["HPAD"]):
+                # large graphs: the program works in the patch-ordered INTERNAL keypoint numbering (graph_sched.tile_schedule): its
+                # logit block / ids are internal tensors, un-permuted into the caller-visible ones behind the last launch
+                sio["graph"].update(tiled=tiled, idx=tiled["idx_internal"])
+                ext = {k: sio[k] for k in ("bits", "x64", "y64")}
+                for k in ext:
+                    sio[k] = torch.zeros_like(ext[k])
+                if teacher:
+                    tb = sio["decode_bits"]
+                    sio["decode_bits"] = torch.zeros_like(tb)
+                    prog.permute_cols(tb, sio["decode_bits"], tiled["perm"], sio["gids"], 13, N, scatter=False)
             sio["bits_tb"] = prog.fixed(sio["bits"])
             em = NetEmitter(prog, sd)
             if cfg["kind"] == "init":
@@ -234,6 +248,10 @@ class HipForwardMixin:
                 sio["seg_tb"] = prog.fixed(sio["seg"])
                 feats, _ = emit_posenet(em, cfg, sio)
                 g = None
+            if ext is not None:
+                prog.permute_cols(sio["bits"], ext["bits"], tiled["perm"], sio["gids"], 13, N, scatter=True)
+                prog.permute_cols(sio["x64"], ext["x64"], tiled["perm"], sio["gids"], 1, N, scatter=True)
+                prog.permute_cols(sio["y64"], ext["y64"], tiled["perm"], sio["gids"], 1, N, scatter=True)
             if want_feats:
                 if io["img_feats"] is None:
                     io["img_feats"] = [torch.empty(B, f.C, f.H, f.W, dtype=torch.float32, device=device) for f in feats]
@@ -249,6 +267,24 @@ class HipForwardMixin:
         torch.cuda.current_stream(device).synchronize()      # weight packing done before temporaries die
         ws.keep.clear()
         return dict(prog=prog, io=io, graph=None, warm=False, side=None)
+
+    def _tile_tables(self, lib, B, N, idx_dev, device):
+        """patch schedule of a large graph (N > 512) as device tensors, built once per module (init-time, host: ~1 s per graph)"""
+        from .. import engine
+        if not engine.USE_EDGE_TILED or N <= 512 or N % 512:
+            return None
+        if getattr(self, "_tiled", None) is None:
+            if getattr(self, "_tile_host", None) is None:        # the graph never changes: the host schedule survives invalidate()
+                from ..graph_sched import tile_schedule
+                pts = self._keypoints() if hasattr(self, "_keypoints") else None
+                self._tile_host = (tile_schedule(self._knn_table().cpu().numpy(), pts.numpy()) if pts is not None else None) or False
+            sc = self._tile_host or None
+            if sc is None:
+                self._tiled = False
+            else:
+                self._tiled = dict(HPAD=sc["HPAD"], NB=sc["NB"], halo_rows=sc["halo_rows"],
+                                   **{k: torch.from_numpy(sc[k]).contiguous().to(device) for k in ("perm", "halo", "nbr", "idx_internal")})
+        return self._tiled or None
 
     # ---- training program (forward in train mode + backward), see ../trainer.py
     def _build_train(self, lib, B, size, stage, device, u8=False):
@@ -404,7 +440,8 @@ class HipForwardMixin:
         B = batch_bucket(Bu) if self.batch_buckets else Bu
         if self.check_weight_versions:
             # eval programs fold BatchNorm and pack weights at build time: an in-place edit of any parameter / buffer since then
-            # (optimizer step, EMA swap, `p.data.copy_`, a child's load_state_dict) bumps its version counter -> rebuild
+            # (optimizer step, EMA `copy_` / `mul_` under no_grad, a child's load_state_dict) bumps its version counter -> rebuild.
+            # (Edits through `p.data` do not move the counter -- torch gives `.data` a counter of its own: call invalidate().)
             if self._sig_tensors is None:
                 self._sig_tensors = list(self.parameters()) + list(self.buffers())
             sig = sum(t._version for t in self._sig_tensors) + len(self._sig_tensors)

@@ -61,6 +61,7 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
         self.res_log2 = res_log2
         self.pre_query_block = nn.ModuleList()
         self.knn_idx = knn(p3d_normed, graph_k)             # (G, N, K) int64, G = 1 or #objects (LM)
+        self._p3d = p3d_normed.detach().float().cpu()        # plain attribute: the tiled EdgeConv's patch schedule (N > 512) needs it
         self.graph_k = graph_k
         self.graph_leaky_slope = graph_leaky_slope
         self.max_batch_size = max_batch_size               # kept for signature parity; no limit is imposed
@@ -77,6 +78,9 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
 
     def _knn_table(self):
         return self.knn_idx
+
+    def _keypoints(self):
+        return self._p3d
 
     def forward(self, img, return_img_feats=False, return_graph_feats=False):
         """init.py:109-128: returns out (B,7,N) | (out, img_feats) | (out, img_feats, graph_feats)."""

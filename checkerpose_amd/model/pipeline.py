@@ -132,6 +132,9 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
     def _knn_table(self):
         return self.init_net.knn_idx
 
+    def _keypoints(self):
+        return self.init_net._p3d
+
     def set_compute_dtype(self, name):
         self.init_net.set_compute_dtype(name)
         return super().set_compute_dtype(name)

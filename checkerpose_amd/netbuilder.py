@@ -410,6 +410,9 @@ class NetEmitter:
             out = self.p.act(1, x.W, Co)
         if self.p.can_fuse_edgeconv(x.W, graph["K"], Cc, Co) and x.C == Cc:
             return self.p.edge_fused(x, ck, wpq, sc, sh, graph["idx"], graph["gids"], out, graph["K"], graph["G"], slope)
+        tl = graph.get("tiled")
+        if tl is not None and x.C == Cc and self.p.can_tile_edgeconv(x.W, graph["K"], Cc, Co, tl["HPAD"]):
+            return self.p.edge_tiled(x, ck, wpq, sc, sh, tl, graph["gids"], out, graph["K"], graph["G"], slope)
         pq = self.p.conv(x, ck, wpq, sc, sh, 1, 1, 1, 0, 2 * Co)
         return self.p.edge_gather(pq, graph["idx"], graph["gids"], out, graph["K"], Co, graph["G"], slope)
 
@@ -485,6 +488,11 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
             tp.conv_backward(c1key, w, f_in, gy, 1, 1, 1, 0)
         tp.tape.append(bwd_conv1x1)
     g = g0
+    if tp is None and io["graph"].get("tiled") is not None:
+        # large graphs (N > 512): from here on the rows follow the INTERNAL keypoint numbering in which 512 consecutive rows are a
+        # compact patch of the kNN graph (graph_sched.tile_schedule); every op between here and the logits is per keypoint or
+        # goes through the (renumbered) graph, and the runtime un-permutes the logit block / ids behind the last launch
+        g = p.permute_rows(g0, p.act(1, N, 64), io["graph"]["tiled"]["perm"], io["graph"]["gids"])
     ng = cfg["init_num_graph_module"]
     for i in range(ng):
         last = i == ng - 1

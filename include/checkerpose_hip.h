@@ -278,6 +278,35 @@ int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_
                       const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
                       int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope);
 
+/* EdgeConv layer for LARGE graphs (N = 1024 .. 32768 keypoints in patches of 512, bf16; BASELINE config #5: npt = 4096), the
+ * LDS-staged gather of cp_edgeconv_fused, tiled (edgeconv_tiled.hip; same reference lines as above).  The caller works in an
+ * INTERNAL keypoint numbering in which every patch of 512 consecutive rows is spatially compact (checkerpose_amd/graph_sched.py:
+ * tile_schedule) and passes, per graph g and patch t:
+ *   halo int32 (G, N/512, HPAD): internal row ids of the patch's out-of-patch neighbour rows (padded with any valid row);
+ *   nbr  int16 (G, N/512, 512, K): every own row's K neighbours as table SLOTS (own row j -> j, halo entry h -> 512 + h).
+ * Two launches: the key table P' = s W1 x of every row (written to `key_table`, cp_edgeconv_tiled_table_bytes, plane-major
+ * [crop][Cout / 8][N][16 B] order-preserving int16 keys), then per (crop, patch) the table slice in LDS by LDS-DMA, gather-max,
+ * Q' on MFMA, LeakyReLU.  x / out / scale / shift as cp_edgeconv_fused; packed_w_fused = cp_pack_edgeconv_fused_weight's image,
+ * packed_w_q = cp_pack_edgeconv_tiled_weight's (Q halves in 32-channel slices).
+ * Supported (cp_edgeconv_tiled_supported): N a multiple of 512 above 512, K <= 20 and a multiple of 4, Cin in {64, 256},
+ * Cout in {64 .. 256 step 64}, HPAD a multiple of 64 with the table in 160 KB of LDS (HPAD <= 1024 at Cin = 256). */
+int cp_edgeconv_tiled_supported(int N, int K, int Cin, int Cout, int HPAD);
+size_t cp_edgeconv_tiled_weight_bytes(int Cin, int Cout);
+size_t cp_edgeconv_tiled_table_bytes(int B, int N, int Cout);
+int cp_pack_edgeconv_tiled_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed);
+int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w_fused,
+                      const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo,
+                      const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
+                      int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope);
+/* The renumbering at the launch program's boundary (perm int32 (G, N): internal row i = original keypoint perm[g][i];
+ * graph_ids (B) or NULL).  Rows of `row_bytes` (a multiple of 16): out[b][i] = in[b][perm[g_b][i]].  Columns of (B, R, N)
+ * arrays of 4- / 8-byte elements (logit block, ids): scatter = 1: out[b][r][perm[g_b][i]] = in[b][r][i] (internal -> original),
+ * scatter = 0: out[b][r][i] = in[b][r][perm[g_b][i]]. */
+int cp_permute_rows(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids, int B, int N,
+                    int row_bytes);
+int cp_permute_cols(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids, int B, int R,
+                    int N, int elem_bytes, int scatter);
+
 /* Index2Feat_module.forward + RoI mask in one launch (bf16): the patch_generator conv (Conv2d(256 -> 64, k = 2, pad = 1),
  * pipeline.py:146-147) evaluated ONLY at the 4 gathered taps of every keypoint (pipeline.py:156-163), times mask (pipeline.py:280):
  *   out[b, n, 64 t + c] = mask[b, n] * (bias[c] + sum_{dy, dx, ci} w[c, ci, dy, dx] * f[b, py - 1 + dy, px - 1 + dx, ci]),

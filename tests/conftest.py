@@ -19,7 +19,7 @@ def lib():
 
 
 def pytest_sessionstart(session):
-    """`-m gpu` sessions on a GPU box: start the 2-rank data-parallel child job of tests/test_gpu_dp.py NOW, before anything in
+    """`-m gpu` sessions on a GPU box: start the 2-rank data-parallel child job of tests/test_gpu_zz_dp.py NOW, before anything in
     this process touches the GPU (torch.cuda.device_count() does not initialise it on this image)."""
     import subprocess
     import tempfile

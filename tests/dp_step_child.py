@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Child program of tests/test_gpu_dp.py: ONE data-parallel training step of the drop-in PoseNet_GNNskip on `WORLD_SIZE` ranks
+"""Child program of tests/test_gpu_zz_dp.py: ONE data-parallel training step of the drop-in PoseNet_GNNskip on `WORLD_SIZE` ranks
 sharing one MI355X, launched by `python -m torch.distributed.run` (gloo by default: a 1-GPU box has no second device for RCCL;
 CHECKERPOSE_BENCH_BACKEND=nccl runs the same checks over RCCL on a multi-GPU node).  Every rank checks and prints:
 
@@ -67,7 +67,8 @@ def main():
         l = loss_of(net)
         if step == 0:
             same_on_all_ranks(flat(net.parameters()), "parameters after the first-step broadcast")
-            same_on_all_ranks(flat(b for b in net.buffers() if b.dtype.is_floating_point and b.numel() > 1), "BatchNorm running statistics")
+            # (BatchNorm running statistics were broadcast too, but this forward has already updated them with each replica's
+            # own batch statistics -- per-replica BatchNorm, as in the reference: no SyncBN there)
         l.backward()
         # the single-replica gradient of the same weights on this rank's shard, reduced explicitly = the reference
         with torch.no_grad():                          # in place: the training program reads the live weights, nothing is rebuilt

@@ -787,6 +787,59 @@ def test_edgeconv_fused_vs_reference_form(lib, monkeypatch, Cc, pfx):
     assert out.coff == 64
 
 
+@pytest.mark.parametrize("N,Cc,pfx", [(4096, 64, "init_net.pre_query_block.0"), (4096, 256, "refine_net.1.pre_query_block.2"),
+                                      (1024, 256, "refine_net.0.pre_query_block.1")])
+def test_edgeconv_tiled_vs_reference_form(lib, N, Cc, pfx):
+    """cp_edgeconv_tiled (N > 512: key-table launch + per-patch LDS-staged gather launch, bf16) == the reference's per-edge
+    conv + BN + LeakyReLU + max (StaticGraph_module, pipeline_lm.py:45-59) on the real LM graphs (per-sample graph ids, three
+    objects), rows renumbered into patches by graph_sched.tile_schedule and un-permuted for the comparison; channel-sliced
+    output, B = 5 (the grid is padded to a multiple of 8 crops)."""
+    from checkerpose_amd.graph_sched import tile_schedule
+    net = build_net(seed=0)
+    sd = net.state_dict()
+    objs = [0, 4, 13]                                                  # LM objects 1, 5, 14 (5: the largest halo)
+    P = lm_p3d(N)[objs]
+    idx3 = O.knn(P, 20)                                                # (3, N, K) original numbering
+    sc = tile_schedule(idx3.numpy(), P.numpy())
+    assert sc is not None and sc["HPAD"] % 64 == 0 and lib.cp_edgeconv_tiled_supported(N, 20, Cc, Cc, sc["HPAD"])
+    gsel = torch.tensor([2, 0, 1, 1, 2])
+    B = 5
+    x = det_tensor("etx%d_%d" % (Cc, N), (B, Cc, N))
+    xb = rnd(x, CP_BF16)
+    ref = torch.cat([_edge_ref(sd, pfx, xb[i:i + 1], idx3[gsel[i]:gsel[i] + 1]) for i in range(B)], 0)        # (B, C', N)
+    w = sd[pfx + ".conv.0.weight"]
+    w1, w2 = w[:, :Cc, 0, 0], w[:, Cc:, 0, 0]
+    bn = pfx + ".conv.1"
+    s_ = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
+    t_ = sd[bn + ".bias"] - sd[bn + ".running_mean"] * s_
+    wpq = torch.cat([w1, w2 - w1], 0).contiguous().to(dev())
+    scale, shift = torch.cat([s_, s_]).to(dev()), torch.cat([torch.zeros_like(t_), t_]).to(dev())
+    pf = torch.empty(lib.cp_edgeconv_fused_weight_bytes(Cc, Cc), dtype=torch.uint8, device=dev())
+    pq = torch.empty(lib.cp_edgeconv_tiled_weight_bytes(Cc, Cc), dtype=torch.uint8, device=dev())
+    _abi.check(lib.cp_pack_edgeconv_fused_weight(st(), wpq.data_ptr(), Cc, Cc, pf.data_ptr()))
+    _abi.check(lib.cp_pack_edgeconv_tiled_weight(st(), wpq.data_ptr(), Cc, Cc, pq.data_ptr()))
+    perm = torch.from_numpy(sc["perm"]).to(dev())
+    halo, nbr = torch.from_numpy(sc["halo"]).contiguous().to(dev()), torch.from_numpy(sc["nbr"]).contiguous().to(dev())
+    gids = gsel.to(torch.int32).to(dev())
+    x_orig = xb.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(dev())            # (B, N, C) original order
+    x_int = torch.empty_like(x_orig)
+    _abi.check(lib.cp_permute_rows(st(), x_orig.data_ptr(), x_int.data_ptr(), perm.data_ptr(), gids.data_ptr(), B, N, Cc * 2))
+    assert torch.equal(x_int.cpu(), torch.stack([x_orig[i].cpu()[sc["perm"][gsel[i]].astype(np.int64)] for i in range(B)]))
+    ktab = torch.empty(lib.cp_edgeconv_tiled_table_bytes(B, N, Cc), dtype=torch.uint8, device=dev())
+    wide = torch.full((B, N, Cc + 64), 7.0, dtype=torch.bfloat16, device=dev())
+    _abi.check(lib.cp_edgeconv_tiled(st(), x_int.data_ptr(), Cc, 0, pf.data_ptr(), pq.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                     halo.data_ptr(), nbr.data_ptr(), gids.data_ptr(), ktab.data_ptr(), wide.data_ptr(), Cc + 64, 64,
+                                     B, N, 20, Cc, Cc, 3, int(sc["HPAD"]), 0.2))
+    torch.cuda.synchronize()
+    got_int = wide.float().cpu()
+    assert float((got_int[..., :64] - 7.0).abs().max()) == 0.0           # channels outside the slice untouched
+    out_f = torch.empty(B, Cc, N, dtype=torch.float32, device=dev())      # un-permute through cp_permute_cols on (B, C, N) fp32
+    src = wide[..., 64:].float().permute(0, 2, 1).contiguous()
+    _abi.check(lib.cp_permute_cols(st(), src.data_ptr(), out_f.data_ptr(), perm.data_ptr(), gids.data_ptr(), B, Cc, N, 4, 1))
+    torch.cuda.synchronize()
+    close(out_f.cpu(), ref, 4e-2)
+
+
 def test_edgeconv_per_sample_graphs_lm(lib):
     """LM twin: each sample gathers along its own object's graph (pipeline_lm.py:55-57), 1-based obj_ids."""
     B, N, K, Cc = 4, 512, 20, 64
@@ -1101,11 +1154,16 @@ def test_e2e_bf16_accuracy_contract(lib, monkeypatch, chain):
     assert fr["xy_id_equal"] >= 0.90 and fr["id_abs_err_mean_px"] <= 0.5, fr
 
 
-def test_e2e_bf16_accuracy_contract_n4096_lm(lib):
+@pytest.mark.parametrize("tiled", [False, True])
+def test_e2e_bf16_accuracy_contract_n4096_lm(lib, monkeypatch, tiled):
     """The same written contract on BASELINE config #5 in the dtype `bench.py --workload lm13_n4096` times: LM shared estimator,
-    per-sample graphs, npt=4096, bf16, against the CPU oracle (pinned for this config by knn_lm4096 + e2e_lm4096_injected)."""
+    per-sample graphs, npt=4096, bf16, against the CPU oracle (pinned for this config by knn_lm4096 + e2e_lm4096_injected);
+    both EdgeConv paths: node GEMM + L2 gather (small batches) and the patch-tiled LDS-staged launches (cp_edgeconv_tiled: the
+    program then runs in the internal patch order, so this also covers the row renumbering and the un-permuted outputs)."""
+    from checkerpose_amd import engine
     from checkerpose_amd.agreement import logit_agreement
     from tests.common import LM_OBJ_IDS
+    monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if tiled else 1 << 30)
     obj = torch.tensor([LM_OBJ_IDS[3], LM_OBJ_IDS[11]])
     net = build_net(npoint=4096, seed=2, lm=True)
     img = det_image(2, seed=32)
@@ -1115,6 +1173,8 @@ def test_e2e_bf16_accuracy_contract_n4096_lm(lib):
     fr = logit_agreement(net(img.to(dev()), None, obj.to(dev())), ref)
     print("bf16 N=4096 LM teacher-forced:", tf)
     print("bf16 N=4096 LM free-running  :", fr)
+    names = [c[2].split(":")[0] for c in net.program_for(2).calls]
+    assert ("edge_tiled" in names) == tiled and ("edge_gather" in names) != tiled
     assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99, tf
     assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, tf
     rows = fr["bit_agreement_per_row"]
@@ -1182,13 +1242,16 @@ def test_batch_buckets_and_inplace_weight_edit(lib):
     assert tuple(net.input_buffer(5).shape) == (5, 3, 256, 256)
     # (b)
     w = net.refine_net[2].query_block.mlps[4].weight
-    w.data.mul_(-1.0)                                       # flips the last x / y bit logits' weight: no hook fires
+    with torch.no_grad():
+        w.mul_(-1.0)                                        # flips the last x / y bit logits' weight: no module hook fires, but the
+    #                                                         tensor's version counter moves (as under an optimizer step / EMA copy_)
     o5b = net(img[:5].to(dev()), None)
     assert not torch.equal(o5b[1][:, -1], o5[1][:, -1])
     sd = {k: v.cpu() for k, v in net.state_dict().items()}
     ref_b, _ = O.posenet_forward(sd, img[:5], net.init_net.knn_idx.cpu(), 512, **oracle_kwargs())
     _cmp_e2e(o5b, ref_b)
-    net.init_net.mlp.bias.data.add_(0.25)                   # a child's parameter, edited through the child
+    with torch.no_grad():
+        net.init_net.mlp.bias.add_(0.25)                    # a child's parameter, edited through the child
     o5c = net(img[:5].to(dev()), None)
     assert float((o5c[0] - o5b[0]).abs().max()) > 0.2
 
