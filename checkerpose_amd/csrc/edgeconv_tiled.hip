@@ -142,16 +142,17 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 // ------------------------------------------------------------------------------------------------ launch 2: gather + Q'
 // weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt = output channel
 // 32 slice + (r >> 2) * 8 + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels 32 s + 8 q + 4 nt + reg
-template <int CIN>
+template <int CIN, bool DB>
 __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledParams p) {
   constexpr int KC = CIN / 32;
   constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
+  constexpr int NTAB = DB ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = ET_BLK + p.HPAD;
   const int PLANE = T * 16;                                         // a multiple of 256 B: bank slot = row mod 16
-  unsigned char* const sP = smem;                                   // [4 planes][T rows][16 B]
-  unsigned char* const sW = smem + 4 * PLANE;                       // 2 x WQ
-  int16_t* const sIdx = (int16_t*)(sW + 2 * WQ);
+  unsigned char* const sP = smem;                                   // NTAB x [4 planes][T rows][16 B]
+  unsigned char* const sW = smem + NTAB * 4 * PLANE;                // DB: one WQ buffer; else two
+  int16_t* const sIdx = (int16_t*)(sW + (DB ? 1 : 2) * WQ);
   float* const sScale = (float*)((unsigned char*)sIdx + ET_IDX);    // [Cout] then shift [Cout] at + 256
   float* const sShift = sScale + 256;
 
@@ -170,12 +171,13 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
   // 16-byte pieces at per-lane rows.  (4 planes x (8 + HPAD / 64) chunks, dealt round-robin to the 8 waves.)
   const int nchunk = 8 + p.HPAD / 64;
   auto table_issue = [&](int s) {
+    unsigned char* const dstb = sP + (DB ? (s & 1) * 4 * PLANE : 0);
     for (int c = wave; c < 4 * nchunk; c += 8) {
       const int pl = c / nchunk, ch = c - pl * nchunk;
       const int slot = ch * 64 + lane;
       const int row = ch < 8 ? t * ET_BLK + slot : halo[slot - ET_BLK];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(4 * s + pl) * p.N + row) * 16),
-                                       (__attribute__((address_space(3))) void*)(sP + pl * PLANE + ch * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dstb + pl * PLANE + ch * 1024), 16, 0, 0);
     }
   };
   const u32x4* const wg = (const u32x4*)p.w;
@@ -186,16 +188,23 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       const int i0 = wave * 64 + 512 * k;
       if (i0 < PIECES)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)s * PIECES + i0 + lane),
-                                         (__attribute__((address_space(3))) void*)(sW + (s & 1) * WQ + i0 * 16), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sW + (DB ? 0 : (s & 1) * WQ) + i0 * 16), 16, 0, 0);
     }
   };
   table_issue(0);
   w_issue(0);
   {
     const int16_t* gi = p.nbr + ((size_t)g * p.NB + t) * ET_BLK * p.K;
-    for (int i = tid; i < ET_BLK * p.K; i += 512) sIdx[(i / p.K) * ET_KMAX + (i % p.K)] = gi[i];
+    if (p.K == ET_KMAX) {                                           // rows already at the LDS pitch: 16-byte copies
+      for (int i = tid; i < ET_BLK * ET_KMAX / 8; i += 512) ((u32x4*)sIdx)[i] = ((const u32x4*)gi)[i];
+    } else {
+      for (int i = tid; i < ET_BLK * p.K; i += 512) sIdx[(i / p.K) * ET_KMAX + (i % p.K)] = gi[i];
+    }
   }
   for (int i = tid; i < p.Cout; i += 512) { sScale[i] = p.scale[p.Cout + i]; sShift[i] = p.shift[p.Cout + i]; }
+  __syncthreads();                                                  // table(0), weights(0), lists, affine: all landed
+  // this wave's 64 x rows -> registers; issued BEHIND the barrier: the first gather needs only the table, the 32 loads per lane
+  // (64 B per row and instruction: the texture path's slowest shape) travel under it and are awaited at the mid-slice barrier
   u32x4 xa[4][KC];
   const size_t row0 = (size_t)b * p.N + (size_t)t * ET_BLK + wave * 64;
 #pragma unroll
@@ -203,35 +212,49 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc)
       xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
-  __syncthreads();                                                  // table(0), weights(0), lists, affine: all landed
 
   for (int s = 0; s < nslice; ++s) {
-    if (s + 1 < nslice) w_issue(s + 1);                             // other buffer: its readers (Q phase s - 1) passed the last barrier
-    // ---- gather-max over the K neighbours out of the LDS table: lane (x, q) = keypoint x of fragment f, plane q
+    // DB: the NEXT slice's table streams into the other buffer (its readers, gather(s - 1), passed the last barrier) under this
+    // whole slice; the single weight buffer was refilled behind the last barrier and is awaited at the mid-slice barrier.
+    // !DB (the table pair does not fit): weights double-buffered, the next table is issued behind the gather's barrier.
+    if (DB) { if (s + 1 < nslice) table_issue(s + 1); }
+    else if (s + 1 < nslice) w_issue(s + 1);
+    // ---- gather-max over the K neighbours out of the LDS table: lane (x, q) = keypoint x of fragment f, plane q.  k outer,
+    // fragments inner: 4 list reads, then 16 table reads in flight per lane (one fragment at a time left the LDS latency bare)
     uint32_t m[4][4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int16_t* my = sIdx + (wave * 64 + f * 16 + x) * ET_KMAX;
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int j = 0; j < 4; ++j) m[f][j] = 0x80008000u;             // int16 minimum
-      const unsigned char* const pq = sP + q * PLANE;
+    {
+      const unsigned char* const pq = sP + (DB ? (s & 1) * 4 * PLANE : 0) + q * PLANE;
+      const int16_t* const my = sIdx + (wave * 64 + x) * ET_KMAX;
       for (int k = 0; k < p.K; k += 4) {                             // K is a multiple of 4 (20)
-        const u32x2 i4 = *(const u32x2*)(my + k);
-        const u32x4 a = *(const u32x4*)(pq + (i4.x & 0xffffu) * 16), c = *(const u32x4*)(pq + (i4.x >> 16) * 16);
-        const u32x4 d = *(const u32x4*)(pq + (i4.y & 0xffffu) * 16), e = *(const u32x4*)(pq + (i4.y >> 16) * 16);
-        m[f][0] = pkmax(pkmax(m[f][0], a.x), pkmax(c.x, pkmax(d.x, e.x)));
-        m[f][1] = pkmax(pkmax(m[f][1], a.y), pkmax(c.y, pkmax(d.y, e.y)));
-        m[f][2] = pkmax(pkmax(m[f][2], a.z), pkmax(c.z, pkmax(d.z, e.z)));
-        m[f][3] = pkmax(pkmax(m[f][3], a.w), pkmax(c.w, pkmax(d.w, e.w)));
+        u32x2 i4[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) i4[f] = *(const u32x2*)(my + f * 16 * ET_KMAX + k);
+        u32x4 a[4], c[4], d[4], e[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          a[f] = *(const u32x4*)(pq + (i4[f].x & 0xffffu) * 16); c[f] = *(const u32x4*)(pq + (i4[f].x >> 16) * 16);
+          d[f] = *(const u32x4*)(pq + (i4[f].y & 0xffffu) * 16); e[f] = *(const u32x4*)(pq + (i4[f].y >> 16) * 16);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          m[f][0] = pkmax(pkmax(m[f][0], a[f].x), pkmax(c[f].x, pkmax(d[f].x, e[f].x)));
+          m[f][1] = pkmax(pkmax(m[f][1], a[f].y), pkmax(c[f].y, pkmax(d[f].y, e[f].y)));
+          m[f][2] = pkmax(pkmax(m[f][2], a[f].z), pkmax(c[f].z, pkmax(d[f].z, e[f].z)));
+          m[f][3] = pkmax(pkmax(m[f][3], a[f].w), pkmax(c[f].w, pkmax(d[f].w, e[f].w)));
+        }
       }
     }
-    __syncthreads();                                                // every gather of this slice is done: the table is free
-    if (s + 1 < nslice) table_issue(s + 1);                         // ... and streams in under the Q' GEMM below
+    __syncthreads();                                                // DB: weights(s) landed.  !DB: every gather done, the table is free
+    if (!DB && s + 1 < nslice) table_issue(s + 1);                  // ... and streams in under the Q' GEMM below
     // ---- Q' = s * ((W2 - W1) x) + t for this slice's 32 channels, from the register-resident rows
     f32x4 acc[4][2];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const unsigned char* const wb = sW + (s & 1) * WQ + lane * 16;
+    const unsigned char* const wb = sW + (DB ? 0 : (s & 1) * WQ) + lane * 16;
     u32x4 wf[2][2];
     wf[0][0] = *(const u32x4*)wb; wf[0][1] = *(const u32x4*)(wb + 1024);
 #pragma unroll
@@ -263,13 +286,14 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
         const float ta = nt ? t1[r] : t0[r], tb = nt ? t1[r + 1] : t0[r + 1];
         const float y0 = __uint_as_float(w2 << 16) + (acc[f][nt][r] * sa + ta);
         const float y1 = __uint_as_float(w2 & 0xffff0000u) + (acc[f][nt][r + 1] * sb + tb);
-        v[2 * j] = y0 > 0.f ? y0 : y0 * p.slope;
-        v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
+        v[2 * j] = fmaxf(y0, y0 * p.slope);                            // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
+        v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
       }
       uint16_t* dst = (uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0;
       *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
     }
-    __syncthreads();                                                // table(s + 1) and weights(s + 1) landed; weights(s) free
+    __syncthreads();                                                // DB: table(s + 1) landed, weights(s) / table(s) free.  !DB: both landed
+    if (DB && s + 1 < nslice) w_issue(s + 1);                       // awaited at the next mid-slice barrier, a whole gather away
   }
 }
 
@@ -318,6 +342,8 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const T* __restrict__
 }
 
 size_t tiled_lds(int Cin, int HPAD) { return (size_t)4 * (ET_BLK + HPAD) * 16 + (size_t)2 * (Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF; }
+// both tables of consecutive slices resident (the next one streams in a whole slice ahead), one weight buffer
+size_t tiled_lds_db(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)(Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF; }
 
 }  // namespace
 
@@ -342,26 +368,25 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
                                  const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
                                  int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope) {
   if (!x || !packed_w_fused || !packed_w_q || !scale || !shift || !halo || !nbr || !key_table || !out || B <= 0 || G <= 0) return CP_ERR_INVALID;
-  if (!cp_edgeconv_tiled_supported(N, K, Cin, Cout, HPAD)) return CP_ERR_INVALID;
+  if (!cp_edgeconv_tiled_supported(N, K, Cin, Cout, HPAD) || !(slope >= 0.f && slope <= 1.f)) return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + Cout > out_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(x) || !cp_aligned16(packed_w_fused) || !cp_aligned16(packed_w_q) || !cp_aligned16(scale) || !cp_aligned16(shift) ||
       !cp_aligned16(out) || !cp_aligned16(key_table) || !cp_aligned16(nbr))
     return CP_ERR_ALIGN;
   const size_t lds1[2] = {(size_t)2 * 2 * 4 * 1024 + 1024, (size_t)2 * 8 * 4 * 1024 + 1024};      // Cin = 64 / 256
-  const size_t lds2 = tiled_lds(Cin, HPAD);
-  static size_t attr1 = 0, attr2 = 0;                       // largest dynamic-LDS size the kernels were allowed so far
-  if (attr1 < lds1[1]) {
+  const bool db = tiled_lds_db(Cin, HPAD) <= 160 * 1024;
+  const size_t lds2 = db ? tiled_lds_db(Cin, HPAD) : tiled_lds(Cin, HPAD);
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int want = 160 * 1024;
     if (hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[0]) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[1]) != hipSuccess)
+        hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[1]) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
       return CP_ERR_HIP;
-    attr1 = lds1[1];
-  }
-  if (attr2 < lds2) {
-    const int want = (int)tiled_lds(256, (int)((160 * 1024 - tiled_lds(256, 0)) / 64 / 64) * 64);    // the largest supported table
-    if (hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
-      return CP_ERR_HIP;
-    attr2 = (size_t)want;
+    attr_done = true;
   }
   EdgeTiledParams p;
   p.x = x; p.scale = scale; p.shift = shift; p.halo = halo; p.nbr = nbr; p.gids = graph_ids; p.ptab = key_table; p.out = out;
@@ -373,8 +398,10 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
   if (Cin == 64) CP_LAUNCH((edgeconv_ptable_kernel<64>), dim3(grid), dim3(512), lds1[0], st, p);
   else CP_LAUNCH((edgeconv_ptable_kernel<256>), dim3(grid), dim3(512), lds1[1], st, p);
   p.w = packed_w_q;
-  if (Cin == 64) CP_LAUNCH((edgeconv_tiled_kernel<64>), dim3(grid), dim3(512), lds2, st, p);
-  else CP_LAUNCH((edgeconv_tiled_kernel<256>), dim3(grid), dim3(512), lds2, st, p);
+  if (Cin == 64 && db) CP_LAUNCH((edgeconv_tiled_kernel<64, true>), dim3(grid), dim3(512), lds2, st, p);
+  else if (Cin == 64) CP_LAUNCH((edgeconv_tiled_kernel<64, false>), dim3(grid), dim3(512), lds2, st, p);
+  else if (db) CP_LAUNCH((edgeconv_tiled_kernel<256, true>), dim3(grid), dim3(512), lds2, st, p);
+  else CP_LAUNCH((edgeconv_tiled_kernel<256, false>), dim3(grid), dim3(512), lds2, st, p);
   return cp_check_launch();
 }
 
