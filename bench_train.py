@@ -180,8 +180,8 @@ def main():
             fl = sum(prog.wgrad_flops[i] for i, _ in w3)
             big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
             from bench import committed_profile
-            tr = [committed_profile(k, "train_%s_b%d" % (a.dtype, B))[0] for k in ("wgrad3x3_kernel", "wgrad_reduce_kernel")]
-            out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel + wgrad_reduce_kernel (%d launches per step)" % len(w3),
+            tr = [committed_profile(k, "train_%s_b%d" % (a.dtype, B))[0] for k in ("wgrad3x3_kernel", "wgrad_reduce_batch_kernel")]
+            out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel (%d launches per step; their pixel-slice partials are summed by the batched wgrad_reduce launches)" % len(w3),
                                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
                                "traffic": round(sum(tr), 2) if all(t is not None for t in tr) else None,

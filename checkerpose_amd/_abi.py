@@ -35,6 +35,13 @@ class CpPackItem(C.Structure):
                 ("total", C.c_uint64)]
 
 
+class CpWgradReduceItem(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("S", C.c_int32), ("GY", C.c_int32), ("co_blocks", C.c_int32),
+                ("ci_blocks", C.c_int32), ("R", C.c_int32), ("Ssz", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("taps_in_block", C.c_int32), ("dw_base", C.c_int64), ("dw_sco", C.c_int64), ("dw_sci", C.c_int64),
+                ("dw_sr", C.c_int64), ("dw_ss", C.c_int64)]
+
+
 class CpWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
@@ -115,6 +122,11 @@ SIGNATURES = {
     "cp_masked_ce_loss": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "cp_conv2d_wgrad": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P]),
     "cp_conv2d_wgrad_ws": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t]),
+    "cp_conv2d_wgrad_scratch_bytes": (C.c_size_t, [C.POINTER(CpWgradDesc)]),
+    "cp_conv2d_wgrad_deferred": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t, C.POINTER(CpWgradReduceItem)]),
+    "cp_conv2d_wgrad_plan": (_I, [C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t, C.POINTER(CpWgradReduceItem)]),
+    "cp_wgrad_reduce_item_blocks": (C.c_uint32, [C.POINTER(CpWgradReduceItem)]),
+    "cp_wgrad_reduce_batch": (_I, [_P, _P, _P, _I, C.c_uint32]),
     "cp_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cp_bn_workspace_bytes": (C.c_size_t, [_I]),
     "cp_bn_train_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),

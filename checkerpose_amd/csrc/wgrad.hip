@@ -21,6 +21,8 @@
 // checkerpose/train.py:319 `loss.backward()`).
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tile[(wco + a * 16 + 4 * g + j) * 64 + wci + b * 16 + xl] = acc[a][b][j];
+        for (int j = 0; j < 4; ++j)      // only the layer's own (co, ci): the reduction reads nothing else, and an 18 x 18 layer
+          if (co0 + wco + a * 16 + 4 * g + j < p.Cout && ci0 + wci + b * 16 + xl < p.Cin)      // would write 92 % padding
+            tile[(wco + a * 16 + 4 * g + j) * 64 + wci + b * 16 + xl] = acc[a][b][j];
     return;
   }
 #pragma unroll
@@ -193,12 +197,12 @@ struct WgradReduceParams {
   int S, GY, co_blocks, ci_blocks, R, Ssz, Cout, Cin, taps_in_block;   // taps_in_block: 9 (all-taps kernel) or 1
   long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
 };
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams p) {
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceParams& p, unsigned block) {
   // block = 16 consecutive dw elements (ci fastest: 64-byte reads) x 16 slice lanes; the lanes stride over the slices
   // (a serial loop over up to 512 slices per element was latency-bound), then an LDS tree adds the 16 partial sums
   __shared__ float red[16][17];
   const int e = threadIdx.x & 15, sl0 = threadIdx.x >> 4;
-  const size_t i = (size_t)blockIdx.x * 16 + e;
+  const size_t i = (size_t)block * 16 + e;
   const size_t total = (size_t)p.R * p.Ssz * p.Cout * p.Cin;
   const bool ok = i < total;
   const size_t ii = ok ? i : 0;
@@ -242,6 +246,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReducePara
                  (long long)(tap % p.Ssz) * p.dw_ss;
     *dst += s;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams p) { wgrad_reduce_block(p, blockIdx.x); }
+
+// every pending reduction of a stretch of the backward in ONE launch (358 launches of ~27 us, each a handful of latency-bound
+// blocks, were 9.7 of the step's 35.7 ms): block -> item by binary search in the exclusive prefix sum of the items' block counts
+static_assert(sizeof(WgradReduceParams) == sizeof(CpWgradReduceItem), "CpWgradReduceItem is the launch-parameter block of one reduction");
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceParams* __restrict__ items, const uint32_t* __restrict__ prefix, int n) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const WgradReduceParams p = items[lo];
+  wgrad_reduce_block(p, blockIdx.x - prefix[lo]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -375,7 +393,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tile[tap * 4096 + (wco + a * 16 + 4 * g + j) * 64 + wci + b * 16 + xl] = acc[tap][a][b][j];
+          for (int j = 0; j < 4; ++j)
+            if (co0 + wco + a * 16 + 4 * g + j < p.Cout && ci0 + wci + b * 16 + xl < p.Cin)
+              tile[tap * 4096 + (wco + a * 16 + 4 * g + j) * 64 + wci + b * 16 + xl] = acc[tap][a][b][j];
     return;
   }
   if (!active) return;
@@ -505,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Para
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int co = a * 16 + 4 * g + j;
-          if (p.ws) p.ws[((size_t)blockIdx.x * 9 + tap) * 4096 + co * 64 + ci] = acc[i][a][b][j];
+          if (p.ws) { if (co < p.Cout && ci < p.Cin) p.ws[((size_t)blockIdx.x * 9 + tap) * 4096 + co * 64 + ci] = acc[i][a][b][j]; }
           else if (co < p.Cout && ci < p.Cin)
             unsafeAtomicAdd(p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / 3) * p.dw_sr +
                                 (long long)(tap % 3) * p.dw_ss, acc[i][a][b][j]);
@@ -514,16 +534,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Para
   }
 }
 
+// mode 0: partial kernel + its reduction (cp_conv2d_wgrad_ws); 1: partial kernel only, *item = the reduction still owed
+// (cp_conv2d_wgrad_deferred); 2: no launch at all, *item as mode 1 would fill it (cp_conv2d_wgrad_plan)
 static int launch_reduce(hipStream_t st, const float* ws, float* dw, int S, int GY, int co_blocks, int ci_blocks, const CpWgradDesc* d,
-                         int taps_in_block) {
+                         int taps_in_block, int mode, CpWgradReduceItem* item) {
   WgradReduceParams r;
   r.ws = ws; r.dw = dw; r.S = S; r.GY = GY; r.co_blocks = co_blocks; r.ci_blocks = ci_blocks; r.R = d->R; r.Ssz = d->S;
   r.Cout = d->Cout; r.Cin = d->Cin; r.taps_in_block = taps_in_block;
   r.dw_base = d->dw_base; r.dw_sco = d->dw_sco; r.dw_sci = d->dw_sci; r.dw_sr = d->dw_sr; r.dw_ss = d->dw_ss;
   const size_t total = (size_t)d->R * d->S * d->Cout * d->Cin;
+  if (mode != 0) {
+    memcpy(item, &r, sizeof(r));
+    return CP_OK;
+  }
   CP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, r);
   return cp_check_launch();
 }
+
+static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
+                      size_t workspace_bytes, int mode, CpWgradReduceItem* item);
 
 extern "C" int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw) {
   return cp_conv2d_wgrad_ws(stream, d, dy, x, dw, nullptr, 0);
@@ -531,6 +560,54 @@ extern "C" int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const v
 
 extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw,
                                   void* workspace, size_t workspace_bytes) {
+  return wgrad_impl(stream, d, dy, x, dw, workspace, workspace_bytes, 0, nullptr);
+}
+
+extern "C" int cp_conv2d_wgrad_deferred(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw,
+                                        void* workspace, size_t workspace_bytes, CpWgradReduceItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  memset(item, 0, sizeof(*item));
+  return wgrad_impl(stream, d, dy, x, dw, workspace, workspace_bytes, 1, item);
+}
+
+extern "C" int cp_conv2d_wgrad_plan(const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
+                                    size_t workspace_bytes, CpWgradReduceItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  memset(item, 0, sizeof(*item));
+  return wgrad_impl(nullptr, d, dy, x, dw, workspace, workspace_bytes, 2, item);
+}
+
+extern "C" size_t cp_conv2d_wgrad_scratch_bytes(const CpWgradDesc* d) {
+  if (!d || d->Cout <= 0 || d->Cin <= 0 || d->R <= 0 || d->S <= 0) return 0;
+  const size_t cob = (d->Cout + 63) / 64, cib = (d->Cin + 63) / 64;
+  // the slice counts the launchers aim for (512 / 256 / 1024 blocks over the tile grid) times one slice of 64 x 64 fp32 tiles
+  const bool taps9 = d->dtype == CP_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W &&
+                     d->W >= 8 && (d->W & (d->W - 1)) == 0 && d->H % (64 / (d->W < 64 ? d->W : 64)) == 0;
+  if (taps9) {
+    const size_t tb = cob * cib, per_slice = tb * 9 * 4096 * sizeof(float);
+    const size_t S = (d->Cout <= 32 && d->Cin <= 32) ? 512 : (256 / tb ? 256 / tb : 1);
+    return S * per_slice;
+  }
+  const size_t tiles = cob * cib * d->R * d->S, per_slice = tiles * 4096 * sizeof(float);
+  return ((1024 + tiles - 1) / tiles) * per_slice;
+}
+
+extern "C" int cp_wgrad_reduce_batch(cp_stream_t stream, const CpWgradReduceItem* items_dev, const uint32_t* block_prefix_dev, int n_items,
+                                     uint32_t total_blocks) {
+  if (n_items < 0) return CP_ERR_INVALID;
+  if (n_items == 0 || total_blocks == 0) return CP_OK;
+  if (!items_dev || !block_prefix_dev) return CP_ERR_INVALID;
+  CP_LAUNCH(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WgradReduceParams*)items_dev, block_prefix_dev, n_items);
+  return cp_check_launch();
+}
+
+extern "C" uint32_t cp_wgrad_reduce_item_blocks(const CpWgradReduceItem* item) {
+  if (!item || !item->ws) return 0;
+  return (uint32_t)(((size_t)item->R * item->Ssz * item->Cout * item->Cin + 15) / 16);
+}
+
+static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
+                      size_t workspace_bytes, int mode, CpWgradReduceItem* item) {
   if (!d || !dy || !x || !dw) return CP_ERR_INVALID;
   if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype);
@@ -573,12 +650,12 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
         if (S < 1) S = 1;
         q.tiles_per_block = (q.n_tiles + S - 1) / S;
         S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
-        CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
-      } else
+        if (mode != 2) CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
+      } else if (mode != 2)
       CP_LAUNCH(wgrad3x3_kernel, dim3((unsigned)S, (unsigned)tb), dim3(256), 0, (hipStream_t)stream, q);
-      int rc3 = cp_check_launch();
+      int rc3 = mode != 2 ? cp_check_launch() : CP_OK;
       if (rc3 || !use_ws) return rc3;
-      return launch_reduce((hipStream_t)stream, q.ws, dw, S, tb, q.co_blocks, q.ci_blocks, d, 9);
+      return launch_reduce((hipStream_t)stream, q.ws, dw, S, tb, q.co_blocks, q.ci_blocks, d, 9, mode, item);
     }
   }
   WgradParams p;
@@ -607,9 +684,10 @@ extern "C" int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, cons
   if (tiles > 65535) return CP_ERR_RANGE;
   p.ws = use_ws ? (float*)workspace : nullptr;
   dim3 grid(nslice, (unsigned)tiles);
-  if (d->dtype == CP_F32) CP_LAUNCH(wgrad_kernel<F32Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (mode == 2) { /* plan only */ }
+  else if (d->dtype == CP_F32) CP_LAUNCH(wgrad_kernel<F32Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else CP_LAUNCH(wgrad_kernel<BF16Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  int rcg = cp_check_launch();
+  int rcg = mode != 2 ? cp_check_launch() : CP_OK;
   if (rcg || !use_ws) return rcg;
-  return launch_reduce((hipStream_t)stream, p.ws, dw, (int)nslice, (int)tiles, p.co_blocks, p.ci_blocks, d, 1);
+  return launch_reduce((hipStream_t)stream, p.ws, dw, (int)nslice, (int)tiles, p.co_blocks, p.ci_blocks, d, 1, mode, item);
 }

@@ -11,11 +11,12 @@ class keeps every saved activation alive until its last backward reader automati
 torch supplies memory and the autograd hook (model/_runtime.py: _TrainFn) only.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc
+from ._abi import CpWgradReduceItem, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc
 from .engine import Act, Program, WeightStore, _rup
 
 
@@ -90,7 +91,11 @@ class TrainProgram(Program):
         self.pslots = pslots       # state-dict key -> element offset into pgrad
         self.nograd = set()        # id(TBuf) of tensors that need no gradient (the input image)
         self._bn_ws = {}           # lane -> BatchNorm partial-sum workspace
-        self.wg_ws = torch.empty(160 << 20, dtype=torch.uint8, device=device)     # weight-gradient slice partials
+        # weight-gradient pixel-slice partials: every layer gets its OWN region of this arena and its reduction is DEFERRED; when the
+        # arena is full (and at the end of the backward) one cp_wgrad_reduce_batch launch settles every pending layer
+        self.wg_ws = torch.empty(int(os.environ.get("CHECKERPOSE_AMD_WGRAD_ARENA_MB", "4096")) << 20, dtype=torch.uint8, device=device)
+        self._wg_off, self._wg_items, self._wg_keys, self.wg_tabs = 0, [], set(), []
+        self.wg_defer = os.environ.get("CHECKERPOSE_AMD_WGRAD_DEFER", "1") != "0"        # A/B: one reduction launch per layer
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._touched, self.pslot_done, self.pslot_done_call = [], {}, {}
@@ -278,10 +283,45 @@ class TrainProgram(Program):
         self.keep.append(d)
         dref = C.byref(d)
         dt, xt = dy.tbuf, x.tbuf
-        wsp, wsn = self.wg_ws.data_ptr(), self.wg_ws.numel()
-        self._add(self.lib.cp_conv2d_wgrad_ws, lambda P: (dref, P(dt), P(xt), dw_ptr, wsp, wsn),
-                  "wgrad:%d->%d k%d s%d %dx%d" % (Cin, Cout, R, stride, x.H, x.W), [dt, xt], [])
+        name = "wgrad:%d->%d k%d s%d %dx%d" % (Cin, Cout, R, stride, x.H, x.W)
+        if not self.wg_defer:
+            wsp, wsn = self.wg_ws.data_ptr(), min(self.wg_ws.numel(), 160 << 20)
+            self._add(self.lib.cp_conv2d_wgrad_ws, lambda P: (dref, P(dt), P(xt), dw_ptr, wsp, wsn), name, [dt, xt], [])
+        else:
+            need = (int(self.lib.cp_conv2d_wgrad_scratch_bytes(dref)) + 255) // 256 * 256
+            if self._wg_off + need > self.wg_ws.numel():
+                self.flush_wgrad()
+            need = min(need, self.wg_ws.numel())
+            wsp = self.wg_ws.data_ptr() + self._wg_off
+            item, spare = CpWgradReduceItem(), CpWgradReduceItem()
+            base = self.wg_ws.data_ptr()      # any aligned non-null pointer: the plan only validates dy / x, it launches nothing
+            _abi.check(self.lib.cp_conv2d_wgrad_plan(dref, base, base, dw_ptr, wsp, need, C.byref(item)), "cp_conv2d_wgrad_plan")
+            self.keep.append(spare)
+            sref = C.byref(spare)
+            self._add(self.lib.cp_conv2d_wgrad_deferred, lambda P: (dref, P(dt), P(xt), dw_ptr, wsp, need, sref), name, [dt, xt], [])
+            if item.ws:                       # this layer owes a reduction (tiny layers add with atomics instead)
+                self._wg_items.append(item)
+                self._wg_off += need
         self.wgrad_flops[len(self.ops) - 1] = 2 * dy.B * d.Ho * d.Wo * R * S * Cin * Cout      # algorithmic, unpadded
+
+    def flush_wgrad(self):
+        """one launch for every weight-gradient reduction owed so far; the parameters touched since the last flush are final
+        only behind it (gradient buckets of the data-parallel step, plan_gradient_buckets)"""
+        if self._wg_items:
+            items = self._wg_items
+            arr = (CpWgradReduceItem * len(items))(*items)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            pre, acc = [0], 0
+            for it in items:
+                acc += int(self.lib.cp_wgrad_reduce_item_blocks(C.byref(it)))
+                pre.append(acc)
+            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+            self.wg_tabs.append((raw, prefix))
+            n = len(items)
+            self._add(self.lib.cp_wgrad_reduce_batch, lambda P: (raw.data_ptr(), prefix.data_ptr(), n, acc), "wgrad_reduce_batch:%d" % n, [], [])
+        for k in self._wg_keys:
+            self.pslot_done[k] = len(self.ops)
+        self._wg_off, self._wg_items, self._wg_keys = 0, [], set()
 
     def weight_dgrad(self, w, Cout, Cin, R, S):
         wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)
@@ -444,6 +484,8 @@ class TrainProgram(Program):
             fn()
             for key in self._touched:
                 self.pslot_done[key] = len(self.ops)
+            self._wg_keys.update(self._touched)
+        self.flush_wgrad()
         self.tape = []
 
     def gradient_buckets(self, nbuckets=4):

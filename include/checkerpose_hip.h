@@ -419,6 +419,27 @@ int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const void* dy, co
 int cp_conv2d_wgrad_ws(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
                        size_t workspace_bytes);
 
+/* Deferred reduction (training step: ~360 weight-gradient launches per backward, each followed by a latency-bound reduction of
+ * its pixel-slice partials): cp_conv2d_wgrad_deferred launches ONLY the partial kernel into `workspace` (which must stay
+ * untouched until the reduction ran: cp_conv2d_wgrad_scratch_bytes() bytes give the launcher its preferred slice count) and
+ * fills *item on the HOST; cp_conv2d_wgrad_plan fills the same item without launching (static launch programs resolve it at
+ * build time).  item->ws == NULL: the layer needs no reduction (atomics / direct stores).  cp_wgrad_reduce_batch runs any number
+ * of owed reductions in ONE launch: items in DEVICE memory + the exclusive prefix sum (n + 1 entries) of
+ * cp_wgrad_reduce_item_blocks() of each.  Sums in slice order: bit-identical to cp_conv2d_wgrad_ws. */
+typedef struct CpWgradReduceItem {
+  const float* ws; float* dw;
+  int32_t S, GY, co_blocks, ci_blocks, R, Ssz, Cout, Cin, taps_in_block;
+  long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
+} CpWgradReduceItem;
+size_t cp_conv2d_wgrad_scratch_bytes(const CpWgradDesc* d);
+int cp_conv2d_wgrad_deferred(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
+                             size_t workspace_bytes, CpWgradReduceItem* item);
+int cp_conv2d_wgrad_plan(const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace, size_t workspace_bytes,
+                         CpWgradReduceItem* item);
+uint32_t cp_wgrad_reduce_item_blocks(const CpWgradReduceItem* item);
+int cp_wgrad_reduce_batch(cp_stream_t stream, const CpWgradReduceItem* items_dev, const uint32_t* block_prefix_dev, int n_items,
+                          uint32_t total_blocks);
+
 /* Weights of the data-gradient of a stride-1 conv: w (Cout,Cin,R,S) fp32 -> wt (Cin,Cout,R,S) fp32 with both taps
  * flipped (wt[ci][co][r][s] = w[co][ci][R-1-r][S-1-s]); dx = conv(dy, wt, stride 1, pad R-1-pad).  (Stride-2 3x3
  * convs use the transposed=1 phase packing of cp_pack_conv_weight on w itself; ConvTranspose2d's data-gradient is a

@@ -6,7 +6,8 @@ CHECKERPOSE_BENCH_BACKEND=nccl runs the same checks over RCCL on a multi-GPU nod
   1. replicas that were seeded DIFFERENTLY start the step with rank 0's parameters and BatchNorm buffers (broadcast on the first
      train step, model/_runtime.py:_run_train);
   2. the bucketed, asynchronous all-reduce issued between the backward's hipGraph segments (parallel.py:
-     backward_with_bucketed_allreduce_) gives EXACTLY mean over ranks of the single-replica gradients (a second replica with
+     backward_with_bucketed_allreduce_) gives the mean over ranks of the single-replica gradients (to 1e-5 of the largest
+     gradient: float atomics in the tiny layers' weight gradients are not run-to-run reproducible) (a second replica with
      dp_allreduce off computes the local gradient; its explicit all-reduce is the reference) -- also on the hipGraph replay;
   3. after the optimizer step all ranks hold identical parameters.
 """
@@ -84,14 +85,13 @@ def main():
         dist.all_reduce(gr, op=dist.ReduceOp.SUM)
         gr = (gr / world).to(dev)
         g_dp = flat(p.grad for p, _ in live)
-        if world == 2:
-            assert torch.equal(g_dp, gr), "step %d: bucketed async all-reduce != mean of the replicas' gradients (max diff %.3e)" % (
-                step, float((g_dp - gr).abs().max()))
-        else:
-            assert float((g_dp - gr).abs().max()) <= 1e-6 * float(gr.abs().max())
+        # (not bit for bit: tiny layers add their weight-gradient partials with float atomics, whose order differs run to run)
+        err, scale = float((g_dp - gr).abs().max()), float(gr.abs().max())
+        assert err <= 1e-5 * scale, "step %d: bucketed async all-reduce != mean of the replicas' gradients (max diff %.3e, scale %.3e)" % (
+            step, err, scale)
         assert float((g_dp - g_ref).abs().max()) > 0, "the ranks' shards differ, so must their local gradients"
         opt.step()
-        same_on_all_ranks(flat(net.parameters()), "parameters after optimizer step %d" % step)
+        same_on_all_ranks(flat(net.parameters()), "parameters after optimizer step %d" % step)   # identical: every rank applies the SAME reduced buffer
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:
