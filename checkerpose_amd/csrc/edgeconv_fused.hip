@@ -95,114 +95,158 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
   __syncthreads();
 
   f32x4 acc[4][4];
-  for (int s = 0; s < nslice; ++s) {
+  auto gemm_half = [&](int u) {                              // acc = W(slice, half) x rows; weights of u in buffer u & 1
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int u = 2 * s + half;
-      if (u + 1 < 2 * nslice) w_issue(u + 1);               // the other buffer: its last readers passed the previous barrier
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* const wb = sW + (u & 1) * EF_WBUF + lane * 16;
+    u32x4 wf[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *(const u32x4*)(wb + nt * 1024);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if (kc + 1 < KC) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[(kc + 1) & 1][nt] = *(const u32x4*)(wb + ((kc + 1) * 4 + nt) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const unsigned char* const wb = sW + (u & 1) * EF_WBUF + lane * 16;
-      u32x4 wf[2][4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *(const u32x4*)(wb + nt * 1024);
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        if (kc + 1 < KC) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) wf[(kc + 1) & 1][nt] = *(const u32x4*)(wb + ((kc + 1) * 4 + nt) * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
-                                                                 acc[f][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int nt = 0; nt < 4; ++nt)
+          acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
+                                                               acc[f][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int s = 0; s < nslice; ++s) {
+    // ---- P' = s * (W1 x) -> bf16 -> sortable keys -> LDS table
+    w_issue(2 * s + 1);                                       // Q half into the other buffer: its last readers passed the previous barrier
+    gemm_half(2 * s);
+    {
       // lane (x, q): keypoint 64 wave + 16 f + x, channels 64 s + 16 q + 4 nt + reg
-      const int c0 = (half ? p.Cout : 0) + s * 64 + q * 16;
-      if (half == 0) {                                      // P' -> bf16 -> sortable keys -> LDS table
-        float sc[16];
+      const int c0 = s * 64 + q * 16;
+      float sc[16];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const f32x4 s4 = *(const f32x4*)(sScale + c0 + 4 * nt);
+      for (int nt = 0; nt < 4; ++nt) {
+        const f32x4 s4 = *(const f32x4*)(sScale + c0 + 4 * nt);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sc[4 * nt + j] = s4[j];
-        }
+        for (int j = 0; j < 4; ++j) sc[4 * nt + j] = s4[j];
+      }
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          u32x4 lo, hi;
-          lo.x = sortable(pack_bf16x2(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
-          lo.y = sortable(pack_bf16x2(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
-          lo.z = sortable(pack_bf16x2(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
-          lo.w = sortable(pack_bf16x2(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
-          hi.x = sortable(pack_bf16x2(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
-          hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
-          hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
-          hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
-          unsigned char* dst = sP + (2 * q) * EF_PLANE + (wave * 64 + f * 16 + x) * 16;       // 16 consecutive rows: 16 slots
-          *(u32x4*)dst = lo;
-          *(u32x4*)(dst + EF_PLANE) = hi;
-        }
-        __syncthreads();                                    // table complete; the Q half of the weights has landed
-      } else {                                              // Q' stays in the accumulators (fp32)
+      for (int f = 0; f < 4; ++f) {
+        u32x4 lo, hi;
+        lo.x = sortable(pack_bf16x2(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+        lo.y = sortable(pack_bf16x2(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+        lo.z = sortable(pack_bf16x2(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+        lo.w = sortable(pack_bf16x2(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+        hi.x = sortable(pack_bf16x2(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+        hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+        hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+        hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+        unsigned char* dst = sP + (2 * q) * EF_PLANE + (wave * 64 + f * 16 + x) * 16;       // 16 consecutive rows: 16 slots
+        *(u32x4*)dst = lo;
+        *(u32x4*)(dst + EF_PLANE) = hi;
+      }
+    }
+    __syncthreads();                                          // table complete; the Q half of the weights has landed
+    if (s + 1 < nslice) w_issue(2 * s + 2);                   // next slice's P half: its buffer's readers (above) passed the barrier
+    // ---- gather-max over the K neighbours out of the LDS table (BEFORE the Q' GEMM: no accumulators are live, so two row
+    // fragments' reads -- 16 ds_read_b128 per lane -- are in flight at once; one fragment at a time left the LDS latency bare).
+    // A ds_read_b128 lane group = the 16 keypoints of a fragment, each reading ITS k-th neighbour's row: slot = row mod 16; the
+    // host orders every keypoint's list so that the 16 rows of a step have different residues (graph_sched.py).
+    uint32_t m[4][8];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const f32x4 s4 = *(const f32x4*)(sScale + c0 + 4 * nt), t4 = *(const f32x4*)(sShift + c0 + 4 * nt);
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
+      for (int j = 0; j < 8; ++j) m[f][j] = 0x80008000u;         // int16 minimum
+    {
+      const unsigned char* const pq = sP + (2 * q) * EF_PLANE;
+      const int16_t* const my = sIdx + (wave * 64 + x) * EF_KMAX;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[f][nt][j] = acc[f][nt][j] * s4[j] + t4[j];
+      for (int fp = 0; fp < 4; fp += 2) {
+        for (int k = 0; k < p.K; k += 4) {                       // K is a multiple of 4 (20)
+          u32x2 i4[2];
+          u32x4 a0[2], a1[2], c0_[2], c1[2], d0[2], d1[2], e0[2], e1[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) i4[h] = *(const u32x2*)(my + (fp + h) * 16 * EF_KMAX + k);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const unsigned char* b0 = pq + (i4[h].x & 0xffffu) * 16;
+            const unsigned char* b1 = pq + (i4[h].x >> 16) * 16;
+            const unsigned char* b2 = pq + (i4[h].y & 0xffffu) * 16;
+            const unsigned char* b3 = pq + (i4[h].y >> 16) * 16;
+            a0[h] = *(const u32x4*)b0; a1[h] = *(const u32x4*)(b0 + EF_PLANE); c0_[h] = *(const u32x4*)b1; c1[h] = *(const u32x4*)(b1 + EF_PLANE);
+            d0[h] = *(const u32x4*)b2; d1[h] = *(const u32x4*)(b2 + EF_PLANE); e0[h] = *(const u32x4*)b3; e1[h] = *(const u32x4*)(b3 + EF_PLANE);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint32_t* mm = m[fp + h];
+            mm[0] = pkmax(pkmax(mm[0], a0[h].x), pkmax(c0_[h].x, pkmax(d0[h].x, e0[h].x)));
+            mm[1] = pkmax(pkmax(mm[1], a0[h].y), pkmax(c0_[h].y, pkmax(d0[h].y, e0[h].y)));
+            mm[2] = pkmax(pkmax(mm[2], a0[h].z), pkmax(c0_[h].z, pkmax(d0[h].z, e0[h].z)));
+            mm[3] = pkmax(pkmax(mm[3], a0[h].w), pkmax(c0_[h].w, pkmax(d0[h].w, e0[h].w)));
+            mm[4] = pkmax(pkmax(mm[4], a1[h].x), pkmax(c1[h].x, pkmax(d1[h].x, e1[h].x)));
+            mm[5] = pkmax(pkmax(mm[5], a1[h].y), pkmax(c1[h].y, pkmax(d1[h].y, e1[h].y)));
+            mm[6] = pkmax(pkmax(mm[6], a1[h].z), pkmax(c1[h].z, pkmax(d1[h].z, e1[h].z)));
+            mm[7] = pkmax(pkmax(mm[7], a1[h].w), pkmax(c1[h].w, pkmax(d1[h].w, e1[h].w)));
+          }
         }
       }
     }
-    // ---- gather-max over the K neighbours out of the LDS table, + Q', LeakyReLU, store
+    // ---- Q' = s * ((W2 - W1) x) + t (fp32, never rounded to bf16), + max, LeakyReLU, store; two row fragments at a time (the
+    // maxima of all four are live: 16 accumulator tiles beside them would spill)
+    {
+      const int c0 = p.Cout + s * 64 + q * 16;
+      const unsigned char* const wb = sW + EF_WBUF + lane * 16;          // u = 2 s + 1 -> buffer 1
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int n = wave * 64 + f * 16 + x;
-      const int16_t* my = sIdx + n * EF_KMAX;
-      uint32_t m[8];
+      for (int fp = 0; fp < 4; fp += 2) {
+        f32x4 aq[2][4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = 0x80008000u;        // int16 minimum
-      for (int k = 0; k < p.K; k += 4) {                     // K is a multiple of 4 (20)
-        const u32x2 i4 = *(const u32x2*)(my + k);
-        const int r0 = (int)(i4.x & 0xffffu), r1 = (int)(i4.x >> 16), r2 = (int)(i4.y & 0xffffu), r3 = (int)(i4.y >> 16);
-        // a ds_read_b128 lane group = the 16 keypoints of this fragment, each reading ITS k-th neighbour's row: slot = row mod 16.
-        // The host orders every keypoint's list so that the 16 rows of a step have different residues (graph_sched.py).
-        const unsigned char* b0 = sP + (2 * q) * EF_PLANE + r0 * 16;
-        const unsigned char* b1 = sP + (2 * q) * EF_PLANE + r1 * 16;
-        const unsigned char* b2 = sP + (2 * q) * EF_PLANE + r2 * 16;
-        const unsigned char* b3 = sP + (2 * q) * EF_PLANE + r3 * 16;
-        const u32x4 a0 = *(const u32x4*)b0, a1 = *(const u32x4*)(b0 + EF_PLANE), c0_ = *(const u32x4*)b1, c1 = *(const u32x4*)(b1 + EF_PLANE);
-        const u32x4 d0 = *(const u32x4*)b2, d1 = *(const u32x4*)(b2 + EF_PLANE), e0 = *(const u32x4*)b3, e1 = *(const u32x4*)(b3 + EF_PLANE);
-        m[0] = pkmax(pkmax(m[0], a0.x), pkmax(c0_.x, pkmax(d0.x, e0.x)));
-        m[1] = pkmax(pkmax(m[1], a0.y), pkmax(c0_.y, pkmax(d0.y, e0.y)));
-        m[2] = pkmax(pkmax(m[2], a0.z), pkmax(c0_.z, pkmax(d0.z, e0.z)));
-        m[3] = pkmax(pkmax(m[3], a0.w), pkmax(c0_.w, pkmax(d0.w, e0.w)));
-        m[4] = pkmax(pkmax(m[4], a1.x), pkmax(c1.x, pkmax(d1.x, e1.x)));
-        m[5] = pkmax(pkmax(m[5], a1.y), pkmax(c1.y, pkmax(d1.y, e1.y)));
-        m[6] = pkmax(pkmax(m[6], a1.z), pkmax(c1.z, pkmax(d1.z, e1.z)));
-        m[7] = pkmax(pkmax(m[7], a1.w), pkmax(c1.w, pkmax(d1.w, e1.w)));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) aq[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 wf[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *(const u32x4*)(wb + nt * 1024);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          if (kc + 1 < KC) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[(kc + 1) & 1][nt] = *(const u32x4*)(wb + ((kc + 1) * 4 + nt) * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              aq[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[fp + h][kc]),
+                                                                  aq[h][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int f = fp + h;
+          const int n = wave * 64 + f * 16 + x;
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t w2 = sortable(m[f][j]);
+            const int nt = j >> 1, r = (j & 1) * 2;
+            const float q0 = aq[h][nt][r] * sScale[c0 + 4 * nt + r] + sShift[c0 + 4 * nt + r];
+            const float q1 = aq[h][nt][r + 1] * sScale[c0 + 4 * nt + r + 1] + sShift[c0 + 4 * nt + r + 1];
+            const float y0 = __uint_as_float(w2 << 16) + q0, y1 = __uint_as_float(w2 & 0xffff0000u) + q1;
+            v[2 * j] = y0 > 0.f ? y0 : y0 * p.slope;
+            v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
+          }
+          uint16_t* dst = (uint16_t*)p.out + ((size_t)b * EF_N + n) * p.out_cs + p.out_coff + s * 64 + q * 16;
+          *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
+          *(u32x4*)(dst + 8) = Vec16<BF16Tag>::pack(v + 8);
+        }
       }
-      float v[16];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t w2 = sortable(m[j]);
-        const int nt = j >> 1, r = (j & 1) * 2;
-        const float q0 = acc[f][nt][r], q1 = acc[f][nt][r + 1];
-        const float y0 = __uint_as_float(w2 << 16) + q0, y1 = __uint_as_float(w2 & 0xffff0000u) + q1;
-        v[2 * j] = y0 > 0.f ? y0 : y0 * p.slope;
-        v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
-      }
-      uint16_t* dst = (uint16_t*)p.out + ((size_t)b * EF_N + n) * p.out_cs + p.out_coff + s * 64 + q * 16;
-      *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
-      *(u32x4*)(dst + 8) = Vec16<BF16Tag>::pack(v + 8);
     }
-    __syncthreads();                                        // every gather of this slice is done: the table may be rewritten
+    __syncthreads();                                        // every gather / Q' read of this slice is done: table and Q buffer free
   }
 }
 
