@@ -1,6 +1,7 @@
 """On-device post-forward decode: the 2D-3D correspondence list the reference builds on the
 host in test.py:294-329 / test_network_with_test_data.py:from_id_to_pose :50-66, computed by one HIP kernel so that
-only (B,N,2) floats + (B,N,3) validity bytes leave the GPU.  PnP itself (Progressive-X / cv2) stays untouched."""
+only (B,N,2) floats + (B,N,3) validity bytes leave the GPU.  The reference's PnP (Progressive-X / cv2) stays untouched and can
+consume these; `solve_pnp_ransac` is the opt-in on-device twin of its cv2 branch (row N4), after which 12 doubles per crop leave."""
 import torch
 
 from . import _abi
@@ -34,3 +35,34 @@ def correspondences(outputs, roi_xy_ori, discard_bd_pixel=0):
                                       p2d.data_ptr(), valid.data_ptr(), count.data_ptr(), B, N, H, W, int(discard_bd_pixel)),
                "cp_correspondences")
     return p2d, valid, count
+
+
+def solve_pnp_ransac(p3d_xyz, p2d, valid, cam_K, column=0, reproj_threshold=2.0, iterations=150, seed=0):
+    """On-device twin of from_id_to_pose's cv2 branch (test_network_with_test_data.py:100-114; defaults reprojErr_thresh=2,
+    cv_max_iters=150): EPnP + RANSAC over the correspondences of `correspondences()`.
+      p3d_xyz (N,3) or (B,N,3) model keypoints in original units; p2d (B,N,2), valid (B,N,3) from correspondences();
+      column 0 = all RoI keypoints | 1 = also inside the full mask | 2 = inside the visible mask (check_seg variants);
+      cam_K (3,3) or (B,3,3).
+    Returns (R (B,3,3) f64, t (B,3,1) f64, inliers (B,N) bool, status (B,) int32: 0 = the reference's identity fallback)."""
+    if not (p2d.is_cuda and valid.is_cuda):
+        raise RuntimeError("checkerpose_amd.postprocess: CUDA/HIP tensors required (no CPU fallback)")
+    lib = _abi.load()
+    dev = p2d.device
+    B, N, _ = p2d.shape
+    if tuple(valid.shape) != (B, N, 3) or valid.dtype != torch.uint8 or not 0 <= column < 3:
+        raise ValueError("valid must be the (B,N,3) uint8 tensor of correspondences(), column in 0..2")
+    p3 = torch.as_tensor(p3d_xyz, dtype=torch.float32, device=dev).contiguous()
+    K = torch.as_tensor(cam_K, dtype=torch.float32, device=dev).contiguous()
+    if p3.shape[-2:] != (N, 3) or K.shape[-2:] != (3, 3):
+        raise ValueError("p3d_xyz must be (N,3) / (B,N,3) and cam_K (3,3) / (B,3,3)")
+    p2 = p2d.contiguous().float()
+    va = valid.contiguous()
+    pose = torch.empty(B, 12, dtype=torch.float64, device=dev)
+    inl = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    scratch = torch.empty(lib.cp_pnp_ransac_scratch_bytes(B, N), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _abi.check(lib.cp_pnp_ransac(st, p3.data_ptr(), 3 * N if p3.dim() == 3 else 0, p2.data_ptr(), va.data_ptr() + column, 3, K.data_ptr(),
+                                 9 if K.dim() == 3 else 0, B, N, float(reproj_threshold), int(iterations), int(seed) & 0xFFFFFFFF,
+                                 pose.data_ptr(), inl.data_ptr(), status.data_ptr(), scratch.data_ptr()), "cp_pnp_ransac")
+    return pose[:, :9].view(B, 3, 3), pose[:, 9:].view(B, 3, 1), inl.bool(), status

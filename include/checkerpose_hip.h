@@ -341,6 +341,23 @@ int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, 
                        const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W,
                        int discard_bd_pixel);
 
+/* Pose from the correspondences, on the device (next-row N4; reference test_network_with_test_data.py:100-114: the call
+ *   cv2.solvePnPRansac(valid_p3d, valid_disc_p2d, cam_K, None, reprojectionError, iterationsCount, flags=cv2.SOLVEPNP_EPNP)
+ * and the identity-pose fallback below 4 valid correspondences), one workgroup per crop, fp64 arithmetic:
+ *   p3d fp32 (N,3) model keypoints in their ORIGINAL units (batch stride p3d_bstride elements; 0 = one object for all crops);
+ *   p2d fp32 (B,N,2) and valid uint8 with `valid_stride` bytes between keypoints = cp_correspondences' outputs (valid + column c,
+ *   stride 3: c = 0 all | 1 in full mask | 2 in visible mask);  cam_K fp32 row-major 3x3 (batch stride K_bstride; 0 = shared);
+ *   RANSAC over `iterations` (<= 256) EPnP hypotheses of 5 correspondences (4 when only 4 are valid) drawn by a counter-based
+ *   hash of (seed, crop, hypothesis), inlier test squared reprojection error <= reproj_threshold^2, the hypothesis with the most
+ *   inliers (>= the sample size; first on ties), final EPnP over its inliers.
+ * Outputs: pose fp64 (B,12) = [R row-major | t], inliers uint8 (B,N), status int32 (B): 1 = solved, 0 = identity fallback.
+ * scratch: cp_pnp_ransac_scratch_bytes(B, N).  opencv-python is not part of the reference's tree: the algorithm is restated from
+ * the publication / OpenCV's structure (oracle/pnp_oracle.py lists the deliberate differences); parity with cv2 is UNPINNED. */
+size_t cp_pnp_ransac_scratch_bytes(int B, int N);
+int cp_pnp_ransac(cp_stream_t stream, const float* p3d, long long p3d_bstride, const float* p2d, const uint8_t* valid,
+                  int valid_stride, const float* cam_K, long long K_bstride, int B, int N, float reproj_threshold,
+                  int iterations, uint32_t seed, double* pose, uint8_t* inliers, int32_t* status, void* scratch);
+
 /* ---------------------------------------------------------------------------------------------
  * Training side: backward of the fused graph ops + the loss head of train.py:307-320.
  * Gradients are fp32; `pq` is the forward's saved GEMM output in `dtype`.

@@ -1,0 +1,142 @@
+"""Row N4 (pose from correspondences).  cv2 is not part of the reference's tree, so parity with it is UNPINNED (oracle/pnp_oracle.py
+says why); what IS checked: the oracle recovers known poses (exact data to 1e-9, 30 % outliers + pixel noise to the noise level, and
+finds exactly the true inlier set), reproduces the reference's identity fallbacks (test_network_with_test_data.py:111-114), and the
+device kernel (cp_pnp_ransac) equals the oracle on the same inputs: same samples (shared counter-based hash), same inlier sets, poses
+to 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pnp_oracle as P
+from checkerpose_amd.synthetic import DATA
+
+K_LMO = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])      # LM-O camera
+
+
+def _model(n=512):
+    return np.load(os.path.join(DATA, "fps_lmo_obj01.npy"))[:n].astype(np.float32).astype(np.float64)      # mm, as the kernel reads them
+
+
+def _pose(rng):
+    a = rng.normal(size=3)
+    a /= np.linalg.norm(a)
+    th = rng.uniform(0.1, np.pi - 0.1)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    return R, np.array([rng.uniform(-120, 120), rng.uniform(-90, 90), rng.uniform(500, 1300)])
+
+
+def make_case(rng, n=512, outlier_frac=0.3, noise=0.5, valid_frac=0.8):
+    xyz = _model(n)
+    R, t = _pose(rng)
+    uv = P.project(xyz, K_LMO, R, t)
+    out = rng.random(n) < outlier_frac
+    uvn = uv + rng.normal(scale=noise, size=uv.shape)
+    uvn[out] += rng.uniform(20, 80, size=(int(out.sum()), 2)) * rng.choice([-1, 1], size=(int(out.sum()), 2))
+    valid = rng.random(n) < valid_frac
+    return xyz, uvn.astype(np.float32).astype(np.float64), valid, out, R, t
+
+
+def test_hash_and_sampling_are_deterministic():
+    assert P._hash32(1, 2, 3, 4) == P._hash32(1, 2, 3, 4) != P._hash32(1, 2, 3, 5)
+    assert [P._hash32(7, b, 11, 0) for b in range(3)] == [714418499, 1957091910, 2981744819]      # known answers shared with pnp.hip
+    s = P.sample_indices(3, 1, 17, 40, 5)
+    assert len(set(s)) == 5 and all(0 <= v < 40 for v in s) and s == P.sample_indices(3, 1, 17, 40, 5)
+
+
+def test_epnp_recovers_exact_poses():
+    rng = np.random.default_rng(0)
+    xyz = _model(64)
+    for n in (4, 5, 6, 64):
+        for _ in range(4):
+            R, t = _pose(rng)
+            uv = P.project(xyz[:n], K_LMO, R, t)
+            Re, te, err = P.epnp(xyz[:n], uv, K_LMO)
+            if n >= 5:
+                assert err < 1e-8 and np.abs(Re - R).max() < 1e-8 and np.abs(te - t).max() < 1e-6, (n, err)
+            else:        # 4 points leave a 4-dimensional null space: EPnP's linearisation + 5 Gauss-Newton steps end NEAR the pose
+                assert err < 1.0 and np.abs(Re - R).max() < 5e-2, (n, err)      # (cv2 switches to a P3P kernel for 4 points)
+            assert abs(np.linalg.det(Re) - 1) < 1e-12
+
+
+def test_ransac_finds_the_true_inlier_set_and_the_pose():
+    rng = np.random.default_rng(1)
+    for crop in range(3):
+        xyz, uv, valid, out, R, t = make_case(rng)
+        Re, te, mask, status = P.solve_pnp_ransac(xyz, uv, valid, K_LMO, 2.0, 150, seed=5, crop=crop)
+        assert status == 1
+        assert not (mask & ~valid).any() and not (mask & out).any()                 # no invalid and no outlier among the inliers
+        assert mask.sum() >= 0.97 * (valid & ~out).sum()                            # 0.5 px noise: a few true inliers fall beyond 2 px
+        assert np.abs(Re - R).max() < 5e-3 and np.linalg.norm(te - t) < 5e-3 * np.linalg.norm(t)
+
+
+def test_reference_fallbacks():
+    xyz = _model(16)
+    rng = np.random.default_rng(2)
+    R, t = _pose(rng)
+    uv = P.project(xyz, K_LMO, R, t)
+    for nvalid in (0, 3):                                   # num_valid < 4 -> R = I, t = 0, inliers None (:111-114)
+        valid = np.zeros(16, bool)
+        valid[:nvalid] = True
+        Re, te, mask, status = P.solve_pnp_ransac(xyz, uv, valid, K_LMO)
+        assert status == 0 and np.array_equal(Re, np.eye(3)) and not te.any() and not mask.any()
+    valid = np.zeros(16, bool)
+    valid[[1, 4, 9, 12]] = True                             # exactly 4: solved from the 4 (cv2 switches to a 4-point kernel there)
+    Re, te, mask, status = P.solve_pnp_ransac(xyz, uv, valid, K_LMO)
+    assert status == 1 and mask.sum() == 4 and P.reprojection_error(xyz[valid], uv[valid], K_LMO, Re, te) < 1.0
+
+
+@pytest.mark.gpu
+def test_device_pnp_equals_oracle():
+    from checkerpose_amd.postprocess import solve_pnp_ransac
+    rng = np.random.default_rng(3)
+    B, N = 6, 512
+    cases = [make_case(rng) for _ in range(B)]
+    cases[4] = make_case(rng, outlier_frac=0.0, noise=0.0, valid_frac=1.0)              # exact data
+    p2d = np.stack([c[1] for c in cases])
+    valid = np.zeros((B, N, 3), np.uint8)
+    for b, c in enumerate(cases):
+        valid[b, :, 0] = 1                                                              # column 0 (all): every keypoint
+        valid[b, :, 1] = c[2]                                                           # column 1: the case's validity mask
+    valid[5, :, 1] = 0
+    valid[5, [3, 70, 200], 1] = 1                                                       # crop 5: 3 valid -> identity fallback
+    dev = torch.device("cuda:0")
+    xyz = cases[0][0]
+    R, t, inl, status = solve_pnp_ransac(torch.from_numpy(xyz).float().to(dev), torch.from_numpy(p2d).float().to(dev),
+                                         torch.from_numpy(valid).to(dev), torch.from_numpy(K_LMO).float().to(dev), column=1,
+                                         reproj_threshold=2.0, iterations=150, seed=9)
+    torch.cuda.synchronize()
+    R, t, inl, status = R.cpu().numpy(), t.cpu().numpy()[:, :, 0], inl.cpu().numpy(), status.cpu().numpy()
+    Kf = K_LMO.astype(np.float32).astype(np.float64)
+    for b, c in enumerate(cases):
+        Ro, to, mo, so = P.solve_pnp_ransac(xyz, p2d[b], valid[b, :, 1].astype(bool), Kf, 2.0, 150, seed=9, crop=b)
+        assert status[b] == so, b
+        assert np.array_equal(inl[b], mo), (b, int(inl[b].sum()), int(mo.sum()))
+        assert np.abs(R[b] - Ro).max() < 1e-6 and np.abs(t[b] - to).max() < 1e-5 * max(1.0, np.linalg.norm(to)), b
+        if b < 5:
+            assert np.abs(R[b] - c[4]).max() < 5e-3 and np.linalg.norm(t[b] - c[5]) < 5e-3 * np.linalg.norm(c[5])
+    assert status[5] == 0 and np.array_equal(R[5], np.eye(3)) and not t[5].any() and not inl[5].any()
+    assert np.abs(R[4] - cases[4][4]).max() < 1e-5                                      # exact data (fp32 inputs): the true pose
+
+
+@pytest.mark.gpu
+def test_device_pnp_consumes_the_forward(lib):
+    """forward -> cp_correspondences -> cp_pnp_ransac without leaving the device (random-init weights: the pose is meaningless, the
+    plumbing is what is checked: shapes, dtypes, status in {0, 1}, inliers a subset of the valid column, proper rotations)"""
+    from checkerpose_amd.postprocess import correspondences, solve_pnp_ransac
+    from checkerpose_amd.synthetic import build_net, det_image, det_tensor
+    dev = torch.device("cuda:0")
+    net = build_net(seed=1).to(dev)
+    with torch.no_grad():
+        out = net(det_image(3, seed=5).to(dev), None)
+    grid = (det_tensor("roi_xy", (3, 2, 64, 64), 300.0) + 320.0).to(dev)
+    p2d, valid, count = correspondences(out, grid)
+    R, t, inl, status = solve_pnp_ransac(torch.from_numpy(_model(512)).float().to(dev), p2d, valid, torch.from_numpy(K_LMO).float().to(dev))
+    torch.cuda.synchronize()
+    assert tuple(R.shape) == (3, 3, 3) and tuple(t.shape) == (3, 3, 1) and R.dtype == torch.float64
+    assert set(status.cpu().tolist()) <= {0, 1}
+    assert not (inl & ~valid[:, :, 0].bool()).any()
+    for b in range(3):
+        assert abs(float(torch.linalg.det(R[b])) - 1.0) < 1e-9 or int(status[b]) == 0
