@@ -140,8 +140,9 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 }
 
 // ------------------------------------------------------------------------------------------------ launch 2: gather + Q'
-// weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt = output channel
-// 32 slice + (r >> 2) * 8 + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels 32 s + 8 q + 4 nt + reg
+// weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt of slice s = 2 j + h
+// = output channel 64 j + (r >> 2) * 16 + 8 h + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels
+// 64 j + 16 q + 8 h + 4 nt + reg
 template <int CIN, bool DB>
 __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledParams p) {
   constexpr int KC = CIN / 32;
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
   const int32_t* const halo = p.halo + ((size_t)g * p.NB + t) * p.HPAD;
   const unsigned char* const tab = (const unsigned char*)p.ptab + (size_t)b * (p.Cout / 8) * p.N * 16;
 
-  // table of slice s: plane pl <- global plane 4 s + pl; 64-row chunks: own rows are one contiguous 1 KB segment, halo rows
+  // slice s = 2 j + h holds channels 64 j + 16 q + 8 h + (0..7) for lane group q (not 32 consecutive ones): after an even / odd
+  // slice pair a lane owns 16 CONSECUTIVE channels of its keypoint and stores 32 bytes -- the four q lanes a full 128-byte line
+  // (16-byte stores per slice wrote every line in two halves, slices apart: 92 MB of HBM writes for a 67 MB output).
+  // table of slice s: plane pl <- global plane 8 j + 2 pl + h; 64-row chunks: own rows are one contiguous 1 KB segment, halo rows
   // 16-byte pieces at per-lane rows.  (4 planes x (8 + HPAD / 64) chunks, dealt round-robin to the 8 waves.)
   const int nchunk = 8 + p.HPAD / 64;
   auto table_issue = [&](int s) {
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       const int pl = c / nchunk, ch = c - pl * nchunk;
       const int slot = ch * 64 + lane;
       const int row = ch < 8 ? t * ET_BLK + slot : halo[slot - ET_BLK];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(4 * s + pl) * p.N + row) * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N + row) * 16),
                                        (__attribute__((address_space(3))) void*)(dstb + pl * PLANE + ch * 1024), 16, 0, 0);
     }
   };
@@ -213,12 +217,16 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
     for (int kc = 0; kc < KC; ++kc)
       xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
 
+  u32x4 held[4];
   for (int s = 0; s < nslice; ++s) {
     // DB: the NEXT slice's table streams into the other buffer (its readers, gather(s - 1), passed the last barrier) under this
     // whole slice; the single weight buffer was refilled behind the last barrier and is awaited at the mid-slice barrier.
     // !DB (the table pair does not fit): weights double-buffered, the next table is issued behind the gather's barrier.
+#ifndef ET_NODMA
     if (DB) { if (s + 1 < nslice) table_issue(s + 1); }
-    else if (s + 1 < nslice) w_issue(s + 1);
+    else
+#endif
+    if (!DB && s + 1 < nslice) w_issue(s + 1);
     // ---- gather-max over the K neighbours out of the LDS table: lane (x, q) = keypoint x of fragment f, plane q.  k outer,
     // fragments inner: 4 list reads, then 16 table reads in flight per lane (one fragment at a time left the LDS latency bare)
     uint32_t m[4][4];
@@ -229,7 +237,11 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
     {
       const unsigned char* const pq = sP + (DB ? (s & 1) * 4 * PLANE : 0) + q * PLANE;
       const int16_t* const my = sIdx + (wave * 64 + x) * ET_KMAX;
+#ifdef ET_NOGATHER                                                    // knock-out builds (tools/edge_tiled_bench.py): results wrong on purpose
+      for (int k = 0; k < 0; k += 4) {
+#else
       for (int k = 0; k < p.K; k += 4) {                             // K is a multiple of 4 (20)
+#endif
         u32x2 i4[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) i4[f] = *(const u32x2*)(my + f * 16 * ET_KMAX + k);
@@ -249,7 +261,9 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       }
     }
     __syncthreads();                                                // DB: weights(s) landed.  !DB: every gather done, the table is free
+#ifndef ET_NODMA
     if (!DB && s + 1 < nslice) table_issue(s + 1);                  // ... and streams in under the Q' GEMM below
+#endif
     // ---- Q' = s * ((W2 - W1) x) + t for this slice's 32 channels, from the register-resident rows
     f32x4 acc[4][2];
 #pragma unroll
@@ -257,8 +271,13 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
     const unsigned char* const wb = sW + (DB ? 0 : (s & 1) * WQ) + lane * 16;
     u32x4 wf[2][2];
     wf[0][0] = *(const u32x4*)wb; wf[0][1] = *(const u32x4*)(wb + 1024);
+#ifdef ET_NOQ
+    constexpr int KCQ = 1;
+#else
+    constexpr int KCQ = KC;
+#endif
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
+    for (int kc = 0; kc < KCQ; ++kc) {
       if (kc + 1 < KC) {
         wf[(kc + 1) & 1][0] = *(const u32x4*)(wb + ((kc + 1) * 2) * 1024);
         wf[(kc + 1) & 1][1] = *(const u32x4*)(wb + ((kc + 1) * 2 + 1) * 1024);
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
                                                                acc[f][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int c0 = s * 32 + q * 8;
+    const int c0 = (s >> 1) * 64 + q * 16 + (s & 1) * 8;
     const f32x4 s0 = *(const f32x4*)(sScale + c0), s1 = *(const f32x4*)(sScale + c0 + 4);
     const f32x4 t0 = *(const f32x4*)(sShift + c0), t1 = *(const f32x4*)(sShift + c0 + 4);
 #pragma unroll
@@ -289,8 +308,13 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
         v[2 * j] = fmaxf(y0, y0 * p.slope);                            // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
         v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
       }
-      uint16_t* dst = (uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0;
-      *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
+      const u32x4 pk = Vec16<BF16Tag>::pack(v);
+      if ((s & 1) == 0) held[f] = pk;                                // even slice: channels c0 .. c0 + 7 wait for their upper neighbours
+      else {
+        uint16_t* dst = (uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0 - 8;
+        *(u32x4*)dst = held[f];
+        *(u32x4*)(dst + 8) = pk;
+      }
     }
     __syncthreads();                                                // DB: table(s + 1) landed, weights(s) / table(s) free.  !DB: both landed
     if (DB && s + 1 < nslice) w_issue(s + 1);                       // awaited at the next mid-slice barrier, a whole gather away
@@ -309,7 +333,7 @@ __global__ void pack_edgeconv_tiled_q_kernel(const float* __restrict__ wpq, uint
   const int kc = (int)(blk % KC);
   const int s = (int)(blk / KC);
   const int r = lane & 15, q = lane >> 4;
-  const int c = s * 32 + (r >> 2) * 8 + nt * 4 + (r & 3);
+  const int c = (s >> 1) * 64 + (r >> 2) * 16 + (s & 1) * 8 + nt * 4 + (r & 3);
   const int cin = kc * 32 + q * 8 + e;
   out[i] = (uint16_t)f32_to_bf16_bits(wpq[((size_t)(Cout + c)) * Cin + cin]);
 }
