@@ -199,10 +199,15 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
   w_issue(0);
   {
     const int16_t* gi = p.nbr + ((size_t)g * p.NB + t) * ET_BLK * p.K;
+    // staged as BYTE offsets into a table plane (slot * 16 < 65536: one shift less per neighbour in the gather)
     if (p.K == ET_KMAX) {                                           // rows already at the LDS pitch: 16-byte copies
-      for (int i = tid; i < ET_BLK * ET_KMAX / 8; i += 512) ((u32x4*)sIdx)[i] = ((const u32x4*)gi)[i];
+      for (int i = tid; i < ET_BLK * ET_KMAX / 8; i += 512) {
+        u32x4 v = ((const u32x4*)gi)[i];
+        v.x = (v.x & 0x0fff0fffu) << 4; v.y = (v.y & 0x0fff0fffu) << 4; v.z = (v.z & 0x0fff0fffu) << 4; v.w = (v.w & 0x0fff0fffu) << 4;
+        ((u32x4*)sIdx)[i] = v;
+      }
     } else {
-      for (int i = tid; i < ET_BLK * p.K; i += 512) sIdx[(i / p.K) * ET_KMAX + (i % p.K)] = gi[i];
+      for (int i = tid; i < ET_BLK * p.K; i += 512) sIdx[(i / p.K) * ET_KMAX + (i % p.K)] = (int16_t)(gi[i] << 4);
     }
   }
   for (int i = tid; i < p.Cout; i += 512) { sScale[i] = p.scale[p.Cout + i]; sShift[i] = p.shift[p.Cout + i]; }
@@ -236,27 +241,62 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       for (int j = 0; j < 4; ++j) m[f][j] = 0x80008000u;             // int16 minimum
     {
       const unsigned char* const pq = sP + (DB ? (s & 1) * 4 * PLANE : 0) + q * PLANE;
-      const int16_t* const my = sIdx + (wave * 64 + x) * ET_KMAX;
+      const uint16_t* const my = (const uint16_t*)sIdx + (wave * 64 + x) * ET_KMAX;
+      auto rd4 = [&](const u32x2& i4, u32x4* r) {                    // the 4 neighbour rows of one list quad
+        r[0] = *(const u32x4*)(pq + (i4.x & 0xffffu)); r[1] = *(const u32x4*)(pq + (i4.x >> 16));
+        r[2] = *(const u32x4*)(pq + (i4.y & 0xffffu)); r[3] = *(const u32x4*)(pq + (i4.y >> 16));
+      };
+      auto mx4 = [&](uint32_t* mm, const u32x4* r) {
+        mm[0] = pkmax(pkmax(mm[0], r[0].x), pkmax(r[1].x, pkmax(r[2].x, r[3].x)));
+        mm[1] = pkmax(pkmax(mm[1], r[0].y), pkmax(r[1].y, pkmax(r[2].y, r[3].y)));
+        mm[2] = pkmax(pkmax(mm[2], r[0].z), pkmax(r[1].z, pkmax(r[2].z, r[3].z)));
+        mm[3] = pkmax(pkmax(mm[3], r[0].w), pkmax(r[1].w, pkmax(r[2].w, r[3].w)));
+      };
 #ifdef ET_NOGATHER                                                    // knock-out builds (tools/edge_tiled_bench.py): results wrong on purpose
-      for (int k = 0; k < 0; k += 4) {
+      if (false) {
 #else
-      for (int k = 0; k < p.K; k += 4) {                             // K is a multiple of 4 (20)
+      if (p.K == ET_KMAX) {
 #endif
-        u32x2 i4[4];
+        // software pipeline over 10 half-steps (list quad k / 4, fragment pair): the NEXT half-step's 8 table reads and the list
+        // quads of the one after are issued before this half-step's 32 packed maxima -- a wave that issued, waited and only then
+        // computed spent 2-3 x its VALU time per slice waiting on the LDS (knock-out: the gather was 46 of the launch's 82 us)
+        u32x4 ra[8], rb[8];
+        u32x2 ia[2], ib[2];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) i4[f] = *(const u32x2*)(my + f * 16 * ET_KMAX + k);
-        u32x4 a[4], c[4], d[4], e[4];
+        for (int h = 0; h < 2; ++h) ia[h] = *(const u32x2*)(my + h * 16 * ET_KMAX);
+        rd4(ia[0], ra); rd4(ia[1], ra + 4);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          a[f] = *(const u32x4*)(pq + (i4[f].x & 0xffffu) * 16); c[f] = *(const u32x4*)(pq + (i4[f].x >> 16) * 16);
-          d[f] = *(const u32x4*)(pq + (i4[f].y & 0xffffu) * 16); e[f] = *(const u32x4*)(pq + (i4[f].y >> 16) * 16);
+        for (int h = 0; h < 2; ++h) ib[h] = *(const u32x2*)(my + (2 + h) * 16 * ET_KMAX);
+#pragma unroll
+        for (int hs = 0; hs < 10; ++hs) {
+          u32x4* const cur = (hs & 1) ? rb : ra;
+          u32x4* const nxt = (hs & 1) ? ra : rb;
+          u32x2* const inx = (hs & 1) ? ia : ib;                      // list quads of half-step hs + 1 (loaded one half-step ago)
+          u32x2* const iaf = (hs & 1) ? ib : ia;                      // ... and the ones of hs + 2 go where hs's were
+          // (LDS results return in order: the list quads go out BEFORE the table reads, so that waiting for them next half-step
+          // does not wait for these 8 reads as well)
+          if (hs + 2 < 10) {
+            const int k2 = 4 * ((hs + 2) >> 1), f2 = 2 * ((hs + 2) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) iaf[h] = *(const u32x2*)(my + (f2 + h) * 16 * ET_KMAX + k2);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (hs + 1 < 10) { rd4(inx[0], nxt); rd4(inx[1], nxt + 4); }
+          __builtin_amdgcn_sched_barrier(0);
+          const int f0 = 2 * (hs & 1);
+          mx4(m[f0], cur); mx4(m[f0 + 1], cur + 4);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else {
+        for (int k = 0; k < p.K; k += 4) {                           // generic K (a multiple of 4): one list quad of all 4 fragments per step
+          u32x2 i4[4];
+          u32x4 r[16];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          m[f][0] = pkmax(pkmax(m[f][0], a[f].x), pkmax(c[f].x, pkmax(d[f].x, e[f].x)));
-          m[f][1] = pkmax(pkmax(m[f][1], a[f].y), pkmax(c[f].y, pkmax(d[f].y, e[f].y)));
-          m[f][2] = pkmax(pkmax(m[f][2], a[f].z), pkmax(c[f].z, pkmax(d[f].z, e[f].z)));
-          m[f][3] = pkmax(pkmax(m[f][3], a[f].w), pkmax(c[f].w, pkmax(d[f].w, e[f].w)));
+          for (int f = 0; f < 4; ++f) i4[f] = *(const u32x2*)(my + f * 16 * ET_KMAX + k);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) rd4(i4[f], r + 4 * f);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) mx4(m[f], r + 4 * f);
         }
       }
     }
