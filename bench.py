@@ -193,6 +193,28 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
     ex["bf16_agreement"] = {"vs": "fp32 HIP path (oracle-pinned <= 1e-4) on 8 crops, random-init weights",
                             "free_running": {k: free[k] for k in keep}, "free_running_rows": free["bit_agreement_per_row"],
                             "teacher_forced": {k: forced[k] for k in keep}, "teacher_forced_rows": forced["bit_agreement_per_row"]}
+    # ---- post-forward rows N2 + N4 on the device: correspondences + EPnP / RANSAC pose for the whole batch (opt-in path; the
+    #      reference does both per image on the host, test_network_with_test_data.py:32-115).  Random-init weights: the poses are
+    #      meaningless, the launch time is what is measured.
+    try:
+        import numpy as np
+        from checkerpose_amd.postprocess import correspondences, solve_pnp_ransac
+        from checkerpose_amd.synthetic import DATA
+        out_main = net_bf16(img_main, None)
+        grid = (det_tensor("roi_xy", (B_main, 2, 64, 64), 300.0) + 320.0).to(dev)
+        xyz = torch.from_numpy(np.load(os.path.join(DATA, "fps_lmo_obj01.npy"))[:npoint]).float().to(dev)
+        Kc = torch.tensor([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]], device=dev)
+
+        def post():
+            p2d, valid, _ = correspondences(out_main, grid)
+            return solve_pnp_ransac(xyz, p2d, valid, Kc)
+        el = timed_steps(post, 10, 2)
+        st_ = post()[3]
+        ex["post_forward"] = {"ms_per_batch": round(el / 10 * 1e3, 3), "batch": B_main, "solved": int(st_.sum()),
+                              "note": "cp_correspondences + cp_pnp_ransac (150 EPnP hypotheses per crop, fp64) for the whole batch, outputs "
+                                      "never leave the device; opt-in rows N2 + N4, not part of `value`"}
+    except Exception as e:          # an extra must never take the headline down
+        ex["post_forward"] = {"error": repr(e)[:200]}
     del net32
     torch.cuda.empty_cache()
     # ---- PCIe-inclusive feed: uint8 HWC crops in pinned host memory -> H2D on a copy stream (double-buffered) ->

@@ -1,16 +1,20 @@
 // Pose from correspondences on the device: the solver call of the reference's from_id_to_pose
 //   cv2.solvePnPRansac(valid_p3d, valid_disc_p2d, cam_K, None, reprojectionError=2, iterationsCount=150, flags=cv2.SOLVEPNP_EPNP)
 // (test_network_with_test_data.py:100-110; identity pose below 4 valid correspondences, :111-114) as a consumer of
-// cp_correspondences' output: ONE launch for the whole batch, one workgroup per crop, so the (B, N, 2) coordinates and validity
+// cp_correspondences' output: TWO launches for the whole batch, so the (B, N, 2) coordinates and validity
 // masks never leave the GPU -- only 12 doubles per crop do.  opencv-python is not vendored by the reference (and absent here): this
 // is the published algorithm -- EPnP (Lepetit, Moreno-Noguer, Fua 2009) in the structure of OpenCV's epnp.cpp inside the RANSAC
 // frame of OpenCV's solvePnPRansac -- restated in oracle/pnp_oracle.py, which states the deliberate differences (sample sequence
 // from a counter-based hash, no early termination).  All arithmetic in fp64.
-//   phase 1  thread 0 compacts the valid indices (ascending);
-//   phase 2  thread h < iterations: draws 5 (4 if only 4 are valid) distinct correspondences, EPnP -> pose h, counts the valid
-//            correspondences with squared reprojection error <= threshold^2;
-//   phase 3  best = most inliers (first on ties, at least a full sample); its inlier list is compacted;
-//   phase 4  EPnP over the inliers: the 78 distinct entries of M^T M by 78 threads, the rest by thread 0.
+//   launch 1 (grid: 64 hypotheses x crop, one wave each; the crop's correspondences staged in LDS, valid indices compacted by
+//            ballot scans): lane h draws 5 (4 if only 4 are valid) distinct correspondences, EPnP -> pose h, counts the valid
+//            correspondences with squared reprojection error <= threshold^2 -> a 14-double record in scratch;
+//   launch 2 (one 256-thread workgroup per crop): best = most inliers (first on ties, at least a full sample); its inlier list
+//            is compacted; EPnP over the inliers with every loop over the points shared by the 256 threads (block reductions:
+//            centroid, scatter matrix, the 78 entries of M^T M, the candidates' centroids / cross-covariances / errors) and
+//            the small dense algebra (12 x 12 Jacobi, betas, Gauss-Newton, 3 x 3 SVD) on single threads.
+// (The first version -- everything in one workgroup, serial passes on thread 0 straight from global memory -- took 7.2 ms per
+// batch whatever its size; see tools/pnp_bench.py.)
 #include "common.h"
 
 namespace {
@@ -19,7 +23,7 @@ struct PnpParams {
   const float* p3d; const float* p2d; const uint8_t* valid; const float* K;
   double* pose; uint8_t* inliers; int32_t* status; int32_t* scratch;
   long long p3d_bs, K_bs;
-  int B, N, valid_stride, iters;
+  int B, N, valid_stride, iters, round;
   float thr;
   uint32_t seed;
 };
@@ -71,6 +75,91 @@ __device__ void jacobi_eig(double* a, double* v) {
           const double vkp = v[k * n + p], vkq = v[k * n + q];
           v[k * n + p] = c * vkp - s * vkq;
           v[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+// the same on matrices that live in LDS with an element stride (launch 1: element e of lane l at [e * 64 + l], conflict-free;
+// launch 2: stride 1).  In private (scratch) memory the ~76 000 dependent loads / stores of a 12 x 12 solve took ~4 ms per wave.
+template <int n>
+__device__ void jacobi_eig_strided(double* a, double* v, int st) {
+#define JA(i, j) a[((i) * n + (j)) * st]
+#define JV(i, j) v[((i) * n + (j)) * st]
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) JV(i, j) = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i) {
+      diag += JA(i, i) * JA(i, i);
+      for (int j = i + 1; j < n; ++j) off += JA(i, j) * JA(i, j);
+    }
+    if (off <= 1e-26 * diag || off == 0.0) break;             // off-diagonal mass below 1e-13 of the diagonal's
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = JA(p, q);
+        if (apq * apq <= 1e-34 * fabs(JA(p, p) * JA(q, q)) || apq == 0.0) continue;      // already negligible: skip the rotation
+        const double theta = (JA(q, q) - JA(p, p)) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {                     // A <- J^T A J
+          const double akp = JA(k, p), akq = JA(k, q);
+          JA(k, p) = c * akp - s * akq;
+          JA(k, q) = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+          const double apk = JA(p, k), aqk = JA(q, k);
+          JA(p, k) = c * apk - s * aqk;
+          JA(q, k) = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+          const double vkp = JV(k, p), vkq = JV(k, q);
+          JV(k, p) = c * vkp - s * vkq;
+          JV(k, q) = s * vkp + c * vkq;
+        }
+      }
+  }
+#undef JA
+#undef JV
+}
+
+// the same solve shared by the first 12 lanes of ONE wave (launch 2's single final solve): lane k owns index k of every 12-long
+// loop; all 12 lanes derive the same rotation from the same three LDS words; LDS operations of a wave execute in program order, so
+// the column / row / eigenvector updates need no barrier between them.  Call with the whole wave converged; lanes >= 12 idle.
+__device__ void jacobi_eig12_wave(double* a, double* v, int lane) {
+  const int k = lane;
+  const bool on = lane < 12;
+  if (on)
+    for (int j = 0; j < 12; ++j) v[k * 12 + j] = k == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < 12; ++i) {
+      diag += a[i * 12 + i] * a[i * 12 + i];
+      for (int j = i + 1; j < 12; ++j) off += a[i * 12 + j] * a[i * 12 + j];
+    }
+    if (off <= 1e-26 * diag || off == 0.0) break;             // every lane reads the same words: uniform decision
+    for (int p = 0; p < 11; ++p)
+      for (int q = p + 1; q < 12; ++q) {
+        const double apq = a[p * 12 + q], app = a[p * 12 + p], aqq = a[q * 12 + q];
+        if (apq * apq <= 1e-34 * fabs(app * aqq) || apq == 0.0) continue;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        if (on) {
+          const double akp = a[k * 12 + p], akq = a[k * 12 + q];
+          a[k * 12 + p] = c * akp - s * akq;
+          a[k * 12 + q] = s * akp + c * akq;
+        }
+        if (on) {
+          const double apk = a[p * 12 + k], aqk = a[q * 12 + k];
+          a[p * 12 + k] = c * apk - s * aqk;
+          a[q * 12 + k] = s * apk + c * aqk;
+          const double vkp = v[k * 12 + p], vkq = v[k * 12 + q];
+          v[k * 12 + p] = c * vkp - s * vkq;
+          v[k * 12 + q] = s * vkp + c * vkq;
         }
       }
   }
@@ -162,6 +251,8 @@ __device__ void procrustes_rotation(const double* m, double* R) {
   if (det < 0.0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
 }
 
+constexpr int PNP_THREADS = 256, PNP_MAX_ITERS = 256, PNP_NMAX = 4096, PNP_HYP = 14;      // doubles per hypothesis record: count, -, 12 pose
+
 struct Points {            // the correspondences of one EPnP call: idx[0 .. n) into this crop's (N, 3) / (N, 2) arrays
   const float* p3d; const float* p2d; const int32_t* idx; int n;
   double fu, fv, uc, vc;
@@ -177,18 +268,12 @@ __device__ __forceinline__ void alphas_of(const Frame& f, const float* pw, doubl
   al[0] = 1.0 - al[1] - al[2] - al[3];
 }
 
-__device__ bool epnp_frame(const Points& P, Frame& f) {
-  const int n = P.n;
-  double c[3] = {0, 0, 0};
-  for (int i = 0; i < n; ++i) { const float* pw = P.p3d + 3 * (size_t)P.idx[i]; c[0] += pw[0]; c[1] += pw[1]; c[2] += pw[2]; }
-  for (int k = 0; k < 3; ++k) f.cw[0][k] = c[k] / n;
-  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, E[9];
-  for (int i = 0; i < n; ++i) {
-    const float* pw = P.p3d + 3 * (size_t)P.idx[i];
-    const double d[3] = {pw[0] - f.cw[0][0], pw[1] - f.cw[0][1], pw[2] - f.cw[0][2]};
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) S[3 * a + b] += d[a] * d[b];
-  }
+// control points from the model points' centroid c and scatter matrix S (row-major 3 x 3, destroyed) -- the PCA of epnp.cpp's
+// choose_control_points -- and the inverse of the barycentric basis
+__device__ bool epnp_frame_from(const double* c, const double* Sin, int n, Frame& f) {
+  double S[9], E[9];
+  for (int i = 0; i < 9; ++i) S[i] = Sin[i];
+  for (int k = 0; k < 3; ++k) f.cw[0][k] = c[k];
   jacobi_eig<3>(S, E);
   int ord[3] = {0, 1, 2};                                  // descending eigenvalues
   for (int i = 0; i < 2; ++i)
@@ -210,6 +295,21 @@ __device__ bool epnp_frame(const Points& P, Frame& f) {
   f.ci[3] = (CC[5] * CC[6] - CC[3] * CC[8]) * id; f.ci[4] = (CC[0] * CC[8] - CC[2] * CC[6]) * id; f.ci[5] = (CC[2] * CC[3] - CC[0] * CC[5]) * id;
   f.ci[6] = (CC[3] * CC[7] - CC[4] * CC[6]) * id; f.ci[7] = (CC[1] * CC[6] - CC[0] * CC[7]) * id; f.ci[8] = (CC[0] * CC[4] - CC[1] * CC[3]) * id;
   return true;
+}
+
+__device__ bool epnp_frame(const Points& P, Frame& f) {
+  const int n = P.n;
+  double c[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) { const float* pw = P.p3d + 3 * (size_t)P.idx[i]; c[0] += pw[0]; c[1] += pw[1]; c[2] += pw[2]; }
+  for (int k = 0; k < 3; ++k) c[k] /= n;
+  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const float* pw = P.p3d + 3 * (size_t)P.idx[i];
+    const double d[3] = {pw[0] - c[0], pw[1] - c[1], pw[2] - c[2]};
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) S[3 * a + b] += d[a] * d[b];
+  }
+  return epnp_frame_from(c, S, n, f);
 }
 
 // the two rows of M that correspondence i contributes: r0 = [a_j fu, 0, a_j (uc - u)]_j, r1 = [0, a_j fv, a_j (vc - v)]_j
@@ -237,10 +337,12 @@ __device__ double reproj_mean(const Points& P, const double* R, const double* t)
   return s / P.n;
 }
 
-// everything behind M^T M (row-major 12 x 12, destroyed): null-space basis, betas, Gauss-Newton, absolute orientation
-__device__ bool epnp_finish(const Points& P, const Frame& f, double* MtM, double* Rout, double* tout) {
-  double V[144];
-  jacobi_eig<12>(MtM, V);
+// behind M^T M (row-major 12 x 12 with element stride st, in LDS like its eigenvector matrix V; destroyed): null-space basis v[4][12], the three beta approximations each refined by 5
+// Gauss-Newton steps, and per approximation the camera-frame control points cc[kind][4][3] (sign fixed: the first point in front of
+// the camera); kok[kind] = that approximation produced finite betas
+__device__ void epnp_betas(const Points& P, const Frame& f, double* MtM, double* V, int st, double (*v)[12], double (*cc)[4][3], bool* kok) {
+  if (st > 0) jacobi_eig_strided<12>(MtM, V, st);            // st < 0: the caller ran jacobi_eig12_wave on (MtM, V), element stride 1
+  else st = 1;
   int ord[4];                                              // the 4 smallest eigenvalues, ascending
   {
     bool used[12];
@@ -248,14 +350,13 @@ __device__ bool epnp_finish(const Points& P, const Frame& f, double* MtM, double
     for (int k = 0; k < 4; ++k) {
       int best = -1;
       for (int i = 0; i < 12; ++i)
-        if (!used[i] && (best < 0 || MtM[13 * i] < MtM[13 * best])) best = i;
+        if (!used[i] && (best < 0 || MtM[13 * i * st] < MtM[13 * best * st])) best = i;
       used[best] = true;
       ord[k] = best;
     }
   }
-  double v[4][12];
   for (int k = 0; k < 4; ++k)
-    for (int i = 0; i < 12; ++i) v[k][i] = V[i * 12 + ord[k]];
+    for (int i = 0; i < 12; ++i) v[k][i] = V[(i * 12 + ord[k]) * st];
   const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
   double L[6][10], rho[6];
   for (int r = 0; r < 6; ++r) {
@@ -269,11 +370,6 @@ __device__ bool epnp_finish(const Points& P, const Frame& f, double* MtM, double
     for (int c = 0; c < 3; ++c) { const double e = f.cw[pa[r]][c] - f.cw[pb[r]][c]; d += e * e; }
     rho[r] = d;
   }
-  double pw0[3] = {0, 0, 0};
-  for (int i = 0; i < P.n; ++i) { const float* pw = P.p3d + 3 * (size_t)P.idx[i]; pw0[0] += pw[0]; pw0[1] += pw[1]; pw0[2] += pw[2]; }
-  for (int c = 0; c < 3; ++c) pw0[c] /= P.n;
-  double best_err = INFINITY;
-  bool found = false;
   for (int kind = 1; kind <= 3; ++kind) {
     double be[4] = {0, 0, 0, 0};
     bool ok;
@@ -306,7 +402,9 @@ __device__ bool epnp_finish(const Points& P, const Frame& f, double* MtM, double
         be[2] = be[0] != 0.0 ? b5[3] / be[0] : 0.0;
       }
     }
-    if (!ok || !(isfinite(be[0]) && isfinite(be[1]) && isfinite(be[2]) && isfinite(be[3]))) continue;
+    ok = ok && isfinite(be[0]) && isfinite(be[1]) && isfinite(be[2]) && isfinite(be[3]);
+    kok[kind - 1] = ok;
+    if (!ok) continue;
     for (int it = 0; it < 5; ++it) {                        // Gauss-Newton on the 6 distance constraints
       double A[6][4], res[6], dx[4];
       for (int r = 0; r < 6; ++r) {
@@ -321,20 +419,37 @@ __device__ bool epnp_finish(const Points& P, const Frame& f, double* MtM, double
       if (!solve_normal<4>(&A[0][0], 4, res, 1e-18, dx)) break;
       for (int k = 0; k < 4; ++k) be[k] += dx[k];
     }
-    // camera-frame control points, sign, absolute orientation
-    double cc[4][3];
+    double (*c4)[3] = cc[kind - 1];
     for (int j = 0; j < 4; ++j)
-      for (int c = 0; c < 3; ++c) cc[j][c] = be[0] * v[0][3 * j + c] + be[1] * v[1][3 * j + c] + be[2] * v[2][3 * j + c] + be[3] * v[3][3 * j + c];
+      for (int c = 0; c < 3; ++c) c4[j][c] = be[0] * v[0][3 * j + c] + be[1] * v[1][3 * j + c] + be[2] * v[2][3 * j + c] + be[3] * v[3][3 * j + c];
+    double al[4];
+    alphas_of(f, P.p3d + 3 * (size_t)P.idx[0], al);
+    const double z0 = al[0] * c4[0][2] + al[1] * c4[1][2] + al[2] * c4[2][2] + al[3] * c4[3][2];
+    if (z0 < 0.0)
+      for (int j = 0; j < 4; ++j)
+        for (int c = 0; c < 3; ++c) c4[j][c] = -c4[j][c];
+  }
+}
+
+// the whole solve behind M^T M on ONE thread (hypotheses of 5 correspondences): absolute orientation of the three candidates, best
+// by mean reprojection error
+__device__ bool epnp_finish(const Points& P, const Frame& f, double* MtM, double* V, int st, double* Rout, double* tout) {
+  double v[4][12], ccs[3][4][3];
+  bool kok[3];
+  epnp_betas(P, f, MtM, V, st, v, ccs, kok);
+  double pw0[3] = {0, 0, 0};
+  for (int i = 0; i < P.n; ++i) { const float* pw = P.p3d + 3 * (size_t)P.idx[i]; pw0[0] += pw[0]; pw0[1] += pw[1]; pw0[2] += pw[2]; }
+  for (int c = 0; c < 3; ++c) pw0[c] /= P.n;
+  double best_err = INFINITY;
+  bool found = false;
+  for (int kind = 0; kind < 3; ++kind) {
+    if (!kok[kind]) continue;
+    double (*cc)[3] = ccs[kind];
     auto pc_of = [&](int i, double* pc) {
       double al[4];
       alphas_of(f, P.p3d + 3 * (size_t)P.idx[i], al);
       for (int c = 0; c < 3; ++c) pc[c] = al[0] * cc[0][c] + al[1] * cc[1][c] + al[2] * cc[2][c] + al[3] * cc[3][c];
     };
-    double p0[3];
-    pc_of(0, p0);
-    if (p0[2] < 0.0)
-      for (int j = 0; j < 4; ++j)
-        for (int c = 0; c < 3; ++c) cc[j][c] = -cc[j][c];
     double pc0[3] = {0, 0, 0};
     for (int i = 0; i < P.n; ++i) { double pc[3]; pc_of(i, pc); pc0[0] += pc[0]; pc0[1] += pc[1]; pc0[2] += pc[2]; }
     for (int c = 0; c < 3; ++c) pc0[c] /= P.n;
@@ -368,163 +483,352 @@ __device__ __forceinline__ bool is_inlier(const Points& P, const double* R, cons
   return du * du + dv * dv <= thr2;
 }
 
-constexpr int PNP_THREADS = 256, PNP_MAX_ITERS = 256;
 
-__global__ __launch_bounds__(PNP_THREADS) void pnp_ransac_kernel(const PnpParams p) {
-  __shared__ double s_pose[PNP_MAX_ITERS][12];
-  __shared__ int s_cnt[PNP_MAX_ITERS];
-  __shared__ double s_mtm[144];
-  __shared__ Frame s_frame;
-  __shared__ int s_nv, s_best, s_ninl, s_ok;
+// ---- shared staging: this crop's correspondences in LDS (every later pass reads them dozens of times), valid indices compacted in
+// ascending order by a block-wide scan.  T = threads of the calling workgroup (a multiple of 64).
+struct CropLds { float* p3d; float* p2d; int32_t* vidx; int* nv; int* wsum; };
+
+template <int T, typename IdxT, typename F>
+__device__ __forceinline__ int block_compact(F flag_of_point, int N, IdxT* out, int* wsum, int tid) {
+  // ascending compaction of the points whose flag is set: chunks of T points, wave ballots + a scan over the waves' counts
+  int base = 0;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int c0 = 0; c0 < N; c0 += T) {
+    const int i = c0 + tid;
+    const bool f = i < N && flag_of_point(i);
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (f) out[off + __popcll(m & ((1ull << lane) - 1ull))] = (IdxT)i;
+    int tot = 0;
+    for (int w = 0; w < T / 64; ++w) tot += wsum[w];
+    base += tot;
+    __syncthreads();
+  }
+  return base;
+}
+
+// OpenCV's RANSACUpdateNumIters(confidence = 0.99, outlier ratio, sample size, max): iterations after which a sample of all
+// inliers has been drawn with that confidence, given the best inlier count so far
+__device__ __forceinline__ int needed_iters(int best, int nv, int m, int iters) {
+  if (best < m) return iters;
+  double ep = 1.0 - (double)best / (double)nv;
+  ep = ep < 0.0 ? 0.0 : (ep > 1.0 ? 1.0 : ep);
+  const double num = log(1.0 - 0.99);
+  double denom = 1.0 - pow(1.0 - ep, (double)m);
+  if (denom < 2.2250738585072014e-308) return 0;
+  denom = log(denom);
+  if (denom >= 0.0 || -num >= (double)iters * (-denom)) return iters;
+  return (int)nearbyint(num / denom);
+}
+// Hypotheses are evaluated in rounds of 64 (one launch each); round r runs only while 64 r is below the number of iterations the
+// rule asks for given the best count of rounds 0 .. r - 1.  Returns how many hypothesis records are valid (a multiple of 64, or iters).
+__device__ __forceinline__ int hypotheses_run(const double* hb, int nv, int m, int iters, int upto_round) {
+  int best = -1, done = iters < 64 ? iters : 64;
+  for (int r = 1; 64 * r < iters && r <= upto_round; ++r) {
+    for (int h = 64 * (r - 1); h < 64 * r; ++h) { const int c = (int)hb[(size_t)h * PNP_HYP]; best = c > best ? c : best; }
+    if (64 * r >= needed_iters(best, nv, m, iters)) return done;
+    done = iters < 64 * (r + 1) ? iters : 64 * (r + 1);
+  }
+  return done;
+}
+
+// ---------------------------------------------------------------------------------------------- launch 1: the hypotheses
+// one launch per round of 64 hypotheses, grid (1, B), one wave per workgroup, a hypothesis per lane (M^T M and its eigenvectors of
+// all 64 lanes in 147 KB of LDS).  Round r > 0 first applies OpenCV's stopping rule to the records of the earlier rounds: with
+// 70 % inliers 25 iterations suffice, so rounds 1 and 2 of the default 150 iterations usually return at once
+__global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const PnpParams p, double* __restrict__ hyp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* const sA = (double*)smem;                          // [144][64]: M^T M of lane l at [e * 64 + l]
+  double* const sV = sA + 144 * 64;                          // [144][64]: its eigenvectors
+  uint16_t* const vidx = (uint16_t*)(sV + 144 * 64);         // [N] valid indices, ascending
+  __shared__ int wsum[1];
   const int b = blockIdx.x, tid = threadIdx.x;
-  Points P;
-  P.p3d = p.p3d + (size_t)b * p.p3d_bs;
+  const uint8_t* valid = p.valid + (size_t)b * p.N * p.valid_stride;
+  const int vs = p.valid_stride;
+  const int nv = block_compact<64>([&](int i) { return valid[(size_t)i * vs] != 0; }, p.N, vidx, wsum, tid);
+  const int h = p.round * 64 + tid;
+  if (nv < 4) return;
+  if (p.round > 0 && hypotheses_run(hyp + (size_t)b * p.iters * PNP_HYP, nv, nv >= 5 ? 5 : 4, p.iters, p.round) <= 64 * p.round)
+    return;                                                  // the rule was satisfied by the earlier rounds: whole workgroup, uniform
+  if (h >= p.iters) return;
+  Points P;                                                  // straight from global memory: the scoring loop reads the SAME point on
+  P.p3d = p.p3d + (size_t)b * p.p3d_bs;                      // every lane (one cache line per wave), the solve only its 5 samples
   P.p2d = p.p2d + (size_t)b * p.N * 2;
   const float* K = p.K + (size_t)b * p.K_bs;
   P.fu = K[0]; P.fv = K[4]; P.uc = K[2]; P.vc = K[5];
-  const uint8_t* valid = p.valid + (size_t)b * p.N * p.valid_stride;
-  int32_t* vidx = p.scratch + (size_t)b * 2 * p.N;         // valid indices, then the inlier list
-  int32_t* iidx = vidx + p.N;
   const double thr2 = (double)p.thr * (double)p.thr;
-  if (tid == 0) {
-    int n = 0;
-    for (int i = 0; i < p.N; ++i)
-      if (valid[(size_t)i * p.valid_stride]) vidx[n++] = i;
-    s_nv = n;
-  }
-  for (int i = tid; i < p.N; i += PNP_THREADS) p.inliers[(size_t)b * p.N + i] = 0;
-  __syncthreads();
-  const int nv = s_nv;
-  double* pose = p.pose + (size_t)b * 12;
-  if (nv < 4) {                                            // the reference's fallback: identity pose, no inliers
-    if (tid == 0) {
-      for (int i = 0; i < 9; ++i) pose[i] = (i % 4 == 0) ? 1.0 : 0.0;
-      pose[9] = pose[10] = pose[11] = 0.0;
-      p.status[b] = 0;
-    }
-    return;
-  }
   const int m = nv >= 5 ? 5 : 4;
-  // ---- hypotheses
-  for (int h = tid; h < p.iters; h += PNP_THREADS) {
-    int32_t sel[5];
-    int got = 0;
-    uint32_t tries = 0;
-    while (got < m) {
-      const int r = (int)(hash32(p.seed, (uint32_t)b, (uint32_t)h, tries++) % (uint32_t)nv);
-      bool dup = false;
-      for (int k = 0; k < got; ++k) dup = dup || sel[k] == vidx[r];
-      if (!dup) sel[got++] = vidx[r];
-    }
-    Points S = P;
-    S.idx = sel; S.n = m;
-    Frame f;
-    double R[9], t[3];
-    bool ok = epnp_frame(S, f);
-    if (ok) {
-      double MtM[144];
-      for (int i = 0; i < 144; ++i) MtM[i] = 0.0;
-      for (int i = 0; i < m; ++i) {
-        double r0[12], r1[12];
-        m_rows(S, f, i, r0, r1);
-        for (int a = 0; a < 12; ++a)
-          for (int c = a; c < 12; ++c) MtM[a * 12 + c] += r0[a] * r0[c] + r1[a] * r1[c];
-      }
+  int32_t sel[5];
+  int got = 0;
+  uint32_t tries = 0;
+  while (got < m) {
+    const int r = (int)(hash32(p.seed, (uint32_t)b, (uint32_t)h, tries++) % (uint32_t)nv);
+    bool dup = false;
+    for (int k = 0; k < got; ++k) dup = dup || sel[k] == (int32_t)vidx[r];
+    if (!dup) sel[got++] = (int32_t)vidx[r];
+  }
+  Points S = P;
+  S.idx = sel; S.n = m;
+  Frame f;
+  double R[9], t[3];
+  bool ok = epnp_frame(S, f);
+  if (ok) {
+    double* const A = sA + tid;
+    for (int i = 0; i < 144; ++i) A[i * 64] = 0.0;
+    for (int i = 0; i < m; ++i) {
+      double r0[12], r1[12];
+      m_rows(S, f, i, r0, r1);
+#pragma unroll
       for (int a = 0; a < 12; ++a)
-        for (int c = 0; c < a; ++c) MtM[a * 12 + c] = MtM[c * 12 + a];
-      ok = epnp_finish(S, f, MtM, R, t);
+#pragma unroll
+        for (int c = a; c < 12; ++c) A[(a * 12 + c) * 64] += r0[a] * r0[c] + r1[a] * r1[c];
     }
-    int cnt = -1;
-    if (ok) {
-      cnt = 0;
-      for (int i = 0; i < nv; ++i) cnt += is_inlier(P, R, t, vidx[i], thr2) ? 1 : 0;
-      for (int i = 0; i < 9; ++i) s_pose[h][i] = R[i];
-      for (int i = 0; i < 3; ++i) s_pose[h][9 + i] = t[i];
-    }
-    s_cnt[h] = cnt;
+    for (int a = 0; a < 12; ++a)
+      for (int c = 0; c < a; ++c) A[(a * 12 + c) * 64] = A[(c * 12 + a) * 64];
+    ok = epnp_finish(S, f, A, sV + tid, 64, R, t);
+  }
+  double* rec = hyp + ((size_t)b * p.iters + h) * PNP_HYP;
+  int cnt = -1;
+  if (ok) {
+    cnt = 0;
+    for (int i = 0; i < nv; ++i) cnt += is_inlier(P, R, t, (int)vidx[i], thr2) ? 1 : 0;
+    for (int i = 0; i < 9; ++i) rec[2 + i] = R[i];
+    for (int i = 0; i < 3; ++i) rec[11 + i] = t[i];
+  }
+  rec[0] = (double)cnt;
+}
+
+// ---------------------------------------------------------------------------------------------- launch 2: selection + final EPnP
+template <int NV>
+__device__ __forceinline__ void block_sum(double* v, double* sred, int tid) {      // v[NV] summed over the 256 threads -> v on every thread
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if (lane == 0) sred[wave * NV + k] = x;
   }
   __syncthreads();
-  if (tid == 0) {
-    int best = -1, bc = m - 1;
-    for (int h = 0; h < p.iters; ++h)
-      if (s_cnt[h] > bc) { bc = s_cnt[h]; best = h; }
-    s_best = best;
-    int n = 0;
-    if (best >= 0) {
-      double R[9], t[3];
-      for (int i = 0; i < 9; ++i) R[i] = s_pose[best][i];
-      for (int i = 0; i < 3; ++i) t[i] = s_pose[best][9 + i];
-      for (int i = 0; i < nv; ++i)
-        if (is_inlier(P, R, t, vidx[i], thr2)) { iidx[n++] = vidx[i]; p.inliers[(size_t)b * p.N + vidx[i]] = 1; }
-    }
-    s_ninl = n;
-    s_ok = 0;
-    if (best >= 0) {
-      Points S = P;
-      S.idx = iidx; S.n = n;
-      s_ok = epnp_frame(S, s_frame) ? 1 : 0;
-    }
-  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = sred[k] + sred[NV + k] + sred[2 * NV + k] + sred[3 * NV + k];
   __syncthreads();
-  if (s_best < 0) {
+}
+
+__global__ __launch_bounds__(PNP_THREADS) void pnp_select_refit_kernel(const PnpParams p, const double* __restrict__ hyp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const s3 = (float*)smem;
+  float* const s2 = s3 + 3 * p.N;
+  int32_t* const vidx = (int32_t*)(s2 + 2 * p.N);
+  int32_t* const iidx = vidx + p.N;
+  bool* const flag = (bool*)(iidx + p.N);
+  __shared__ double sred[4 * 27];
+  __shared__ double s_mtm[144], s_evec[144];
+  __shared__ double s_cc[3][4][3], s_Rt[3][12];
+  __shared__ Frame s_frame;
+  __shared__ int wsum[PNP_THREADS / 64], s_best, s_ok, s_kok[3];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* g3 = p.p3d + (size_t)b * p.p3d_bs;
+  const float* g2 = p.p2d + (size_t)b * p.N * 2;
+  const uint8_t* valid = p.valid + (size_t)b * p.N * p.valid_stride;
+  for (int i = tid; i < 3 * p.N; i += PNP_THREADS) s3[i] = g3[i];
+  for (int i = tid; i < 2 * p.N; i += PNP_THREADS) s2[i] = g2[i];
+  for (int i = tid; i < p.N; i += PNP_THREADS) { flag[i] = valid[(size_t)i * p.valid_stride] != 0; p.inliers[(size_t)b * p.N + i] = 0; }
+  __syncthreads();
+  const int nv = block_compact<PNP_THREADS>([&](int i) { return flag[i]; }, p.N, vidx, wsum, tid);
+  double* pose = p.pose + (size_t)b * 12;
+  auto identity = [&]() {                                    // the reference's fallback: identity pose, no inliers
     if (tid == 0) {
       for (int i = 0; i < 9; ++i) pose[i] = (i % 4 == 0) ? 1.0 : 0.0;
       pose[9] = pose[10] = pose[11] = 0.0;
       p.status[b] = 0;
     }
-    return;
+  };
+  if (nv < 4) { identity(); return; }
+  const int m = nv >= 5 ? 5 : 4;
+  Points P;
+  P.p3d = s3; P.p2d = s2;
+  const float* K = p.K + (size_t)b * p.K_bs;
+  P.fu = K[0]; P.fv = K[4]; P.uc = K[2]; P.vc = K[5];
+  const double thr2 = (double)p.thr * (double)p.thr;
+  const double* hb = hyp + (size_t)b * p.iters * PNP_HYP;
+  if (tid == 0) {                                            // most inliers, first on ties, at least a full sample
+    int best = -1, bc = m - 1;
+    const int nrun = hypotheses_run(hb, nv, m, p.iters, PNP_MAX_ITERS / 64);
+    for (int h = 0; h < nrun; ++h) {
+      const int c = (int)hb[(size_t)h * PNP_HYP];
+      if (c > bc) { bc = c; best = h; }
+    }
+    s_best = best;
   }
-  // ---- final EPnP over the inliers: entry (a, c), a <= c, of M^T M per thread
+  __syncthreads();
+  const int best = s_best;
+  if (best < 0) { identity(); return; }
+  double Rb[9], tb[3];
+  for (int i = 0; i < 9; ++i) Rb[i] = hb[(size_t)best * PNP_HYP + 2 + i];
+  for (int i = 0; i < 3; ++i) tb[i] = hb[(size_t)best * PNP_HYP + 11 + i];
+  __syncthreads();
+  for (int i = tid; i < p.N; i += PNP_THREADS) flag[i] = false;
+  __syncthreads();
+  for (int i = tid; i < nv; i += PNP_THREADS) {
+    const int k = vidx[i];
+    const bool in = is_inlier(P, Rb, tb, k, thr2);
+    flag[k] = in;
+    if (in) p.inliers[(size_t)b * p.N + k] = 1;
+  }
+  __syncthreads();
+  const int n = block_compact<PNP_THREADS>([&](int i) { return flag[i]; }, p.N, iidx, wsum, tid);
   Points S = P;
-  S.idx = iidx; S.n = s_ninl;
-  if (s_ok && tid < 78) {
+  S.idx = iidx; S.n = n;
+  // ---- final EPnP over the n inliers, loops over the points shared by the 256 threads, the small dense algebra on thread 0
+  double acc[27];
+  for (int k = 0; k < 3; ++k) acc[k] = 0.0;
+  for (int i = tid; i < n; i += PNP_THREADS) { const float* pw = s3 + 3 * iidx[i]; acc[0] += pw[0]; acc[1] += pw[1]; acc[2] += pw[2]; }
+  block_sum<3>(acc, sred, tid);
+  const double pw0[3] = {acc[0] / n, acc[1] / n, acc[2] / n};
+  for (int k = 0; k < 6; ++k) acc[k] = 0.0;
+  for (int i = tid; i < n; i += PNP_THREADS) {
+    const float* pw = s3 + 3 * iidx[i];
+    const double d0 = pw[0] - pw0[0], d1 = pw[1] - pw0[1], d2 = pw[2] - pw0[2];
+    acc[0] += d0 * d0; acc[1] += d0 * d1; acc[2] += d0 * d2; acc[3] += d1 * d1; acc[4] += d1 * d2; acc[5] += d2 * d2;
+  }
+  block_sum<6>(acc, sred, tid);
+  if (tid == 0) {
+    const double Sm[9] = {acc[0], acc[1], acc[2], acc[1], acc[3], acc[4], acc[2], acc[4], acc[5]};
+    s_ok = epnp_frame_from(pw0, Sm, n, s_frame) ? 1 : 0;
+  }
+  __syncthreads();
+  bool ok = s_ok != 0;
+  if (ok && tid < 78) {                                      // entry (a, c), a <= c, of M^T M per thread
     int a = 0, rem = tid;
     while (rem >= 12 - a) { rem -= 12 - a; ++a; }
     const int c = a + rem;
-    double acc = 0.0;
-    for (int i = 0; i < S.n; ++i) {
+    double e = 0.0;
+    for (int i = 0; i < n; ++i) {
       double r0[12], r1[12];
       m_rows(S, s_frame, i, r0, r1);
-      acc += r0[a] * r0[c] + r1[a] * r1[c];
+      e += r0[a] * r0[c] + r1[a] * r1[c];
     }
-    s_mtm[a * 12 + c] = acc;
-    s_mtm[c * 12 + a] = acc;
+    s_mtm[a * 12 + c] = e;
+    s_mtm[c * 12 + a] = e;
   }
   __syncthreads();
+  if (ok && tid < 64) jacobi_eig12_wave(s_mtm, s_evec, tid);  // wave 0: the 12 x 12 eigen-solve on 12 lanes
+  __syncthreads();
+  if (ok && tid == 0) {                                      // null-space basis, betas of the three approximations, camera-frame control points
+    double v[4][12], cc[3][4][3];
+    bool kok[3];
+    epnp_betas(S, s_frame, s_mtm, s_evec, -1, v, cc, kok);
+    for (int k = 0; k < 3; ++k) {
+      s_kok[k] = kok[k] ? 1 : 0;
+      for (int j = 0; j < 4; ++j)
+        for (int c = 0; c < 3; ++c) s_cc[k][j][c] = cc[k][j][c];
+    }
+  }
+  __syncthreads();
+  if (ok) {
+    // pc0 of the three candidates (9 sums), then their cross-covariances with the model points (27 sums), then their errors (3)
+    auto pc_of = [&](int k, int i, double* pc) {
+      double al[4];
+      alphas_of(s_frame, s3 + 3 * iidx[i], al);
+      for (int c = 0; c < 3; ++c) pc[c] = al[0] * s_cc[k][0][c] + al[1] * s_cc[k][1][c] + al[2] * s_cc[k][2][c] + al[3] * s_cc[k][3][c];
+    };
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int i = tid; i < n; i += PNP_THREADS)
+      for (int k = 0; k < 3; ++k) { double pc[3]; pc_of(k, i, pc); acc[3 * k] += pc[0]; acc[3 * k + 1] += pc[1]; acc[3 * k + 2] += pc[2]; }
+    block_sum<9>(acc, sred, tid);
+    double pc0[3][3];
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) pc0[k][c] = acc[3 * k + c] / n;
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    for (int i = tid; i < n; i += PNP_THREADS) {
+      const float* pw = s3 + 3 * iidx[i];
+      for (int k = 0; k < 3; ++k) {
+        double pc[3];
+        pc_of(k, i, pc);
+        for (int a = 0; a < 3; ++a)
+          for (int c = 0; c < 3; ++c) acc[9 * k + 3 * a + c] += (pc[a] - pc0[k][a]) * (pw[c] - pw0[c]);
+      }
+    }
+    block_sum<27>(acc, sred, tid);
+    if (tid < 3 && s_kok[tid]) {                             // absolute orientation of candidate `tid`
+      double R[9], t[3];
+      procrustes_rotation(acc + 9 * tid, R);
+      for (int a = 0; a < 3; ++a) t[a] = pc0[tid][a] - (R[3 * a] * pw0[0] + R[3 * a + 1] * pw0[1] + R[3 * a + 2] * pw0[2]);
+      for (int i = 0; i < 9; ++i) s_Rt[tid][i] = R[i];
+      for (int i = 0; i < 3; ++i) s_Rt[tid][9 + i] = t[i];
+    }
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) acc[k] = 0.0;
+    for (int i = tid; i < n; i += PNP_THREADS) {
+      const int kk = iidx[i];
+      const float* pw = s3 + 3 * kk;
+      for (int k = 0; k < 3; ++k) {
+        if (!s_kok[k]) continue;
+        const double* R = s_Rt[k];
+        const double X = R[0] * pw[0] + R[1] * pw[1] + R[2] * pw[2] + R[9], Y = R[3] * pw[0] + R[4] * pw[1] + R[5] * pw[2] + R[10];
+        const double iz = 1.0 / (R[6] * pw[0] + R[7] * pw[1] + R[8] * pw[2] + R[11]);
+        const double du = P.uc + P.fu * X * iz - s2[2 * kk], dv = P.vc + P.fv * Y * iz - s2[2 * kk + 1];
+        acc[k] += sqrt(du * du + dv * dv);
+      }
+    }
+    block_sum<3>(acc, sred, tid);
+    if (tid == 0) {
+      int pick = -1;
+      double be = INFINITY;
+      for (int k = 0; k < 3; ++k)
+        if (s_kok[k] && isfinite(acc[k]) && acc[k] < be) { be = acc[k]; pick = k; }
+      if (pick >= 0) {
+        for (int i = 0; i < 12; ++i) pose[i] = s_Rt[pick][i];
+      } else ok = false;
+      s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    ok = s_ok != 0;
+  }
   if (tid == 0) {
-    double R[9], t[3];
-    bool ok = s_ok != 0;
-    if (ok) {
-      double MtM[144];
-      for (int i = 0; i < 144; ++i) MtM[i] = s_mtm[i];
-      ok = epnp_finish(S, s_frame, MtM, R, t);
+    if (!ok) {                                               // degenerate inlier set: keep the winning hypothesis
+      for (int i = 0; i < 9; ++i) pose[i] = Rb[i];
+      for (int i = 0; i < 3; ++i) pose[9 + i] = tb[i];
     }
-    if (!ok) {                                             // degenerate inlier set: keep the winning hypothesis
-      for (int i = 0; i < 9; ++i) R[i] = s_pose[s_best][i];
-      for (int i = 0; i < 3; ++i) t[i] = s_pose[s_best][9 + i];
-    }
-    for (int i = 0; i < 9; ++i) pose[i] = R[i];
-    for (int i = 0; i < 3; ++i) pose[9 + i] = t[i];
     p.status[b] = 1;
   }
 }
 
 }  // namespace
 
-extern "C" size_t cp_pnp_ransac_scratch_bytes(int B, int N) { return (size_t)B * 2 * N * sizeof(int32_t); }
+extern "C" size_t cp_pnp_ransac_scratch_bytes(int B, int N) { (void)N; return (size_t)B * PNP_MAX_ITERS * PNP_HYP * sizeof(double); }
 
 extern "C" int cp_pnp_ransac(cp_stream_t stream, const float* p3d, long long p3d_bstride, const float* p2d, const uint8_t* valid,
                              int valid_stride, const float* cam_K, long long K_bstride, int B, int N, float reproj_threshold,
                              int iterations, uint32_t seed, double* pose, uint8_t* inliers, int32_t* status, void* scratch) {
   if (!p3d || !p2d || !valid || !cam_K || !pose || !inliers || !status || !scratch) return CP_ERR_INVALID;
-  if (B <= 0 || N <= 0 || valid_stride <= 0 || iterations <= 0 || iterations > PNP_MAX_ITERS || !(reproj_threshold > 0.f)) return CP_ERR_INVALID;
+  if (B <= 0 || N <= 0 || N > PNP_NMAX || valid_stride <= 0 || iterations <= 0 || iterations > PNP_MAX_ITERS || !(reproj_threshold > 0.f))
+    return CP_ERR_INVALID;
   if (p3d_bstride != 0 && p3d_bstride < 3LL * N) return CP_ERR_INVALID;
   if (K_bstride != 0 && K_bstride < 9) return CP_ERR_INVALID;
-  if (((uintptr_t)pose & 7) || ((uintptr_t)scratch & 3) || ((uintptr_t)status & 3)) return CP_ERR_ALIGN;
+  if (((uintptr_t)pose & 7) || ((uintptr_t)scratch & 7) || ((uintptr_t)status & 3)) return CP_ERR_ALIGN;
   PnpParams p;
-  p.p3d = p3d; p.p2d = p2d; p.valid = valid; p.K = cam_K; p.pose = pose; p.inliers = inliers; p.status = status; p.scratch = (int32_t*)scratch;
+  p.p3d = p3d; p.p2d = p2d; p.valid = valid; p.K = cam_K; p.pose = pose; p.inliers = inliers; p.status = status; p.scratch = nullptr;
   p.p3d_bs = p3d_bstride; p.K_bs = K_bstride; p.B = B; p.N = N; p.valid_stride = valid_stride; p.iters = iterations; p.thr = reproj_threshold;
   p.seed = seed;
-  CP_LAUNCH(pnp_ransac_kernel, dim3((unsigned)B), dim3(PNP_THREADS), 0, (hipStream_t)stream, p);
+  const size_t lds1 = (size_t)2 * 144 * 64 * 8 + (size_t)N * 2 + 16, lds2 = (size_t)N * (5 * 4 + 8 + 1) + 16;
+  static size_t attr = 0;
+  if (attr < lds2) {
+    if (hipFuncSetAttribute((const void*)pnp_hypotheses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 144 * 64 * 8 + PNP_NMAX * 2 + 16)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)pnp_select_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PNP_NMAX * 29 + 16)) != hipSuccess)
+      return CP_ERR_HIP;
+    attr = (size_t)PNP_NMAX * 29 + 16;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int r = 0; 64 * r < iterations; ++r) {
+    p.round = r;
+    CP_LAUNCH(pnp_hypotheses_kernel, dim3((unsigned)B), dim3(64), lds1, st, p, (double*)scratch);
+  }
+  p.round = 0;
+  CP_LAUNCH(pnp_select_refit_kernel, dim3((unsigned)B), dim3(PNP_THREADS), lds2, st, p, (const double*)scratch);
   return cp_check_launch();
 }

@@ -209,6 +209,9 @@ class Program:
         self.flops = 0         # dense MACs*2 issued through cp_conv2d_igemm (algorithmic, unpadded)
         self.conv_log = _ConvLog(self)     # (name, M, Cout, K, flops, family, bytes) per MFMA launch -- bench roofline uses it
         self._rw = {}          # op index -> (reads, writes): dead-launch elimination in finalize(dce=True), hazards of run_dag
+        # launch selection by batch size (module globals = the measured crossovers); HipForwardMixin.set_kernel_selection pins one
+        # selection for every batch size, so a crop's bf16 bits do not depend on the size of the batch it arrives in
+        self.chain_min, self.stem_min, self.edge_min, self.splitk = CHAIN_MIN_BATCH, STEM_MIN_BATCH, EDGE_FUSED_MIN_BATCH, USE_SPLITK
         self._raw = {}         # (ptr, nbytes) -> TBuf of a raw-pointer operand (see raw())
 
     # ---- tensors
@@ -310,9 +313,9 @@ class Program:
         gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
                 and not transposed and row_map is None and wCout >= 96 and x.Cphys >= kmin)
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
-                   and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= CHAIN_MIN_BATCH
+                   and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= self.chain_min
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
-        if (USE_SPLITK and not transposed and row_map is None and (halo or gemm or s2small)
+        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small)
                 and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
                                                     R * S * x.Cphys, _rup(wCout, self.E))):
             halo = gemm = s2small = False      # small batch: the generic kernel's split-K variant beats the tiled specialists
@@ -342,7 +345,7 @@ class Program:
         d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
         d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = R, S, stride, pad, Ho, Wo
         d.act, d.slope = act, slope
-        d.ksplit = 0 if USE_SPLITK else -1
+        d.ksplit = 0 if self.splitk else -1
         if ostr is None:
             if out is None:
                 out = self.act(Ho, Wo, Cout)
@@ -382,7 +385,7 @@ class Program:
 
     def would_splitk(self, M, K, Cout):
         """small-batch regime: cp_conv2d_igemm would run this conv as its split-K variant (M output pixels, K = R*S*Cin physical)"""
-        return bool(USE_SPLITK and self.lib.cp_conv2d_igemm_splitk(self.dtype, M, K, _rup(Cout, self.E)))
+        return bool(self.splitk and self.lib.cp_conv2d_igemm_splitk(self.dtype, M, K, _rup(Cout, self.E)))
 
     def can_conv_up2x(self, H, W, Cout):
         """(H, W): the low-resolution input; the conv runs at (2H, 2W), which must tile like the plain halo kernel's maps"""
@@ -489,7 +492,7 @@ class Program:
         return out
 
     def can_fuse_stem(self, size):
-        return USE_STEM and self.dtype == CP_BF16 and self.B >= STEM_MIN_BATCH and size % 64 == 0
+        return USE_STEM and self.dtype == CP_BF16 and self.B >= self.stem_min and size % 64 == 0
 
     def hr_stem(self, img_t, size, k1, w1, s1, t1, k2, w2, s2, t2):
         """timm hrnet stem (conv1-bn1-relu-conv2-bn2-relu) from the NCHW fp32 image in one launch (cp_hr_stem)"""
@@ -517,7 +520,7 @@ class Program:
         return out
 
     def can_chain(self, C_, H, W):
-        return (USE_CHAIN and self.dtype == CP_BF16 and self.B >= CHAIN_MIN_BATCH and bool(self.lib.cp_hr_chain_supported(C_, H, W)))
+        return (USE_CHAIN and self.dtype == CP_BF16 and self.B >= self.chain_min and bool(self.lib.cp_hr_chain_supported(C_, H, W)))
 
     def hr_chain(self, name, srcs, shifts, relu_in, ws, affs, C_, H, W):
         """4 BasicBlocks of an HRNet branch on relu(sum of `srcs` (nearest-upsampled by 2^shift)) in ONE launch
@@ -548,7 +551,7 @@ class Program:
         return out
 
     def can_fuse_out(self, x: Act):
-        return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= CHAIN_MIN_BATCH and x.coff == 0 and x.cstride == x.Cphys
+        return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= self.chain_min and x.coff == 0 and x.cstride == x.Cphys
                 and bool(self.lib.cp_hr_fuse_out_supported(x.H, x.W, x.Cphys)))
 
     def hr_fuse_out(self, x: Act, convs):
@@ -683,7 +686,7 @@ class Program:
         return out
 
     def can_fuse_edgeconv(self, N, K, Cin, Cout):
-        return (USE_EDGE_FUSED and self.dtype == CP_BF16 and self.B >= EDGE_FUSED_MIN_BATCH
+        return (USE_EDGE_FUSED and self.dtype == CP_BF16 and self.B >= self.edge_min
                 and bool(self.lib.cp_edgeconv_fused_supported(N, K, Cin, Cout)))
 
     def edge_fused(self, x: Act, wkey, wpq, scale, shift, idx_t, gids_t, out: Act, K, G, slope):
@@ -722,7 +725,7 @@ class Program:
 
     def can_tile_edgeconv(self, N, K, Cin, Cout, HPAD):
         """large graphs: one workgroup per (crop, patch of 512 keypoints) -- needs B * N / 512 workgroups to fill the chip"""
-        return (USE_EDGE_TILED and self.dtype == CP_BF16 and N > 512 and N % 512 == 0 and self.B * (N // 512) >= EDGE_FUSED_MIN_BATCH
+        return (USE_EDGE_TILED and self.dtype == CP_BF16 and N > 512 and N % 512 == 0 and self.B * (N // 512) >= self.edge_min
                 and bool(self.lib.cp_edgeconv_tiled_supported(N, K, Cin, Cout, HPAD)))
 
     def edge_tiled(self, x: Act, wkey, wpq, scale, shift, tiled, gids_t, out: Act, K, G, slope):

@@ -127,6 +127,7 @@ class HipForwardMixin:
         self.use_dag = os.environ.get("CHECKERPOSE_AMD_DAG", "0") == "1"       # dataflow capture (Program.run_dag) instead of fork/join lanes
         self.batch_splits = int(os.environ.get("CHECKERPOSE_AMD_SPLITS", "1"))   # concurrent batch slices per forward (measured: 1 is fastest; 2 and 4 lose 8 % / 30 % at B=128)
         self.clone_outputs = True
+        self.kernel_selection = os.environ.get("CHECKERPOSE_AMD_SELECTION", "auto")
         self.batch_buckets = os.environ.get("CHECKERPOSE_AMD_BUCKETS", "1") != "0"   # eval: pad ragged batches to a cached size
         self.check_weight_versions = os.environ.get("CHECKERPOSE_AMD_CHECK_VERSIONS", "1") != "0"   # eval: detect in-place weight edits
         self._sig_tensors = None
@@ -159,6 +160,21 @@ class HipForwardMixin:
         if hasattr(self, "_programs"):
             self.invalidate()
         return r
+
+    def set_kernel_selection(self, mode):
+        """Which launches a bf16 program is made of depends on the batch size ("auto": per-conv / split-K launches for small
+        batches, per-crop LDS-resident launches from 40-96 crops: the measured crossovers), and the two selections accumulate in
+        a different order -- the same crop gives different bf16 bits at batch 32 and batch 64.  "per_crop" / "tiled" pin ONE
+        selection for every batch size (bit-reproducible across batch sizes, at the price of the other regime's speed)."""
+        if mode not in ("auto", "per_crop", "tiled"):
+            raise ValueError("kernel selection must be 'auto', 'per_crop' or 'tiled'")
+        self.kernel_selection = mode
+        child = getattr(self, "init_net", None)
+        if child is not None and hasattr(child, "kernel_selection"):
+            child.kernel_selection = mode
+            child.invalidate()
+        self.invalidate()
+        return self
 
     def set_compute_dtype(self, name):
         if name not in DTYPES:
@@ -227,6 +243,12 @@ class HipForwardMixin:
             sl = slice(si * Bs, (si + 1) * Bs)
             sio = {k: (v[sl] if torch.is_tensor(v) else ([t[sl] for t in v] if isinstance(v, list) else v)) for k, v in io.items()}
             prog = Program(lib, ws, dtype, Bs, device)
+            if self.kernel_selection == "per_crop":
+                prog.chain_min = prog.stem_min = prog.edge_min = 1
+                prog.splitk = False
+            elif self.kernel_selection == "tiled":
+                prog.chain_min = prog.stem_min = prog.edge_min = 1 << 30
+                prog.splitk = False
             sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
             ext = None
             if tiled is not None and prog.can_tile_edgeconv(N, idx.shape[2], 64, 64, tiled["HPAD"]):

@@ -17,8 +17,9 @@ output.  What is restated here is the PUBLISHED algorithm:
     error <= threshold^2 as the inlier test, the hypothesis with the most inliers (first one on ties, at least the sample size),
     a final EPnP over its inliers; the returned inlier list is that hypothesis' set.
 Deliberate differences (no way to pin them, and nothing downstream depends on them): the sample sequence comes from a counter-based
-hash (`sample_indices`, shared bit for bit with the device kernel) instead of OpenCV's MWC generator; all `iterations` hypotheses
-are always evaluated (OpenCV stops early at confidence 0.99), so the result is the best of a superset; small linear systems are
+hash (`sample_indices`, shared bit for bit with the device kernel) instead of OpenCV's MWC generator; OpenCV's stopping rule
+(RANSACUpdateNumIters at confidence 0.99) is applied between rounds of 64 hypotheses, not after every better model, so at least as
+many hypotheses are evaluated as OpenCV would; small linear systems are
 solved through the normal equations instead of an SVD; with exactly 4 valid correspondences EPnP runs on the 4 (OpenCV switches to
 a P3P kernel there).  Known-answer anchoring instead of golden vectors: synthetic poses with
 exact and outlier-contaminated correspondences must be recovered (tests/test_pnp.py).
@@ -164,6 +165,21 @@ def reprojection_error(pw, uv, K, R, t):
     return float(np.sqrt(((project(pw, K, R, t) - uv) ** 2).sum(1)).mean())
 
 
+def needed_iterations(best, nv, m, iterations, confidence=0.99):
+    """OpenCV RANSACUpdateNumIters: iterations after which an all-inlier sample has been drawn with `confidence`"""
+    if best < m:
+        return iterations
+    ep = min(max(1.0 - best / nv, 0.0), 1.0)
+    num = np.log(1.0 - confidence)
+    denom = 1.0 - (1.0 - ep) ** m
+    if denom < np.finfo(np.float64).tiny:
+        return 0
+    denom = np.log(denom)
+    if denom >= 0 or -num >= iterations * (-denom):
+        return iterations
+    return int(np.rint(num / denom))
+
+
 def solve_pnp_ransac(p3d, p2d, valid, K, threshold=2.0, iterations=150, seed=0, crop=0):
     """p3d (N,3), p2d (N,2), valid (N,) bool, K (3,3).  Returns (R, t, inlier mask (N,) bool, status): status 0 = the
     reference's identity fallback (fewer than 4 valid points, or no hypothesis with a full sample of inliers)."""
@@ -175,7 +191,11 @@ def solve_pnp_ransac(p3d, p2d, valid, K, threshold=2.0, iterations=150, seed=0, 
         return ident
     m = 5 if nv >= 5 else 4
     best_cnt, best_mask = m - 1, None
+    counts = []
     for h in range(iterations):
+        if h > 0 and h % 64 == 0 and h >= needed_iterations(max(counts), nv, m, iterations):
+            break                                              # OpenCV's stopping rule, applied between rounds of 64 hypotheses
+        counts.append(-1)
         s = vid[sample_indices(seed, crop, h, nv, m)]
         try:
             R, t, err = epnp(p3d[s], p2d[s], K)
@@ -185,6 +205,7 @@ def solve_pnp_ransac(p3d, p2d, valid, K, threshold=2.0, iterations=150, seed=0, 
             continue
         d2 = ((project(p3d[vid], K, R, t) - p2d[vid]) ** 2).sum(1)
         inl = d2 <= threshold * threshold
+        counts[-1] = int(inl.sum())
         if inl.sum() > best_cnt:
             best_cnt, best_mask = int(inl.sum()), inl
     if best_mask is None:

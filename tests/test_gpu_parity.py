@@ -1256,6 +1256,23 @@ def test_batch_buckets_and_inplace_weight_edit(lib):
     assert float((o5c[0] - o5b[0]).abs().max()) > 0.2
 
 
+@pytest.mark.parametrize("mode", ["per_crop", "tiled"])
+def test_kernel_selection_pins_bits_across_batch_sizes(lib, mode):
+    """`auto` picks per-conv / split-K launches below 40-96 crops and per-crop LDS-resident launches above (other accumulation
+    order -> other bf16 bits for the same crop); `set_kernel_selection("per_crop" | "tiled")` pins ONE selection, after which a
+    crop's outputs are bit-identical at batch 3 and inside a batch of 96 (across the `auto` crossovers)."""
+    net = build_net(seed=1).to(dev()).set_compute_dtype("bf16").set_kernel_selection(mode)
+    img3 = det_image(3, seed=3).to(dev())
+    small = net(img3, None)
+    big = net(img3.repeat(32, 1, 1, 1), None)
+    for a, b in zip(small, big):
+        assert b.shape[0] == 96 and torch.equal(b, a.repeat(32, *([1] * (a.dim() - 1))))
+    names = {c[2].split(":")[0] for c in net.program_for(3).calls}
+    assert ("hr_chain" in names) == (mode == "per_crop") and ("edge_fused" in names) == (mode == "per_crop")
+    auto = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
+    assert "hr_chain" not in {c[2].split(":")[0] for c in auto.program_for(3).calls} if auto(img3, None) is not None else True
+
+
 def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     """B=16 is run as two concurrent 8-crop slice graphs (CHECKERPOSE_AMD_SPLITS=2): identical, bit for bit, to the
     unsplit sequential replay; bf16 so the test is cheap on the CPU side (no oracle needed: pure scheduling check)."""
