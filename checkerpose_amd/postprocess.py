@@ -66,3 +66,46 @@ def solve_pnp_ransac(p3d_xyz, p2d, valid, cam_K, column=0, reproj_threshold=2.0,
                                  9 if K.dim() == 3 else 0, B, N, float(reproj_threshold), int(iterations), int(seed) & 0xFFFFFFFF,
                                  pose.data_ptr(), inl.data_ptr(), status.data_ptr(), scratch.data_ptr()), "cp_pnp_ransac")
     return pose[:, :9].view(B, 3, 3), pose[:, 9:].view(B, 3, 1), inl.bool(), status
+
+
+def from_id_to_pose(p3d_xyz, roi_xy_ori, cam_K, roi_mask_bit, pixel_x_id, pixel_y_id, check_seg=False, seg_mask=None,
+                    use_progressivex=False, neighborhood_ball_radius=20, spatial_coherence_weight=0.1, prog_max_iters=400,
+                    discard_bd_pixel=0, return_inliers=False, reprojErr_thresh=2, cv_max_iters=150, device="cuda:0", seed=0):
+    """Same name, arguments (numpy arrays of ONE image) and returns as the reference's `from_id_to_pose`
+    (test_network_with_test_data.py:32-115), with its cv2 branch running on the device (`cp_pnp_ransac`):
+      the validity mask is built exactly as :50-66 (RoI bit > 0.5, optional seg mask at the predicted pixel, optional border
+      discard), then EPnP + RANSAC (reprojErr_thresh, cv_max_iters) -> R (3,3), t (3,1) [, inlier indices into ALL keypoints];
+      fewer than 4 valid correspondences -> R = I, t = 0, inliers None (:111-114).
+    `use_progressivex=True` is the third-party pyprogressivex solver of the reference and is not rebuilt: ValueError.
+    For whole batches straight from the network's outputs use correspondences() + solve_pnp_ransac() instead."""
+    import numpy as np
+    if use_progressivex:
+        raise ValueError("use_progressivex=True needs the third-party pyprogressivex solver; only the cv2 (EPnP + RANSAC) branch is built")
+    num_all_pt = p3d_xyz.shape[0]
+    roi_h, roi_w, _ = roi_xy_ori.shape
+    disc_p2d = roi_xy_ori[pixel_y_id, pixel_x_id]
+    valid_mask = (roi_mask_bit[:, 0] > 0.5)
+    if check_seg:
+        valid_mask = np.logical_and(valid_mask, seg_mask[pixel_y_id, pixel_x_id] > 0.5)
+    if discard_bd_pixel > 0:
+        bd_mask = np.zeros((roi_h, roi_w))
+        bd_mask[discard_bd_pixel:(roi_h - discard_bd_pixel), discard_bd_pixel:(roi_w - discard_bd_pixel)] = 1.0
+        valid_mask = np.logical_and(valid_mask, bd_mask[pixel_y_id, pixel_x_id] > 0.5)
+    if int(valid_mask.sum()) < 4:
+        R_predict, t_predict, inliers = np.eye(3), np.zeros((3, 1)), None
+    else:
+        dev = torch.device(device)
+        valid = torch.zeros(1, num_all_pt, 3, dtype=torch.uint8, device=dev)
+        valid[0, :, 0] = torch.from_numpy(np.ascontiguousarray(valid_mask)).to(dev)
+        p2d = torch.from_numpy(np.ascontiguousarray(disc_p2d, dtype=np.float32)).to(dev)[None]
+        R, t, inl, status = solve_pnp_ransac(torch.from_numpy(np.ascontiguousarray(p3d_xyz, dtype=np.float32)).to(dev), p2d, valid,
+                                             torch.from_numpy(np.ascontiguousarray(cam_K, dtype=np.float32)).to(dev), column=0,
+                                             reproj_threshold=float(reprojErr_thresh), iterations=min(int(cv_max_iters), 256), seed=seed)
+        if int(status[0]) == 1:
+            R_predict, t_predict = R[0].cpu().numpy(), t[0].cpu().numpy()
+            inliers = np.nonzero(inl[0].cpu().numpy())[0]
+        else:                                     # no hypothesis with a full sample of inliers: cv2 reports failure; identity like :111-114
+            R_predict, t_predict, inliers = np.eye(3), np.zeros((3, 1)), None
+    if return_inliers:
+        return R_predict, t_predict, inliers
+    return R_predict, t_predict

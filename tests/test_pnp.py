@@ -149,3 +149,71 @@ def test_device_pnp_consumes_the_forward(lib):
     assert not (inl & ~valid[:, :, 0].bool()).any()
     for b in range(3):
         assert abs(float(torch.linalg.det(R[b])) - 1.0) < 1e-9 or int(status[b]) == 0
+
+
+@pytest.mark.gpu
+def test_from_id_to_pose_drop_in_signature():
+    """checkerpose_amd.postprocess.from_id_to_pose: the reference's signature (numpy arrays of one image), validity mask as
+    test_network_with_test_data.py:50-66 (checked against the reference-made n2 fixture's index lists), pose from the device solver."""
+    from checkerpose_amd.postprocess import from_id_to_pose
+    from tests.common import golden
+    rng = np.random.default_rng(7)
+    xyz = _model(512)
+    R, t = _pose(rng)
+    uv = P.project(xyz, K_LMO, R, t)
+    # a 64x64 RoI grid whose cell centres are the image coordinates; each keypoint "predicts" the cell nearest to its projection
+    xs = np.linspace(uv[:, 0].min() - 1, uv[:, 0].max() + 1, 64)
+    ys = np.linspace(uv[:, 1].min() - 1, uv[:, 1].max() + 1, 64)
+    roi_xy = np.stack(np.meshgrid(xs, ys), -1)                                          # (H, W, 2) = (x, y)
+    xid = np.abs(uv[:, 0:1] - xs[None]).argmin(1)
+    yid = np.abs(uv[:, 1:2] - ys[None]).argmin(1)
+    roi_bit = (rng.random((512, 1)) < 0.85).astype(np.float32)
+    seg = (rng.random((64, 64)) < 0.9).astype(np.float32)
+    cell = max(xs[1] - xs[0], ys[1] - ys[0])
+    Re, te, inl = from_id_to_pose(xyz, roi_xy, K_LMO, roi_bit, xid, yid, check_seg=True, seg_mask=seg, discard_bd_pixel=2,
+                                  return_inliers=True, reprojErr_thresh=cell, cv_max_iters=150)
+    want = (roi_bit[:, 0] > 0.5) & (seg[yid, xid] > 0.5) & (xid >= 2) & (xid < 62) & (yid >= 2) & (yid < 62)
+    assert inl is not None and set(inl.tolist()) <= set(np.nonzero(want)[0].tolist()) and len(inl) > 0.8 * want.sum()
+    assert Re.shape == (3, 3) and te.shape == (3, 1)
+    assert np.abs(Re - R).max() < 0.05 and np.linalg.norm(te[:, 0] - t) < 0.05 * np.linalg.norm(t)      # quantised to the 64x64 grid
+    assert len(from_id_to_pose(xyz, roi_xy, K_LMO, roi_bit, xid, yid)) == 2
+    Rf, tf, inf_ = from_id_to_pose(xyz, roi_xy, K_LMO, np.zeros((512, 1), np.float32), xid, yid, return_inliers=True)
+    assert np.array_equal(Rf, np.eye(3)) and not tf.any() and inf_ is None             # :111-114
+    with pytest.raises(ValueError):
+        from_id_to_pose(xyz, roi_xy, K_LMO, roi_bit, xid, yid, use_progressivex=True)
+
+
+def test_from_id_to_pose_hands_the_solver_the_reference_lists(monkeypatch):
+    """CPU: the drop-in from_id_to_pose builds exactly the (valid_p3d, valid_disc_p2d) lists the REFERENCE's own function handed to
+    its (recording) solver -- n2_from_id_to_pose.npz, made by tests/golden/make_golden_r2.py from the reference's code -- for
+    check_seg in {False, full, visib} x discard_bd_pixel in {0, 2}; the device solver is replaced by a recorder here."""
+    import torch
+    from checkerpose_amd import postprocess as PP
+    from checkerpose_amd.detweights import det_tensor
+    from tests.common import golden
+    g, e = golden("n2_from_id_to_pose"), golden("e2e_injected")
+    rec = {}
+
+    def recorder(p3d, p2d, valid, K, column=0, reproj_threshold=2.0, iterations=150, seed=0):
+        rec["valid"], rec["p2d"] = valid[0, :, column].numpy().astype(bool), p2d[0].numpy()
+        n = p2d.shape[1]
+        return (torch.eye(3, dtype=torch.float64)[None], torch.zeros(1, 3, 1, dtype=torch.float64), valid[:, :, column].bool(),
+                torch.ones(1, dtype=torch.int32))
+    monkeypatch.setattr(PP, "solve_pnp_ransac", recorder)
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))   # noqa: E731
+    roi = np.where(sig(e["roi"]) > 0.5, 1.0, 0.0).transpose(0, 2, 1)                       # test.py:294-303
+    seg = np.where(sig(e["seg"] - g["seg_shift"]) > 0.5, 1.0, 0.0)                         # test.py:313-314
+    seg_visib, seg_full = seg[:, 0], seg[:, 1]
+    xid, yid = e["xid"].astype(np.int64), e["yid"].astype(np.int64)
+    grid = (det_tensor(str(g["grid_name"]), (2, 2, 64, 64), float(g["grid_scale"])) + float(g["grid_shift"])).numpy().transpose(0, 2, 3, 1)
+    xyz = _model(512)
+    for b in range(2):
+        for cs, sm in (("all", None), ("full", seg_full), ("visib", seg_visib)):
+            for bd in (0, 2):
+                key = "b%d_%s_bd%d" % (b, cs, bd)
+                R, t, inl = PP.from_id_to_pose(xyz, grid[b], np.eye(3), roi[b], xid[b], yid[b], check_seg=sm is not None,
+                                               seg_mask=None if sm is None else sm[b], discard_bd_pixel=bd, return_inliers=True,
+                                               device="cpu")
+                assert np.nonzero(rec["valid"])[0].tolist() == g[key + "_idx"].tolist(), key
+                assert np.array_equal(rec["p2d"][rec["valid"]], g[key + "_p2d"]), key
+                assert inl.tolist() == g[key + "_idx"].tolist()                           # the recorder calls every valid point an inlier
