@@ -1091,6 +1091,24 @@ def test_e2e_n4096_dense_keypoints(lib):
     _cmp_e2e(net(img.to(dev()), None), ref)
 
 
+_ORACLE_CACHE = {}
+
+
+def _lm4096_case():
+    """config #5's test case (LM twin, 4096 keypoints, seed 2, objects LM_OBJ_IDS[3] / [11]) and its CPU-oracle forward, computed
+    once per session: three tests share it (fp32 e2e, bf16 contract on both EdgeConv paths) and the oracle takes ~10 s"""
+    if "lm4096" not in _ORACLE_CACHE:
+        from tests.common import LM_OBJ_IDS
+        obj = torch.tensor([LM_OBJ_IDS[3], LM_OBJ_IDS[11]])
+        net = build_net(npoint=4096, seed=2, lm=True)                 # seed with a mixed RoI bit (47 %), margin 5.6e-5
+        img = det_image(2, seed=32)
+        ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx[obj - 1], 4096, **oracle_kwargs())
+        _ORACLE_CACHE["lm4096"] = (obj, {k: v.clone() for k, v in net.state_dict().items()}, img, ref)
+    obj, sd, img, ref = _ORACLE_CACHE["lm4096"]
+    net = build_net(npoint=4096, seed=2, lm=True)
+    return obj, net, img, ref
+
+
 def _teacher_bits(ref):
     B, N = ref[0].shape[0], ref[0].shape[2]
     t = torch.zeros(B, 13, N)
@@ -1103,11 +1121,7 @@ def test_e2e_lm13_n4096_config5(lib):
     pipeline_lm.py:392-425) at npt=4096 dense keypoints, obj_ids from the 13 evaluated LM objects
     (test_network_with_test_data.py:533), fp32 path vs the oracle (pinned for this config by knn_lm4096 +
     e2e_lm4096_injected).  Teacher-forced per stage unconditionally; free-running too when the decision margin allows."""
-    from tests.common import LM_OBJ_IDS
-    obj = torch.tensor([LM_OBJ_IDS[3], LM_OBJ_IDS[11]])
-    net = build_net(npoint=4096, seed=2, lm=True)                 # seed with a mixed RoI bit (47 %), margin 5.6e-5
-    img = det_image(2, seed=32)
-    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx[obj - 1], 4096, **oracle_kwargs())
+    obj, net, img, ref = _lm4096_case()
     z = torch.cat([ref[0], ref[1][:, :-1], ref[2][:, :-1]], 1)
     margin = float(z.abs().min())
     net = net.to(dev())
@@ -1164,10 +1178,7 @@ def test_e2e_bf16_accuracy_contract_n4096_lm(lib, monkeypatch, tiled):
     from checkerpose_amd.agreement import logit_agreement
     from tests.common import LM_OBJ_IDS
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if tiled else 1 << 30)
-    obj = torch.tensor([LM_OBJ_IDS[3], LM_OBJ_IDS[11]])
-    net = build_net(npoint=4096, seed=2, lm=True)
-    img = det_image(2, seed=32)
-    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx[obj - 1], 4096, **oracle_kwargs())
+    obj, net, img, ref = _lm4096_case()
     net = net.to(dev()).set_compute_dtype("bf16")
     tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()), obj_ids=obj.to(dev())), ref)
     fr = logit_agreement(net(img.to(dev()), None, obj.to(dev())), ref)
@@ -1419,29 +1430,52 @@ def test_full_batch_size_property_batch_independence(lib, dt, monkeypatch):
 YCBV_FP32 = (1, 6, 11, 16, 21)
 
 
-@pytest.mark.parametrize("obj", list(range(1, 22)))
+@pytest.mark.parametrize("obj", YCBV_FP32)
 def test_e2e_ycbv_object_graph(lib, obj):
-    """BASELINE config #4: every one of the 21 YCB-V objects (its own FPS keypoints -> its own kNN graph, pinned by the
-    reference-made knn_ycbv512 fixture in test_oracle.py, and its own weights: the reference trains one network per object,
-    train.py:384,396).  fp32 <= 1e-4 + ids bit-exact vs the oracle on objects 1/6/11/16/21; bf16 (the dtype
-    `bench.py --workload ycbv_rr21` times) teacher-forced against the contract of DESIGN.md §5 on all 21."""
+    """BASELINE config #4: a YCB-V object = its own FPS keypoints -> its own kNN graph (pinned by the reference-made knn_ycbv512
+    fixture in test_oracle.py) and its own weights (the reference trains one network per object, train.py:384,396; bench.py's
+    ycbv_rr21 uses seed = object id too).  Five per-object networks: fp32 <= 1e-4 + ids bit-exact vs the oracle, and the bf16
+    teacher-forced contract of DESIGN.md §5.  All 21 graphs run in test_e2e_ycbv_all_21_graphs_one_batch."""
     from checkerpose_amd.agreement import logit_agreement
     from tests.common import ycbv_p3d
     p3d = ycbv_p3d(obj, 512)
-    net = build_net(p3d=p3d, seed=obj)                      # bench.py's ycbv_rr21 uses seed = object id too
+    net = build_net(p3d=p3d, seed=obj)
     img = det_image(1, seed=40 + obj)
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
     assert not torch.equal(net.init_net.knn_idx, O.knn(ape_p3d(512), 20))       # really a different graph
     net = net.to(dev())
-    if obj in YCBV_FP32:
-        out_t = net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()))
-        _cmp_e2e(out_t, ref)
-        z = torch.cat([ref[0], ref[1][:, :-1], ref[2][:, :-1]], 1)
-        if float(z.abs().min()) > 4e-5:                     # free-running parity is only well-posed with a decision margin
-            _cmp_e2e(net(img.to(dev()), None), ref)
+    out_t = net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()))
+    _cmp_e2e(out_t, ref)
+    z = torch.cat([ref[0], ref[1][:, :-1], ref[2][:, :-1]], 1)
+    if float(z.abs().min()) > 4e-5:                     # free-running parity is only well-posed with a decision margin
+        _cmp_e2e(net(img.to(dev()), None), ref)
     net.set_compute_dtype("bf16")
     tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev())), ref)
     # one crop = 512 decisions per logit row (the contract's 98 % per row is stated over the >= 2048 of a 4-crop batch: with
     # random-init weights a row whose logits sit near 0 loses ~10 of 512 to bf16 rounding): all 13 rows together >= 99 %, no row < 96 %
     assert tf["bit_agreement_all_rows"] >= 0.99 and tf["bit_agreement_min_row"] >= 0.96 and tf["seg_agreement"] >= 0.99, (obj, tf)
     assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, (obj, tf)
+
+
+def test_e2e_ycbv_all_21_graphs_one_batch(lib):
+    """All 21 YCB-V kNN graphs in ONE forward: the per-sample-graph twin (pipeline_lm.py:55-57 semantics) built over the 21 objects'
+    keypoints, a batch of 21 crops with obj_ids 1..21 -- every graph gathers for its own crop; fp32 teacher-forced <= 1e-4 vs the
+    oracle (which gathers through `knn_idx[obj_ids - 1]`), and the bf16 contract over the 21 x 512 decisions per row."""
+    from checkerpose_amd.agreement import logit_agreement
+    from tests.common import ycbv_p3d
+    p3d = torch.cat([ycbv_p3d(o, 512) for o in range(1, 22)], 0)               # (21, 3, 512)
+    net = build_net(p3d=p3d, seed=4, lm=True)
+    assert tuple(net.init_net.knn_idx.shape) == (21, 512, 20)
+    g = golden("knn_ycbv512")
+    for k, o in enumerate(g["objs"]):                                           # the tables the forward gathers through = the reference's
+        assert (np.sort(net.init_net.knn_idx[o - 1].numpy(), 1) == np.sort(g["idx"][k].astype(np.int64), 1)).all()
+    obj = torch.arange(1, 22)
+    img = det_image(21, seed=77)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx[obj - 1], 512, **oracle_kwargs())
+    net = net.to(dev())
+    out_t = net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()), obj_ids=obj.to(dev()))
+    _cmp_e2e(out_t, ref)
+    net.set_compute_dtype("bf16")
+    tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()), obj_ids=obj.to(dev())), ref)
+    assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99, tf
+    assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, tf
