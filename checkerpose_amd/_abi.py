@@ -149,6 +149,9 @@ SIGNATURES = {
     "cp_bn_bwd_accumulate": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _P]),
     "cp_bn_bwd_apply": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
                              _I, _P, _P]),
+    "cp_bn_train_fused": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "cp_bn_bwd_fused": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
+                             _I, _P, _P]),
     "cp_edge_train_workspace_bytes": (C.c_size_t, [_I, _I]),
     "cp_edgeconv_train_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P, _P, _P,
                                    _I, _I, _I, _I, _I, _F]),

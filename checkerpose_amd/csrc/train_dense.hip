@@ -202,9 +202,8 @@ struct ColsumParams {
 };
 
 template <typename Tag, int MODE>
-__global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
+__device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red) {
   constexpr int E = Tag::E;
-  __shared__ double red[256 * 2 * E];
   const int tid = threadIdx.x;
   const int rl = tid / p.G, piece = tid - rl * p.G;
   double s1[E], s2[E];
@@ -255,6 +254,12 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
     if (p.acc) unsafeAtomicAdd(p.acc + ((blockIdx.x & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
     else p.partial[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
   }
+}
+
+template <typename Tag, int MODE>
+__global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
+  __shared__ double red[256 * 2 * Tag::E];
+  colsum2_body<Tag, MODE>(p, red);
 }
 
 static int colsum_plan(int M, int Cphys, int E, int* G, int* RL, int* nblk, int* rpb) {
@@ -740,10 +745,8 @@ struct BnApplyParams {
 };
 
 template <typename Tag>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
+__device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_coef) {      // [2][Cphys]: scale | shift, once per block
   constexpr int E = Tag::E;
-  using T = typename Tag::elem;
-  extern __shared__ float s_coef[];                  // [2][Cphys]: scale | shift, computed once per block
   const int Cphys = p.G * E;
   const double inv = 1.0 / p.count;
   for (int c = threadIdx.x; c < Cphys; c += 256) {
@@ -769,9 +772,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
     s_coef[c] = sc;
     s_coef[Cphys + c] = sh;
   }
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M*G
-  if (i >= p.total) return;
+}
+
+template <typename Tag>
+__device__ __forceinline__ void bn_apply_piece(const BnApplyParams& p, const float* s_coef, size_t i) {      // piece i of M * G
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const int Cphys = p.G * E;
   const int g = (int)(i % p.G);
   const size_t m = i / p.G;
   float v[E], r[E];
@@ -789,6 +796,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
     else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
   }
   *(u32x4*)((T*)p.y + m * p.y_cs + p.y_coff + g * E) = Vec16<Tag>::pack(v);
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
+  extern __shared__ float s_coef[];
+  bn_apply_coef<Tag>(p, s_coef);
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M*G
+  if (i < p.total) bn_apply_piece<Tag>(p, s_coef, i);
+}
+
+// ---- statistics + apply in ONE launch (the training step runs ~670 such pairs of 6-13 us launches): every block adds its rows'
+// column sums to the layer's accumulators, all blocks meet at a grid barrier, then every block derives scale / shift from the
+// complete sums and applies them to THE SAME rows (still in the L2).  The grid (<= 256 blocks of 256 threads, 32 KB of LDS) is
+// always co-resident on the 256 CUs, and nothing a waiting block depends on can be blocked by it; the spin is bounded all the same.
+// MEASURED NEGATIVE (round 3, bench_train.py, B = 32): 42.3 ms per step (256 blocks, poll every ~0.85 us) / 44.1 (128 blocks) /
+// 52.5 (64) / 50.5 (512 blocks, fast polling) against 35.7 ms for the two-launch forms -- the barrier (an atomic arrival + polls
+// of one L2 word by every block) costs >= 10 us per launch, more than the second launch it saves.  Kept as an opt-in
+// (CHECKERPOSE_AMD_BN_FUSED=1) and as a tested entry point; the training program uses the two-launch forms.
+__device__ __forceinline__ void cp_grid_barrier(uint32_t* counter, unsigned nblocks) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    unsigned spins = 0;
+#ifndef CP_BAR_SLEEP
+#define CP_BAR_SLEEP 32
+#endif
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(CP_BAR_SLEEP);
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const ColsumParams cs, const BnApplyParams ap, uint32_t* counter) {
+  __shared__ double red[256 * 2 * Tag::E];
+  extern __shared__ float s_coef[];
+  colsum2_body<Tag, 0>(cs, red);
+  cp_grid_barrier(counter, gridDim.x);
+  bn_apply_coef<Tag>(ap, s_coef);
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * cs.rpb * ap.G;
+  size_t hi = lo + (size_t)cs.rpb * ap.G;
+  hi = hi < ap.total ? hi : ap.total;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) bn_apply_piece<Tag>(ap, s_coef, i);
 }
 
 extern "C" int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const double* acc,
@@ -843,11 +896,9 @@ struct BnBwdApplyParams {
 };
 
 template <typename Tag>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParams pp) {
+__device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s_cf) {       // [4][Cphys]: a | b | cr | mu, once per block
   constexpr int E = Tag::E;
-  using T = typename Tag::elem;
   const BnBwdParams& p = pp.q;
-  extern __shared__ float s_cf[];                    // [4][Cphys]: a | b | cr | mu, once per block
   const int Cphys = p.G * E;
   const double inv = 1.0 / pp.count;
   for (int c = threadIdx.x; c < Cphys; c += 256) {
@@ -870,9 +921,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParam
     }
     s_cf[c] = ca; s_cf[Cphys + c] = cb; s_cf[2 * Cphys + c] = cr; s_cf[3 * Cphys + c] = mu;
   }
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.total) return;
+}
+
+template <typename Tag>
+__device__ __forceinline__ void bn_bwd_piece(const BnBwdParams& p, const float* s_cf, size_t i) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const int Cphys = p.G * E;
   const int g = (int)(i % p.G);
   const size_t m = i / p.G;
   float dz[E], t[E];
@@ -910,6 +965,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParam
   *(u32x4*)((T*)p.dx + m * p.dx_cs + p.dx_coff + g * E) = Vec16<Tag>::pack(o);
 }
 
+template <typename Tag>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParams pp) {
+  extern __shared__ float s_cf[];
+  bn_bwd_coef<Tag>(pp, s_cf);
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < pp.q.total) bn_bwd_piece<Tag>(pp.q, s_cf, i);
+}
+
+// backward twin of bn_fused_fwd_kernel: sums of dz and dz * xhat over this block's rows -> barrier -> dx in place over the same rows
+template <typename Tag>
+__global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const ColsumParams cs, const BnBwdApplyParams pp, uint32_t* counter) {
+  __shared__ double red[256 * 2 * Tag::E];
+  extern __shared__ float s_cf[];
+  colsum2_body<Tag, 1>(cs, red);
+  cp_grid_barrier(counter, gridDim.x);
+  bn_bwd_coef<Tag>(pp, s_cf);
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * cs.rpb * pp.q.G;
+  size_t hi = lo + (size_t)cs.rpb * pp.q.G;
+  hi = hi < pp.q.total ? hi : pp.q.total;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) bn_bwd_piece<Tag>(pp.q, s_cf, i);
+}
+
 extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
                                int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
                                const float* rstd, const float* gamma, const double* acc, int M, int C, int act, float slope,
@@ -935,5 +1014,82 @@ extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, in
   const size_t lds = (size_t)4 * Cphys * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_bwd_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
   else CP_LAUNCH(bn_bwd_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
+  return cp_check_launch();
+}
+
+
+#ifndef CP_BAR_BLOCKS
+#define CP_BAR_BLOCKS 256
+#endif
+// fewer, fatter blocks than the two-launch forms: every block polls the barrier counter, and hundreds of pollers on one L2 word
+// slow the arrivals down
+static int colsum_plan_fused(int M, int Cphys, int E, int* G, int* RL, int* nblk, int* rpb) {
+  *G = Cphys / E;
+  if (*G > 256) return CP_ERR_INVALID;
+  *RL = 256 / *G;
+  int nb = M / 64;
+  nb = nb < 1 ? 1 : (nb > CP_BAR_BLOCKS ? CP_BAR_BLOCKS : nb);
+  *rpb = (M + nb - 1) / nb;
+  *nblk = (M + *rpb - 1) / *rpb;
+  return CP_OK;
+}
+
+// ---- fused entry points: the statistics pass and the apply pass of a train-mode BatchNorm in ONE launch (grid barrier between them).
+// `acc` as above (zeroed by the caller once per step); `counter`: 4 zeroed bytes of the same arena, one per call.
+extern "C" int cp_bn_train_fused(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, double* acc, uint32_t* counter,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                 float eps, const void* res, int res_cstride, int res_coff, void* y, int y_cstride, int y_coff, int M,
+                                 int C, int act, float slope, float* mean, float* rstd) {
+  if (!acc || !counter || !mean || !rstd || M <= 0 || C <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
+  int rc;
+  if ((rc = check_cl(dtype, x, x_cstride, x_coff, Cphys)) || (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (res && (rc = check_cl(dtype, res, res_cstride, res_coff, Cphys))) return rc;
+  ColsumParams cs = {};
+  int nblk;
+  if ((rc = colsum_plan_fused(M, Cphys, E, &cs.G, &cs.RL, &nblk, &cs.rpb))) return rc;
+  cs.a = x; cs.a_cs = x_cstride; cs.a_coff = x_coff; cs.M = M; cs.acc = acc; cs.acc_stride = Cvec;
+  BnApplyParams p;
+  p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.res = res; p.r_cs = res_cstride; p.r_coff = res_coff;
+  p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = Cvec; p.C = C; p.count = (double)M;
+  p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum; p.rmean = running_mean; p.rvar = running_var;
+  p.mean = mean; p.rstd = rstd; p.G = Cphys / E; p.act = act; p.slope = slope; p.total = (size_t)M * p.G;
+  const size_t lds = (size_t)2 * Cphys * sizeof(float);
+  if (dtype == CP_F32) CP_LAUNCH(bn_fused_fwd_kernel<F32Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, p, counter);
+  else CP_LAUNCH(bn_fused_fwd_kernel<BF16Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, p, counter);
+  return cp_check_launch();
+}
+
+extern "C" int cp_bn_bwd_fused(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride,
+                               int y_coff, const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd,
+                               const float* gamma, double* acc, uint32_t* counter, int M, int C, int act, float slope, void* dx,
+                               int dx_cstride, int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate,
+                               float* dgamma, float* dbeta) {
+  if (!acc || !counter || M <= 0 || C <= 0 || (x && (!mean || !rstd))) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
+  int rc;
+  if ((rc = check_cl(dtype, dy, dy_cstride, dy_coff, Cphys)) || (rc = check_cl(dtype, dx, dx_cstride, dx_coff, Cphys))) return rc;
+  const void* yy = act == CP_ACT_NONE ? nullptr : y;
+  if (act != CP_ACT_NONE && (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
+  if (x && (rc = check_cl(dtype, x, x_cstride, x_coff, Cphys))) return rc;
+  if (dres && (rc = check_cl(dtype, dres, dres_cstride, dres_coff, Cphys))) return rc;
+  ColsumParams cs = {};
+  int nblk;
+  if ((rc = colsum_plan_fused(M, Cphys, E, &cs.G, &cs.RL, &nblk, &cs.rpb))) return rc;
+  cs.a = dy; cs.a_cs = dy_cstride; cs.a_coff = dy_coff; cs.y = yy; cs.y_cs = y_cstride; cs.y_coff = y_coff;
+  cs.x = x; cs.x_cs = x_cstride; cs.x_coff = x_coff; cs.mean = mean; cs.rstd = rstd; cs.slope = act == CP_ACT_RELU ? 0.f : slope; cs.act = act;
+  cs.M = M; cs.acc = acc; cs.acc_stride = Cvec;
+  BnBwdApplyParams pp;
+  BnBwdParams& q = pp.q;
+  q.dy = dy; q.dy_cs = dy_cstride; q.dy_coff = dy_coff; q.y = yy; q.y_cs = y_cstride; q.y_coff = y_coff;
+  q.x = x; q.x_cs = x_cstride; q.x_coff = x_coff; q.dx = dx; q.dx_cs = dx_cstride; q.dx_coff = dx_coff;
+  q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
+  q.coef = nullptr; q.Cvec = Cvec; q.G = Cphys / E; q.slope = act == CP_ACT_RELU ? 0.f : slope; q.total = (size_t)M * q.G;
+  pp.acc = acc; pp.C = C; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
+  const size_t lds = (size_t)4 * Cphys * sizeof(float);
+  if (dtype == CP_F32) CP_LAUNCH(bn_fused_bwd_kernel<F32Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, pp, counter);
+  else CP_LAUNCH(bn_fused_bwd_kernel<BF16Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, pp, counter);
   return cp_check_launch();
 }

@@ -96,6 +96,9 @@ class TrainProgram(Program):
         self.wg_ws = torch.empty(int(os.environ.get("CHECKERPOSE_AMD_WGRAD_ARENA_MB", "4096")) << 20, dtype=torch.uint8, device=device)
         self._wg_off, self._wg_items, self._wg_keys, self.wg_tabs = 0, [], set(), []
         self.wg_defer = os.environ.get("CHECKERPOSE_AMD_WGRAD_DEFER", "1") != "0"        # A/B: one reduction launch per layer
+        # BatchNorm statistics + apply in ONE launch each way (grid barrier in between): measured SLOWER on MI355X -- 42.3 ms per step
+        # at best (256 blocks, slow polling) against 35.7 ms for the two-launch forms: the barrier costs >= 10 us per launch -> off
+        self.bn_fused = os.environ.get("CHECKERPOSE_AMD_BN_FUSED", "0") == "1"
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._touched, self.pslot_done, self.pslot_done_call = [], {}, {}
@@ -204,8 +207,11 @@ class TrainProgram(Program):
     # consumer kernel derives the coefficients itself) -- the accumulators of the whole step are zero-filled by ONE launch
     def _acc_slot(self, C_):
         off = self.acc_total
-        self.acc_total += int(self.lib.cp_bn_acc_doubles(C_))
+        self.acc_total += int(self.lib.cp_bn_acc_doubles(C_)) + 2      # + the fused launches' barrier counter (zeroed with the sums)
         return off
+
+    def _ctr_ptr(self, off, C_):
+        return self.acc_arena.data_ptr() + 8 * (off + int(self.lib.cp_bn_acc_doubles(C_)))
 
     def _acc_ptr(self, off):
         return self.acc_arena.data_ptr() + 8 * off
@@ -217,6 +223,9 @@ class TrainProgram(Program):
         xt = x.tbuf
         M = x.B * x.H * x.W
         off = bn["acc"]
+        if self.bn_fused:                 # statistics + apply in one launch: emitted by bn_apply (same tensor, directly behind)
+            bn["stats_of"] = x
+            return bn
         self._add(self.lib.cp_bn_stats_accumulate, lambda P: (self.dtype, P(xt), M, C_, x.cstride, x.coff, self._acc_ptr(off)),
                   "bn_stats", [xt], [])
         return bn
@@ -229,6 +238,13 @@ class TrainProgram(Program):
         off = bn["acc"]
         a1 = (bn["gamma"].data_ptr(), bn["beta"].data_ptr(), bn["rmean"].data_ptr(), bn["rvar"].data_ptr(), bn["momentum"], bn["eps"])
         mp, rp = bn["mean"].data_ptr(), bn["rstd"].data_ptr()
+        if bn.pop("stats_of", None) is x:
+            Cc = bn["C"]
+            self._add(self.lib.cp_bn_train_fused,
+                      lambda P: (self.dtype, P(xt), x.cstride, x.coff, self._acc_ptr(off), self._ctr_ptr(off, Cc)) + a1 +
+                                (P(rt) if rt is not None else None, rcs, rco, P(ot), out.cstride, out.coff, M, x.C, act, slope, mp, rp),
+                      "bn_fused", [xt, rt], [ot])
+            return out
         self._add(self.lib.cp_bn_apply,
                   lambda P: (self.dtype, P(xt), x.cstride, x.coff, self._acc_ptr(off)) + a1 +
                             (P(rt) if rt is not None else None, rcs, rco, P(ot), out.cstride, out.coff, M, x.C, act, slope, mp, rp),
@@ -261,6 +277,14 @@ class TrainProgram(Program):
         rcs, rco = (raw.cstride, raw.coff) if raw is not None else (0, 0)
         gcs, gco = (gres.cstride, gres.coff) if gres is not None else (0, 0)
         off = self._acc_slot(C_)
+        if self.bn_fused:
+            self._add(self.lib.cp_bn_bwd_fused,
+                      lambda P: (self.dtype, P(gt), gy.cstride, gy.coff, P(yt) if yt is not None else None, ycs, yco,
+                                 P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, gam_p, self._acc_ptr(off), self._ctr_ptr(off, C_),
+                                 M, C_, act, slope, P(gt), gy.cstride, gy.coff, P(grt) if grt is not None else None, gcs, gco, 1,
+                                 dgamma_ptr, dbeta_ptr),
+                      "bn_bwd_fused", [gt, yt, rt, grt], [gt, grt])
+            return
         self._add(self.lib.cp_bn_bwd_accumulate,
                   lambda P: (self.dtype, P(gt), gy.cstride, gy.coff, P(yt) if yt is not None else None, ycs, yco,
                              P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, M, C_, act, slope, self._acc_ptr(off)),

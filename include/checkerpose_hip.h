@@ -506,6 +506,17 @@ int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, int dy_cstrid
                     int y_coff, const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd,
                     const float* gamma, const double* acc, int M, int C, int act, float slope, void* dx, int dx_cstride,
                     int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma, float* dbeta);
+/* The same two passes in ONE launch each (round 3): statistics over a block's rows -> grid barrier -> apply to the same rows.
+ * `counter`: 4 zeroed bytes per call (zero them with the accumulators).  The grid (<= 512 blocks) is always co-resident on an
+ * MI355X; the barrier's spin is bounded.  Arguments as cp_bn_stats_accumulate + cp_bn_apply / cp_bn_bwd_accumulate + cp_bn_bwd_apply. */
+int cp_bn_train_fused(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, double* acc, uint32_t* counter,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      const void* res, int res_cstride, int res_coff, void* y, int y_cstride, int y_coff, int M, int C, int act,
+                      float slope, float* mean, float* rstd);
+int cp_bn_bwd_fused(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride,
+                    int y_coff, const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd, const float* gamma,
+                    double* acc, uint32_t* counter, int M, int C, int act, float slope, void* dx, int dx_cstride, int dx_coff,
+                    void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma, float* dbeta);
 
 /* Train-mode EdgeConv in factored form (StaticGraph_module init.py:54-68 with BatchNorm2d batch statistics over the
  * B*N*K edges), see csrc/train_edge.hip.  pq (B,N,2C) = raw node GEMM output [P | Q] (W rows [W1 ; W2-W1], no

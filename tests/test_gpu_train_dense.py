@@ -528,6 +528,62 @@ def test_bn_two_launch_forms(lib, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", [(2, 18, 16, 16, ACT_RELU, True), (3, 64, 8, 8, ACT_LEAKY, False), (32, 18, 64, 64, ACT_RELU, True),
+                                  (4, 256, 64, 64, ACT_RELU, False)])
+def test_bn_fused_launches_equal_the_two_launch_forms(lib, dtype, case):
+    """cp_bn_train_fused / cp_bn_bwd_fused (statistics -> grid barrier -> apply in ONE launch) against the two-launch forms on the same
+    inputs: the same arithmetic from the same accumulators (fp64 atomics: only the order of the sums differs), incl. a full grid
+    (512 blocks at 32 x 64 x 64 rows) and a wide layer; replayed three times with re-zeroed accumulators / counters."""
+    B, Cc, H, W, act, has_res = case
+    M = B * H * W
+    x = rnd(det_tensor("bf_x%s" % (case,), (B, Cc, H, W)) * 1.5 + 0.3, dtype)
+    res = rnd(det_tensor("bf_r%s" % (case,), (B, Cc, H, W)), dtype) if has_res else None
+    dy = rnd(det_tensor("bf_d%s" % (case,), (B, Cc, H, W)), dtype)
+    g_d = (1.0 + 0.5 * det_tensor("bf_g%s" % (case,), (Cc,))).to(dev())
+    b_d = (0.2 * det_tensor("bf_b%s" % (case,), (Cc,))).to(dev())
+    xc, dyc0 = to_cl(x, dtype), to_cl(dy, dtype)
+    rc_ = to_cl(res, dtype) if has_res else None
+    cs = xc.shape[-1]
+    nacc = lib.cp_bn_acc_doubles(Cc)
+
+    def run(fused):
+        rm_d, rv_d = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+        mean, rstd = _vec(Cc), _vec(Cc)
+        acc = torch.zeros(2, nacc + 2, dtype=torch.float64, device=dev())                 # [fwd | bwd]: sums + barrier counter
+        yc, dyc = torch.empty_like(xc), dyc0.clone()
+        dres = torch.zeros_like(xc) if has_res else None
+        dg, db = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+        rp = rc_.data_ptr() if has_res else None
+        drp = dres.data_ptr() if has_res else None
+        if fused:
+            _abi.check(lib.cp_bn_train_fused(st(), dtype, xc.data_ptr(), cs, 0, acc[0].data_ptr(), acc[0].data_ptr() + 8 * nacc, g_d.data_ptr(),
+                                             b_d.data_ptr(), rm_d.data_ptr(), rv_d.data_ptr(), 0.1, 1e-5, rp, cs, 0, yc.data_ptr(), cs, 0, M, Cc,
+                                             act, 0.2, mean.data_ptr(), rstd.data_ptr()), "bn fused")
+            _abi.check(lib.cp_bn_bwd_fused(st(), dtype, dyc.data_ptr(), cs, 0, yc.data_ptr(), cs, 0, xc.data_ptr(), cs, 0, mean.data_ptr(),
+                                           rstd.data_ptr(), g_d.data_ptr(), acc[1].data_ptr(), acc[1].data_ptr() + 8 * nacc, M, Cc, act, 0.2,
+                                           dyc.data_ptr(), cs, 0, drp, cs, 0, 1, dg.data_ptr(), db.data_ptr()), "bn bwd fused")
+        else:
+            _abi.check(lib.cp_bn_stats_accumulate(st(), dtype, xc.data_ptr(), M, Cc, cs, 0, acc[0].data_ptr()), "stats acc")
+            _abi.check(lib.cp_bn_apply(st(), dtype, xc.data_ptr(), cs, 0, acc[0].data_ptr(), g_d.data_ptr(), b_d.data_ptr(), rm_d.data_ptr(),
+                                       rv_d.data_ptr(), 0.1, 1e-5, rp, cs, 0, yc.data_ptr(), cs, 0, M, Cc, act, 0.2, mean.data_ptr(),
+                                       rstd.data_ptr()), "bn apply")
+            _abi.check(lib.cp_bn_bwd_accumulate(st(), dtype, dyc.data_ptr(), cs, 0, yc.data_ptr(), cs, 0, xc.data_ptr(), cs, 0, mean.data_ptr(),
+                                                rstd.data_ptr(), M, Cc, act, 0.2, acc[1].data_ptr()), "bwd acc")
+            _abi.check(lib.cp_bn_bwd_apply(st(), dtype, dyc.data_ptr(), cs, 0, yc.data_ptr(), cs, 0, xc.data_ptr(), cs, 0, mean.data_ptr(),
+                                           rstd.data_ptr(), g_d.data_ptr(), acc[1].data_ptr(), M, Cc, act, 0.2, dyc.data_ptr(), cs, 0, drp, cs, 0,
+                                           1, dg.data_ptr(), db.data_ptr()), "bwd apply")
+        torch.cuda.synchronize()
+        return [t.float().cpu() for t in (yc, dyc, mean, rstd, rm_d, rv_d, dg, db)] + ([dres.float().cpu()] if has_res else [])
+
+    ref = run(False)
+    for _ in range(3):
+        got = run(True)
+        for a, b in zip(got, ref):
+            sc = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= (2e-2 if dtype == CP_BF16 else 2e-5) * sc       # bf16: one output ulp where a sum's order moved a rounding
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 def test_pack_batch_matches_single_launch_packers(lib, dtype):
     """cp_pack_batch (one launch over a device table of items) produces bit-identical images to the single-launch entry points
     for every item kind: generic (plain, row-mapped, ConvTranspose phase), halo small / regular / wide, GEMM, dgrad view,
