@@ -1,0 +1,61 @@
+"""CPU: host-side logic added in round 3 -- the patch schedule of the tiled EdgeConv (graph_sched.tile_schedule), the batch buckets
+of the eval runtime and the RANSAC stopping rule shared by the PnP oracle and kernel."""
+import numpy as np
+import torch
+
+from checkerpose_amd.graph_sched import schedule_block, tile_schedule
+from checkerpose_amd.model.init import knn
+from tests.common import lm_p3d
+
+
+def test_tile_schedule_invariants_on_lm_graphs():
+    """The renumbering is a permutation, every patch's halo list holds exactly its out-of-patch neighbours, the slot lists rebuild
+    the ORIGINAL graph (as sets per keypoint: the max over a neighbourhood ignores order), and the internal-numbering table matches."""
+    P = lm_p3d(4096)[[1, 4]]                                       # LM objects 2 and 5 (5: the largest halo of the 15)
+    idx = knn(P, 20).numpy()
+    sc = tile_schedule(idx, P.numpy())
+    assert sc is not None and sc["NB"] == 8 and sc["HPAD"] % 64 == 0 and sc["HPAD"] >= int(sc["halo_rows"].max())
+    for g in range(2):
+        perm, inv = sc["perm"][g].astype(np.int64), sc["inv"][g].astype(np.int64)
+        assert sorted(perm.tolist()) == list(range(4096)) and (inv[perm] == np.arange(4096)).all()
+        assert (sc["idx_internal"][g] == inv[idx[g][perm]]).all()
+        for t in range(8):
+            own = np.arange(512) + 512 * t
+            nbrs_int = sc["idx_internal"][g][own]                  # (512, 20) internal ids
+            outside = np.unique(nbrs_int[(nbrs_int < 512 * t) | (nbrs_int >= 512 * (t + 1))])
+            n = int(sc["halo_rows"][g, t])
+            assert n == len(outside) and (sc["halo"][g, t, :n] == outside).all()
+            assert (sc["halo"][g, t, n:] == 512 * t).all()          # padding: a valid row of the patch
+            table = np.concatenate([own, sc["halo"][g, t]])         # slot -> internal row
+            rebuilt = perm[table[sc["nbr"][g, t].astype(np.int64)]]            # (512, 20) ORIGINAL keypoint ids
+            want = idx[g][perm[own]]
+            assert (np.sort(rebuilt, 1) == np.sort(want, 1)).all()
+            assert int(sc["nbr"][g, t].max()) < 512 + n
+    assert tile_schedule(idx[:, :512], P.numpy()[:, :, :512]) is None       # one patch: the N = 512 kernel's case
+    assert tile_schedule(idx, P.numpy(), hpad_max=64) is None               # table would not fit: caller falls back to the L2 gather
+
+
+def test_schedule_block_is_a_permutation_of_every_list():
+    rng = np.random.default_rng(0)
+    rows = rng.integers(0, 896, size=(16, 20))
+    out, clashes = schedule_block(rows.copy())
+    assert (np.sort(out, 1) == np.sort(rows, 1)).all() and 0 <= clashes <= 16 * 20
+
+
+def test_batch_buckets():
+    from checkerpose_amd.model._runtime import batch_bucket
+    got = [batch_bucket(b) for b in range(1, 66)]
+    assert all(g >= b for g, b in zip(got, range(1, 66)))
+    assert all(2 * g < 3 * b for g, b in zip(got, range(1, 66)))              # the bucket is under 1.5x the request
+    assert sorted(set(got)) == [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96]
+    assert [batch_bucket(b) for b in (100, 128, 129, 200, 256, 257, 1000)] == [128, 128, 192, 256, 256, 384, 1024]
+
+
+def test_ransac_stopping_rule_known_values():
+    """OpenCV's RANSACUpdateNumIters at confidence 0.99: log(0.01) / log(1 - w^m)"""
+    from oracle.pnp_oracle import needed_iterations
+    assert needed_iterations(70, 100, 5, 150) == 25                 # 70 % inliers, 5-point samples
+    assert needed_iterations(100, 100, 5, 150) == 0                 # all inliers: done
+    assert needed_iterations(4, 100, 5, 150) == 150                 # fewer inliers than a sample: keep going
+    assert needed_iterations(30, 100, 5, 150) == 150                # 0.3^5: would need 1893 > max
+    assert needed_iterations(50, 100, 4, 150) == 71
