@@ -471,7 +471,7 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
 
 extern "C" int cp_permute_rows(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids,
                                int B, int N, int row_bytes) {
-  if (!in || !out || !perm || B <= 0 || N <= 0 || row_bytes <= 0 || row_bytes % 16) return CP_ERR_INVALID;
+  if (!in || !out || in == out || !perm || B <= 0 || N <= 0 || row_bytes <= 0 || row_bytes % 16) return CP_ERR_INVALID;    // not in place
   if (!cp_aligned16(in) || !cp_aligned16(out)) return CP_ERR_ALIGN;
   const size_t total = (size_t)B * N * (row_bytes / 16);
   CP_LAUNCH(permute_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)in, (u32x4*)out,
@@ -481,7 +481,7 @@ extern "C" int cp_permute_rows(cp_stream_t stream, const void* in, void* out, co
 
 extern "C" int cp_permute_cols(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids,
                                int B, int R, int N, int elem_bytes, int scatter) {
-  if (!in || !out || !perm || B <= 0 || R <= 0 || N <= 0 || (elem_bytes != 4 && elem_bytes != 8)) return CP_ERR_INVALID;
+  if (!in || !out || in == out || !perm || B <= 0 || R <= 0 || N <= 0 || (elem_bytes != 4 && elem_bytes != 8)) return CP_ERR_INVALID;
   const size_t total = (size_t)B * R * N;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (elem_bytes == 4)

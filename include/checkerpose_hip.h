@@ -301,7 +301,7 @@ int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstride, int in_
 /* The renumbering at the launch program's boundary (perm int32 (G, N): internal row i = original keypoint perm[g][i];
  * graph_ids (B) or NULL).  Rows of `row_bytes` (a multiple of 16): out[b][i] = in[b][perm[g_b][i]].  Columns of (B, R, N)
  * arrays of 4- / 8-byte elements (logit block, ids): scatter = 1: out[b][r][perm[g_b][i]] = in[b][r][i] (internal -> original),
- * scatter = 0: out[b][r][i] = in[b][r][perm[g_b][i]]. */
+ * scatter = 0: out[b][r][i] = in[b][r][perm[g_b][i]].  Not in place (in == out: CP_ERR_INVALID). */
 int cp_permute_rows(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids, int B, int N,
                     int row_bytes);
 int cp_permute_cols(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids, int B, int R,
