@@ -42,6 +42,15 @@ class CpWgradReduceItem(C.Structure):
                 ("dw_sr", C.c_int64), ("dw_ss", C.c_int64)]
 
 
+CP_BN_ITEM_STATS, CP_BN_ITEM_APPLY, CP_BN_ITEM_BWD_SUMS, CP_BN_ITEM_BWD_APPLY = 0, 1, 2, 3       # include/checkerpose_hip.h
+BN_GROUP_MAX = 16                      # CP_BN_GROUP_MAX
+
+
+class CpBnItem(C.Structure):          # one layer's pass in a grouped BatchNorm launch (cp_bn_item_* fill it; params is opaque)
+    _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("blocks", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("params", C.c_uint64 * 24)]
+
+
 class CpWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
@@ -149,6 +158,13 @@ SIGNATURES = {
     "cp_bn_bwd_accumulate": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _P]),
     "cp_bn_bwd_apply": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
                              _I, _P, _P]),
+    "cp_bn_item_stats": (_I, [_I, _P, _I, _I, _I, _I, _P, C.POINTER(CpBnItem)]),
+    "cp_bn_item_apply": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P,
+                              C.POINTER(CpBnItem)]),
+    "cp_bn_item_bwd_sums": (_I, [_I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _P, C.POINTER(CpBnItem)]),
+    "cp_bn_item_bwd_apply": (_I, [_I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
+                                  _I, _P, _P, C.POINTER(CpBnItem)]),
+    "cp_bn_group": (_I, [_P, _I, _I, _P, _P, _I, C.c_uint32, C.c_uint32]),
     "cp_bn_train_fused": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "cp_bn_bwd_fused": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _P, _I, _I,
                              _I, _P, _P]),

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <cstring>
 
 // ------------------------------------------------------------------------------------------------ small plumbing
 // zero fill / device copy as plain kernels: they sit inside the captured training graphs between kernel nodes (memset /
@@ -202,7 +203,7 @@ struct ColsumParams {
 };
 
 template <typename Tag, int MODE>
-__device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red) {
+__device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red, unsigned bid) {
   constexpr int E = Tag::E;
   const int tid = threadIdx.x;
   const int rl = tid / p.G, piece = tid - rl * p.G;
@@ -210,14 +211,14 @@ __device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red)
 #pragma unroll
   for (int j = 0; j < E; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
   if (rl < p.RL) {
-    const int m_end = min((int)(blockIdx.x + 1) * p.rpb, p.M);
+    const int m_end = min((int)(bid + 1) * p.rpb, p.M);
     float mu[E], rs[E];
     if (MODE == 1 && p.x) {
 #pragma unroll
       for (int j = 0; j < E; ++j) { mu[j] = p.mean[piece * E + j]; rs[j] = p.rstd[piece * E + j]; }
     }
 #pragma unroll 4
-    for (int m = blockIdx.x * p.rpb + rl; m < m_end; m += p.RL) {
+    for (int m = bid * p.rpb + rl; m < m_end; m += p.RL) {
       float a[E];
       Vec16<Tag>::unpack(*(const u32x4*)((const typename Tag::elem*)p.a + (size_t)m * p.a_cs + p.a_coff + piece * E), a);
       if (MODE == 0) {
@@ -251,15 +252,15 @@ __device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red)
     const int pc = c / E, j = c - pc * E;
     double s = 0.0;
     for (int r = 0; r < p.RL; ++r) s += red[(r * p.G + pc) * 2 * E + which * E + j];
-    if (p.acc) unsafeAtomicAdd(p.acc + ((blockIdx.x & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
-    else p.partial[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
+    if (p.acc) unsafeAtomicAdd(p.acc + ((bid & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
+    else p.partial[((size_t)bid * 2 + which) * CP + c] = s;
   }
 }
 
 template <typename Tag, int MODE>
 __global__ __launch_bounds__(256) void colsum2_kernel(const ColsumParams p) {
   __shared__ double red[256 * 2 * Tag::E];
-  colsum2_body<Tag, MODE>(p, red);
+  colsum2_body<Tag, MODE>(p, red, blockIdx.x);
 }
 
 static int colsum_plan(int M, int Cphys, int E, int* G, int* RL, int* nblk, int* rpb) {
@@ -716,17 +717,25 @@ static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, 
 
 extern "C" size_t cp_bn_acc_doubles(int C) { return (size_t)CP_BN_ACC_SETS * 2 * ((size_t)(C + 15) / 16 * 16); }
 
-extern "C" int cp_bn_stats_accumulate(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff,
-                                      double* acc) {
+static int build_bn_stats(int dtype, const void* x, int M, int C, int x_cstride, int x_coff, double* acc, ColsumParams* out, int* nblk) {
   if (!acc || M <= 0 || C <= 0) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
   int rc = check_cl(dtype, x, x_cstride, x_coff, Cphys);
   if (rc) return rc;
   ColsumParams p = {};
-  int nblk;
-  if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, &nblk, &p.rpb))) return rc;
+  if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, nblk, &p.rpb))) return rc;
   p.a = x; p.a_cs = x_cstride; p.a_coff = x_coff; p.M = M; p.acc = acc; p.acc_stride = Cvec;
+  *out = p;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_stats_accumulate(cp_stream_t stream, int dtype, const void* x, int M, int C, int x_cstride, int x_coff,
+                                      double* acc) {
+  ColsumParams p;
+  int nblk;
+  const int rc = build_bn_stats(dtype, x, M, C, x_cstride, x_coff, acc, &p, &nblk);
+  if (rc) return rc;
   if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
   else CP_LAUNCH((colsum2_kernel<BF16Tag, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
   return cp_check_launch();
@@ -745,7 +754,7 @@ struct BnApplyParams {
 };
 
 template <typename Tag>
-__device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_coef) {      // [2][Cphys]: scale | shift, once per block
+__device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_coef, bool first) {      // [2][Cphys]: scale | shift, once per block
   constexpr int E = Tag::E;
   const int Cphys = p.G * E;
   const double inv = 1.0 / p.count;
@@ -762,7 +771,7 @@ __device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_c
       const float gm = p.gamma ? p.gamma[c] : 1.f, bt = p.beta ? p.beta[c] : 0.f;
       sc = gm * rs;
       sh = bt - (float)mu * sc;
-      if (blockIdx.x == 0) {                       // one block writes the saved statistics + running stats
+      if (first) {                                 // one block writes the saved statistics + running stats
         p.mean[c] = (float)mu;
         p.rstd[c] = rs;
         if (p.rmean) p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)mu;
@@ -801,7 +810,7 @@ __device__ __forceinline__ void bn_apply_piece(const BnApplyParams& p, const flo
 template <typename Tag>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
   extern __shared__ float s_coef[];
-  bn_apply_coef<Tag>(p, s_coef);
+  bn_apply_coef<Tag>(p, s_coef, blockIdx.x == 0);
   __syncthreads();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M*G
   if (i < p.total) bn_apply_piece<Tag>(p, s_coef, i);
@@ -834,9 +843,9 @@ template <typename Tag>
 __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const ColsumParams cs, const BnApplyParams ap, uint32_t* counter) {
   __shared__ double red[256 * 2 * Tag::E];
   extern __shared__ float s_coef[];
-  colsum2_body<Tag, 0>(cs, red);
+  colsum2_body<Tag, 0>(cs, red, blockIdx.x);
   cp_grid_barrier(counter, gridDim.x);
-  bn_apply_coef<Tag>(ap, s_coef);
+  bn_apply_coef<Tag>(ap, s_coef, blockIdx.x == 0);
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * cs.rpb * ap.G;
   size_t hi = lo + (size_t)cs.rpb * ap.G;
@@ -844,10 +853,10 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const ColsumParams cs
   for (size_t i = lo + threadIdx.x; i < hi; i += 256) bn_apply_piece<Tag>(ap, s_coef, i);
 }
 
-extern "C" int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const double* acc,
-                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                           float eps, const void* res, int res_cstride, int res_coff, void* y, int y_cstride, int y_coff, int M,
-                           int C, int act, float slope, float* mean, float* rstd) {
+static int build_bn_apply(int dtype, const void* x, int x_cstride, int x_coff, const double* acc, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, const void* res, int res_cstride,
+                          int res_coff, void* y, int y_cstride, int y_coff, int M, int C, int act, float slope, float* mean, float* rstd,
+                          BnApplyParams* out, unsigned* blocks, int* Cphys_out) {
   if (!acc || !mean || !rstd || M <= 0 || C <= 0) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E;
@@ -859,16 +868,31 @@ extern "C" int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_c
   p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = (C + 15) / 16 * 16; p.C = C; p.count = (double)M;
   p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum; p.rmean = running_mean; p.rvar = running_var;
   p.mean = mean; p.rstd = rstd; p.G = Cphys / E; p.act = act; p.slope = slope; p.total = (size_t)M * p.G;
-  const unsigned blocks = (unsigned)((p.total + 255) / 256);
+  *out = p;
+  *blocks = (unsigned)((p.total + 255) / 256);
+  *Cphys_out = Cphys;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_cstride, int x_coff, const double* acc,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                           float eps, const void* res, int res_cstride, int res_coff, void* y, int y_cstride, int y_coff, int M,
+                           int C, int act, float slope, float* mean, float* rstd) {
+  BnApplyParams p;
+  unsigned blocks;
+  int Cphys;
+  const int rc = build_bn_apply(dtype, x, x_cstride, x_coff, acc, gamma, beta, running_mean, running_var, momentum, eps, res, res_cstride,
+                                res_coff, y, y_cstride, y_coff, M, C, act, slope, mean, rstd, &p, &blocks, &Cphys);
+  if (rc) return rc;
   const size_t lds = (size_t)2 * Cphys * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
   else CP_LAUNCH(bn_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
   return cp_check_launch();
 }
 
-extern "C" int cp_bn_bwd_accumulate(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
-                                    int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
-                                    const float* rstd, int M, int C, int act, float slope, double* acc) {
+static int build_bn_bwd_sums(int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride, int y_coff, const void* x,
+                             int x_cstride, int x_coff, const float* mean, const float* rstd, int M, int C, int act, float slope, double* acc,
+                             ColsumParams* out, int* nblk) {
   if (!acc || M <= 0 || C <= 0 || (x && (!mean || !rstd))) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
@@ -878,11 +902,22 @@ extern "C" int cp_bn_bwd_accumulate(cp_stream_t stream, int dtype, const void* d
   if (act != CP_ACT_NONE && (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
   if (x && (rc = check_cl(dtype, x, x_cstride, x_coff, Cphys))) return rc;
   ColsumParams p = {};
-  int nblk;
-  if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, &nblk, &p.rpb))) return rc;
+  if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, nblk, &p.rpb))) return rc;
   p.a = dy; p.a_cs = dy_cstride; p.a_coff = dy_coff; p.y = yy; p.y_cs = y_cstride; p.y_coff = y_coff;
   p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.mean = mean; p.rstd = rstd; p.slope = act == CP_ACT_RELU ? 0.f : slope; p.act = act;
   p.M = M; p.acc = acc; p.acc_stride = Cvec;
+  *out = p;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_bwd_accumulate(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                                    int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                                    const float* rstd, int M, int C, int act, float slope, double* acc) {
+  ColsumParams p;
+  int nblk;
+  const int rc = build_bn_bwd_sums(dtype, dy, dy_cstride, dy_coff, y, y_cstride, y_coff, x, x_cstride, x_coff, mean, rstd, M, C, act, slope,
+                                   acc, &p, &nblk);
+  if (rc) return rc;
   if (dtype == CP_F32) CP_LAUNCH((colsum2_kernel<F32Tag, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
   else CP_LAUNCH((colsum2_kernel<BF16Tag, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
   return cp_check_launch();
@@ -896,7 +931,7 @@ struct BnBwdApplyParams {
 };
 
 template <typename Tag>
-__device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s_cf) {       // [4][Cphys]: a | b | cr | mu, once per block
+__device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s_cf, bool first) {       // [4][Cphys]: a | b | cr | mu, once per block
   constexpr int E = Tag::E;
   const BnBwdParams& p = pp.q;
   const int Cphys = p.G * E;
@@ -914,7 +949,7 @@ __device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s
         cr = (float)(s2 * inv) * rs;
         mu = pp.mean[c];
       }
-      if (blockIdx.x == 0) {
+      if (first) {
         if (pp.dbeta) pp.dbeta[c] = (float)s1;
         if (p.x && pp.dgamma) pp.dgamma[c] = (float)s2;
       }
@@ -968,7 +1003,7 @@ __device__ __forceinline__ void bn_bwd_piece(const BnBwdParams& p, const float* 
 template <typename Tag>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParams pp) {
   extern __shared__ float s_cf[];
-  bn_bwd_coef<Tag>(pp, s_cf);
+  bn_bwd_coef<Tag>(pp, s_cf, blockIdx.x == 0);
   __syncthreads();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < pp.q.total) bn_bwd_piece<Tag>(pp.q, s_cf, i);
@@ -979,9 +1014,9 @@ template <typename Tag>
 __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const ColsumParams cs, const BnBwdApplyParams pp, uint32_t* counter) {
   __shared__ double red[256 * 2 * Tag::E];
   extern __shared__ float s_cf[];
-  colsum2_body<Tag, 1>(cs, red);
+  colsum2_body<Tag, 1>(cs, red, blockIdx.x);
   cp_grid_barrier(counter, gridDim.x);
-  bn_bwd_coef<Tag>(pp, s_cf);
+  bn_bwd_coef<Tag>(pp, s_cf, blockIdx.x == 0);
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * cs.rpb * pp.q.G;
   size_t hi = lo + (size_t)cs.rpb * pp.q.G;
@@ -989,11 +1024,11 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const ColsumParams cs
   for (size_t i = lo + threadIdx.x; i < hi; i += 256) bn_bwd_piece<Tag>(pp.q, s_cf, i);
 }
 
-extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
-                               int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
-                               const float* rstd, const float* gamma, const double* acc, int M, int C, int act, float slope,
-                               void* dx, int dx_cstride, int dx_coff, void* dres, int dres_cstride, int dres_coff,
-                               int dres_accumulate, float* dgamma, float* dbeta) {
+static int build_bn_bwd_apply(int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride, int y_coff, const void* x,
+                              int x_cstride, int x_coff, const float* mean, const float* rstd, const float* gamma, const double* acc, int M,
+                              int C, int act, float slope, void* dx, int dx_cstride, int dx_coff, void* dres, int dres_cstride,
+                              int dres_coff, int dres_accumulate, float* dgamma, float* dbeta, BnBwdApplyParams* out, unsigned* blocks,
+                              int* Cphys_out) {
   if (!acc || M <= 0 || C <= 0 || (x && (!mean || !rstd))) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E;
@@ -1010,10 +1045,145 @@ extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, in
   q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
   q.coef = nullptr; q.Cvec = (C + 15) / 16 * 16; q.G = Cphys / E; q.slope = act == CP_ACT_RELU ? 0.f : slope; q.total = (size_t)M * q.G;
   pp.acc = acc; pp.C = C; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
-  const unsigned blocks = (unsigned)((q.total + 255) / 256);
+  *out = pp;
+  *blocks = (unsigned)((q.total + 255) / 256);
+  *Cphys_out = Cphys;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y,
+                               int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* mean,
+                               const float* rstd, const float* gamma, const double* acc, int M, int C, int act, float slope,
+                               void* dx, int dx_cstride, int dx_coff, void* dres, int dres_cstride, int dres_coff,
+                               int dres_accumulate, float* dgamma, float* dbeta) {
+  BnBwdApplyParams pp;
+  unsigned blocks;
+  int Cphys;
+  const int rc = build_bn_bwd_apply(dtype, dy, dy_cstride, dy_coff, y, y_cstride, y_coff, x, x_cstride, x_coff, mean, rstd, gamma, acc, M, C,
+                                    act, slope, dx, dx_cstride, dx_coff, dres, dres_cstride, dres_coff, dres_accumulate, dgamma, dbeta,
+                                    &pp, &blocks, &Cphys);
+  if (rc) return rc;
   const size_t lds = (size_t)4 * Cphys * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_bwd_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
   else CP_LAUNCH(bn_bwd_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
+  return cp_check_launch();
+}
+
+// ---- grouped launches: the BatchNorm passes of INDEPENDENT layers (the 2-4 branches of an HRNet module at the same depth, the fuse-layer
+// convs of a module) in ONE launch each.  At the training batch (32 crops) a single pass is a 5-13 us launch over 0.3-5 MB -- latency,
+// not bandwidth; the step ran ~1 340 of them.  An item is the parameter block of one layer's pass, built on the host by cp_bn_item_*
+// (same arguments and checks as the single-layer entry points), the table lives in device memory, block b belongs to the item k with
+// prefix[k] <= b < prefix[k + 1].
+union BnItemU {
+  ColsumParams cs;
+  BnApplyParams ap;
+  BnBwdApplyParams bp;
+  unsigned long long pad[CP_BN_ITEM_BYTES / 8];
+};
+static_assert(sizeof(BnItemU) == CP_BN_ITEM_BYTES, "CpBnItem too small for the parameter blocks");
+
+template <typename Tag, int KIND>
+__global__ __launch_bounds__(256) void bn_group_kernel(const CpBnItem* __restrict__ items, const uint32_t* __restrict__ prefix, int n) {
+  int k = 0;
+  while (k + 1 < n && blockIdx.x >= prefix[k + 1]) ++k;
+  const unsigned bid = blockIdx.x - prefix[k];
+  const BnItemU& it = *(const BnItemU*)items[k].params;
+  if constexpr (KIND == CP_BN_ITEM_STATS || KIND == CP_BN_ITEM_BWD_SUMS) {
+    __shared__ double red[256 * 2 * Tag::E];
+    colsum2_body<Tag, KIND == CP_BN_ITEM_STATS ? 0 : 1>(it.cs, red, bid);
+  } else if constexpr (KIND == CP_BN_ITEM_APPLY) {
+    extern __shared__ float s_coef[];
+    bn_apply_coef<Tag>(it.ap, s_coef, bid == 0);
+    __syncthreads();
+    const size_t i = (size_t)bid * 256 + threadIdx.x;
+    if (i < it.ap.total) bn_apply_piece<Tag>(it.ap, s_coef, i);
+  } else {
+    extern __shared__ float s_coef[];
+    bn_bwd_coef<Tag>(it.bp, s_coef, bid == 0);
+    __syncthreads();
+    const size_t i = (size_t)bid * 256 + threadIdx.x;
+    if (i < it.bp.q.total) bn_bwd_piece<Tag>(it.bp.q, s_coef, i);
+  }
+}
+
+extern "C" int cp_bn_item_stats(int dtype, const void* x, int M, int C, int x_cstride, int x_coff, double* acc, CpBnItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  BnItemU u = {};
+  int nblk;
+  const int rc = build_bn_stats(dtype, x, M, C, x_cstride, x_coff, acc, &u.cs, &nblk);
+  if (rc) return rc;
+  memcpy(item->params, &u, sizeof(u));
+  item->kind = CP_BN_ITEM_STATS; item->dtype = dtype; item->blocks = (uint32_t)nblk; item->lds_bytes = 0;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_item_apply(int dtype, const void* x, int x_cstride, int x_coff, const double* acc, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, const void* res, int res_cstride,
+                                int res_coff, void* y, int y_cstride, int y_coff, int M, int C, int act, float slope, float* mean,
+                                float* rstd, CpBnItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  BnItemU u = {};
+  unsigned blocks;
+  int Cphys;
+  const int rc = build_bn_apply(dtype, x, x_cstride, x_coff, acc, gamma, beta, running_mean, running_var, momentum, eps, res, res_cstride,
+                                res_coff, y, y_cstride, y_coff, M, C, act, slope, mean, rstd, &u.ap, &blocks, &Cphys);
+  if (rc) return rc;
+  memcpy(item->params, &u, sizeof(u));
+  item->kind = CP_BN_ITEM_APPLY; item->dtype = dtype; item->blocks = blocks; item->lds_bytes = (uint32_t)(2 * Cphys * sizeof(float));
+  return CP_OK;
+}
+
+extern "C" int cp_bn_item_bwd_sums(int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride, int y_coff,
+                                   const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd, int M, int C, int act,
+                                   float slope, double* acc, CpBnItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  BnItemU u = {};
+  int nblk;
+  const int rc = build_bn_bwd_sums(dtype, dy, dy_cstride, dy_coff, y, y_cstride, y_coff, x, x_cstride, x_coff, mean, rstd, M, C, act, slope,
+                                   acc, &u.cs, &nblk);
+  if (rc) return rc;
+  memcpy(item->params, &u, sizeof(u));
+  item->kind = CP_BN_ITEM_BWD_SUMS; item->dtype = dtype; item->blocks = (uint32_t)nblk; item->lds_bytes = 0;
+  return CP_OK;
+}
+
+extern "C" int cp_bn_item_bwd_apply(int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride, int y_coff,
+                                    const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd, const float* gamma,
+                                    const double* acc, int M, int C, int act, float slope, void* dx, int dx_cstride, int dx_coff,
+                                    void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma, float* dbeta,
+                                    CpBnItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  BnItemU u = {};
+  unsigned blocks;
+  int Cphys;
+  const int rc = build_bn_bwd_apply(dtype, dy, dy_cstride, dy_coff, y, y_cstride, y_coff, x, x_cstride, x_coff, mean, rstd, gamma, acc, M, C,
+                                    act, slope, dx, dx_cstride, dx_coff, dres, dres_cstride, dres_coff, dres_accumulate, dgamma, dbeta,
+                                    &u.bp, &blocks, &Cphys);
+  if (rc) return rc;
+  memcpy(item->params, &u, sizeof(u));
+  item->kind = CP_BN_ITEM_BWD_APPLY; item->dtype = dtype; item->blocks = blocks; item->lds_bytes = (uint32_t)(4 * Cphys * sizeof(float));
+  return CP_OK;
+}
+
+template <typename Tag>
+static void launch_bn_group(int kind, unsigned blocks, size_t lds, hipStream_t st, const CpBnItem* items, const uint32_t* prefix, int n) {
+  switch (kind) {
+    case CP_BN_ITEM_STATS: CP_LAUNCH((bn_group_kernel<Tag, CP_BN_ITEM_STATS>), dim3(blocks), dim3(256), 0, st, items, prefix, n); break;
+    case CP_BN_ITEM_APPLY: CP_LAUNCH((bn_group_kernel<Tag, CP_BN_ITEM_APPLY>), dim3(blocks), dim3(256), lds, st, items, prefix, n); break;
+    case CP_BN_ITEM_BWD_SUMS: CP_LAUNCH((bn_group_kernel<Tag, CP_BN_ITEM_BWD_SUMS>), dim3(blocks), dim3(256), 0, st, items, prefix, n); break;
+    default: CP_LAUNCH((bn_group_kernel<Tag, CP_BN_ITEM_BWD_APPLY>), dim3(blocks), dim3(256), lds, st, items, prefix, n); break;
+  }
+}
+
+extern "C" int cp_bn_group(cp_stream_t stream, int dtype, int kind, const CpBnItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                           uint32_t total_blocks, uint32_t lds_bytes) {
+  if (!items_dev || !prefix_dev || n_items <= 0 || n_items > CP_BN_GROUP_MAX || total_blocks == 0 || lds_bytes > 48 * 1024)
+    return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (kind < CP_BN_ITEM_STATS || kind > CP_BN_ITEM_BWD_APPLY) return CP_ERR_INVALID;
+  if (!cp_aligned16(items_dev)) return CP_ERR_ALIGN;
+  if (dtype == CP_F32) launch_bn_group<F32Tag>(kind, total_blocks, lds_bytes, (hipStream_t)stream, items_dev, prefix_dev, n_items);
+  else launch_bn_group<BF16Tag>(kind, total_blocks, lds_bytes, (hipStream_t)stream, items_dev, prefix_dev, n_items);
   return cp_check_launch();
 }
 

@@ -75,6 +75,84 @@ class NetEmitter:
         tp.tape.append(bwd)
         return y
 
+    def conv_bn_group(self, specs):
+        """Training program: conv + train-mode BatchNorm (+residual) (+ReLU) of INDEPENDENT layers -- the convs one launch each, their
+        BatchNorm passes grouped (trainer.bn_train_group / bn_bwd_group: one launch per pass for the whole group).
+        specs: [(x, conv key, bn key, k, stride, pad, relu, residual)] -> [y]"""
+        tp = self.tp
+        members, recs = [], []
+        for x, conv, bn, k, stride, pad, relu, residual in specs:
+            w = self.W(conv + ".weight")
+            Cout = w.shape[0]
+            raw = tp.conv(x, conv, w, tp.const_vec(Cout, True), tp.const_vec(Cout, False), k, k, stride, pad, Cout)
+            recs.append((x, conv, bn, w, k, stride, pad, ACT_RELU if relu else ACT_NONE, residual, raw))
+        ys = []
+        for x, conv, bn, w, k, stride, pad, act, residual, raw in recs:
+            y = tp.act(raw.H, raw.W, raw.C)
+            members.append((raw, raw.C, self.W(bn + ".weight"), self.W(bn + ".bias"), self.sd[bn + ".running_mean"],
+                            self.sd[bn + ".running_var"], residual, y, act, 0.0))
+            self.bn_counters.append(self.sd[bn + ".num_batches_tracked"])
+            if act != ACT_NONE:
+                tp.kinks[bn] = y
+            ys.append(y)
+        sts = tp.bn_train_group(members)
+
+        def bwd():
+            live = [(r, y, st) for r, y, st in zip(recs, ys, sts) if y.tbuf in tp.grads]
+            if not live:
+                return
+            gys = [tp.grad_of(y) for _, y, _ in live]
+            tp.bn_bwd_group([(gy, y, r[9], st, r[7], 0.0, tp.grad_of(r[8]) if r[8] is not None else None,
+                              tp.pg_ptr(r[2] + ".weight"), tp.pg_ptr(r[2] + ".bias")) for gy, (r, y, st) in zip(gys, live)])
+            for gy, (r, y, st) in zip(gys, live):
+                tp.conv_backward(r[1], r[3], r[0], gy, r[4], r[4], r[5], r[6])
+        tp.tape.append(bwd)
+        return ys
+
+    def _hr_module_train(self, pfx, xs):
+        """hr_module for the training program, emitted DEPTH-major: block k / conv c of every branch, then ONE grouped launch per
+        BatchNorm pass for all of them (the branches are independent until the fuse layers); likewise the fuse convs level by level"""
+        nb = len(xs)
+        xs = [self._materialize(x) for x in xs]
+        for k in range(4):
+            bp = ["%s.branches.%d.%d" % (pfx, j, k) for j in range(nb)]
+            assert not any((q + ".downsample.0.weight") in self.sd for q in bp)
+            ys = self.conv_bn_group([(xs[j], bp[j] + ".conv1", bp[j] + ".bn1", 3, 1, 1, True, None) for j in range(nb)])
+            xs = self.conv_bn_group([(ys[j], bp[j] + ".conv2", bp[j] + ".bn2", 3, 1, 1, True, xs[j]) for j in range(nb)])
+        terms = [[None] * nb for _ in range(nb)]
+        for i in range(nb):
+            terms[i][i] = xs[i]
+        cur = {}
+        pairs = [(i, j) for j in range(nb) for i in range(nb) if i != j]
+        level = 0
+        while True:
+            specs, who = [], []
+            for i, j in pairs:
+                q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+                if j > i:
+                    if level == 0:
+                        specs.append((xs[j], q + ".0", q + ".1", 1, 1, 0, False, None))
+                        who.append((i, j))
+                elif level < i - j:
+                    src = xs[j] if level == 0 else cur[(i, j)]
+                    specs.append((src, "%s.%d.0" % (q, level), "%s.%d.1" % (q, level), 3, 2, 1, level != i - j - 1, None))
+                    who.append((i, j))
+            if not specs:
+                break
+            for (i, j), y in zip(who, self.conv_bn_group(specs)):
+                cur[(i, j)] = y
+            level += 1
+        for i, j in pairs:
+            terms[i][j] = cur[(i, j)]
+        outs = []
+        for i in range(nb):
+            out = self.p.act(xs[i].H, xs[i].W, xs[i].C)
+            shifts = [max(j - i, 0) for j in range(nb)]
+            outs.append(self.p.fuse_sum(terms[i], shifts, out, relu=True))
+            self.tp.kinks["%s.fuse%d" % (pfx, i)] = out
+            self._fuse_sum_tape(out, list(terms[i]), shifts)
+        return outs
+
     def _bias_vec(self, key, n):
         return self.tp.live_vec(n, [(0, self.W(key + ".bias"), 0, n)])
 
@@ -194,6 +272,8 @@ class NetEmitter:
         chain launch (engine.hr_chain, bf16) sums + ReLUs them while staging its map into LDS, other consumers
         materialise them (fuse_sum launch)."""
         nb = len(xs)
+        if self.tp is not None and self.tp.bn_grouped and nb > 1:
+            return self._hr_module_train(pfx, xs)
         xs = list(xs)
         p = self.p
         # lane j: branch j's four BasicBlocks; then lane i runs the fuse-layer conv chains INTO branch i (it waits for the

@@ -16,7 +16,8 @@ import os
 import torch
 
 from . import _abi
-from ._abi import CpWgradReduceItem, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc
+from ._abi import (CpWgradReduceItem, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc, CpBnItem, BN_GROUP_MAX,
+                   CP_BN_ITEM_STATS, CP_BN_ITEM_APPLY, CP_BN_ITEM_BWD_SUMS, CP_BN_ITEM_BWD_APPLY)
 from .engine import Act, Program, WeightStore, _rup
 
 
@@ -99,6 +100,8 @@ class TrainProgram(Program):
         # BatchNorm statistics + apply in ONE launch each way (grid barrier in between): measured SLOWER on MI355X -- 42.3 ms per step
         # at best (256 blocks, slow polling) against 35.7 ms for the two-launch forms: the barrier costs >= 10 us per launch -> off
         self.bn_fused = os.environ.get("CHECKERPOSE_AMD_BN_FUSED", "0") == "1"
+        # the BatchNorm passes of independent layers (HRNet branches at equal depth, a module's fuse convs) in one launch each
+        self.bn_grouped = os.environ.get("CHECKERPOSE_AMD_BN_GROUPED", "1") != "0"
         self.wgrad_flops = {}      # op index -> algorithmic FLOPs of that weight-gradient launch (bench_train roofline)
         self.n_fwd_ops = None
         self._touched, self.pslot_done, self.pslot_done_call = [], {}, {}
@@ -294,6 +297,115 @@ class TrainProgram(Program):
                              P(rt) if rt is not None else None, rcs, rco, mean_p, rstd_p, gam_p, self._acc_ptr(off), M, C_, act, slope,
                              P(gt), gy.cstride, gy.coff, P(grt) if grt is not None else None, gcs, gco, 1, dgamma_ptr, dbeta_ptr),
                   "bn_bwd", [gt, yt, rt, grt], [gt, grt])
+
+    # ---- grouped BatchNorm passes: the same pass of INDEPENDENT layers (the branches of an HRNet module at equal depth, the fuse
+    # convs of a module) in ONE launch (cp_bn_group): at B = 32 a single pass is a 5-13 us launch over 0.3-5 MB, latency not bandwidth
+    def _bn_group(self, kind, builders, name, reads, writes):
+        """builders: callables P -> CpBnItem, run when the workspace is planned (pointers are final then)"""
+        def argb(P):
+            items = [b(P) for b in builders]
+            arr = (CpBnItem * len(items))(*items)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            pre = [0]
+            for it in items:
+                pre.append(pre[-1] + int(it.blocks))
+            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+            self.keep += [raw, prefix]
+            return (self.dtype, kind, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1], max(int(it.lds_bytes) for it in items))
+        self._add(self.lib.cp_bn_group, argb, name, reads, writes)
+
+    def bn_train_group(self, members):
+        """members: [(raw Act, C, gamma, beta, rmean, rvar, residual Act | None, out Act, act, slope)] of independent layers ->
+        [bn dict]; statistics of all of them in one launch, apply (+residual, +activation) in a second one"""
+        if len(members) == 1 or self.bn_fused or not self.bn_grouped:
+            out = []
+            for raw, C_, g, b, rm, rv, res, y, act, slope in members:
+                bn = self.bn_stats(raw, C_, g, b, rm, rv)
+                self.bn_apply(raw, bn, res, y, act, slope)
+                out.append(bn)
+            return out
+        bns, sb, ab, reads_s, reads_a, writes_a = [], [], [], [], [], []
+        lib, dt = self.lib, self.dtype
+        for raw, C_, g, b, rm, rv, res, y, act, slope in members:
+            bn = dict(mean=self.vec(C_), rstd=self.vec(C_), gamma=g, beta=b, rmean=rm, rvar=rv, C=C_, acc=self._acc_slot(C_),
+                      momentum=0.1, eps=1e-5)
+            self.keep += [g, b, rm, rv]
+            bns.append(bn)
+            M = raw.B * raw.H * raw.W
+
+            def stats(P, raw=raw, C_=C_, M=M, off=bn["acc"]):
+                it = CpBnItem()
+                _abi.check(lib.cp_bn_item_stats(dt, P(raw.tbuf), M, C_, raw.cstride, raw.coff, self._acc_ptr(off), C.byref(it)), "cp_bn_item_stats")
+                return it
+
+            def apply_(P, raw=raw, M=M, bn=bn, res=res, y=y, act=act, slope=slope):
+                it = CpBnItem()
+                rp, rcs, rco = (P(res.tbuf), res.cstride, res.coff) if res is not None else (None, 0, 0)
+                _abi.check(lib.cp_bn_item_apply(dt, P(raw.tbuf), raw.cstride, raw.coff, self._acc_ptr(bn["acc"]), bn["gamma"].data_ptr(),
+                                                bn["beta"].data_ptr(), bn["rmean"].data_ptr(), bn["rvar"].data_ptr(), bn["momentum"],
+                                                bn["eps"], rp, rcs, rco, P(y.tbuf), y.cstride, y.coff, M, raw.C, act, slope,
+                                                bn["mean"].data_ptr(), bn["rstd"].data_ptr(), C.byref(it)), "cp_bn_item_apply")
+                return it
+            sb.append(stats)
+            ab.append(apply_)
+            reads_s.append(raw.tbuf)
+            reads_a += [raw.tbuf] + ([res.tbuf] if res is not None else [])
+            writes_a.append(y.tbuf)
+        for lo in range(0, len(members), BN_GROUP_MAX):
+            hi = lo + BN_GROUP_MAX
+            self._bn_group(CP_BN_ITEM_STATS, sb[lo:hi], "bn_stats_group:%d" % len(sb[lo:hi]), reads_s, [])
+        for lo in range(0, len(members), BN_GROUP_MAX):
+            hi = lo + BN_GROUP_MAX
+            self._bn_group(CP_BN_ITEM_APPLY, ab[lo:hi], "bn_apply_group:%d" % len(ab[lo:hi]), reads_a, writes_a)
+        return bns
+
+    def bn_bwd_group(self, members):
+        """members: [(gy, y, raw, bn, act, slope, gres, dgamma_ptr, dbeta_ptr)] as bn_bwd's arguments, independent layers"""
+        if len(members) == 1 or self.bn_fused or not self.bn_grouped:
+            for m in members:
+                self.bn_bwd(*m)
+            return
+        lib, dt = self.lib, self.dtype
+        sb, ab, reads_s, reads_a, writes_a = [], [], [], [], []
+        for gy, y, raw, bn, act, slope, gres, dgp, dbp in members:
+            use_y = y is not None and act != ACT_NONE
+            M, C_ = gy.B * gy.H * gy.W, gy.C
+            off = self._acc_slot(C_)
+            mean_p = bn["mean"].data_ptr() if bn else None
+            rstd_p = bn["rstd"].data_ptr() if bn else None
+            gam_p = bn["gamma"].data_ptr() if bn else None
+
+            def ptrs(P, gy=gy, y=y, raw=raw, use_y=use_y):
+                yv = (P(y.tbuf), y.cstride, y.coff) if use_y else (None, 0, 0)
+                xv = (P(raw.tbuf), raw.cstride, raw.coff) if raw is not None else (None, 0, 0)
+                return (dt, P(gy.tbuf), gy.cstride, gy.coff) + yv + xv
+
+            def sums(P, ptrs=ptrs, M=M, C_=C_, act=act, slope=slope, off=off, mean_p=mean_p, rstd_p=rstd_p):
+                it = CpBnItem()
+                _abi.check(lib.cp_bn_item_bwd_sums(*(ptrs(P) + (mean_p, rstd_p, M, C_, act, slope, self._acc_ptr(off), C.byref(it)))),
+                           "cp_bn_item_bwd_sums")
+                return it
+
+            def apply_(P, ptrs=ptrs, gy=gy, gres=gres, M=M, C_=C_, act=act, slope=slope, off=off, mean_p=mean_p, rstd_p=rstd_p,
+                       gam_p=gam_p, dgp=dgp, dbp=dbp):
+                it = CpBnItem()
+                gr = (P(gres.tbuf), gres.cstride, gres.coff) if gres is not None else (None, 0, 0)
+                _abi.check(lib.cp_bn_item_bwd_apply(*(ptrs(P) + (mean_p, rstd_p, gam_p, self._acc_ptr(off), M, C_, act, slope,
+                                                                 P(gy.tbuf), gy.cstride, gy.coff) + gr + (1, dgp, dbp, C.byref(it)))),
+                           "cp_bn_item_bwd_apply")
+                return it
+            sb.append(sums)
+            ab.append(apply_)
+            rd = [gy.tbuf] + ([y.tbuf] if use_y else []) + ([raw.tbuf] if raw is not None else [])
+            reads_s += rd
+            reads_a += rd + ([gres.tbuf] if gres is not None else [])
+            writes_a += [gy.tbuf] + ([gres.tbuf] if gres is not None else [])
+        for lo in range(0, len(members), BN_GROUP_MAX):
+            hi = lo + BN_GROUP_MAX
+            self._bn_group(CP_BN_ITEM_BWD_SUMS, sb[lo:hi], "bn_bwd_acc_group:%d" % len(sb[lo:hi]), reads_s, [])
+        for lo in range(0, len(members), BN_GROUP_MAX):
+            hi = lo + BN_GROUP_MAX
+            self._bn_group(CP_BN_ITEM_BWD_APPLY, ab[lo:hi], "bn_bwd_group:%d" % len(ab[lo:hi]), reads_a, writes_a)
 
     # ---- dense layer backward
     def wgrad(self, dy: Act, x: Act, dw_ptr, Cout, Cin, R, S, stride, pad, Ho=None, Wo=None, base=0, sco=None, sci=None):

@@ -518,6 +518,36 @@ int cp_bn_bwd_fused(cp_stream_t stream, int dtype, const void* dy, int dy_cstrid
                     double* acc, uint32_t* counter, int M, int C, int act, float slope, void* dx, int dx_cstride, int dx_coff,
                     void* dres, int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma, float* dbeta);
 
+/* Grouped BatchNorm passes: the same pass (statistics / apply / backward sums / backward apply) of up to CP_BN_GROUP_MAX
+ * INDEPENDENT layers in ONE launch -- the branches of an HRNet module at equal depth (timm HighResolutionModule.forward runs
+ * them one after the other; at the reference's training batch of 32 each pass is a 5-13 us launch over 0.3-5 MB).
+ * cp_bn_item_* take the arguments of cp_bn_stats_accumulate / cp_bn_apply / cp_bn_bwd_accumulate / cp_bn_bwd_apply, run the
+ * same checks and fill one item on the HOST (nothing is launched).  cp_bn_group: `items_dev` = the items of ONE kind and
+ * dtype copied to device memory, `prefix_dev` = exclusive prefix sum (n_items + 1 entries) of item.blocks, `lds_bytes` = the
+ * largest item.lds_bytes.  Every item behaves exactly as its single-layer launch (same block plan, same arithmetic). */
+#define CP_BN_ITEM_BYTES 192
+#define CP_BN_GROUP_MAX 16
+enum { CP_BN_ITEM_STATS = 0, CP_BN_ITEM_APPLY = 1, CP_BN_ITEM_BWD_SUMS = 2, CP_BN_ITEM_BWD_APPLY = 3 };
+typedef struct CpBnItem {
+  int32_t kind, dtype;
+  uint32_t blocks, lds_bytes;
+  unsigned long long params[CP_BN_ITEM_BYTES / 8];      /* opaque: the kernel's parameter block */
+} CpBnItem;
+int cp_bn_item_stats(int dtype, const void* x, int M, int C, int x_cstride, int x_coff, double* acc, CpBnItem* item);
+int cp_bn_item_apply(int dtype, const void* x, int x_cstride, int x_coff, const double* acc, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, const void* res, int res_cstride,
+                     int res_coff, void* y, int y_cstride, int y_coff, int M, int C, int act, float slope, float* mean, float* rstd,
+                     CpBnItem* item);
+int cp_bn_item_bwd_sums(int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride, int y_coff,
+                        const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd, int M, int C, int act,
+                        float slope, double* acc, CpBnItem* item);
+int cp_bn_item_bwd_apply(int dtype, const void* dy, int dy_cstride, int dy_coff, const void* y, int y_cstride, int y_coff,
+                         const void* x, int x_cstride, int x_coff, const float* mean, const float* rstd, const float* gamma,
+                         const double* acc, int M, int C, int act, float slope, void* dx, int dx_cstride, int dx_coff, void* dres,
+                         int dres_cstride, int dres_coff, int dres_accumulate, float* dgamma, float* dbeta, CpBnItem* item);
+int cp_bn_group(cp_stream_t stream, int dtype, int kind, const CpBnItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                uint32_t total_blocks, uint32_t lds_bytes);
+
 /* Train-mode EdgeConv in factored form (StaticGraph_module init.py:54-68 with BatchNorm2d batch statistics over the
  * B*N*K edges), see csrc/train_edge.hip.  pq (B,N,2C) = raw node GEMM output [P | Q] (W rows [W1 ; W2-W1], no
  * affine); kstar (B,N,C) uint8 receives the arg-max neighbour slot; scale/shift/mean/rstd: C floats each.

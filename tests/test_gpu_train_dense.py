@@ -584,6 +584,131 @@ def test_bn_fused_launches_equal_the_two_launch_forms(lib, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_bn_group_launches_equal_the_single_layer_launches(lib, dtype):
+    """cp_bn_group (the four BatchNorm passes of several independent layers, one launch per pass over a device table of cp_bn_item_*
+    parameter blocks) against the single-layer launches on the same inputs -- the shapes of an HRNet stage-4 module at the training
+    batch (18/36/72/144 channels at 64/32/16/8 squared), with and without a residual, ReLU / LeakyReLU / no activation, a channel
+    slice of a wider buffer, and a bias-only layer (raw NULL) in the backward.  Same block plan and arithmetic per item: the apply
+    passes are bit-identical given equal sums; the fp64 atomics may land in another order (last-bit differences in the sums)."""
+    from checkerpose_amd._abi import CpBnItem, CP_BN_ITEM_STATS, CP_BN_ITEM_APPLY, CP_BN_ITEM_BWD_SUMS, CP_BN_ITEM_BWD_APPLY
+    import ctypes as C
+    B = 8
+    cases = [(18, 64, ACT_RELU, True, 0), (36, 32, ACT_RELU, False, 0), (72, 16, ACT_LEAKY, True, 0), (144, 8, ACT_NONE, False, 0),
+             (18, 32, ACT_RELU, True, 24)]                     # last: channels [24, 42) of a 48-channel buffer
+    E = 8 if dtype == CP_BF16 else 4
+    L = []
+    for n, (Cc, H, act, has_res, coff) in enumerate(cases):
+        M = B * H * H
+        x = rnd(det_tensor("bg_x%d" % n, (B, Cc, H, H)) * 1.5 + 0.3, dtype)
+        xc = to_cl(x, dtype)
+        if coff:                                             # embed in a wider buffer
+            wide = torch.zeros(B, H, H, 48, dtype=xc.dtype, device=dev())
+            wide[..., coff:coff + xc.shape[-1]] = xc
+            xc, cs = wide, 48
+        else:
+            cs = xc.shape[-1]
+        rc_ = to_cl(rnd(det_tensor("bg_r%d" % n, (B, Cc, H, H)), dtype), dtype) if has_res else None
+        dyc0 = to_cl(rnd(det_tensor("bg_d%d" % n, (B, Cc, H, H)), dtype), dtype)
+        L.append(dict(C=Cc, M=M, act=act, xc=xc, cs=cs, coff=coff, rc=rc_, dyc0=dyc0, g=(1.0 + 0.5 * det_tensor("bg_g%d" % n, (Cc,))).to(dev()),
+                      b=(0.2 * det_tensor("bg_b%d" % n, (Cc,))).to(dev()), nacc=lib.cp_bn_acc_doubles(Cc)))
+    Cb, Mb = 24, B * 16 * 16                                  # a bias-only layer's backward (no BatchNorm input): raw NULL, no dgamma
+    dyb0 = to_cl(rnd(det_tensor("bg_db", (B, Cb, 16, 16)), dtype), dtype)
+    yb = to_cl(rnd(det_tensor("bg_yb", (B, Cb, 16, 16)), dtype), dtype)
+
+    def group(kind, items):
+        arr = (CpBnItem * len(items))(*items)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+        pre = [0]
+        for it in items:
+            assert it.kind == kind and it.dtype == dtype and it.blocks > 0
+            pre.append(pre[-1] + it.blocks)
+        prefix = torch.tensor(pre, dtype=torch.int32, device=dev())
+        _abi.check(lib.cp_bn_group(st(), dtype, kind, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1], max(it.lds_bytes for it in items)),
+                   "cp_bn_group")
+        torch.cuda.synchronize()
+
+    def run(grouped):
+        S = []
+        for l in L:
+            Cc = l["C"]
+            S.append(dict(rm=torch.zeros(Cc, device=dev()), rv=torch.ones(Cc, device=dev()), mean=_vec(Cc), rstd=_vec(Cc),
+                          acc=torch.zeros(2, l["nacc"], dtype=torch.float64, device=dev()), yc=torch.zeros_like(l["dyc0"]), dyc=l["dyc0"].clone(),
+                          dres=torch.zeros_like(l["dyc0"]) if l["rc"] is not None else None, dg=torch.zeros(Cc, device=dev()),
+                          db=torch.zeros(Cc, device=dev())))
+        accb = torch.zeros(lib.cp_bn_acc_doubles(Cb), dtype=torch.float64, device=dev())
+        dyb, dbb = dyb0.clone(), torch.zeros(Cb, device=dev())
+        ycs = S[0]["yc"].shape[-1]
+
+        def a_stats(l, s):
+            return (dtype, l["xc"].data_ptr(), l["M"], l["C"], l["cs"], l["coff"], s["acc"][0].data_ptr())
+
+        def a_apply(l, s):
+            rp = l["rc"].data_ptr() if l["rc"] is not None else None
+            return (dtype, l["xc"].data_ptr(), l["cs"], l["coff"], s["acc"][0].data_ptr(), l["g"].data_ptr(), l["b"].data_ptr(), s["rm"].data_ptr(),
+                    s["rv"].data_ptr(), 0.1, 1e-5, rp, s["yc"].shape[-1], 0, s["yc"].data_ptr(), s["yc"].shape[-1], 0, l["M"], l["C"], l["act"], 0.2,
+                    s["mean"].data_ptr(), s["rstd"].data_ptr())
+
+        def a_bsums(l, s):
+            w = s["yc"].shape[-1]
+            return (dtype, s["dyc"].data_ptr(), w, 0, s["yc"].data_ptr(), w, 0, l["xc"].data_ptr(), l["cs"], l["coff"], s["mean"].data_ptr(),
+                    s["rstd"].data_ptr(), l["M"], l["C"], l["act"], 0.2, s["acc"][1].data_ptr())
+
+        def a_bapply(l, s):
+            w = s["yc"].shape[-1]
+            drp = s["dres"].data_ptr() if s["dres"] is not None else None
+            return (dtype, s["dyc"].data_ptr(), w, 0, s["yc"].data_ptr(), w, 0, l["xc"].data_ptr(), l["cs"], l["coff"], s["mean"].data_ptr(),
+                    s["rstd"].data_ptr(), l["g"].data_ptr(), s["acc"][1].data_ptr(), l["M"], l["C"], l["act"], 0.2, s["dyc"].data_ptr(), w, 0,
+                    drp, w, 0, 1, s["dg"].data_ptr(), s["db"].data_ptr())
+        wb = dyb.shape[-1]
+        bias_sums = (dtype, dyb.data_ptr(), wb, 0, yb.data_ptr(), wb, 0, None, 0, 0, None, None, Mb, Cb, ACT_LEAKY, 0.1, accb.data_ptr())
+        bias_apply = (dtype, dyb.data_ptr(), wb, 0, yb.data_ptr(), wb, 0, None, 0, 0, None, None, None, accb.data_ptr(), Mb, Cb, ACT_LEAKY, 0.1,
+                      dyb.data_ptr(), wb, 0, None, 0, 0, 1, None, dbb.data_ptr())
+        if grouped:
+            def items(fn, argsets):
+                out = []
+                for a in argsets:
+                    it = CpBnItem()
+                    _abi.check(fn(*(a + (C.byref(it),))), "item")
+                    out.append(it)
+                return out
+            group(CP_BN_ITEM_STATS, items(lib.cp_bn_item_stats, [a_stats(l, s) for l, s in zip(L, S)]))
+            group(CP_BN_ITEM_APPLY, items(lib.cp_bn_item_apply, [a_apply(l, s) for l, s in zip(L, S)]))
+            group(CP_BN_ITEM_BWD_SUMS, items(lib.cp_bn_item_bwd_sums, [a_bsums(l, s) for l, s in zip(L, S)] + [bias_sums]))
+            group(CP_BN_ITEM_BWD_APPLY, items(lib.cp_bn_item_bwd_apply, [a_bapply(l, s) for l, s in zip(L, S)] + [bias_apply]))
+        else:
+            for l, s in zip(L, S):
+                a = a_stats(l, s)
+                _abi.check(lib.cp_bn_stats_accumulate(st(), *a), "stats")
+                _abi.check(lib.cp_bn_apply(st(), *a_apply(l, s)), "apply")
+                _abi.check(lib.cp_bn_bwd_accumulate(st(), *a_bsums(l, s)), "bwd sums")
+                _abi.check(lib.cp_bn_bwd_apply(st(), *a_bapply(l, s)), "bwd apply")
+            _abi.check(lib.cp_bn_bwd_accumulate(st(), *bias_sums), "bias sums")
+            _abi.check(lib.cp_bn_bwd_apply(st(), *bias_apply), "bias apply")
+        torch.cuda.synchronize()
+        out = []
+        for s in S:
+            out += [s[k].float().cpu() for k in ("yc", "dyc", "mean", "rstd", "rm", "rv", "dg", "db")] + ([s["dres"].float().cpu()] if s["dres"] is not None else [])
+        return out + [dyb.float().cpu(), dbb.cpu()]
+
+    ref = run(False)
+    for _ in range(2):
+        got = run(True)
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            sc = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= (2e-2 if dtype == CP_BF16 else 2e-5) * sc
+    # the host-side item builders run the single-layer entry points' checks
+    it = CpBnItem()
+    x = L[0]["xc"]
+    accz = torch.zeros(512, dtype=torch.float64, device=dev())
+    S_ptr = accz.data_ptr()
+    assert lib.cp_bn_item_stats(dtype, x.data_ptr(), 0, 18, x.shape[-1], 0, S_ptr, C.byref(it)) != 0
+    assert lib.cp_bn_item_stats(dtype, x.data_ptr(), 64, 18, x.shape[-1], 3, S_ptr, C.byref(it)) != 0          # channel offset off the vector grid
+    assert lib.cp_bn_group(st(), dtype, 7, x.data_ptr(), x.data_ptr(), 1, 1, 0) != 0
+    assert lib.cp_bn_group(st(), dtype, 0, x.data_ptr(), x.data_ptr(), 17, 1, 0) != 0                           # more than CP_BN_GROUP_MAX items
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 def test_pack_batch_matches_single_launch_packers(lib, dtype):
     """cp_pack_batch (one launch over a device table of items) produces bit-identical images to the single-launch entry points
     for every item kind: generic (plain, row-mapped, ConvTranspose phase), halo small / regular / wide, GEMM, dgrad view,
