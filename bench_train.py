@@ -8,7 +8,8 @@ forward); same launch contract:
 
 A "step" = the body of reference train.py:300-320 on one batch of B synthetic 256x256 crops per GPU, already resident in
 HBM: zero_grad, PoseNet_GNNskip forward in train mode (batch-statistics BatchNorm), the five losses, backward through the
-HIP training program, ONE all-reduce of the flat fp32 gradient buffer over RCCL (N > 1), torch's fused Adam step.
+HIP training program, ONE all-reduce of the flat fp32 gradient buffer over RCCL (N > 1), the Adam step (checkerpose_amd.optim.Adam:
+one launch; CHECKERPOSE_BENCH_TORCH_ADAM=1: torch's fused Adam).
 Prints one JSON line on rank 0: crops/s (whole job), ms/step, and the per-kernel device time of the step's launch
 program (HIP events, eager replay) with achieved TFLOP/s of the weight-gradient kernel.
 """
@@ -101,7 +102,9 @@ def main():
     m_vis = (det_tensor("t_mv", (B, 128, 128), seed=rank) > 0).float().to(dev)
     m_full = (det_tensor("t_mf", (B, 128, 128), seed=rank) > -0.3).float().to(dev)
     roi_loss, bit_loss, seg_loss = UnmaskedCodeLoss("BCE"), MaskedCodeLoss("BCE"), MaskLoss_interpolate()
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
+    from checkerpose_amd.optim import Adam                 # optim.Adam(net.parameters(), lr) of train.py:246 as ONE launch per step
+    opt = (torch.optim.Adam(net.parameters(), lr=2e-4, fused=True) if os.environ.get("CHECKERPOSE_BENCH_TORCH_ADAM") == "1"
+           else Adam(net.parameters(), lr=2e-4))
     p3d = torch.zeros(1, 3, N, device=dev).expand(B, -1, -1)
 
     def step():

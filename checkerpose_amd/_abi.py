@@ -51,6 +51,18 @@ class CpBnItem(C.Structure):          # one layer's pass in a grouped BatchNorm 
                 ("params", C.c_uint64 * 24)]
 
 
+CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16, CP_WGRAD_ITEM_GENERIC_F32 = 0, 1, 2, 3
+
+
+class CpWgradItem(C.Structure):       # one layer's partial-sum launch in a grouped weight-gradient launch (params is opaque)
+    _fields_ = [("kind", C.c_int32), ("blocks", C.c_uint32), ("gx", C.c_uint32), ("gy", C.c_uint32), ("params", C.c_uint64 * 20)]
+
+
+class CpOptItem(C.Structure):         # one parameter tensor of a cp_adam_multi / cp_sgd_multi launch
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_uint64), ("step0", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
 class CpWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
@@ -136,6 +148,11 @@ SIGNATURES = {
     "cp_conv2d_wgrad_scratch_bytes": (C.c_size_t, [C.POINTER(CpWgradDesc)]),
     "cp_conv2d_wgrad_deferred": (_I, [_P, C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t, C.POINTER(CpWgradReduceItem)]),
     "cp_conv2d_wgrad_plan": (_I, [C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t, C.POINTER(CpWgradReduceItem)]),
+    "cp_conv2d_wgrad_item": (_I, [C.POINTER(CpWgradDesc), _P, _P, _P, _P, C.c_size_t, _I, C.POINTER(CpWgradItem), C.POINTER(CpWgradReduceItem)]),
+    "cp_wgrad_group": (_I, [_P, _I, _P, _P, _I, C.c_uint32]),
+    "cp_opt_item_blocks": (C.c_uint32, [C.c_uint64]),
+    "cp_adam_multi": (_I, [_P, _P, _P, _I, C.c_uint32, _F, _F, _F, _F, _F, _I]),
+    "cp_sgd_multi": (_I, [_P, _P, _P, _I, C.c_uint32, _F, _F, _F, _I]),
     "cp_wgrad_reduce_item_blocks": (C.c_uint32, [C.POINTER(CpWgradReduceItem)]),
     "cp_wgrad_reduce_batch": (_I, [_P, _P, _P, _I, C.c_uint32]),
     "cp_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -1087,22 +1087,25 @@ __global__ __launch_bounds__(256) void bn_group_kernel(const CpBnItem* __restric
   int k = 0;
   while (k + 1 < n && blockIdx.x >= prefix[k + 1]) ++k;
   const unsigned bid = blockIdx.x - prefix[k];
-  const BnItemU& it = *(const BnItemU*)items[k].params;
+  const BnItemU* it = (const BnItemU*)items[k].params;
   if constexpr (KIND == CP_BN_ITEM_STATS || KIND == CP_BN_ITEM_BWD_SUMS) {
     __shared__ double red[256 * 2 * Tag::E];
-    colsum2_body<Tag, KIND == CP_BN_ITEM_STATS ? 0 : 1>(it.cs, red, bid);
+    const ColsumParams p = it->cs;                 // block-uniform copy (SGPRs)
+    colsum2_body<Tag, KIND == CP_BN_ITEM_STATS ? 0 : 1>(p, red, bid);
   } else if constexpr (KIND == CP_BN_ITEM_APPLY) {
     extern __shared__ float s_coef[];
-    bn_apply_coef<Tag>(it.ap, s_coef, bid == 0);
+    const BnApplyParams p = it->ap;
+    bn_apply_coef<Tag>(p, s_coef, bid == 0);
     __syncthreads();
     const size_t i = (size_t)bid * 256 + threadIdx.x;
-    if (i < it.ap.total) bn_apply_piece<Tag>(it.ap, s_coef, i);
+    if (i < p.total) bn_apply_piece<Tag>(p, s_coef, i);
   } else {
     extern __shared__ float s_coef[];
-    bn_bwd_coef<Tag>(it.bp, s_coef, bid == 0);
+    const BnBwdApplyParams p = it->bp;
+    bn_bwd_coef<Tag>(p, s_coef, bid == 0);
     __syncthreads();
     const size_t i = (size_t)bid * 256 + threadIdx.x;
-    if (i < it.bp.q.total) bn_bwd_piece<Tag>(it.bp.q, s_coef, i);
+    if (i < p.q.total) bn_bwd_piece<Tag>(p.q, s_coef, i);
   }
 }
 

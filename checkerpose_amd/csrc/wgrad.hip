@@ -43,7 +43,7 @@ template <> struct WgCfg<BF16Tag> { static constexpr int PITCH = 160, PPR = 8; }
 template <> struct WgCfg<F32Tag> { static constexpr int PITCH = 320, PPR = 16; };
 
 template <typename Tag>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const unsigned bx, const unsigned by, const unsigned gy) {
   constexpr int E = Tag::E;
   constexpr int PITCH = WgCfg<Tag>::PITCH, PPR = WgCfg<Tag>::PPR;
   constexpr int NLD = 64 * PPR / 256;           // 16-byte pieces per thread per operand per stage (2 bf16 / 4 f32)
@@ -55,12 +55,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xl = lane & 15, g = lane >> 4;
-  int t = blockIdx.y;
+  int t = (int)by;
   const int cob = t % p.co_blocks; t /= p.co_blocks;
   const int cib = t % p.ci_blocks; t /= p.ci_blocks;
   const int r = t / p.S, s = t - r * p.S;
   const int co0 = cob * 64, ci0 = cib * 64;
-  const int m_begin = blockIdx.x * p.slice;
+  const int m_begin = (int)bx * p.slice;
   const int m_end = min(m_begin + p.slice, p.M);
 
   // this thread's pieces: row = i*(256/PPR) + tid/PPR, piece = tid % PPR
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   // D[co][ci]: lane holds rows co = 4g+j (j = 0..3), column ci = xl of every tile
   if (p.ws) {        // plain stores of the block's partial tile; wgrad_reduce_kernel sums the slices (no atomics)
-    float* tile = p.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4096;
+    float* tile = p.ws + ((size_t)bx * gy + by) * 4096;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       }
     }
 }
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) { wgrad_body<Tag>(p, blockIdx.x, blockIdx.y, gridDim.y); }
 
 // dw[co][ci][r][s] += sum over the pixel slices of the partial tiles (deterministic order).  Thread = one dw element,
 // ci fastest (coalesced reads of the 64-float tile rows).
@@ -279,7 +282,7 @@ struct Wgrad3Params {
   float* ws;                       // [slice][blockIdx.y][tap][64][64]
 };
 
-__global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
+__device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p, const unsigned bx, const unsigned by, const unsigned gy) {
   constexpr int PITCH = 160, XROWS = 200, NX = 7;
   __shared__ __attribute__((aligned(16))) unsigned char lds[(64 + XROWS) * PITCH];
   unsigned char* ldy = lds;
@@ -287,12 +290,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xl = lane & 15, g = lane >> 4, q = xl >> 2, pp = xl & 3;
-  const int cob = blockIdx.y % p.co_blocks, cib = blockIdx.y / p.co_blocks;
+  const int cob = (int)by % p.co_blocks, cib = (int)by / p.co_blocks;
   const int co0 = cob * 64, ci0 = cib * 64;
   const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
   const bool active = (co0 + wco < p.Cout) && (ci0 + wci < p.Cin);          // wave-uniform
   const int TW2 = p.TW + 2, HR = (p.TH + 2) * TW2;
-  const int t_begin = blockIdx.x * p.tiles_per_block;
+  const int t_begin = (int)bx * p.tiles_per_block;
   const int t_end = min(t_begin + p.tiles_per_block, p.n_tiles);
 
   const int prow = tid >> 3, pc = tid & 7;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
   }
   if (p.ws) {        // partial tile of this block; quadrants outside the layer's channels are never read back
     if (!active) return;
-    float* tile = p.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 9 * 4096;
+    float* tile = p.ws + ((size_t)bx * gy + by) * 9 * 4096;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -417,11 +420,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) {
       }
 }
 
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) { wgrad3x3_body(p, blockIdx.x, blockIdx.y, gridDim.y); }
+
 // <= 32 x 32 channel layers (the 18-channel HRNet branch): in the kernel above only ONE wave has a non-empty quadrant.  Here
 // the four waves split the nine TAPS of the single 32 x 32 quadrant (wave w: taps w, w+4, w+8), rows are 32 channels wide
 // (pitch 96 B: 8 consecutive rows still fall on disjoint bank octets), 12 accumulator tiles per wave -> ~100 VGPRs and
 // 25 KB of LDS, so several blocks share a CU and hide each other's global -> LDS latency.
-__global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Params p) {
+__device__ __forceinline__ void wgrad3x3_small_body(const Wgrad3Params& p, const unsigned bx) {
   constexpr int PITCH = 96, XROWS = 200, NX = 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[(64 + XROWS) * PITCH];
   unsigned char* ldy = lds;
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Para
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xl = lane & 15, g = lane >> 4, q = xl >> 2, pp = xl & 3;
   const int TW2 = p.TW + 2, HR = (p.TH + 2) * TW2;
-  const int t_begin = blockIdx.x * p.tiles_per_block;
+  const int t_begin = (int)bx * p.tiles_per_block;
   const int t_end = min(t_begin + p.tiles_per_block, p.n_tiles);
   const int prow = tid >> 2, pc = tid & 3;              // 4 pieces (32 channels) per row
   const bool dy_cok = pc * 8 < p.Cout, x_cok = pc * 8 < p.Cin;
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Para
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int co = a * 16 + 4 * g + j;
-          if (p.ws) { if (co < p.Cout && ci < p.Cin) p.ws[((size_t)blockIdx.x * 9 + tap) * 4096 + co * 64 + ci] = acc[i][a][b][j]; }
+          if (p.ws) { if (co < p.Cout && ci < p.Cin) p.ws[((size_t)bx * 9 + tap) * 4096 + co * 64 + ci] = acc[i][a][b][j]; }
           else if (co < p.Cout && ci < p.Cin)
             unsafeAtomicAdd(p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / 3) * p.dw_sr +
                                 (long long)(tap % 3) * p.dw_ss, acc[i][a][b][j]);
@@ -533,6 +538,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Para
       }
   }
 }
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Params p) { wgrad3x3_small_body(p, blockIdx.x); }
 
 // mode 0: partial kernel + its reduction (cp_conv2d_wgrad_ws); 1: partial kernel only, *item = the reduction still owed
 // (cp_conv2d_wgrad_deferred); 2: no launch at all, *item as mode 1 would fill it (cp_conv2d_wgrad_plan)
@@ -552,7 +559,7 @@ static int launch_reduce(hipStream_t st, const float* ws, float* dw, int S, int 
 }
 
 static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
-                      size_t workspace_bytes, int mode, CpWgradReduceItem* item);
+                      size_t workspace_bytes, int mode, CpWgradReduceItem* item, int target_blocks = 0, CpWgradItem* citem = nullptr);
 
 extern "C" int cp_conv2d_wgrad(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw) {
   return cp_conv2d_wgrad_ws(stream, d, dy, x, dw, nullptr, 0);
@@ -606,9 +613,13 @@ extern "C" uint32_t cp_wgrad_reduce_item_blocks(const CpWgradReduceItem* item) {
   return (uint32_t)(((size_t)item->R * item->Ssz * item->Cout * item->Cin + 15) / 16);
 }
 
+// mode 3: nothing is launched; *citem describes the partial-sum launch (for cp_wgrad_group), *item the reduction it owes.
+// target_blocks > 0: the pixel slices are cut for about that many workgroups instead of a whole GPU's worth (a grouped launch fills
+// the GPU with SEVERAL layers: fewer, longer slices per layer -> less partial-sum traffic, the fixed cost of a block amortised)
 static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace,
-                      size_t workspace_bytes, int mode, CpWgradReduceItem* item) {
+                      size_t workspace_bytes, int mode, CpWgradReduceItem* item, int target_blocks, CpWgradItem* citem) {
   if (!d || !dy || !x || !dw) return CP_ERR_INVALID;
+  const bool launch = mode == 0 || mode == 1;
   if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype);
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->R <= 0 || d->S <= 0 || d->stride <= 0 ||
@@ -635,7 +646,7 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
       const int tb = q.co_blocks * q.ci_blocks;
       const size_t per_slice = (size_t)tb * 9 * 4096 * sizeof(float);
       const bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
-      int S = (use_ws ? 256 : 1024) / tb;              // one block per CU (400 VGPRs): one round of blocks
+      int S = (target_blocks > 0 ? target_blocks : (use_ws ? 256 : 1024)) / tb;              // one block per CU (400 VGPRs): one round of blocks
       if (S > q.n_tiles / 2) S = q.n_tiles / 2;
       if (use_ws && (size_t)S * per_slice > workspace_bytes) S = (int)(workspace_bytes / per_slice);
       if (S < 1) S = 1;
@@ -644,16 +655,23 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
       q.ws = use_ws ? (float*)workspace : nullptr;
       const bool small = d->Cout <= 32 && d->Cin <= 32 && !cp_knob("CP_WGRAD_NO_SMALL");
       if (small) {                                    // tap-split variant: more, lighter blocks (several per CU)
-        S = (use_ws ? 512 : 1024);
+        S = target_blocks > 0 ? target_blocks : (use_ws ? 512 : 1024);
         if (S > q.n_tiles / 2) S = q.n_tiles / 2;
         if (use_ws && (size_t)S * per_slice > workspace_bytes) S = (int)(workspace_bytes / per_slice);
         if (S < 1) S = 1;
         q.tiles_per_block = (q.n_tiles + S - 1) / S;
         S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
-        if (mode != 2) CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
-      } else if (mode != 2)
-      CP_LAUNCH(wgrad3x3_kernel, dim3((unsigned)S, (unsigned)tb), dim3(256), 0, (hipStream_t)stream, q);
-      int rc3 = mode != 2 ? cp_check_launch() : CP_OK;
+        if (launch) CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
+      } else if (launch)
+        CP_LAUNCH(wgrad3x3_kernel, dim3((unsigned)S, (unsigned)tb), dim3(256), 0, (hipStream_t)stream, q);
+      if (mode == 3) {
+        static_assert(sizeof(Wgrad3Params) <= CP_WGRAD_ITEM_BYTES, "CpWgradItem too small");
+        memset(citem, 0, sizeof(*citem));
+        citem->kind = small ? CP_WGRAD_ITEM_3X3_SMALL : CP_WGRAD_ITEM_3X3;
+        citem->gx = (uint32_t)S; citem->gy = small ? 1u : (uint32_t)tb; citem->blocks = citem->gx * citem->gy;
+        memcpy(citem->params, &q, sizeof(q));
+      }
+      int rc3 = launch ? cp_check_launch() : CP_OK;
       if (rc3 || !use_ws) return rc3;
       return launch_reduce((hipStream_t)stream, q.ws, dw, S, tb, q.co_blocks, q.ci_blocks, d, 9, mode, item);
     }
@@ -670,7 +688,7 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
   const long long tiles = (long long)p.co_blocks * p.ci_blocks * d->R * d->S;
   const size_t per_slice = (size_t)tiles * 4096 * sizeof(float);
   bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
-  long long want = ((use_ws ? 1024 : 2048) + tiles - 1) / tiles;  // slices wanted
+  long long want = ((target_blocks > 0 ? target_blocks : (use_ws ? 1024 : 2048)) + tiles - 1) / tiles;  // slices wanted
   if (use_ws && (size_t)want * per_slice > workspace_bytes) want = (long long)(workspace_bytes / per_slice);
   long long slice = (M + want - 1) / want;
   slice = (slice + 63) / 64 * 64;
@@ -684,10 +702,68 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
   if (tiles > 65535) return CP_ERR_RANGE;
   p.ws = use_ws ? (float*)workspace : nullptr;
   dim3 grid(nslice, (unsigned)tiles);
-  if (mode == 2) { /* plan only */ }
+  if (mode == 3) {
+    static_assert(sizeof(WgradParams) <= CP_WGRAD_ITEM_BYTES, "CpWgradItem too small");
+    memset(citem, 0, sizeof(*citem));
+    citem->kind = d->dtype == CP_F32 ? CP_WGRAD_ITEM_GENERIC_F32 : CP_WGRAD_ITEM_GENERIC_BF16;
+    citem->gx = nslice; citem->gy = (uint32_t)tiles; citem->blocks = citem->gx * citem->gy;
+    memcpy(citem->params, &p, sizeof(p));
+  } else if (!launch) { /* plan only */ }
   else if (d->dtype == CP_F32) CP_LAUNCH(wgrad_kernel<F32Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else CP_LAUNCH(wgrad_kernel<BF16Tag>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  int rcg = mode != 2 ? cp_check_launch() : CP_OK;
+  int rcg = launch ? cp_check_launch() : CP_OK;
   if (rcg || !use_ws) return rcg;
   return launch_reduce((hipStream_t)stream, p.ws, dw, (int)nslice, (int)tiles, p.co_blocks, p.ci_blocks, d, 1, mode, item);
+}
+
+// ---- grouped launches: the partial-sum kernels of SEVERAL layers in one launch (a device table of parameter blocks built by
+// cp_conv2d_wgrad_item; block b belongs to item k with prefix[k] <= b < prefix[k+1]; inside the item blockIdx.x runs fastest).
+// One launch per kernel kind.  The ~340 weight-gradient launches of the B = 32 training step were 9-23 us each for 1-8 tiles of work
+// per block (fixed cost: cold instruction cache, prologue / epilogue of a 400-VGPR block) and every layer cut its pixels into a
+// whole GPU's worth of slices (2.4 GB of partial tiles per step).
+template <int KIND>
+__global__ __launch_bounds__(256, KIND == CP_WGRAD_ITEM_3X3_SMALL ? 2 : 1) void wgrad_group_kernel(const CpWgradItem* __restrict__ items,
+                                                                                                const uint32_t* __restrict__ prefix, int n) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const unsigned b = blockIdx.x - prefix[lo], gx = items[lo].gx, gy = items[lo].gy;
+  const unsigned by = b / gx, bx = b - by * gx;
+  if constexpr (KIND == CP_WGRAD_ITEM_3X3) {
+    const Wgrad3Params p = *(const Wgrad3Params*)items[lo].params;
+    wgrad3x3_body(p, bx, by, gy);
+  } else if constexpr (KIND == CP_WGRAD_ITEM_3X3_SMALL) {
+    const Wgrad3Params p = *(const Wgrad3Params*)items[lo].params;
+    wgrad3x3_small_body(p, bx);
+  } else if constexpr (KIND == CP_WGRAD_ITEM_GENERIC_BF16) {
+    const WgradParams p = *(const WgradParams*)items[lo].params;
+    wgrad_body<BF16Tag>(p, bx, by, gy);
+  } else {
+    const WgradParams p = *(const WgradParams*)items[lo].params;
+    wgrad_body<F32Tag>(p, bx, by, gy);
+  }
+}
+
+extern "C" int cp_conv2d_wgrad_item(const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace, size_t workspace_bytes,
+                                    int target_blocks, CpWgradItem* compute, CpWgradReduceItem* reduce) {
+  if (!compute || !reduce || target_blocks < 0) return CP_ERR_INVALID;
+  memset(reduce, 0, sizeof(*reduce));
+  return wgrad_impl(nullptr, d, dy, x, dw, workspace, workspace_bytes, 3, reduce, target_blocks, compute);
+}
+
+extern "C" int cp_wgrad_group(cp_stream_t stream, int kind, const CpWgradItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                              uint32_t total_blocks) {
+  if (!items_dev || !prefix_dev || n_items <= 0 || total_blocks == 0) return CP_ERR_INVALID;
+  if (!cp_aligned16(items_dev)) return CP_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  switch (kind) {
+    case CP_WGRAD_ITEM_3X3: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_3X3>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
+    case CP_WGRAD_ITEM_3X3_SMALL: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_3X3_SMALL>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
+    case CP_WGRAD_ITEM_GENERIC_BF16: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_GENERIC_BF16>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
+    case CP_WGRAD_ITEM_GENERIC_F32: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_GENERIC_F32>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
+    default: return CP_ERR_INVALID;
+  }
+  return cp_check_launch();
 }

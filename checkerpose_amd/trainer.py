@@ -16,7 +16,8 @@ import os
 import torch
 
 from . import _abi
-from ._abi import (CpWgradReduceItem, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc, CpBnItem, BN_GROUP_MAX,
+from ._abi import (CpWgradReduceItem, CpWgradItem, CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16,
+                   CP_WGRAD_ITEM_GENERIC_F32, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc, CpBnItem, BN_GROUP_MAX,
                    CP_BN_ITEM_STATS, CP_BN_ITEM_APPLY, CP_BN_ITEM_BWD_SUMS, CP_BN_ITEM_BWD_APPLY)
 from .engine import Act, Program, WeightStore, _rup
 
@@ -97,6 +98,16 @@ class TrainProgram(Program):
         self.wg_ws = torch.empty(int(os.environ.get("CHECKERPOSE_AMD_WGRAD_ARENA_MB", "4096")) << 20, dtype=torch.uint8, device=device)
         self._wg_off, self._wg_items, self._wg_keys, self.wg_tabs = 0, [], set(), []
         self.wg_defer = os.environ.get("CHECKERPOSE_AMD_WGRAD_DEFER", "1") != "0"        # A/B: one reduction launch per layer
+        # grouped weight gradients: the partial-sum launches of up to wg_group_n layers wait for each other and go out as ONE launch
+        # per kernel kind (cp_wgrad_group), every layer cut into its share of wg_group_blocks workgroups instead of a GPU's worth
+        self.wg_group = self.wg_defer and os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP", "1") != "0"
+        self.wg_group_n = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_N", "24"))
+        self.wg_group_flops = float(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_GFLOP", "8")) * 1e9     # bigger layers launch alone
+        gb = [int(v) for v in os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_BLOCKS", "512,1024,1024").split(",")]
+        self.wg_group_blocks = {CP_WGRAD_ITEM_3X3: gb[0], CP_WGRAD_ITEM_3X3_SMALL: gb[1], CP_WGRAD_ITEM_GENERIC_BF16: gb[2],
+                                CP_WGRAD_ITEM_GENERIC_F32: gb[2]}
+        self.wg_reduce_n = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_REDUCE_N", "96"))
+        self._wgc_pending = []
         # BatchNorm statistics + apply in ONE launch each way (grid barrier in between): measured SLOWER on MI355X -- 42.3 ms per step
         # at best (256 blocks, slow polling) against 35.7 ms for the two-launch forms: the barrier costs >= 10 us per launch -> off
         self.bn_fused = os.environ.get("CHECKERPOSE_AMD_BN_FUSED", "0") == "1"
@@ -420,13 +431,21 @@ class TrainProgram(Program):
         dref = C.byref(d)
         dt, xt = dy.tbuf, x.tbuf
         name = "wgrad:%d->%d k%d s%d %dx%d" % (Cin, Cout, R, stride, x.H, x.W)
+        flops = 2 * dy.B * d.Ho * d.Wo * R * S * Cin * Cout                # algorithmic, unpadded
+        if self.wg_group and flops < self.wg_group_flops:
+            self._wgc_pending.append(dict(d=d, dref=dref, dt=dt, xt=xt, dw=dw_ptr, flops=flops, k3s1=(R == 3 and stride == 1),
+                                          pix=dy.B * d.Ho * d.Wo, cc=((Cout + 63) // 64) * ((Cin + 63) // 64), taps=R * S))
+            if len(self._wgc_pending) >= self.wg_group_n:
+                self.flush_wgrad_compute()
+            return
         if not self.wg_defer:
             wsp, wsn = self.wg_ws.data_ptr(), min(self.wg_ws.numel(), 160 << 20)
             self._add(self.lib.cp_conv2d_wgrad_ws, lambda P: (dref, P(dt), P(xt), dw_ptr, wsp, wsn), name, [dt, xt], [])
         else:
             need = (int(self.lib.cp_conv2d_wgrad_scratch_bytes(dref)) + 255) // 256 * 256
             if self._wg_off + need > self.wg_ws.numel():
-                self.flush_wgrad()
+                self.flush_wgrad_compute()
+                self._flush_wgrad_reduce()
             need = min(need, self.wg_ws.numel())
             wsp = self.wg_ws.data_ptr() + self._wg_off
             item, spare = CpWgradReduceItem(), CpWgradReduceItem()
@@ -438,11 +457,75 @@ class TrainProgram(Program):
             if item.ws:                       # this layer owes a reduction (tiny layers add with atomics instead)
                 self._wg_items.append(item)
                 self._wg_off += need
-        self.wgrad_flops[len(self.ops) - 1] = 2 * dy.B * d.Ho * d.Wo * R * S * Cin * Cout      # algorithmic, unpadded
+        self.wgrad_flops[len(self.ops) - 1] = flops
 
-    def flush_wgrad(self):
-        """one launch for every weight-gradient reduction owed so far; the parameters touched since the last flush are final
-        only behind it (gradient buckets of the data-parallel step, plan_gradient_buckets)"""
+    def flush_wgrad_compute(self):
+        """the partial-sum launches of the waiting layers: ONE launch per kernel kind.  A layer's share of the launch's workgroups is
+        proportional to its work (pixels x channel blocks), so all blocks of a launch run about equally long."""
+        pend, self._wgc_pending = self._wgc_pending, []
+        if not pend:
+            return
+        lib, arena, asz = self.lib, self.wg_ws.data_ptr(), self.wg_ws.numel()
+        for m in pend:                        # kernel kind of every layer (depends on the descriptor only)
+            ci, ri = CpWgradItem(), CpWgradReduceItem()
+            _abi.check(lib.cp_conv2d_wgrad_item(m["dref"], arena, arena, m["dw"], arena, asz, 0, C.byref(ci), C.byref(ri)), "cp_conv2d_wgrad_item")
+            m["kind"] = int(ci.kind)
+            m["work"] = m["pix"] * m["cc"] * (1 if ci.kind in (CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL) else m["taps"])
+        kinds = sorted({m["kind"] for m in pend})
+        for kind in kinds:                    # every layer's share of its launch, and the partial tiles that share needs
+            mem = [m for m in pend if m["kind"] == kind]
+            total = float(sum(m["work"] for m in mem))
+            for m in mem:
+                m["target"] = max(1, int(round(self.wg_group_blocks[kind] * m["work"] / total)))
+                ci, ri = CpWgradItem(), CpWgradReduceItem()
+                _abi.check(lib.cp_conv2d_wgrad_item(m["dref"], arena, arena, m["dw"], arena, asz, m["target"], C.byref(ci), C.byref(ri)), "cp_conv2d_wgrad_item")
+                m["need"] = (int(ri.S) * int(ri.GY) * int(ri.taps_in_block) * 4096 * 4 + 255) // 256 * 256 if ri.ws else 0
+                m["blocks"] = int(ci.blocks)
+        need_all = sum(m["need"] for m in pend)
+        assert need_all <= asz, "weight-gradient arena smaller than one group's partial tiles"
+        if self._wg_off + need_all > asz:     # the reductions owed so far (their producers are all emitted) free the arena
+            self._flush_wgrad_reduce()
+        for kind in kinds:
+            mem = [m for m in pend if m["kind"] == kind]
+            builders = []
+            for m in mem:
+                if m["need"]:
+                    m["wsp"], m["wsn"] = arena + self._wg_off, m["need"]
+                    ci, ri = CpWgradItem(), CpWgradReduceItem()
+                    _abi.check(lib.cp_conv2d_wgrad_item(m["dref"], arena, arena, m["dw"], m["wsp"], m["wsn"], m["target"], C.byref(ci), C.byref(ri)),
+                               "cp_conv2d_wgrad_item")
+                    assert ri.ws == m["wsp"] and int(ci.blocks) == m["blocks"]
+                    self._wg_items.append(ri)
+                    self._wg_off += m["need"]
+                else:
+                    m["wsp"], m["wsn"] = arena, asz
+
+                def build(P, m=m):
+                    it, spare = CpWgradItem(), CpWgradReduceItem()
+                    _abi.check(lib.cp_conv2d_wgrad_item(m["dref"], P(m["dt"]), P(m["xt"]), m["dw"], m["wsp"], m["wsn"], m["target"], C.byref(it),
+                                                        C.byref(spare)), "cp_conv2d_wgrad_item")
+                    assert int(it.blocks) == m["blocks"] and int(it.kind) == m["kind"]
+                    return it
+                builders.append(build)
+
+            def argb(P, builders=builders, kind=kind):
+                items = [b(P) for b in builders]
+                arr = (CpWgradItem * len(items))(*items)
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                pre = [0]
+                for it in items:
+                    pre.append(pre[-1] + int(it.blocks))
+                prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+                self.keep += [raw, prefix]
+                return (kind, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1])
+            k3 = all(m["k3s1"] for m in mem)
+            self._add(lib.cp_wgrad_group, argb, "wgrad_group:%s x%d" % (" k3 s1 " if k3 else "mixed", len(mem)),
+                      [t for m in mem for t in (m["dt"], m["xt"])], [])
+            self.wgrad_flops[len(self.ops) - 1] = sum(m["flops"] for m in mem)
+        if len(self._wg_items) >= self.wg_reduce_n:        # settle in a few instalments: the data-parallel step's gradient buckets
+            self.flush_wgrad()                              # complete (and start their all-reduce) while the backward goes on
+
+    def _flush_wgrad_reduce(self):
         if self._wg_items:
             items = self._wg_items
             arr = (CpWgradReduceItem * len(items))(*items)
@@ -455,9 +538,16 @@ class TrainProgram(Program):
             self.wg_tabs.append((raw, prefix))
             n = len(items)
             self._add(self.lib.cp_wgrad_reduce_batch, lambda P: (raw.data_ptr(), prefix.data_ptr(), n, acc), "wgrad_reduce_batch:%d" % n, [], [])
+        self._wg_off, self._wg_items = 0, []
+
+    def flush_wgrad(self):
+        """every weight-gradient launch still waiting, then one launch for every reduction owed so far; the parameters touched since
+        the last flush are final only behind it (gradient buckets of the data-parallel step, plan_gradient_buckets)"""
+        self.flush_wgrad_compute()
+        self._flush_wgrad_reduce()
         for k in self._wg_keys:
             self.pslot_done[k] = len(self.ops)
-        self._wg_off, self._wg_items, self._wg_keys = 0, [], set()
+        self._wg_keys = set()
 
     def weight_dgrad(self, w, Cout, Cin, R, S):
         wt = self.scratch_f32(Cout * Cin * R * S).view(Cin, Cout, R, S)

@@ -457,6 +457,41 @@ uint32_t cp_wgrad_reduce_item_blocks(const CpWgradReduceItem* item);
 int cp_wgrad_reduce_batch(cp_stream_t stream, const CpWgradReduceItem* items_dev, const uint32_t* block_prefix_dev, int n_items,
                           uint32_t total_blocks);
 
+/* Grouped weight gradients: the partial-sum launches of SEVERAL layers in one launch per kernel kind.  cp_conv2d_wgrad_item =
+ * cp_conv2d_wgrad_plan that also describes the layer's partial-sum launch in `compute` (nothing is launched) and cuts the layer's
+ * pixels for about `target_blocks` workgroups (0: a whole GPU's worth, as the single-layer launches do) -- a caller that groups
+ * n layers hands each its share of ~512 workgroups, which shrinks the partial tiles by the same factor.  reduce->ws == NULL: the
+ * layer adds with atomics, it owes no reduction.  cp_wgrad_group: `items_dev` = items of ONE kind in device memory, `prefix_dev`
+ * the exclusive prefix sum (n_items + 1 entries) of item.blocks.  Results equal the single-layer launches' up to fp32 summation
+ * order across slices. */
+#define CP_WGRAD_ITEM_BYTES 160
+enum { CP_WGRAD_ITEM_3X3 = 0, CP_WGRAD_ITEM_3X3_SMALL = 1, CP_WGRAD_ITEM_GENERIC_BF16 = 2, CP_WGRAD_ITEM_GENERIC_F32 = 3 };
+typedef struct CpWgradItem {
+  int32_t kind;
+  uint32_t blocks, gx, gy;
+  unsigned long long params[CP_WGRAD_ITEM_BYTES / 8];      /* opaque: the kernel's parameter block */
+} CpWgradItem;
+int cp_conv2d_wgrad_item(const CpWgradDesc* d, const void* dy, const void* x, float* dw, void* workspace, size_t workspace_bytes,
+                         int target_blocks, CpWgradItem* compute, CpWgradReduceItem* reduce);
+int cp_wgrad_group(cp_stream_t stream, int kind, const CpWgradItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                   uint32_t total_blocks);
+
+/* Optimizer step over ALL parameter tensors in one launch (the reference's train.py:244-246,320: optim.Adam(net.parameters(), lr) or
+ * optim.SGD(..., momentum=0.9); optimizer.step() per batch).  items (device memory): parameter, its gradient and the optimizer state of
+ * one tensor, fp32, n elements; prefix = exclusive prefix sum (n_items + 1) of cp_opt_item_blocks(n).  cp_adam_multi = torch.optim.Adam
+ * (amsgrad off; weight_decay is L2, added to the gradient; `step` counts from 1 and must exceed every item's step0);
+ * cp_sgd_multi = torch.optim.SGD (dampening 0, no nesterov; m = momentum buffer, first_step: buf := grad; momentum 0: m may be NULL). */
+typedef struct CpOptItem {
+  float* p; const float* g; float* m; float* v;
+  uint64_t n;
+  uint32_t step0, pad;       /* Adam: the tensor's own step count is `step` - step0 (torch counts per parameter) */
+} CpOptItem;
+uint32_t cp_opt_item_blocks(uint64_t numel);
+int cp_adam_multi(cp_stream_t stream, const CpOptItem* items_dev, const uint32_t* prefix_dev, int n_items, uint32_t total_blocks, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step);
+int cp_sgd_multi(cp_stream_t stream, const CpOptItem* items_dev, const uint32_t* prefix_dev, int n_items, uint32_t total_blocks, float lr,
+                 float momentum, float weight_decay, int first_step);
+
 /* Weights of the data-gradient of a stride-1 conv: w (Cout,Cin,R,S) fp32 -> wt (Cin,Cout,R,S) fp32 with both taps
  * flipped (wt[ci][co][r][s] = w[co][ci][R-1-r][S-1-s]); dx = conv(dy, wt, stride 1, pad R-1-pad).  (Stride-2 3x3
  * convs use the transposed=1 phase packing of cp_pack_conv_weight on w itself; ConvTranspose2d's data-gradient is a

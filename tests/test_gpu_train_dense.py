@@ -584,6 +584,67 @@ def test_bn_fused_launches_equal_the_two_launch_forms(lib, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_wgrad_group_equals_the_single_layer_launches(lib, dtype):
+    """cp_wgrad_group (the partial-sum launches of several layers in one launch per kernel kind, every layer cut for its share of the
+    workgroups) + ONE cp_wgrad_reduce_batch against cp_conv2d_wgrad_ws layer by layer: all-taps 3x3 layers (36 / 72 / 144 channels),
+    the <= 32-channel variant, generic layers (1x1, 3x3 stride 2, a tiny one that adds with atomics), channel offsets."""
+    from checkerpose_amd._abi import CpWgradItem, CpWgradReduceItem
+    E = 8 if dtype == CP_BF16 else 4
+    layers = [  # (B, Cin, H, W, Cout, k, stride, pad, share of the workgroups)
+        (4, 36, 32, 32, 36, 3, 1, 1, 40), (4, 72, 16, 16, 72, 3, 1, 1, 24), (2, 144, 8, 8, 144, 3, 1, 1, 9), (4, 18, 64, 64, 18, 3, 1, 1, 64),
+        (4, 18, 32, 32, 18, 3, 1, 1, 16), (4, 36, 32, 32, 18, 1, 1, 0, 12), (4, 18, 64, 64, 36, 3, 2, 1, 30), (2, 144, 8, 8, 72, 1, 1, 0, 6),
+        (2, 8, 8, 8, 8, 1, 1, 0, 2)]
+    arena = torch.empty(256 << 20, dtype=torch.uint8, device=dev())
+    off, keep, comp, red, want, dws = 0, [], {}, [], [], []
+    for n, (B, Cin, H, W, Cout, k, stride, pad, share) in enumerate(layers):
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        x_cl = to_cl(rnd(det_tensor("wgg_x%d" % n, (B, Cin, H, W)), dtype), dtype)
+        dy_cl = to_cl(rnd(det_tensor("wgg_d%d" % n, (B, Cout, Ho, Wo)), dtype), dtype)
+        want.append(_wgrad(lib, dtype, dy_cl, x_cl, Cout, Cin, k, k, stride, pad, 0, 0, True))
+        dw = torch.zeros(Cout, Cin, k, k, dtype=torch.float32, device=dev())
+        d = CpWgradDesc()
+        d.dtype, d.B, d.H, d.W, d.Ho, d.Wo = dtype, B, H, W, Ho, Wo
+        d.Cout, d.dy_cstride, d.dy_coff, d.Cin, d.x_cstride, d.x_coff = Cout, dy_cl.shape[-1], 0, Cin, x_cl.shape[-1], 0
+        d.R, d.S, d.stride, d.pad = k, k, stride, pad
+        d.dw_base, d.dw_sco, d.dw_sci, d.dw_sr, d.dw_ss = 0, Cin * k * k, k * k, k, 1
+        ci, ri = CpWgradItem(), CpWgradReduceItem()
+        _abi.check(lib.cp_conv2d_wgrad_item(C.byref(d), dy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr(), arena.data_ptr() + off, arena.numel() - off,
+                                            share, C.byref(ci), C.byref(ri)), "wgrad item")
+        assert ci.blocks == ci.gx * ci.gy and ci.blocks > 0
+        if dtype == CP_BF16 and k == 3 and stride == 1:
+            assert ci.kind == (1 if max(Cin, Cout) <= 32 else 0) and ci.blocks <= max(share, ci.gy)      # the share is respected
+        if ri.ws:
+            off += (ri.S * ri.GY * ri.taps_in_block * 4096 * 4 + 255) // 256 * 256
+            red.append(ri)
+        comp.setdefault(int(ci.kind), []).append(ci)
+        keep += [x_cl, dy_cl, d]
+        dws.append(dw)
+    assert off <= arena.numel()
+    for kind, items in sorted(comp.items()):
+        arr = (CpWgradItem * len(items))(*items)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+        pre = [0]
+        for it in items:
+            pre.append(pre[-1] + it.blocks)
+        prefix = torch.tensor(pre, dtype=torch.int32, device=dev())
+        _abi.check(lib.cp_wgrad_group(st(), kind, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1]), "cp_wgrad_group")
+        keep += [raw, prefix]
+    arr = (CpWgradReduceItem * len(red))(*red)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    pre = [0]
+    for it in red:
+        pre.append(pre[-1] + lib.cp_wgrad_reduce_item_blocks(C.byref(it)))
+    prefix = torch.tensor(pre, dtype=torch.int32, device=dev())
+    _abi.check(lib.cp_wgrad_reduce_batch(st(), raw.data_ptr(), prefix.data_ptr(), len(red), pre[-1]), "reduce batch")
+    torch.cuda.synchronize()
+    assert len(red) < len(layers)                    # the tiny layer added with atomics
+    for n, (dw, w) in enumerate(zip(dws, want)):
+        sc = float(w.abs().max()) + 1e-30
+        assert float((dw.cpu() - w).abs().max()) / sc < 1e-5, layers[n]
+    assert lib.cp_wgrad_group(st(), 9, raw.data_ptr(), prefix.data_ptr(), 1, 1) != 0
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 def test_bn_group_launches_equal_the_single_layer_launches(lib, dtype):
     """cp_bn_group (the four BatchNorm passes of several independent layers, one launch per pass over a device table of cp_bn_item_*
     parameter blocks) against the single-layer launches on the same inputs -- the shapes of an HRNet stage-4 module at the training

@@ -169,3 +169,65 @@ def test_train_ops_reject_bad_arguments(lib):
     assert lib.cp_mask_loss(None, 1, 10, 1, 1, 64, 64, 64, 64, 1, None, 10, 1) < 0              # batch stride < h*w
     assert lib.cp_edgeconv_gather_max_bwd(None, 0, None, None, None, None, None, None, None, None, 1, 1, 1, 4, 1, 4, 0, 0.2) < 0
     assert lib.cp_index2feat_gather_bwd(None, None, None, None, None, None, 1, 1, 1, 1, 4, 2, 16, 0) < 0
+
+
+def _opt_problem(seed=0):
+    """parameter tensors of assorted sizes (incl. > one block, odd sizes) whose gradients are slices of ONE flat buffer at odd
+    offsets -- exactly how the training program hands them out (4-byte aligned only)"""
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 3, 3, 3), (18,), (5000,), (36, 18, 3, 3), (1,), (2049,), (144, 144, 3, 3)]
+    params = [torch.randn(s, generator=g) for s in shapes]
+    n = sum(p.numel() for p in params)
+    grads = [torch.randn(5, n + 3, generator=g) * 0.1 for _ in range(1)][0]
+    return shapes, params, grads
+
+
+@pytest.mark.parametrize("kind", ["adam", "adam_wd", "sgd_mom", "sgd_plain_wd"])
+def test_multi_tensor_optimizers_match_torch(kind):
+    """checkerpose_amd.optim.Adam / SGD (ONE launch over all tensors) against torch.optim on the same parameters and gradients for 5
+    steps; the last tensor receives its first gradient at step 3 (torch counts steps per parameter); state_dict round trip after 3
+    steps into a fresh optimizer continues identically and loads into torch's own optimizer."""
+    from checkerpose_amd import optim as O
+    shapes, p0, grads = _opt_problem()
+    mk = {"adam": (lambda ps: O.Adam(ps, lr=2e-3), lambda ps: torch.optim.Adam(ps, lr=2e-3)),
+          "adam_wd": (lambda ps: O.Adam(ps, lr=1e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.05),
+                      lambda ps: torch.optim.Adam(ps, lr=1e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.05)),
+          "sgd_mom": (lambda ps: O.SGD(ps, lr=0.05, momentum=0.9), lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9)),
+          "sgd_plain_wd": (lambda ps: O.SGD(ps, lr=0.05, weight_decay=0.01), lambda ps: torch.optim.SGD(ps, lr=0.05, weight_decay=0.01))}[kind]
+
+    def run(make, steps, resume_from=None, resume_make=None):
+        ps = [torch.nn.Parameter(p.clone().to(DEV)) for p in p0]
+        opt = make(ps)
+        flat = torch.zeros(grads.shape[1], device=DEV)
+        sd = None
+        for t in range(steps):
+            flat.copy_(grads[t].to(DEV))
+            off = 1                                                          # odd offset: views are 4-byte aligned only
+            for i, p in enumerate(ps):
+                p.grad = flat[off:off + p.numel()].view_as(p) if (i + 1 < len(ps) or t >= 2) else None
+                off += p.numel()
+            opt.step()
+            if resume_from is not None and t + 1 == resume_from:
+                sd = opt.state_dict()
+                opt = (resume_make or make)(ps)
+                opt.load_state_dict(sd)
+        torch.cuda.synchronize()
+        return [p.detach().cpu() for p in ps], opt
+
+    want, _ = run(mk[1], 5)
+    got, opt = run(mk[0], 5)
+    for a, b, s in zip(got, want, shapes):
+        assert float((a - b).abs().max()) <= 2e-6 * (float(b.abs().max()) + 1e-6), s
+    got2, _ = run(mk[0], 5, resume_from=3)
+    for a, b in zip(got2, got):
+        assert torch.equal(a, b)
+    got3, _ = run(mk[0], 5, resume_from=3, resume_make=mk[1])               # our state loads into torch's optimizer
+    for a, b, s in zip(got3, want, shapes):
+        assert float((a - b).abs().max()) <= 2e-6 * (float(b.abs().max()) + 1e-6), s
+    sd = opt.state_dict()
+    steps = sorted({int(v["step"]) for v in sd["state"].values()})
+    assert steps == [3, 5] and "_cp_table" not in sd["param_groups"][0]
+    with pytest.raises(RuntimeError):
+        bad = torch.nn.Parameter(torch.zeros(4, device=DEV, dtype=torch.float64))
+        bad.grad = torch.zeros_like(bad)
+        O.Adam([bad]).step()
