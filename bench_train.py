@@ -64,8 +64,9 @@ def cpu_baseline(npoint, seconds=20.0, B=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps: the first ~10 replays of freshly captured hipGraphs run slower (one-time, ~100 ms in total)")
     ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step (reference config: batch_size 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--npoint", type=int, default=512)

@@ -63,6 +63,11 @@ class CpOptItem(C.Structure):         # one parameter tensor of a cp_adam_multi 
                 ("pad", C.c_uint32)]
 
 
+class CpFuseBwdItem(C.Structure):
+    _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("dsrc", C.c_void_p), ("Hs", C.c_int32), ("Ws", C.c_int32), ("CG", C.c_int32),
+                ("shift", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32), ("total", C.c_uint64)]
+
+
 class CpWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
@@ -193,6 +198,8 @@ SIGNATURES = {
     "cp_edge_weight_view": (_I, [_P, _P, _I, _I, _I, _P]),
     "cp_upsample2x_bilinear_ac_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_fuse_sum_act_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_fuse_sum_act_bwd_item": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(CpFuseBwdItem), C.POINTER(C.c_uint32)]),
+    "cp_fuse_sum_act_bwd_group": (_I, [_P, _I, _P, _P, _I, C.c_uint32]),
     "cp_maxpool3x3s2_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     "cp_memset_zero": (_I, [_P, _P, C.c_size_t]),
     "cp_strided_to_nhwc": (_I, [_P, _I, _P, _I, _L, _L, _L, _L, _P, _I, _I, _I, _I]),

@@ -247,6 +247,28 @@ __device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red,
   for (int j = 0; j < E; ++j) { red[tid * 2 * E + j] = s1[j]; red[tid * 2 * E + E + j] = s2[j]; }
   __syncthreads();
   const int CP = p.G * E;
+  if (2 * CP <= 128) {
+    // narrow layers (<= 64 channels: RL = 256 / G is 32 .. 128 rows): a serial loop over RL rows by 2*CP threads was the longest
+    // phase of these latency-bound launches -- T = 256 / (2*CP) threads share each column's rows, a second step adds their T sums
+    __shared__ double red2[256];
+    const int T = 256 / (2 * CP);
+    const int o = tid % (2 * CP), part = tid / (2 * CP);
+    const int which = o / CP, c = o - which * CP;
+    const int pc = c / E, j = c - pc * E;
+    if (part < T) {
+      double s = 0.0;
+      for (int r = part; r < p.RL; r += T) s += red[(r * p.G + pc) * 2 * E + which * E + j];
+      red2[part * 2 * CP + o] = s;
+    }
+    __syncthreads();
+    if (tid < 2 * CP) {
+      double s = 0.0;
+      for (int k = 0; k < T; ++k) s += red2[k * 2 * CP + tid];
+      if (p.acc) unsafeAtomicAdd(p.acc + ((bid & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
+      else p.partial[((size_t)bid * 2 + which) * CP + c] = s;
+    }
+    return;
+  }
   for (int o = tid; o < 2 * CP; o += 256) {
     const int which = o / CP, c = o - which * CP;
     const int pc = c / E, j = c - pc * E;
@@ -571,28 +593,32 @@ extern "C" int cp_upsample2x_bilinear_ac_bwd(cp_stream_t stream, int dtype, cons
 }
 
 // Backward of cp_fuse_sum_act for ONE source: dsrc[b,y,x,:] (+)= sum over the 2^sh x 2^sh block of dout * [out > 0]
+struct FuseBwdParams {       // == CpFuseBwdItem
+  const void* dout; const void* out; void* dsrc;
+  int Hs, Ws, CG, sh, relu, accumulate;
+  unsigned long long total;
+};
+static_assert(sizeof(FuseBwdParams) == sizeof(CpFuseBwdItem), "CpFuseBwdItem layout");
+
 template <typename Tag>
-__global__ void fuse_sum_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ out, void* __restrict__ dsrc, int Hs,
-                                    int Ws, int CG, int sh, int relu, int accumulate, size_t total) {
+__device__ __forceinline__ void fuse_sum_bwd_elem(const FuseBwdParams& p, size_t i) {      // i over B*Hs*Ws*CG
   constexpr int E = Tag::E;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*Hs*Ws*CG
-  if (i >= total) return;
-  const int g = (int)(i % CG);
-  size_t t = i / CG;
-  const int x = (int)(t % Ws); t /= Ws;
-  const int y = (int)(t % Hs);
-  const size_t b = t / Hs;
-  const int n = 1 << sh, H = Hs << sh, W = Ws << sh;
+  const int g = (int)(i % p.CG);
+  size_t t = i / p.CG;
+  const int x = (int)(t % p.Ws); t /= p.Ws;
+  const int y = (int)(t % p.Hs);
+  const size_t b = t / p.Hs;
+  const int sh = p.sh, n = 1 << sh, H = p.Hs << sh, W = p.Ws << sh;
   float acc[E];
 #pragma unroll
   for (int j = 0; j < E; ++j) acc[j] = 0.f;
   for (int dy = 0; dy < n; ++dy)
     for (int dx = 0; dx < n; ++dx) {
-      const size_t v = ((b * H + (y << sh) + dy) * W + (x << sh) + dx) * CG + g;
+      const size_t v = ((b * H + (y << sh) + dy) * W + (x << sh) + dx) * p.CG + g;
       float d[E], o[E];
-      Vec16<Tag>::unpack(((const u32x4*)dout)[v], d);
-      if (relu) {
-        Vec16<Tag>::unpack(((const u32x4*)out)[v], o);
+      Vec16<Tag>::unpack(((const u32x4*)p.dout)[v], d);
+      if (p.relu) {
+        Vec16<Tag>::unpack(((const u32x4*)p.out)[v], o);
 #pragma unroll
         for (int j = 0; j < E; ++j) acc[j] += o[j] > 0.f ? d[j] : 0.f;
       } else {
@@ -600,28 +626,72 @@ __global__ void fuse_sum_bwd_kernel(const void* __restrict__ dout, const void* _
         for (int j = 0; j < E; ++j) acc[j] += d[j];
       }
     }
-  if (accumulate) {
+  if (p.accumulate) {
     float o[E];
-    Vec16<Tag>::unpack(((const u32x4*)dsrc)[i], o);
+    Vec16<Tag>::unpack(((const u32x4*)p.dsrc)[i], o);
 #pragma unroll
     for (int j = 0; j < E; ++j) acc[j] += o[j];
   }
-  ((u32x4*)dsrc)[i] = Vec16<Tag>::pack(acc);
+  ((u32x4*)p.dsrc)[i] = Vec16<Tag>::pack(acc);
 }
 
-extern "C" int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs,
-                                   int Ws, int C, int shift, int relu, int accumulate) {
+template <typename Tag>
+__global__ void fuse_sum_bwd_kernel(const FuseBwdParams p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.total) fuse_sum_bwd_elem<Tag>(p, i);
+}
+
+// every (output, term) pair of an HRNet module's fuse layer in one launch: the pairs write distinct gradient tensors
+template <typename Tag>
+__global__ __launch_bounds__(256) void fuse_sum_bwd_group_kernel(const FuseBwdParams* __restrict__ items, const uint32_t* __restrict__ prefix, int n) {
+  int k = 0;
+  while (k + 1 < n && blockIdx.x >= prefix[k + 1]) ++k;
+  const FuseBwdParams p = items[k];
+  const size_t i = (size_t)(blockIdx.x - prefix[k]) * 256 + threadIdx.x;
+  if (i < p.total) fuse_sum_bwd_elem<Tag>(p, i);
+}
+
+static int build_fuse_bwd(int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws, int C, int shift, int relu,
+                          int accumulate, FuseBwdParams* p) {
   if (!dout || !dsrc || (relu && !out) || B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || shift < 0 || shift > 5) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype);
   if (C % E || !cp_aligned16(dout) || !cp_aligned16(dsrc) || (out && !cp_aligned16(out))) return CP_ERR_ALIGN;
-  const int CG = C / E;
-  const size_t total = (size_t)B * Hs * Ws * CG;
-  const unsigned blocks = (unsigned)((total + 255) / 256);
+  p->dout = dout; p->out = out; p->dsrc = dsrc; p->Hs = Hs; p->Ws = Ws; p->CG = C / E; p->sh = shift; p->relu = relu; p->accumulate = accumulate;
+  p->total = (unsigned long long)B * Hs * Ws * p->CG;
+  return CP_OK;
+}
+
+extern "C" int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs,
+                                   int Ws, int C, int shift, int relu, int accumulate) {
+  FuseBwdParams p;
+  const int rc = build_fuse_bwd(dtype, dout, out, dsrc, B, Hs, Ws, C, shift, relu, accumulate, &p);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((p.total + 255) / 256);
+  if (dtype == CP_F32) CP_LAUNCH(fuse_sum_bwd_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else CP_LAUNCH(fuse_sum_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return cp_check_launch();
+}
+
+extern "C" int cp_fuse_sum_act_bwd_item(int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws, int C, int shift,
+                                        int relu, int accumulate, CpFuseBwdItem* item, uint32_t* blocks) {
+  if (!item || !blocks) return CP_ERR_INVALID;
+  FuseBwdParams p;
+  const int rc = build_fuse_bwd(dtype, dout, out, dsrc, B, Hs, Ws, C, shift, relu, accumulate, &p);
+  if (rc) return rc;
+  memcpy(item, &p, sizeof(p));
+  *blocks = (uint32_t)((p.total + 255) / 256);
+  return CP_OK;
+}
+
+extern "C" int cp_fuse_sum_act_bwd_group(cp_stream_t stream, int dtype, const CpFuseBwdItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                                         uint32_t total_blocks) {
+  if (!items_dev || !prefix_dev || n_items <= 0 || n_items > 64 || total_blocks == 0) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
   if (dtype == CP_F32)
-    CP_LAUNCH(fuse_sum_bwd_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, out, dsrc, Hs, Ws, CG, shift, relu, accumulate, total);
+    CP_LAUNCH(fuse_sum_bwd_group_kernel<F32Tag>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const FuseBwdParams*)items_dev, prefix_dev, n_items);
   else
-    CP_LAUNCH(fuse_sum_bwd_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, out, dsrc, Hs, Ws, CG, shift, relu, accumulate, total);
+    CP_LAUNCH(fuse_sum_bwd_group_kernel<BF16Tag>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const FuseBwdParams*)items_dev, prefix_dev, n_items);
   return cp_check_launch();
 }
 

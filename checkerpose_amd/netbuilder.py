@@ -144,13 +144,21 @@ class NetEmitter:
             level += 1
         for i, j in pairs:
             terms[i][j] = cur[(i, j)]
-        outs = []
+        outs, recs = [], []
         for i in range(nb):
             out = self.p.act(xs[i].H, xs[i].W, xs[i].C)
             shifts = [max(j - i, 0) for j in range(nb)]
             outs.append(self.p.fuse_sum(terms[i], shifts, out, relu=True))
             self.tp.kinks["%s.fuse%d" % (pfx, i)] = out
-            self._fuse_sum_tape(out, list(terms[i]), shifts)
+            recs.append((out, list(terms[i]), shifts))
+        tp = self.tp
+
+        def bwd():                        # the whole fuse layer's backward in one launch: every (output, term) pair has its own gradient tensor
+            mem = [(tp.grad_of(out), out, tp.grad_of(s_), sh, True) for out, srcs, shifts in recs if out.tbuf in tp.grads
+                   for s_, sh in zip(srcs, shifts)]
+            if mem:
+                tp.fuse_sum_bwd_group(mem)
+        tp.tape.append(bwd)
         return outs
 
     def _bias_vec(self, key, n):

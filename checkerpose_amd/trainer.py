@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import _abi
-from ._abi import (CpWgradReduceItem, CpWgradItem, CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16,
+from ._abi import (CpWgradReduceItem, CpWgradItem, CpFuseBwdItem, CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16,
                    CP_WGRAD_ITEM_GENERIC_F32, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc, CpBnItem, BN_GROUP_MAX,
                    CP_BN_ITEM_STATS, CP_BN_ITEM_APPLY, CP_BN_ITEM_BWD_SUMS, CP_BN_ITEM_BWD_APPLY)
 from .engine import Act, Program, WeightStore, _rup
@@ -101,8 +101,8 @@ class TrainProgram(Program):
         # grouped weight gradients: the partial-sum launches of up to wg_group_n layers wait for each other and go out as ONE launch
         # per kernel kind (cp_wgrad_group), every layer cut into its share of wg_group_blocks workgroups instead of a GPU's worth
         self.wg_group = self.wg_defer and os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP", "1") != "0"
-        self.wg_group_n = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_N", "24"))
-        self.wg_group_flops = float(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_GFLOP", "8")) * 1e9     # bigger layers launch alone
+        self.wg_group_n = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_N", "64"))
+        self.wg_group_flops = float(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_GFLOP", "40")) * 1e9     # bigger layers launch alone
         gb = [int(v) for v in os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_BLOCKS", "512,1024,1024").split(",")]
         self.wg_group_blocks = {CP_WGRAD_ITEM_3X3: gb[0], CP_WGRAD_ITEM_3X3_SMALL: gb[1], CP_WGRAD_ITEM_GENERIC_BF16: gb[2],
                                 CP_WGRAD_ITEM_GENERIC_F32: gb[2]}
@@ -592,6 +592,32 @@ class TrainProgram(Program):
         gt, ot, st_ = gout.tbuf, out.tbuf, gsrc.tbuf
         tail = (gsrc.B, gsrc.H, gsrc.W, gsrc.Cphys, int(shift), 1 if relu else 0, 1)
         self._add(self.lib.cp_fuse_sum_act_bwd, lambda P: (self.dtype, P(gt), P(ot), P(st_)) + tail, "fuse_sum_bwd", [gt, ot, st_], [st_])
+
+    def fuse_sum_bwd_group(self, members):
+        """members: [(gout, out, gsrc, shift, relu)] writing DISTINCT gradient tensors (a module's whole fuse layer): one launch"""
+        if len(members) == 1 or not self.bn_grouped:
+            for m in members:
+                self.fuse_sum_bwd(*m)
+            return
+        lib, dt = self.lib, self.dtype
+        for lo in range(0, len(members), 64):
+            mem = members[lo:lo + 64]
+
+            def argb(P, mem=mem):
+                items, pre = [], [0]
+                for gout, out, gsrc, shift, relu in mem:
+                    it, nb = CpFuseBwdItem(), C.c_uint32()
+                    _abi.check(lib.cp_fuse_sum_act_bwd_item(dt, P(gout.tbuf), P(out.tbuf), P(gsrc.tbuf), gsrc.B, gsrc.H, gsrc.W, gsrc.Cphys,
+                                                            int(shift), 1 if relu else 0, 1, C.byref(it), C.byref(nb)), "cp_fuse_sum_act_bwd_item")
+                    items.append(it)
+                    pre.append(pre[-1] + nb.value)
+                arr = (CpFuseBwdItem * len(items))(*items)
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+                self.keep += [raw, prefix]
+                return (dt, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1])
+            tbs = [t for gout, out, gsrc, _, _ in mem for t in (gout.tbuf, out.tbuf, gsrc.tbuf)]
+            self._add(lib.cp_fuse_sum_act_bwd_group, argb, "fuse_sum_bwd_group:%d" % len(mem), tbs, [m[2].tbuf for m in mem])
 
     def maxpool_bwd(self, x: Act, gout: Act, gin: Act):
         xt, gt, it = x.tbuf, gout.tbuf, gin.tbuf

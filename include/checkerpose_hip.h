@@ -609,6 +609,18 @@ int cp_upsample2x_bilinear_ac_bwd(cp_stream_t stream, int dtype, const void* dou
                                   int out_cstride, int out_coff, int in_cstride, int in_coff, int accumulate);
 int cp_fuse_sum_act_bwd(cp_stream_t stream, int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws,
                         int C, int shift, int relu, int accumulate);
+/* ... and every (output, term) pair of one fuse layer in ONE launch (the pairs write distinct gradient tensors): the item is
+ * cp_fuse_sum_act_bwd's argument list checked and packed on the host, `blocks` its workgroup count; items_dev / prefix_dev as for
+ * the other grouped launches (<= 64 items). */
+typedef struct CpFuseBwdItem {
+  const void* dout; const void* out; void* dsrc;
+  int32_t Hs, Ws, CG, shift, relu, accumulate;
+  uint64_t total;
+} CpFuseBwdItem;
+int cp_fuse_sum_act_bwd_item(int dtype, const void* dout, const void* out, void* dsrc, int B, int Hs, int Ws, int C, int shift, int relu,
+                             int accumulate, CpFuseBwdItem* item, uint32_t* blocks);
+int cp_fuse_sum_act_bwd_group(cp_stream_t stream, int dtype, const CpFuseBwdItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                              uint32_t total_blocks);
 /* Backward of cp_maxpool3x3s2 (resnet34 stem): x (B,H,W,C) forward input, dout (B,H/2,W/2,C), din (+)= routed gradient
  * (first maximum of each window in row-major order takes it, as ATen's CPU kernel does). */
 int cp_maxpool3x3s2_bwd(cp_stream_t stream, int dtype, const void* x, const void* dout, void* din, int B, int H, int W, int C,
