@@ -68,6 +68,10 @@ class CpFuseBwdItem(C.Structure):
                 ("shift", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32), ("total", C.c_uint64)]
 
 
+class CpConvGroupItem(C.Structure):   # one layer of a grouped small-Cout conv launch (cp_conv3x3_halo_item fills it; params is opaque)
+    _fields_ = [("NT", C.c_int32), ("blocks", C.c_uint32), ("lds_bytes", C.c_uint32), ("pad", C.c_uint32), ("params", C.c_uint64 * 25)]
+
+
 class CpWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32),
@@ -90,6 +94,9 @@ SIGNATURES = {
     "cp_packed_halo_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "cp_pack_conv3x3_halo_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_conv3x3_halo": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
+    "cp_conv3x3_halo_group_supported": (_I, [_I, _I, _I, _I]),
+    "cp_conv3x3_halo_item": (_I, [C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P, C.POINTER(CpConvGroupItem)]),
+    "cp_conv3x3_halo_group": (_I, [_P, _I, _P, _P, _I, C.c_uint32, C.c_uint32]),
     "cp_conv3x3_s2_small_supported": (_I, [_I, _I, _I, _I]),
     "cp_conv3x3_s2_small_weight_bytes": (C.c_size_t, [_I, _I]),
     "cp_pack_conv3x3_s2_small_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),

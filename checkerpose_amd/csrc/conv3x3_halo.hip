@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <cstring>
 
 struct HaloParams {
   const void* in; const void* w; const float* scale; const float* shift; const void* res; void* out;
@@ -771,6 +772,164 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Grouped small-Cout convs: SEVERAL independent 3x3 layers (the branches of an HRNet module at equal depth, forward or
+// data-gradient, at the training batch of 32) in one launch.  Same algorithm as conv3x3_halo_s_kernel with the tile count NT a
+// RUN-TIME value (<= 5; block-uniform branches around the unrolled tile loops), one HaloParams per layer in a device table, block b
+// belongs to the layer k with prefix[k] <= b < prefix[k + 1].  At B = 32 each of these layers alone is a ~9 us launch for < 1 GFLOP.
+struct HaloGroupItem {          // == CpConvGroupItem
+  int32_t NT; uint32_t blocks, lds_bytes, pad;
+  HaloParams p;
+};
+static_assert(sizeof(HaloGroupItem) == sizeof(CpConvGroupItem), "CpConvGroupItem layout");
+
+template <typename Tag, int NTM>
+__global__ __launch_bounds__(256) void conv3x3_halo_s_group_kernel(const HaloGroupItem* __restrict__ items, const uint32_t* __restrict__ prefix,
+                                                                   int n) {
+  constexpr int E = Tag::E;
+  constexpr int KCH = 4 * E;
+  constexpr int ES = 16 / E;
+  constexpr int WITERM = (9 * NTM * 64 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [A: HBUF][W: 9*NT KiB]
+  unsigned char* const sA = smem;
+  unsigned char* const sW = smem + HBUF;
+
+  int k = 0;
+  while (k + 1 < n && blockIdx.x >= prefix[k + 1]) ++k;
+  const HaloParams p = items[k].p;
+  const int NT = items[k].NT;
+  const int WPIECES = 9 * NT * 64;
+  const int t = (int)(blockIdx.x - prefix[k]);
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int b = t / tpi;
+  const int trem = t - b * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * HTH, x0 = tx * HTW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  uint32_t s_goff[3], s_lds[3];
+  int s_cq[3];
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const int i = tid + 256 * kk;
+    const int hp = i >> 2, pq = i & 3;
+    const int py = hp / HPW, px = hp - py * HPW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = (hp < HPH * HPW) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    s_goff[kk] = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + pq * E) : 0xFFFFFFFFu;
+    s_lds[kk] = (uint32_t)(pq * HPLANE + hp * 16);
+    s_cq[kk] = pq * E;
+  }
+
+  f32x4 acc[2][NTM];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t a_lane = (uint32_t)(q * HPLANE + (2 * wave * HPW + x) * 16);
+  const int ox = x0 + x;
+  const int chq = q * 4 * NT;
+  long long obase[2];
+  bool rok[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int oy = y0 + 2 * wave + mt;
+    rok[mt] = (oy < p.H) & (ox < p.W);
+    obase[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + chq;
+  }
+  f32x4 rv[2][NTM];
+  if (p.res) {          // all residual loads before the first store (res may alias out: the data-gradient accumulates in place)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTM; ++nt) {
+        rv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nt < NT && rok[mt] && chq + nt * 4 < p.Cout) {
+          if (E == 4) rv[mt][nt] = *(const f32x4*)((const float*)p.res + obase[mt] + nt * 4);
+          else {
+            const u32x2 r2 = *(const u32x2*)((const uint16_t*)p.res + obase[mt] + nt * 4);
+            rv[mt][nt] = f32x4{__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xffff0000u),
+                               __uint_as_float(r2.y << 16), __uint_as_float(r2.y & 0xffff0000u)};
+          }
+        }
+      }
+  }
+  for (int c = 0; c < p.nchunk; ++c) {
+    const int c0 = c * KCH;
+    u32x4 sv[3], wv[WITERM];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      const bool ok = (s_goff[kk] != 0xFFFFFFFFu) & (c0 + s_cq[kk] < p.Cin);
+      const uint32_t off = ok ? (s_goff[kk] + (uint32_t)c0) * ES : 0x80000000u;
+      sv[kk] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+#pragma unroll
+    for (int kk = 0; kk < WITERM; ++kk) {
+      const int i = tid + 256 * kk;
+      const uint32_t off = i < WPIECES ? ((uint32_t)c * (uint32_t)WPIECES + (uint32_t)i) * 16u : 0x80000000u;
+      wv[kk] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+    }
+    if (c > 0) __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) *(u32x4*)(sA + s_lds[kk]) = sv[kk];
+#pragma unroll
+    for (int kk = 0; kk < WITERM; ++kk) {
+      const int i = tid + 256 * kk;
+      if (i < WPIECES) *(u32x4*)(sW + i * 16) = wv[kk];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s2 = tap - 3 * r;
+      const unsigned char* ab = sA + a_lane + (r * HPW + s2) * 16;
+      const u32x4 a0 = *(const u32x4*)(ab);
+      const u32x4 a1 = *(const u32x4*)(ab + HPW * 16);
+#pragma unroll
+      for (int nt = 0; nt < NTM; ++nt) {
+        if (nt < NT) {
+          const u32x4 w = *(const u32x4*)(sW + (tap * NT + nt) * 1024 + lane * 16);
+          MmaH<Tag>::run(w, a0, acc[0][nt]);
+          MmaH<Tag>::run(w, a1, acc[1][nt]);
+        }
+      }
+    }
+  }
+
+  if (ox >= p.W) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (!rok[mt]) continue;
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) {
+      const int ch = chq + nt * 4;
+      if (nt >= NT || ch >= p.Cout) continue;
+      const f32x4 sc = *(const f32x4*)(p.scale + ch), sh = *(const f32x4*)(p.shift + ch);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * sc[j] + sh[j];
+      if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rv[mt][nt][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      }
+      if (E == 4) *(f32x4*)((float*)p.out + obase[mt] + nt * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + obase[mt] + nt * 4) = pk; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fused BasicBlock (timm resnet.BasicBlock inside the HRNet branches):
 //     out = relu( bn2(conv3x3( relu(bn1(conv3x3(x))) )) + x )          C -> C channels, C <= 32, one 64-byte chunk
 // The 18-channel branch at 64x64 is the critical path of every HRNet module (8 convs in series, each HBM-bound);
@@ -1249,8 +1408,8 @@ extern "C" int cp_pack_item_halo(int dtype, const float* w, int Cout, int Cin, i
   return CP_OK;
 }
 
-extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
-                               const float* scale, const float* shift, const void* residual, void* out) {
+static int build_halo_params(const CpConvDesc* d, const void* in, const void* packed_w, const float* scale, const float* shift,
+                             const void* residual, void* out, HaloParams* pp, long long* tiles) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
   if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
@@ -1281,6 +1440,17 @@ extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   if (wb >= (1ull << 31)) return CP_ERR_RANGE;
   p.w_bytes = (uint32_t)wb;
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
+  *pp = p;
+  *tiles = tt;
+  return CP_OK;
+}
+
+extern "C" int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
+                               const float* scale, const float* shift, const void* residual, void* out) {
+  HaloParams p;
+  long long tt;
+  const int rcb = build_halo_params(d, in, packed_w, scale, shift, residual, out, &p, &tt);
+  if (rcb) return rcb;
   if (halo_small(d->Cout)) {   // d->Cout is the PHYSICAL count; the pack call used the logical one -> same tile count
     const int NT = (d->Cout + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
@@ -1477,6 +1647,51 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
   } else {
     if (NT == 1) CP_LAUNCH((basicblock_fused_kernel<BF16Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
     else CP_LAUNCH((basicblock_fused_kernel<BF16Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
+  }
+  return cp_check_launch();
+}
+
+// ---- grouped small-Cout convs (see conv3x3_halo_s_group_kernel)
+static int build_halo_params(const CpConvDesc* d, const void* in, const void* packed_w, const float* scale, const float* shift,
+                             const void* residual, void* out, HaloParams* pp, long long* tiles);
+
+extern "C" int cp_conv3x3_halo_group_supported(int dtype, int H, int W, int Cout_phys) {
+  return ((dtype == CP_F32 || dtype == CP_BF16) && H >= 8 && W >= 16 && Cout_phys > 0 && Cout_phys <= 80 && halo_small(Cout_phys)) ? 1 : 0;
+}
+
+extern "C" int cp_conv3x3_halo_item(const CpConvDesc* d, const void* in, const void* packed_w, const float* scale, const float* shift,
+                                    const void* residual, void* out, CpConvGroupItem* item) {
+  if (!item) return CP_ERR_INVALID;
+  HaloGroupItem it;
+  memset(&it, 0, sizeof(it));
+  long long tt;
+  const int rc = build_halo_params(d, in, packed_w, scale, shift, residual, out, &it.p, &tt);
+  if (rc) return rc;
+  if (!cp_conv3x3_halo_group_supported(d->dtype, d->H, d->W, d->Cout)) return CP_ERR_INVALID;
+  it.NT = (d->Cout + 15) / 16;
+  it.blocks = (uint32_t)tt;
+  it.lds_bytes = (uint32_t)(HBUF + 9 * it.NT * 1024);
+  memcpy(item, &it, sizeof(it));
+  return CP_OK;
+}
+
+extern "C" int cp_conv3x3_halo_group(cp_stream_t stream, int dtype, const CpConvGroupItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                                     uint32_t total_blocks, uint32_t lds_bytes) {
+  if (!items_dev || !prefix_dev || n_items <= 0 || n_items > 16 || total_blocks == 0 || lds_bytes < HBUF + 9 * 1024 ||
+      lds_bytes > HBUF + 9 * 5 * 1024)
+    return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (!cp_aligned16(items_dev)) return CP_ERR_ALIGN;
+  // the kernel is built for <= 3 and <= 5 channel tiles per layer (registers and LDS per block follow the LARGEST layer of the group)
+  const bool small = lds_bytes <= HBUF + 9 * 3 * 1024;
+  const HaloGroupItem* it = (const HaloGroupItem*)items_dev;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CP_F32) {
+    if (small) CP_LAUNCH((conv3x3_halo_s_group_kernel<F32Tag, 3>), dim3(total_blocks), dim3(256), lds_bytes, st, it, prefix_dev, n_items);
+    else CP_LAUNCH((conv3x3_halo_s_group_kernel<F32Tag, 5>), dim3(total_blocks), dim3(256), lds_bytes, st, it, prefix_dev, n_items);
+  } else {
+    if (small) CP_LAUNCH((conv3x3_halo_s_group_kernel<BF16Tag, 3>), dim3(total_blocks), dim3(256), lds_bytes, st, it, prefix_dev, n_items);
+    else CP_LAUNCH((conv3x3_halo_s_group_kernel<BF16Tag, 5>), dim3(total_blocks), dim3(256), lds_bytes, st, it, prefix_dev, n_items);
   }
   return cp_check_launch();
 }

@@ -778,6 +778,11 @@ static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, 
   static const int rows_per_block = cp_knob("CP_BN_ACC_ROWS") ? atoi(cp_knob("CP_BN_ACC_ROWS")) : 64;
   int nb = M / rows_per_block;                            // as many blocks as the partial-sum variant ...
   int cap = 65536 / (2 * Cphys);                          // ... but at most ~64k atomics per launch (~30 G atomics/s)
+  // ... unless the tensor is big: 128 blocks on 256 CUs streamed the 64 x 64 x 256-channel maps of layer1 at 3.5 TB/s (57 us per
+  // backward pass); from `elems_per_block` elements per block on, more blocks pay for their atomics
+  static const long long elems_per_block = cp_knob("CP_BN_ACC_ELEMS") ? atoll(cp_knob("CP_BN_ACC_ELEMS")) : 65536;
+  const long long by_size = (long long)M * Cphys / elems_per_block;
+  if (by_size > cap) cap = (int)(by_size > max_blocks ? max_blocks : by_size);
   cap = cap < 32 ? 32 : (cap > max_blocks ? max_blocks : cap);
   nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
   *rpb = (M + nb - 1) / nb;

@@ -17,6 +17,7 @@
 // crop's tables are served by that XCD's L2; the reverse graph (rev_ptr / rev_edge, static per object) turns every
 // scatter into a deterministic gather.  Per-channel sums: fp64 block partials + one finalize launch.
 #include "common.h"
+#include <cstring>
 
 int cp_bn_finalize_launch(hipStream_t st, const double* partial, int nblk, int CP, int C, double count, const float* gamma,
                           const float* beta, float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
@@ -103,7 +104,19 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeTrainParams 
 #pragma unroll
       for (int e = 0; e < E; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
       const int32_t* my = s_idx + kp_l * p.K;
-      for (int k = 0; k < p.K; ++k) {
+      int k = 0;
+      for (; k + 4 <= p.K; k += 4) {        // four rows in flight
+        u32x4 r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r4[u] = rows[(size_t)my[k + u] * (2 * TPK) + cg];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          Vec16<Tag>::unpack(r4[u], f);
+#pragma unroll
+          for (int e = 0; e < E; ++e) { a1[e] += f[e]; a2[e] += f[e] * f[e]; }
+        }
+      }
+      for (; k < p.K; ++k) {
         Vec16<Tag>::unpack(rows[(size_t)my[k] * (2 * TPK) + cg], f);
 #pragma unroll
         for (int e = 0; e < E; ++e) { a1[e] += f[e]; a2[e] += f[e] * f[e]; }
@@ -163,7 +176,22 @@ __global__ __launch_bounds__(256) void edge_train_fwd_kernel(const EdgeTrainPara
 #pragma unroll
     for (int e = 0; e < E; ++e) { m[e] = -INFINITY; ks[e] = 0; }
     const int32_t* my = s_idx2 + kp_l * p.K;
-    for (int k = 0; k < p.K; ++k) {
+    int k = 0;
+    for (; k + 4 <= p.K; k += 4) {          // four rows in flight; the comparisons stay in list order (first arg-max wins)
+      u32x4 r4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r4[u] = rows[(size_t)my[k + u] * (2 * TPK) + cg];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        Vec16<Tag>::unpack(r4[u], f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float v = f[e] * sc[e];
+          if (v > m[e]) { m[e] = v; ks[e] = k + u; }
+        }
+      }
+    }
+    for (; k < p.K; ++k) {
       Vec16<Tag>::unpack(rows[(size_t)my[k] * (2 * TPK) + cg], f);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -218,7 +246,19 @@ __global__ __launch_bounds__(256) void edge_train_bwd_kernel(const EdgeTrainPara
 #pragma unroll
     for (int e = 0; e < E; ++e) S[e] = 0.f;
     const int32_t* my = s_idx3 + kp_l * p.K;
-    for (int k = 0; k < p.K; ++k) {
+    int k = 0;
+    for (; k + 4 <= p.K; k += 4) {          // four rows in flight (one dependent L2 round trip per row made this loop a latency chain)
+      u32x4 r4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r4[u] = rows[(size_t)my[k + u] * (2 * TPK) + cg];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        Vec16<Tag>::unpack(r4[u], f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) S[e] += f[e];
+      }
+    }
+    for (; k < p.K; ++k) {
       Vec16<Tag>::unpack(rows[(size_t)my[k] * (2 * TPK) + cg], f);
 #pragma unroll
       for (int e = 0; e < E; ++e) S[e] += f[e];
@@ -237,19 +277,40 @@ __global__ __launch_bounds__(256) void edge_train_bwd_kernel(const EdgeTrainPara
 #pragma unroll
     for (int e = 0; e < E; ++e) { G[e] = 0.f; R[e] = 0.f; }
     const int e0 = rp[j], e1 = rp[j + 1];
-    for (int t = e0; t < e1; ++t) {
-      const int eid = re[t];
-      const int i = eid / p.K, k = eid - i * p.K;
-      const size_t ni = (size_t)b * p.N + i;
-      Vec16<Tag>::unpack(rows[(size_t)i * (2 * TPK) + TPK + cg], f);
-      float gi[E], oi[E];
-      Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.gout + ni * p.g_cs + p.g_coff + cg * E), gi);
-      Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.out + ni * p.out_cs + p.out_coff + cg * E), oi);
-      const uint8_t* ks = p.kstar + ni * C + cg * E;
+    for (int t0 = e0; t0 < e1; t0 += 4) {    // four reverse edges in flight (edge id -> three rows + the arg-max bytes: two dependent trips each)
+      int ei[4], kk[4];
+      bool ok[4];
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        R[e] += f[e];
-        if ((int)ks[e] == k) G[e] += oi[e] > 0.f ? gi[e] : gi[e] * p.slope;
+      for (int u = 0; u < 4; ++u) {
+        ok[u] = t0 + u < e1;
+        const int eid = re[ok[u] ? t0 + u : e1 - 1];
+        ei[u] = eid / p.K;
+        kk[u] = eid - ei[u] * p.K;
+      }
+      u32x4 rq[4], rg[4], ro[4];
+      uint8_t ks[4][E];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t ni = (size_t)b * p.N + ei[u];
+        rq[u] = rows[(size_t)ei[u] * (2 * TPK) + TPK + cg];
+        rg[u] = *(const u32x4*)((const T*)p.gout + ni * p.g_cs + p.g_coff + cg * E);
+        ro[u] = *(const u32x4*)((const T*)p.out + ni * p.out_cs + p.out_coff + cg * E);
+        const uint8_t* kp = p.kstar + ni * C + cg * E;
+        if (E == 8) { const uint2 v = *(const uint2*)kp; memcpy(ks[u], &v, 8); }
+        else { const uint32_t v = *(const uint32_t*)kp; memcpy(ks[u], &v, 4); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        float gi[E], oi[E];
+        Vec16<Tag>::unpack(rq[u], f);
+        Vec16<Tag>::unpack(rg[u], gi);
+        Vec16<Tag>::unpack(ro[u], oi);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          R[e] += f[e];
+          if ((int)ks[u][e] == kk[u]) G[e] += oi[e] > 0.f ? gi[e] : gi[e] * p.slope;
+        }
       }
     }
     const float deg = (float)(e1 - e0);

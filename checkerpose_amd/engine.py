@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc, CpFuseConv
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc, CpConvGroupItem, CpFuseConv
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
@@ -25,6 +25,8 @@ USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet 
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
 EDGE_SCHED = os.environ.get("CHECKERPOSE_AMD_EDGE_SCHED", "1") != "0"   # A/B: bank-conflict-aware neighbour order for edge_fused
+USE_CONV_GROUP = os.environ.get("CHECKERPOSE_AMD_CONV_GROUP", "0") == "1"    # training: independent small 3x3 convs in one launch (measured: no gain)
+CONV_GROUP_MAX_C = int(os.environ.get("CHECKERPOSE_AMD_CONV_GROUP_MAXC", "48"))
 USE_SPLITK = os.environ.get("CHECKERPOSE_AMD_SPLITK", "1") != "0"     # small-batch split-K routing (cp_conv2d_igemm_splitk)
 GEMM_WS_SMALL_K = os.environ.get("CHECKERPOSE_AMD_GEMM_WS_SMALL_K", "1") != "0"   # A/B: weight-stationary GEMM from K = 64
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
@@ -382,6 +384,78 @@ class Program:
                   + R * S * wCin * wCout * self.es)          # algorithmic: input + output (+ residual) + weights, unpadded
         self.conv_log.append((wkey, x.B * Ho * Wo, wCout, R * S * wCin, fl, fam, nbytes))
         return out
+
+    def conv3x3_group(self, members):
+        """INDEPENDENT 3x3 / stride 1 / pad 1 convs (the branches of an HRNet module at equal depth) -> one cp_conv3x3_halo_group launch
+        for those the grouped kernel supports (<= 80 output channels, map >= 8 x 16), plain conv() launches for the rest.
+        members: [(x, wkey, w, scale, shift, act, slope, residual, out)]; no two members may write the same tensor.  -> [out Act]"""
+        lib = self.lib
+        outs, grp = [None] * len(members), []
+        for i, (x, wkey, w, scale, shift, act, slope, residual, out) in enumerate(members):
+            wCout, wCin = w.shape[0], w.shape[1]
+            if wCin != x.C:
+                raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
+            if USE_CONV_GROUP and _rup(wCout, self.E) <= CONV_GROUP_MAX_C and lib.cp_conv3x3_halo_group_supported(self.dtype, x.H, x.W, _rup(wCout, self.E)):
+                grp.append(i)
+            else:
+                outs[i] = self.conv(x, wkey, w, scale, shift, 3, 3, 1, 1, wCout, act, slope, residual=residual, out=out)
+        if len(grp) == 1:
+            x, wkey, w, scale, shift, act, slope, residual, out = members[grp[0]]
+            outs[grp[0]] = self.conv(x, wkey, w, scale, shift, 3, 3, 1, 1, w.shape[0], act, slope, residual=residual, out=out)
+            grp = []
+        if not grp:
+            return outs
+        builders, reads, writes, names = [], [], [], []
+        for i in grp:
+            x, wkey, w, scale, shift, act, slope, residual, out = members[i]
+            wCout, wCin = w.shape[0], w.shape[1]
+            packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
+            sc, sh = self.ws.affine(wkey + "#0", scale, shift, wCout)
+            if out is None:
+                out = self.act(x.H, x.W, wCout)
+            d = CpConvDesc()
+            d.dtype, d.out_f32 = self.dtype, 0
+            d.B, d.H, d.W = x.B, x.H, x.W
+            d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
+            d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 3, 3, 1, 1, x.H, x.W
+            d.act, d.slope, d.ksplit = act, slope, -1
+            d.Cout = out.Cphys
+            d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = out.coff, out.H * out.W * out.cstride, out.W * out.cstride, out.cstride, 1
+            if residual is not None:
+                assert (residual.cstride, residual.coff, residual.H, residual.W) == (out.cstride, out.coff, out.H, out.W), \
+                    "residual must share the output layout"
+            self.keep += [d, packed, sc, sh]
+            rtb = residual.tbuf if residual is not None else None
+
+            def build(P, d=d, xtb=x.tbuf, rtb=rtb, otb=out.tbuf, pw=packed.data_ptr(), ps=sc.data_ptr(), pt=sh.data_ptr(), wkey=wkey):
+                it = CpConvGroupItem()
+                _abi.check(lib.cp_conv3x3_halo_item(C.byref(d), P(xtb), pw, ps, pt, P(rtb) if rtb is not None else None, P(otb), C.byref(it)),
+                           "cp_conv3x3_halo_item(%s)" % wkey)
+                return it
+            builders.append(build)
+            reads += [x.tbuf] + ([rtb] if rtb is not None else [])
+            writes.append(out.tbuf)
+            names.append(wkey)
+            outs[i] = out
+            fl = 2 * x.B * x.H * x.W * 9 * wCin * wCout
+            self.flops += fl
+            nbytes = (x.B * x.H * x.W * (wCin + wCout * (2 if residual is not None else 1)) + 9 * wCin * wCout) * self.es
+            self.conv_log.append((wkey, x.B * x.H * x.W, wCout, 9 * wCin, fl, "conv3x3_halo_group", nbytes))
+        assert len(set(id(t) for t in writes)) == len(writes), "conv3x3_group: two members write the same tensor"
+        dt = self.dtype
+
+        def argb(P):
+            items = [b(P) for b in builders]
+            arr = (CpConvGroupItem * len(items))(*items)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            pre = [0]
+            for it in items:
+                pre.append(pre[-1] + int(it.blocks))
+            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+            self.keep += [raw, prefix]
+            return (dt, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1], max(int(it.lds_bytes) for it in items))
+        self._add(lib.cp_conv3x3_halo_group, argb, "conv3x3_halo_group:" + names[0] + "+%d" % (len(names) - 1), reads, writes)
+        return outs
 
     def would_splitk(self, M, K, Cout):
         """small-batch regime: cp_conv2d_igemm would run this conv as its split-K variant (M output pixels, K = R*S*Cin physical)"""

@@ -81,10 +81,14 @@ class NetEmitter:
         specs: [(x, conv key, bn key, k, stride, pad, relu, residual)] -> [y]"""
         tp = self.tp
         members, recs = [], []
-        for x, conv, bn, k, stride, pad, relu, residual in specs:
-            w = self.W(conv + ".weight")
-            Cout = w.shape[0]
-            raw = tp.conv(x, conv, w, tp.const_vec(Cout, True), tp.const_vec(Cout, False), k, k, stride, pad, Cout)
+        ws = [self.W(conv + ".weight") for _, conv, *_ in specs]
+        if all((k, stride, pad) == (3, 1, 1) for _, _, _, k, stride, pad, _, _ in specs):        # the convs themselves grouped too
+            raws = tp.conv3x3_group([(x, conv, w, tp.const_vec(w.shape[0], True), tp.const_vec(w.shape[0], False), ACT_NONE, 0.0, None, None)
+                                     for (x, conv, *_), w in zip(specs, ws)])
+        else:
+            raws = [tp.conv(x, conv, w, tp.const_vec(w.shape[0], True), tp.const_vec(w.shape[0], False), k, k, stride, pad, w.shape[0])
+                    for (x, conv, _, k, stride, pad, _, _), w in zip(specs, ws)]
+        for (x, conv, bn, k, stride, pad, relu, residual), w, raw in zip(specs, ws, raws):
             recs.append((x, conv, bn, w, k, stride, pad, ACT_RELU if relu else ACT_NONE, residual, raw))
         ys = []
         for x, conv, bn, w, k, stride, pad, act, residual, raw in recs:
@@ -104,8 +108,7 @@ class NetEmitter:
             gys = [tp.grad_of(y) for _, y, _ in live]
             tp.bn_bwd_group([(gy, y, r[9], st, r[7], 0.0, tp.grad_of(r[8]) if r[8] is not None else None,
                               tp.pg_ptr(r[2] + ".weight"), tp.pg_ptr(r[2] + ".bias")) for gy, (r, y, st) in zip(gys, live)])
-            for gy, (r, y, st) in zip(gys, live):
-                tp.conv_backward(r[1], r[3], r[0], gy, r[4], r[4], r[5], r[6])
+            tp.conv_backward_group([(r[1], r[3], r[0], gy, r[4], r[4], r[5], r[6]) for gy, (r, y, st) in zip(gys, live)])
         tp.tape.append(bwd)
         return ys
 

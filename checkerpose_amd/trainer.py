@@ -561,8 +561,34 @@ class TrainProgram(Program):
         """g = d loss / d (raw conv output) in channels-last; accumulates into grad(x), writes the weight gradient."""
         Cout, Cin = w.shape[0], w.shape[1]
         self.wgrad(g, x, self.pg_ptr(key + ".weight"), Cout, Cin, R, S, stride, pad)
-        if not self.needs_grad(x):
-            return
+        if self.needs_grad(x):
+            self._dgrad(key, w, x, g, R, S, stride, pad)
+
+    def conv_backward_group(self, members):
+        """conv_backward of INDEPENDENT layers [(key, w, x, g, R, S, stride, pad)]: the 3x3 / stride 1 data-gradient convs go out as
+        grouped launches (engine.conv3x3_group; members that accumulate into the same input gradient in separate rounds)"""
+        dg = []
+        for key, w, x, g, R, S, stride, pad in members:
+            Cout, Cin = w.shape[0], w.shape[1]
+            self.wgrad(g, x, self.pg_ptr(key + ".weight"), Cout, Cin, R, S, stride, pad)
+            if not self.needs_grad(x):
+                continue
+            if stride == 1 and R == 3 and S == 3 and pad == 1:
+                gx = self.grad_of(x)
+                wt = self.weight_dgrad(w, Cout, Cin, 3, 3)
+                dg.append((g, key + "#dgrad", wt, self.const_vec(Cin, True), self.const_vec(Cin, False), ACT_NONE, 0.0, gx, gx))
+            else:
+                self._dgrad(key, w, x, g, R, S, stride, pad)
+        while dg:
+            seen, now, later = set(), [], []
+            for m in dg:
+                (later if id(m[8].tbuf) in seen else now).append(m)
+                seen.add(id(m[8].tbuf))
+            self.conv3x3_group(now)
+            dg = later
+
+    def _dgrad(self, key, w, x: Act, g: Act, R, S, stride, pad):
+        Cout, Cin = w.shape[0], w.shape[1]
         gx = self.grad_of(x)
         one, zero = self.const_vec(Cin, True), self.const_vec(Cin, False)
         if stride == 1:
@@ -582,7 +608,6 @@ class TrainProgram(Program):
         else:
             raise RuntimeError("no data-gradient path for conv %s (k=%d, stride=%d, pad=%d)" % (key, R, stride, pad))
 
-    # ---- resampling backward
     def upsample2x_bwd(self, gout: Act, gin: Act):
         gt, it = gout.tbuf, gin.tbuf
         tail = (gin.B, gin.H, gin.W, gin.Cphys, gout.cstride, gout.coff, gin.cstride, gin.coff, 1)

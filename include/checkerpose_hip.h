@@ -115,6 +115,21 @@ int cp_pack_conv3x3_halo_weight(cp_stream_t stream, int dtype, const float* w, i
                                 void* packed);
 int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                     const float* scale, const float* shift, const void* residual, void* out);
+/* Grouped form for small layers: up to 16 INDEPENDENT 3x3 / stride 1 / pad 1 convs with <= 80 physical output channels on maps of at
+ * least 8 x 16 pixels (the branches of an HRNet module at equal depth -- timm HighResolutionModule.forward runs them one after the
+ * other; at the training batch each is a ~9 us launch) in ONE launch.  cp_conv3x3_halo_item: cp_conv3x3_halo's arguments, checked
+ * and packed on the host (weights packed as for cp_conv3x3_halo); cp_conv3x3_halo_group: items in device memory, prefix = exclusive
+ * prefix sum (n_items + 1) of item.blocks, lds_bytes = the largest item.lds_bytes.  Results are bit-identical to the single launches.
+ * A residual may alias the output (in-place accumulation) but no two items may write the same tensor. */
+typedef struct CpConvGroupItem {
+  int32_t NT; uint32_t blocks, lds_bytes, pad;
+  unsigned long long params[25];       /* opaque: the kernel's parameter block */
+} CpConvGroupItem;
+int cp_conv3x3_halo_group_supported(int dtype, int H, int W, int Cout_phys);
+int cp_conv3x3_halo_item(const CpConvDesc* d, const void* in, const void* packed_w, const float* scale, const float* shift,
+                         const void* residual, void* out, CpConvGroupItem* item);
+int cp_conv3x3_halo_group(cp_stream_t stream, int dtype, const CpConvGroupItem* items_dev, const uint32_t* prefix_dev, int n_items,
+                          uint32_t total_blocks, uint32_t lds_bytes);
 
 /* conv3x3( UpsamplingBilinear2d(scale_factor=2)(in) ) without the upsampled tensor: the decoder's `up_net[1..2]` upsample + first
  * conv (pipeline.py:199-200, get_gdrn_upsample_module).  Descriptor as cp_conv3x3_halo, except that d->H, d->W (= Ho, Wo, both

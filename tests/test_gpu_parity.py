@@ -194,6 +194,67 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
     assert lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
 
 
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+def test_conv3x3_halo_group_bitwise_equals_single_launches(lib, dtype):
+    """cp_conv3x3_halo_group (several independent small 3x3 convs in ONE launch: the branches of an HRNet module at equal depth,
+    training forward and data-gradient) == cp_conv3x3_halo layer by layer, bit for bit: 18 / 36 / 72 / 64 / 80-channel layers on
+    64 / 32 / 16-pixel and ragged maps, ReLU / none, a residual that ALIASES the output (the data-gradient accumulates in place), and
+    an input that is a channel slice; unsupported members (8 x 8 map, 144 channels) are refused by the item builder."""
+    from checkerpose_amd._abi import CpConvGroupItem
+    E = 8 if dtype == CP_BF16 else 4
+    cases = [(4, 18, 64, 64, 18, ACT_RELU, False), (4, 36, 32, 32, 36, ACT_NONE, True), (4, 72, 16, 16, 72, ACT_NONE, True),
+             (2, 64, 13, 21, 64, ACT_RELU, False), (2, 24, 8, 16, 80, ACT_NONE, False), (3, 18, 32, 32, 36, ACT_RELU, False)]
+    items, keep, want, outs = [], [], [], []
+    for n, (B, Cin, H, W, Cout, act, inplace) in enumerate(cases):
+        x = det_tensor("hgx%d" % n, (B, Cin, H, W))
+        w = det_tensor("hgw%d" % n, (Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5 * 1.7)
+        xin = to_cl(x, dtype)
+        cop = rup(Cout, E)
+        pw = torch.empty(lib.cp_packed_halo_weight_bytes(dtype, Cout, xin.shape[-1]), dtype=torch.uint8, device=dev())
+        wd = w.contiguous().to(dev())
+        _abi.check(lib.cp_pack_conv3x3_halo_weight(st(), dtype, wd.data_ptr(), Cout, Cin, xin.shape[-1], pw.data_ptr()))
+        n16 = rup(Cout, 16)
+        sc = torch.zeros(n16); sc[:Cout] = 1.0 + 0.3 * det_tensor("hgs%d" % n, (Cout,))
+        sh = torch.zeros(n16); sh[:Cout] = 0.2 * det_tensor("hgt%d" % n, (Cout,))
+        sc, sh = sc.to(dev()), sh.to(dev())
+        acc0 = to_cl(det_tensor("hgr%d" % n, (B, Cout, H, W)), dtype) if inplace else None
+        d = CpConvDesc()
+        d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+        d.Cin, d.in_cstride, d.in_coff = xin.shape[-1], xin.shape[-1], 0
+        d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 3, 3, 1, 1, H, W, cop, act, 0.0
+        d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, H * W * cop, W * cop, cop, 1
+        a = acc0.clone() if inplace else torch.full((B, H, W, cop), float("nan"), dtype=DT[dtype], device=dev())
+        _abi.check(lib.cp_conv3x3_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                       a.data_ptr() if inplace else None, a.data_ptr()), "halo conv")
+        want.append(a)
+        o = acc0.clone() if inplace else torch.full((B, H, W, cop), float("nan"), dtype=DT[dtype], device=dev())
+        it = CpConvGroupItem()
+        _abi.check(lib.cp_conv3x3_halo_item(C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                            o.data_ptr() if inplace else None, o.data_ptr(), C.byref(it)), "halo item")
+        assert it.NT == (cop + 15) // 16 and it.blocks == B * ((H + 7) // 8) * ((W + 15) // 16)
+        items.append(it)
+        outs.append(o)
+        keep += [xin, pw, wd, sc, sh, d]
+    arr = (CpConvGroupItem * len(items))(*items)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    pre = [0]
+    for it in items:
+        pre.append(pre[-1] + it.blocks)
+    prefix = torch.tensor(pre, dtype=torch.int32, device=dev())
+    _abi.check(lib.cp_conv3x3_halo_group(st(), dtype, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1], max(it.lds_bytes for it in items)),
+               "halo group")
+    torch.cuda.synchronize()
+    for n, (a, o) in enumerate(zip(want, outs)):
+        assert torch.equal(a.view(torch.uint8), o.view(torch.uint8)), cases[n]
+    d.H = d.W = d.Ho = d.Wo = 8                             # 8 x 8 map: not for the grouped kernel (nor for cp_conv3x3_halo's tiles)
+    it = CpConvGroupItem()
+    assert lib.cp_conv3x3_halo_item(C.byref(d), keep[0].data_ptr(), keep[1].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), None,
+                                    outs[0].data_ptr(), C.byref(it)) != 0
+    assert lib.cp_conv3x3_halo_group_supported(dtype, 8, 8, 24) == 0 and lib.cp_conv3x3_halo_group_supported(dtype, 16, 16, 144) == 0
+    assert lib.cp_conv3x3_halo_group_supported(dtype, 16, 16, 72) == 1
+    assert lib.cp_conv3x3_halo_group(st(), dtype, raw.data_ptr(), prefix.data_ptr(), 17, pre[-1], items[0].lds_bytes) != 0
+
+
 SEG_CASES = [  # (B, Cin, H, W, S)
     (2, 256, 16, 32, 2),     # exact tiles
     (1, 64, 13, 21, 2),      # ragged tile rows / cols (masked stores, lanes past the image still shuffle)
