@@ -774,16 +774,18 @@ static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, 
   *G = Cphys / E;
   if (*G > 256) return CP_ERR_INVALID;
   *RL = 256 / *G;
-  static const int max_blocks = cp_knob("CP_BN_ACC_BLOCKS") ? atoi(cp_knob("CP_BN_ACC_BLOCKS")) : 512;
+  static const int max_blocks = cp_knob("CP_BN_ACC_BLOCKS") ? atoi(cp_knob("CP_BN_ACC_BLOCKS")) : 256;
   static const int rows_per_block = cp_knob("CP_BN_ACC_ROWS") ? atoi(cp_knob("CP_BN_ACC_ROWS")) : 64;
   int nb = M / rows_per_block;                            // as many blocks as the partial-sum variant ...
   int cap = 65536 / (2 * Cphys);                          // ... but at most ~64k atomics per launch (~30 G atomics/s)
   // ... unless the tensor is big: 128 blocks on 256 CUs streamed the 64 x 64 x 256-channel maps of layer1 at 3.5 TB/s (57 us per
-  // backward pass); from `elems_per_block` elements per block on, more blocks pay for their atomics
-  static const long long elems_per_block = cp_knob("CP_BN_ACC_ELEMS") ? atoll(cp_knob("CP_BN_ACC_ELEMS")) : 65536;
+  // backward pass); from `elems_per_block` elements per block on, more blocks pay for their atomics.  Measured on the B = 32 training
+  // step (KNOBS=1 build): narrow layers 512 -> 256 blocks -0.55 ms, big-tensor rule at 16 K elements / <= 768 blocks another -0.4 ms
+  static const long long elems_per_block = cp_knob("CP_BN_ACC_ELEMS") ? atoll(cp_knob("CP_BN_ACC_ELEMS")) : 16384;
+  static const int big_blocks = cp_knob("CP_BN_ACC_BIGBLOCKS") ? atoi(cp_knob("CP_BN_ACC_BIGBLOCKS")) : 768;
   const long long by_size = (long long)M * Cphys / elems_per_block;
-  if (by_size > cap) cap = (int)(by_size > max_blocks ? max_blocks : by_size);
   cap = cap < 32 ? 32 : (cap > max_blocks ? max_blocks : cap);
+  if (by_size > cap) cap = (int)(by_size > big_blocks ? big_blocks : by_size);
   nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
   *rpb = (M + nb - 1) / nb;
   *nblk = (M + *rpb - 1) / *rpb;
@@ -858,19 +860,34 @@ __device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_c
   }
 }
 
+// a piece's operands are fetched BEFORE the coefficient prologue (whose accumulator loads are a memory round trip of their own): the
+// two latencies overlap instead of adding up -- these launches are a few microseconds long
 template <typename Tag>
-__device__ __forceinline__ void bn_apply_piece(const BnApplyParams& p, const float* s_coef, size_t i) {      // piece i of M * G
+struct BnApplyOperands { u32x4 x, r; };
+
+template <typename Tag>
+__device__ __forceinline__ void bn_apply_fetch(const BnApplyParams& p, size_t i, BnApplyOperands<Tag>& o) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const int g = (int)(i % p.G);
+  const size_t m = i / p.G;
+  o.x = *(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E);
+  if (p.res) o.r = *(const u32x4*)((const T*)p.res + m * p.r_cs + p.r_coff + g * E);
+}
+
+template <typename Tag>
+__device__ __forceinline__ void bn_apply_finish(const BnApplyParams& p, const float* s_coef, size_t i, const BnApplyOperands<Tag>& o) {
   constexpr int E = Tag::E;
   using T = typename Tag::elem;
   const int Cphys = p.G * E;
   const int g = (int)(i % p.G);
   const size_t m = i / p.G;
   float v[E], r[E];
-  Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E), v);
+  Vec16<Tag>::unpack(o.x, v);
 #pragma unroll
   for (int j = 0; j < E; ++j) v[j] = v[j] * s_coef[g * E + j] + s_coef[Cphys + g * E + j];
   if (p.res) {
-    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.res + m * p.r_cs + p.r_coff + g * E), r);
+    Vec16<Tag>::unpack(o.r, r);
 #pragma unroll
     for (int j = 0; j < E; ++j) v[j] += r[j];
   }
@@ -883,12 +900,26 @@ __device__ __forceinline__ void bn_apply_piece(const BnApplyParams& p, const flo
 }
 
 template <typename Tag>
+__device__ __forceinline__ void bn_apply_piece(const BnApplyParams& p, const float* s_coef, size_t i) {      // piece i of M * G
+  BnApplyOperands<Tag> o;
+  bn_apply_fetch<Tag>(p, i, o);
+  bn_apply_finish<Tag>(p, s_coef, i, o);
+}
+
+template <typename Tag>
+__device__ __forceinline__ void bn_apply_block(const BnApplyParams& p, float* s_coef, unsigned bid) {
+  const size_t i = (size_t)bid * 256 + threadIdx.x;   // over M*G
+  BnApplyOperands<Tag> o;
+  if (i < p.total) bn_apply_fetch<Tag>(p, i, o);
+  bn_apply_coef<Tag>(p, s_coef, bid == 0);
+  __syncthreads();
+  if (i < p.total) bn_apply_finish<Tag>(p, s_coef, i, o);
+}
+
+template <typename Tag>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
   extern __shared__ float s_coef[];
-  bn_apply_coef<Tag>(p, s_coef, blockIdx.x == 0);
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M*G
-  if (i < p.total) bn_apply_piece<Tag>(p, s_coef, i);
+  bn_apply_block<Tag>(p, s_coef, blockIdx.x);
 }
 
 // ---- statistics + apply in ONE launch (the training step runs ~670 such pairs of 6-13 us launches): every block adds its rows'
@@ -1034,23 +1065,38 @@ __device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s
 }
 
 template <typename Tag>
-__device__ __forceinline__ void bn_bwd_piece(const BnBwdParams& p, const float* s_cf, size_t i) {
+struct BnBwdOperands { u32x4 dy, y, dres, x; };
+
+template <typename Tag>
+__device__ __forceinline__ void bn_bwd_fetch(const BnBwdParams& p, size_t i, BnBwdOperands<Tag>& o) {
+  constexpr int E = Tag::E;
+  using T = typename Tag::elem;
+  const int g = (int)(i % p.G);
+  const size_t m = i / p.G;
+  o.dy = *(const u32x4*)((const T*)p.dy + m * p.dy_cs + p.dy_coff + g * E);
+  if (p.y) o.y = *(const u32x4*)((const T*)p.y + m * p.y_cs + p.y_coff + g * E);
+  if (p.dres && p.dr_acc) o.dres = *(const u32x4*)((const T*)p.dres + m * p.dr_cs + p.dr_coff + g * E);
+  if (p.x) o.x = *(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E);
+}
+
+template <typename Tag>
+__device__ __forceinline__ void bn_bwd_finish(const BnBwdParams& p, const float* s_cf, size_t i, const BnBwdOperands<Tag>& ops) {
   constexpr int E = Tag::E;
   using T = typename Tag::elem;
   const int Cphys = p.G * E;
   const int g = (int)(i % p.G);
   const size_t m = i / p.G;
   float dz[E], t[E];
-  Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.dy + m * p.dy_cs + p.dy_coff + g * E), dz);
+  Vec16<Tag>::unpack(ops.dy, dz);
   if (p.y) {
-    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.y + m * p.y_cs + p.y_coff + g * E), t);
+    Vec16<Tag>::unpack(ops.y, t);
 #pragma unroll
     for (int j = 0; j < E; ++j) dz[j] = t[j] > 0.f ? dz[j] : dz[j] * p.slope;
   }
   if (p.dres) {
     float o[E];
     if (p.dr_acc) {
-      Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.dres + m * p.dr_cs + p.dr_coff + g * E), o);
+      Vec16<Tag>::unpack(ops.dres, o);
 #pragma unroll
       for (int j = 0; j < E; ++j) o[j] += dz[j];
     } else {
@@ -1062,7 +1108,7 @@ __device__ __forceinline__ void bn_bwd_piece(const BnBwdParams& p, const float* 
   float o[E];
   if (p.x) {
     float xv[E];
-    Vec16<Tag>::unpack(*(const u32x4*)((const T*)p.x + m * p.x_cs + p.x_coff + g * E), xv);
+    Vec16<Tag>::unpack(ops.x, xv);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
       const int c = g * E + j;
@@ -1076,12 +1122,26 @@ __device__ __forceinline__ void bn_bwd_piece(const BnBwdParams& p, const float* 
 }
 
 template <typename Tag>
+__device__ __forceinline__ void bn_bwd_piece(const BnBwdParams& p, const float* s_cf, size_t i) {
+  BnBwdOperands<Tag> o;
+  bn_bwd_fetch<Tag>(p, i, o);
+  bn_bwd_finish<Tag>(p, s_cf, i, o);
+}
+
+template <typename Tag>
+__device__ __forceinline__ void bn_bwd_block(const BnBwdApplyParams& pp, float* s_cf, unsigned bid) {
+  const size_t i = (size_t)bid * 256 + threadIdx.x;
+  BnBwdOperands<Tag> o;
+  if (i < pp.q.total) bn_bwd_fetch<Tag>(pp.q, i, o);        // all loads (dx / dres may alias dy: in place) before any store of this thread
+  bn_bwd_coef<Tag>(pp, s_cf, bid == 0);
+  __syncthreads();
+  if (i < pp.q.total) bn_bwd_finish<Tag>(pp.q, s_cf, i, o);
+}
+
+template <typename Tag>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyParams pp) {
   extern __shared__ float s_cf[];
-  bn_bwd_coef<Tag>(pp, s_cf, blockIdx.x == 0);
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < pp.q.total) bn_bwd_piece<Tag>(pp.q, s_cf, i);
+  bn_bwd_block<Tag>(pp, s_cf, blockIdx.x);
 }
 
 // backward twin of bn_fused_fwd_kernel: sums of dz and dz * xhat over this block's rows -> barrier -> dx in place over the same rows
@@ -1170,17 +1230,11 @@ __global__ __launch_bounds__(256) void bn_group_kernel(const CpBnItem* __restric
   } else if constexpr (KIND == CP_BN_ITEM_APPLY) {
     extern __shared__ float s_coef[];
     const BnApplyParams p = it->ap;
-    bn_apply_coef<Tag>(p, s_coef, bid == 0);
-    __syncthreads();
-    const size_t i = (size_t)bid * 256 + threadIdx.x;
-    if (i < p.total) bn_apply_piece<Tag>(p, s_coef, i);
+    bn_apply_block<Tag>(p, s_coef, bid);
   } else {
     extern __shared__ float s_coef[];
     const BnBwdApplyParams p = it->bp;
-    bn_bwd_coef<Tag>(p, s_coef, bid == 0);
-    __syncthreads();
-    const size_t i = (size_t)bid * 256 + threadIdx.x;
-    if (i < p.q.total) bn_bwd_piece<Tag>(p.q, s_coef, i);
+    bn_bwd_block<Tag>(p, s_coef, bid);
   }
 }
 
