@@ -134,9 +134,13 @@ def _profile_steps(path):
     """forwards covered by a committed kernel summary: the stats run is `bench.py --steps 5` = 5 timed + 3 warm-up + 1 program
     build forward = 9 (every decoder launch appears exactly twice per forward: calls of the dominant kernel / 2)"""
     import csv
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    for r in rows:
         if r["kernel"].startswith("conv3x3_halo4_kernel<BF16Tag, false, true"):
             return max(int(r["calls"]) // 2, 1)
+    for r in rows:                                  # a bench_train.py summary: three code losses (roi, x bits, y bits) per training step
+        if r["kernel"] == "code_loss_kernel":
+            return max(int(r["calls"]) // 3, 1)
     return 9
 
 

@@ -183,13 +183,15 @@ def main():
             ms = sum(t for _, t in w3)
             fl = sum(prog.wgrad_flops[i] for i, _ in w3)
             big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
-            from bench import committed_profile
-            tr = [committed_profile(k, "train_%s_b%d" % (a.dtype, B))[0] for k in ("wgrad3x3_kernel", "wgrad_reduce_batch_kernel")]
-            out["roofline"] = {"bound": "mfma", "kernel": "wgrad3x3_kernel (%d launches per step; their pixel-slice partials are summed by the batched wgrad_reduce launches)" % len(w3),
+            from bench import _profile_prefix_mb_per_step
+            n_single = sum(1 for i, _ in w3 if not prog.calls[i][2].startswith("wgrad_group"))
+            tr, trf = _profile_prefix_mb_per_step("wgrad", "train_%s_b%d" % (a.dtype, B))
+            out["roofline"] = {"bound": "mfma", "kernel": "all-taps 3x3 weight gradient: wgrad3x3_kernel (%d single launches per step, the layers above %g GFLOP) + "
+                                                          "wgrad_group_kernel (%d grouped launches: the smaller layers, several per launch); the pixel-slice partials "
+                                                          "are summed by the batched wgrad_reduce launches" % (n_single, prog.wg_group_flops / 1e9, len(w3) - n_single),
                                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
-                               "traffic": round(sum(tr), 2) if all(t is not None for t in tr) else None,
-                               "traffic_unit": "MB of HBM read+write per launch pair (rocprofv3 PMC, profiles/)",
+                               "traffic": tr, "traffic_unit": "MB of HBM read+write per STEP, all weight-gradient kernels incl. the reductions (rocprofv3 PMC, %s)" % trf,
                                "algorithmic_gflop_per_step": round(fl / 1e9, 1), "ms_per_step": round(ms, 3),
                                "largest_launch": {"name": prog.calls[big[0]][2], "gflop": round(prog.wgrad_flops[big[0]] / 1e9, 1),
                                                   "us": round(big[1] * 1e3, 1),

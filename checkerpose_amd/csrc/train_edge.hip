@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void edge_train_fwd_kernel(const EdgeTrainPara
 template <typename Tag, int TPK>
 __global__ __launch_bounds__(256) void edge_train_bwd_kernel(const EdgeTrainParams p) {
   constexpr int E = Tag::E, KPB = 256 / TPK, C = TPK * E;
+  constexpr int RU = 6;      // reverse edges in flight: 222 VGPRs, still two waves per SIMD (8: 256+ VGPRs, one wave)
   using T = typename Tag::elem;
   extern __shared__ __attribute__((aligned(16))) int32_t s_idx3[];
   int b, sidx, g;
@@ -277,20 +278,20 @@ __global__ __launch_bounds__(256) void edge_train_bwd_kernel(const EdgeTrainPara
 #pragma unroll
     for (int e = 0; e < E; ++e) { G[e] = 0.f; R[e] = 0.f; }
     const int e0 = rp[j], e1 = rp[j + 1];
-    for (int t0 = e0; t0 < e1; t0 += 4) {    // four reverse edges in flight (edge id -> three rows + the arg-max bytes: two dependent trips each)
-      int ei[4], kk[4];
-      bool ok[4];
+    for (int t0 = e0; t0 < e1; t0 += RU) {    // RU reverse edges in flight (edge id -> three rows + the arg-max bytes: two dependent trips each)
+      int ei[RU], kk[RU];
+      bool ok[RU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RU; ++u) {
         ok[u] = t0 + u < e1;
         const int eid = re[ok[u] ? t0 + u : e1 - 1];
         ei[u] = eid / p.K;
         kk[u] = eid - ei[u] * p.K;
       }
-      u32x4 rq[4], rg[4], ro[4];
-      uint8_t ks[4][E];
+      u32x4 rq[RU], rg[RU], ro[RU];
+      uint8_t ks[RU][E];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RU; ++u) {
         const size_t ni = (size_t)b * p.N + ei[u];
         rq[u] = rows[(size_t)ei[u] * (2 * TPK) + TPK + cg];
         rg[u] = *(const u32x4*)((const T*)p.gout + ni * p.g_cs + p.g_coff + cg * E);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void edge_train_bwd_kernel(const EdgeTrainPara
         else { const uint32_t v = *(const uint32_t*)kp; memcpy(ks[u], &v, 4); }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RU; ++u) {
         if (!ok[u]) continue;
         float gi[E], oi[E];
         Vec16<Tag>::unpack(rq[u], f);

@@ -200,12 +200,17 @@ struct WgradReduceParams {
   int S, GY, co_blocks, ci_blocks, R, Ssz, Cout, Cin, taps_in_block;   // taps_in_block: 9 (all-taps kernel) or 1
   long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
 };
+// slice lanes per dw element: 16 for layers cut into many slices; the grouped launches cut most layers into 1-8 slices, where 16
+// lanes per element left 15 of 16 threads idle and the step's reductions ran 1.3 M blocks of 16 elements at < 1 TB/s
+__host__ __device__ __forceinline__ int wgrad_reduce_lanes(int S) { return S >= 16 ? 16 : (S > 8 ? 16 : (S > 4 ? 8 : (S > 2 ? 4 : (S > 1 ? 2 : 1)))); }
+
 __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceParams& p, unsigned block) {
-  // block = 16 consecutive dw elements (ci fastest: 64-byte reads) x 16 slice lanes; the lanes stride over the slices
-  // (a serial loop over up to 512 slices per element was latency-bound), then an LDS tree adds the 16 partial sums
-  __shared__ float red[16][17];
-  const int e = threadIdx.x & 15, sl0 = threadIdx.x >> 4;
-  const size_t i = (size_t)block * 16 + e;
+  // block = EPB = 256 / L consecutive dw elements (ci fastest: coalesced reads of the 64-float tile rows) x L slice lanes; the lanes
+  // stride over the slices (a serial loop over up to 512 slices per element was latency-bound), then the L partial sums are added
+  __shared__ float red[272];
+  const int L = wgrad_reduce_lanes(p.S), EPB = 256 / L;
+  const int e = threadIdx.x % EPB, sl0 = threadIdx.x / EPB;
+  const size_t i = (size_t)block * EPB + e;
   const size_t total = (size_t)p.R * p.Ssz * p.Cout * p.Cin;
   const bool ok = i < total;
   const size_t ii = ok ? i : 0;
@@ -226,28 +231,31 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceParams& p, u
   }
   off += (size_t)(co & 63) * 64 + (ci & 63);
   // 8 slices' loads in flight per lane (one dependent load per iteration made the kernel a chain of memory latencies: 16
-  // round trips at 256 slices); the additions stay in slice order, so the sum does not depend on the unroll factor
+  // round trips at 256 slices); the order of the additions is fixed by S alone
   float acc = 0.f;
   if (ok) {
     int sl = sl0;
-    for (; sl + 7 * 16 < p.S; sl += 8 * 16) {
+    for (; sl + 7 * L < p.S; sl += 8 * L) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p.ws[off + (size_t)(sl + 16 * u) * stride];
+      for (int u = 0; u < 8; ++u) v[u] = p.ws[off + (size_t)(sl + L * u) * stride];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; sl < p.S; sl += 16) acc += p.ws[off + (size_t)sl * stride];
+    for (; sl < p.S; sl += L) acc += p.ws[off + (size_t)sl * stride];
   }
-  red[sl0][e] = acc;
+  float* dst = p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / p.Ssz) * p.dw_sr +
+               (long long)(tap % p.Ssz) * p.dw_ss;
+  if (L == 1) {                      // block-uniform
+    if (ok) *dst += acc;
+    return;
+  }
+  red[sl0 * (EPB + 1) + e] = acc;
   __syncthreads();
   if (sl0 == 0 && ok) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += red[k][e];
-    float* dst = p.dw + p.dw_base + (long long)co * p.dw_sco + (long long)ci * p.dw_sci + (long long)(tap / p.Ssz) * p.dw_sr +
-                 (long long)(tap % p.Ssz) * p.dw_ss;
-    *dst += s;
+    float s_ = 0.f;
+    for (int k = 0; k < L; ++k) s_ += red[k * (EPB + 1) + e];
+    *dst += s_;
   }
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams p) { wgrad_reduce_block(p, blockIdx.x); }
@@ -554,7 +562,8 @@ static int launch_reduce(hipStream_t st, const float* ws, float* dw, int S, int 
     memcpy(item, &r, sizeof(r));
     return CP_OK;
   }
-  CP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, r);
+  const size_t epb = 256 / wgrad_reduce_lanes(S);
+  CP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + epb - 1) / epb)), dim3(256), 0, st, r);
   return cp_check_launch();
 }
 
@@ -610,7 +619,8 @@ extern "C" int cp_wgrad_reduce_batch(cp_stream_t stream, const CpWgradReduceItem
 
 extern "C" uint32_t cp_wgrad_reduce_item_blocks(const CpWgradReduceItem* item) {
   if (!item || !item->ws) return 0;
-  return (uint32_t)(((size_t)item->R * item->Ssz * item->Cout * item->Cin + 15) / 16);
+  const size_t epb = 256 / wgrad_reduce_lanes(item->S);
+  return (uint32_t)(((size_t)item->R * item->Ssz * item->Cout * item->Cin + epb - 1) / epb);
 }
 
 // mode 3: nothing is launched; *citem describes the partial-sum launch (for cp_wgrad_group), *item the reduction it owes.
