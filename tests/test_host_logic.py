@@ -59,3 +59,25 @@ def test_ransac_stopping_rule_known_values():
     assert needed_iterations(4, 100, 5, 150) == 150                 # fewer inliers than a sample: keep going
     assert needed_iterations(30, 100, 5, 150) == 150                # 0.3^5: would need 1893 > max
     assert needed_iterations(50, 100, 4, 150) == 71
+
+
+def test_optimizers_refuse_cpu_tensors_and_keep_torch_defaults():
+    """checkerpose_amd.optim.Adam / SGD are HIP launches: parameters on the CPU raise (no torch fallback); the constructor takes the
+    reference's arguments (train.py:244-246) and the param_groups carry torch's keys so state_dicts travel both ways"""
+    import pytest
+    from checkerpose_amd import optim as O
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    for opt in (O.Adam([p], lr=1e-3), O.SGD([p], lr=0.1, momentum=0.9)):
+        with pytest.raises(RuntimeError, match="one GPU only"):
+            opt.step()
+        assert torch.equal(p.detach(), torch.zeros(8))                        # untouched
+        opt.zero_grad()
+        assert p.grad is None
+        p.grad = torch.ones(8)
+    ga, gt = O.Adam([p], lr=2e-4).param_groups[0], torch.optim.Adam([p], lr=2e-4).param_groups[0]
+    assert {k: ga[k] for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize")} == {k: gt[k] for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize")}
+    gs, gu = O.SGD([p], lr=0.1, momentum=0.9).param_groups[0], torch.optim.SGD([p], lr=0.1, momentum=0.9).param_groups[0]
+    assert {k: gs[k] for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")} == {k: gu[k] for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")}
+    with pytest.raises(ValueError):
+        O.Adam([p], lr=-1.0)
