@@ -482,7 +482,9 @@ class TrainProgram(Program):
                 m["need"] = (int(ri.S) * int(ri.GY) * int(ri.taps_in_block) * 4096 * 4 + 255) // 256 * 256 if ri.ws else 0
                 m["blocks"] = int(ci.blocks)
         need_all = sum(m["need"] for m in pend)
-        assert need_all <= asz, "weight-gradient arena smaller than one group's partial tiles"
+        if need_all > asz:
+            raise RuntimeError("checkerpose_amd: the weight-gradient arena (%d MB, CHECKERPOSE_AMD_WGRAD_ARENA_MB) is smaller than the partial "
+                               "tiles of one group of layers (%d MB)" % (asz >> 20, (need_all >> 20) + 1))
         if self._wg_off + need_all > asz:     # the reductions owed so far (their producers are all emitted) free the arena
             self._flush_wgrad_reduce()
         for kind in kinds:
