@@ -52,6 +52,7 @@ class CpBnItem(C.Structure):          # one layer's pass in a grouped BatchNorm 
 
 
 CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16, CP_WGRAD_ITEM_GENERIC_F32 = 0, 1, 2, 3
+CP_WGRAD_ITEM_3X3_S2_SMALL = 4
 
 
 class CpWgradItem(C.Structure):       # one layer's partial-sum launch in a grouped weight-gradient launch (params is opaque)

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradRedu
 // layer's channels (18/36-channel HRNet branches) skip the MFMAs but keep staging.
 struct Wgrad3Params {
   const void* dy; const void* x; float* dw;
-  int H, W, TH, TW, tiles_x, tiles_img, n_tiles, tiles_per_block;
+  int H, W, TH, TW, tiles_x, tiles_img, n_tiles, tiles_per_block;   // H, W: the OUTPUT map (dy); tiles of TH x TW = 64 output pixels
+  int Hi, Wi;                                                        // the input map (x): H, W at stride 1, 2H, 2W at stride 2
   int Cout, dy_cs, dy_coff, Cin, x_cs, x_coff;
   int co_blocks, ci_blocks;
   long long dw_base, dw_sco, dw_sci, dw_sr, dw_ss;
@@ -333,8 +334,8 @@ __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p, const unsig
         if (row < HR) {
           const int hy = row / TW2, hx = row - hy * TW2;
           const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            rx[i] = *(const u32x4*)((const uint16_t*)p.x + ((size_t)(b * p.H + iy) * p.W + ix) * p.x_cs + p.x_coff + ci0 + pc * 8);
+          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+            rx[i] = *(const u32x4*)((const uint16_t*)p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_coff + ci0 + pc * 8);
         }
       }
     }
@@ -434,15 +435,18 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const Wgrad3Params p) { w
 // the four waves split the nine TAPS of the single 32 x 32 quadrant (wave w: taps w, w+4, w+8), rows are 32 channels wide
 // (pitch 96 B: 8 consecutive rows still fall on disjoint bank octets), 12 accumulator tiles per wave -> ~100 VGPRs and
 // 25 KB of LDS, so several blocks share a CU and hide each other's global -> LDS latency.
+// STRIDE 2 (round 3: the 18 -> 18 down-sampling convs of the fuse layers): the x halo of a tile is (2 TH + 1) x (2 TW + 1) input pixels
+// (TW <= 16: <= 297 rows), an output pixel's operand row for tap (r, s) is halo row (2 y + r, 2 x + s) -- still a per-lane row address.
+template <int STRIDE>
 __device__ __forceinline__ void wgrad3x3_small_body(const Wgrad3Params& p, const unsigned bx) {
-  constexpr int PITCH = 96, XROWS = 200, NX = 4;
+  constexpr int PITCH = 96, XROWS = STRIDE == 1 ? 200 : 304, NX = STRIDE == 1 ? 4 : 5;
   __shared__ __attribute__((aligned(16))) unsigned char lds[(64 + XROWS) * PITCH];
   unsigned char* ldy = lds;
   unsigned char* lx = lds + 64 * PITCH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xl = lane & 15, g = lane >> 4, q = xl >> 2, pp = xl & 3;
-  const int TW2 = p.TW + 2, HR = (p.TH + 2) * TW2;
+  const int TW2 = STRIDE * (p.TW - 1) + 3, HR = (STRIDE * (p.TH - 1) + 3) * TW2;
   const int t_begin = (int)bx * p.tiles_per_block;
   const int t_end = min(t_begin + p.tiles_per_block, p.n_tiles);
   const int prow = tid >> 2, pc = tid & 3;              // 4 pieces (32 channels) per row
@@ -466,9 +470,9 @@ __device__ __forceinline__ void wgrad3x3_small_body(const Wgrad3Params& p, const
         const int row = i * 64 + prow;
         if (row < HR) {
           const int hy = row / TW2, hx = row - hy * TW2;
-          const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            rx[i] = *(const u32x4*)((const uint16_t*)p.x + ((size_t)(b * p.H + iy) * p.W + ix) * p.x_cs + p.x_coff + pc * 8);
+          const int iy = STRIDE * ty0 - 1 + hy, ix = STRIDE * tx0 - 1 + hx;
+          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+            rx[i] = *(const u32x4*)((const uint16_t*)p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_coff + pc * 8);
         }
       }
     }
@@ -499,7 +503,7 @@ __device__ __forceinline__ void wgrad3x3_small_body(const Wgrad3Params& p, const
 #pragma unroll
     for (int sc = 0; sc < 2; ++sc) {
       const int p_lo = sc * 32 + 4 * g + q, p_hi = p_lo + 16;
-      const int h_lo = (p_lo / p.TW) * TW2 + (p_lo % p.TW), h_hi = (p_hi / p.TW) * TW2 + (p_hi % p.TW);
+      const int h_lo = STRIDE * ((p_lo / p.TW) * TW2 + (p_lo % p.TW)), h_hi = STRIDE * ((p_hi / p.TW) * TW2 + (p_hi % p.TW));
       bf16x8 fa[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -547,7 +551,8 @@ __device__ __forceinline__ void wgrad3x3_small_body(const Wgrad3Params& p, const
   }
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Params p) { wgrad3x3_small_body(p, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void wgrad3x3_small_kernel(const Wgrad3Params p) { wgrad3x3_small_body<1>(p, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void wgrad3x3_s2_small_kernel(const Wgrad3Params p) { wgrad3x3_small_body<2>(p, blockIdx.x); }
 
 // mode 0: partial kernel + its reduction (cp_conv2d_wgrad_ws); 1: partial kernel only, *item = the reduction still owed
 // (cp_conv2d_wgrad_deferred); 2: no launch at all, *item as mode 1 would fill it (cp_conv2d_wgrad_plan)
@@ -593,12 +598,29 @@ extern "C" int cp_conv2d_wgrad_plan(const CpWgradDesc* d, const void* dy, const 
   return wgrad_impl(nullptr, d, dy, x, dw, workspace, workspace_bytes, 2, item);
 }
 
+// 3x3 / pad 1 layers in bf16 on power-of-two OUTPUT maps, stride 1 (same size) or 2 (half size): the all-taps kernels.  TW x TH = 64
+// output pixels per tile; stride 2 keeps TW <= 16 so that the (2 TH + 1) x (2 TW + 1) input halo fits the LDS rows.
+static bool wgrad_all_taps(const CpWgradDesc* d, int* TW_out, int* TH_out) {
+  if (d->dtype != CP_BF16 || d->R != 3 || d->S != 3 || d->pad != 1 || cp_knob("CP_WGRAD_GENERIC")) return false;
+  const bool s1 = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
+  // stride 2: only the <= 32 x 32-channel layers -- measured on the training step, the one-block-per-CU kernel on the wider stride-2
+  // layers (18 -> 36 .. 72 -> 144, 3 -> 64: mostly padding in 64 x 64 channel tiles) lost 0.2 ms against the per-tap kernel, whose
+  // re-reads the L2 absorbs; that variant was removed again
+  const bool s2 = d->stride == 2 && d->H == 2 * d->Ho && d->W == 2 * d->Wo && d->Cout <= 32 && d->Cin <= 32 && !cp_knob("CP_WGRAD_NO_S2");
+  if (!s1 && !s2) return false;
+  if (d->Wo < 8 || (d->Wo & (d->Wo - 1))) return false;
+  const int cap = s1 ? 64 : 16;
+  const int TW = d->Wo < cap ? d->Wo : cap, TH = 64 / TW;
+  if (d->Ho % TH) return false;
+  if (TW_out) { *TW_out = TW; *TH_out = TH; }
+  return true;
+}
+
 extern "C" size_t cp_conv2d_wgrad_scratch_bytes(const CpWgradDesc* d) {
   if (!d || d->Cout <= 0 || d->Cin <= 0 || d->R <= 0 || d->S <= 0) return 0;
   const size_t cob = (d->Cout + 63) / 64, cib = (d->Cin + 63) / 64;
   // the slice counts the launchers aim for (512 / 256 / 1024 blocks over the tile grid) times one slice of 64 x 64 fp32 tiles
-  const bool taps9 = d->dtype == CP_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W &&
-                     d->W >= 8 && (d->W & (d->W - 1)) == 0 && d->H % (64 / (d->W < 64 ? d->W : 64)) == 0;
+  const bool taps9 = wgrad_all_taps(d, nullptr, nullptr);
   if (taps9) {
     const size_t tb = cob * cib, per_slice = tb * 9 * 4096 * sizeof(float);
     const size_t S = (d->Cout <= 32 && d->Cin <= 32) ? 512 : (256 / tb ? 256 / tb : 1);
@@ -642,14 +664,14 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
   if (!cp_aligned16(dy) || !cp_aligned16(x) || ((uintptr_t)dw & 3)) return CP_ERR_ALIGN;
   const long long M = (long long)d->B * d->Ho * d->Wo;
   if (M >= (1LL << 31) || (long long)d->B * d->H * d->W >= (1LL << 31)) return CP_ERR_RANGE;
-  // 3x3 / s1 / p1 in bf16 on power-of-two maps: all-taps kernel
-  if (d->dtype == CP_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W &&
-      d->W >= 8 && (d->W & (d->W - 1)) == 0 && !cp_knob("CP_WGRAD_GENERIC")) {
-    const int TW = d->W < 64 ? d->W : 64, TH = 64 / TW;
-    if (d->H % TH == 0) {
+  // 3x3 / p1 in bf16 on power-of-two maps, stride 1 or 2: all-taps kernels
+  int TW, TH;
+  if (wgrad_all_taps(d, &TW, &TH)) {
+    {
+      const bool s2 = d->stride == 2;
       Wgrad3Params q;
-      q.dy = dy; q.x = x; q.dw = dw; q.H = d->H; q.W = d->W; q.TH = TH; q.TW = TW;
-      q.tiles_x = d->W / TW; q.tiles_img = q.tiles_x * (d->H / TH); q.n_tiles = d->B * q.tiles_img;
+      q.dy = dy; q.x = x; q.dw = dw; q.H = d->Ho; q.W = d->Wo; q.Hi = d->H; q.Wi = d->W; q.TH = TH; q.TW = TW;
+      q.tiles_x = d->Wo / TW; q.tiles_img = q.tiles_x * (d->Ho / TH); q.n_tiles = d->B * q.tiles_img;
       q.Cout = d->Cout; q.dy_cs = d->dy_cstride; q.dy_coff = d->dy_coff; q.Cin = d->Cin; q.x_cs = d->x_cstride; q.x_coff = d->x_coff;
       q.co_blocks = (d->Cout + 63) / 64; q.ci_blocks = (d->Cin + 63) / 64;
       q.dw_base = d->dw_base; q.dw_sco = d->dw_sco; q.dw_sci = d->dw_sci; q.dw_sr = d->dw_sr; q.dw_ss = d->dw_ss;
@@ -671,13 +693,16 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
         if (S < 1) S = 1;
         q.tiles_per_block = (q.n_tiles + S - 1) / S;
         S = (q.n_tiles + q.tiles_per_block - 1) / q.tiles_per_block;
-        if (launch) CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
+        if (launch) {
+          if (s2) CP_LAUNCH(wgrad3x3_s2_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
+          else CP_LAUNCH(wgrad3x3_small_kernel, dim3((unsigned)S, 1), dim3(256), 0, (hipStream_t)stream, q);
+        }
       } else if (launch)
         CP_LAUNCH(wgrad3x3_kernel, dim3((unsigned)S, (unsigned)tb), dim3(256), 0, (hipStream_t)stream, q);
       if (mode == 3) {
         static_assert(sizeof(Wgrad3Params) <= CP_WGRAD_ITEM_BYTES, "CpWgradItem too small");
         memset(citem, 0, sizeof(*citem));
-        citem->kind = small ? CP_WGRAD_ITEM_3X3_SMALL : CP_WGRAD_ITEM_3X3;
+        citem->kind = s2 ? CP_WGRAD_ITEM_3X3_S2_SMALL : (small ? CP_WGRAD_ITEM_3X3_SMALL : CP_WGRAD_ITEM_3X3);      // s2 implies small
         citem->gx = (uint32_t)S; citem->gy = small ? 1u : (uint32_t)tb; citem->blocks = citem->gx * citem->gy;
         memcpy(citem->params, &q, sizeof(q));
       }
@@ -732,7 +757,7 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
 // per block (fixed cost: cold instruction cache, prologue / epilogue of a 400-VGPR block) and every layer cut its pixels into a
 // whole GPU's worth of slices (2.4 GB of partial tiles per step).
 template <int KIND>
-__global__ __launch_bounds__(256, KIND == CP_WGRAD_ITEM_3X3_SMALL ? 2 : 1) void wgrad_group_kernel(const CpWgradItem* __restrict__ items,
+__global__ __launch_bounds__(256, (KIND == CP_WGRAD_ITEM_3X3_SMALL || KIND == CP_WGRAD_ITEM_3X3_S2_SMALL) ? 2 : 1) void wgrad_group_kernel(const CpWgradItem* __restrict__ items,
                                                                                                 const uint32_t* __restrict__ prefix, int n) {
   int lo = 0, hi = n;
   while (hi - lo > 1) {
@@ -744,9 +769,9 @@ __global__ __launch_bounds__(256, KIND == CP_WGRAD_ITEM_3X3_SMALL ? 2 : 1) void 
   if constexpr (KIND == CP_WGRAD_ITEM_3X3) {
     const Wgrad3Params p = *(const Wgrad3Params*)items[lo].params;
     wgrad3x3_body(p, bx, by, gy);
-  } else if constexpr (KIND == CP_WGRAD_ITEM_3X3_SMALL) {
+  } else if constexpr (KIND == CP_WGRAD_ITEM_3X3_SMALL || KIND == CP_WGRAD_ITEM_3X3_S2_SMALL) {
     const Wgrad3Params p = *(const Wgrad3Params*)items[lo].params;
-    wgrad3x3_small_body(p, bx);
+    wgrad3x3_small_body<KIND == CP_WGRAD_ITEM_3X3_SMALL ? 1 : 2>(p, bx);
   } else if constexpr (KIND == CP_WGRAD_ITEM_GENERIC_BF16) {
     const WgradParams p = *(const WgradParams*)items[lo].params;
     wgrad_body<BF16Tag>(p, bx, by, gy);
@@ -773,6 +798,7 @@ extern "C" int cp_wgrad_group(cp_stream_t stream, int kind, const CpWgradItem* i
     case CP_WGRAD_ITEM_3X3_SMALL: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_3X3_SMALL>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
     case CP_WGRAD_ITEM_GENERIC_BF16: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_GENERIC_BF16>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
     case CP_WGRAD_ITEM_GENERIC_F32: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_GENERIC_F32>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
+    case CP_WGRAD_ITEM_3X3_S2_SMALL: CP_LAUNCH(wgrad_group_kernel<CP_WGRAD_ITEM_3X3_S2_SMALL>, dim3(total_blocks), dim3(256), 0, st, items_dev, prefix_dev, n_items); break;
     default: return CP_ERR_INVALID;
   }
   return cp_check_launch();

@@ -16,10 +16,13 @@ import os
 import torch
 
 from . import _abi
-from ._abi import (CpWgradReduceItem, CpWgradItem, CpFuseBwdItem, CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16,
+from ._abi import (CpWgradReduceItem, CpWgradItem, CpFuseBwdItem, CP_WGRAD_ITEM_3X3_S2_SMALL, CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_GENERIC_BF16,
                    CP_WGRAD_ITEM_GENERIC_F32, ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpPackItem, CpWgradDesc, CpBnItem, BN_GROUP_MAX,
                    CP_BN_ITEM_STATS, CP_BN_ITEM_APPLY, CP_BN_ITEM_BWD_SUMS, CP_BN_ITEM_BWD_APPLY)
 from .engine import Act, Program, WeightStore, _rup
+
+
+ALL_TAPS_KINDS = (CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL, CP_WGRAD_ITEM_3X3_S2_SMALL)      # one block = all nine taps
 
 
 class TrainWeightStore(WeightStore):
@@ -105,7 +108,7 @@ class TrainProgram(Program):
         self.wg_group_flops = float(os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_GFLOP", "40")) * 1e9     # bigger layers launch alone
         gb = [int(v) for v in os.environ.get("CHECKERPOSE_AMD_WGRAD_GROUP_BLOCKS", "512,1024,1024").split(",")]
         self.wg_group_blocks = {CP_WGRAD_ITEM_3X3: gb[0], CP_WGRAD_ITEM_3X3_SMALL: gb[1], CP_WGRAD_ITEM_GENERIC_BF16: gb[2],
-                                CP_WGRAD_ITEM_GENERIC_F32: gb[2]}
+                                CP_WGRAD_ITEM_GENERIC_F32: gb[2], CP_WGRAD_ITEM_3X3_S2_SMALL: gb[1]}
         self.wg_reduce_n = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_REDUCE_N", "96"))
         self._wgc_pending = []
         # BatchNorm statistics + apply in ONE launch each way (grid barrier in between): measured SLOWER on MI355X -- 42.3 ms per step
@@ -470,7 +473,7 @@ class TrainProgram(Program):
             ci, ri = CpWgradItem(), CpWgradReduceItem()
             _abi.check(lib.cp_conv2d_wgrad_item(m["dref"], arena, arena, m["dw"], arena, asz, 0, C.byref(ci), C.byref(ri)), "cp_conv2d_wgrad_item")
             m["kind"] = int(ci.kind)
-            m["work"] = m["pix"] * m["cc"] * (1 if ci.kind in (CP_WGRAD_ITEM_3X3, CP_WGRAD_ITEM_3X3_SMALL) else m["taps"])
+            m["work"] = m["pix"] * m["cc"] * (1 if ci.kind in ALL_TAPS_KINDS else m["taps"])
         kinds = sorted({m["kind"] for m in pend})
         for kind in kinds:                    # every layer's share of its launch, and the partial tiles that share needs
             mem = [m for m in pend if m["kind"] == kind]

@@ -480,7 +480,8 @@ int cp_wgrad_reduce_batch(cp_stream_t stream, const CpWgradReduceItem* items_dev
  * the exclusive prefix sum (n_items + 1 entries) of item.blocks.  Results equal the single-layer launches' up to fp32 summation
  * order across slices. */
 #define CP_WGRAD_ITEM_BYTES 160
-enum { CP_WGRAD_ITEM_3X3 = 0, CP_WGRAD_ITEM_3X3_SMALL = 1, CP_WGRAD_ITEM_GENERIC_BF16 = 2, CP_WGRAD_ITEM_GENERIC_F32 = 3 };
+enum { CP_WGRAD_ITEM_3X3 = 0, CP_WGRAD_ITEM_3X3_SMALL = 1, CP_WGRAD_ITEM_GENERIC_BF16 = 2, CP_WGRAD_ITEM_GENERIC_F32 = 3,
+       CP_WGRAD_ITEM_3X3_S2_SMALL = 4 };      /* all-taps kernels: stride 1 (0, 1); stride 2, <= 32 x 32 channels (4) */
 typedef struct CpWgradItem {
   int32_t kind;
   uint32_t blocks, gx, gy;

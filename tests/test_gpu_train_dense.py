@@ -55,7 +55,12 @@ WGRAD_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad)
     (3, 64, 16, 16, 64, 3, 1, 1),
     (1, 256, 8, 8, 256, 3, 1, 1),      # 4x4 channel blocks
     (2, 3, 32, 32, 64, 3, 2, 1),       # stem, 3 input channels
-    (2, 36, 14, 18, 72, 3, 2, 1),      # stride 2, odd-ish sizes
+    (2, 36, 14, 18, 72, 3, 2, 1),      # stride 2, odd-ish sizes (generic per-tap kernel)
+    (2, 18, 64, 64, 18, 3, 2, 1),      # stride 2 on power-of-two maps, <= 32 x 32 channels: all-taps kernel (fuse layers 64 -> 32)
+    (3, 24, 32, 32, 32, 3, 2, 1),      # ... 16 x 16 output
+    (2, 18, 16, 16, 18, 3, 2, 1),      # ... 8 x 8 output (one 8 x 8 tile per image)
+    (3, 18, 32, 32, 72, 3, 2, 1),      # stride 2, wide output: the per-tap kernel
+    (2, 3, 64, 64, 64, 3, 2, 1),       # the stem: 3 input channels
     (2, 144, 8, 8, 18, 1, 1, 0),       # fuse 1x1
     (2, 256, 16, 16, 64, 2, 1, 1),     # patch_generator k=2 pad=1
     (3, 64, 1, 100, 128, 1, 1, 0),     # linear over keypoints, pixel tail
@@ -593,7 +598,7 @@ def test_wgrad_group_equals_the_single_layer_launches(lib, dtype):
     layers = [  # (B, Cin, H, W, Cout, k, stride, pad, share of the workgroups)
         (4, 36, 32, 32, 36, 3, 1, 1, 40), (4, 72, 16, 16, 72, 3, 1, 1, 24), (2, 144, 8, 8, 144, 3, 1, 1, 9), (4, 18, 64, 64, 18, 3, 1, 1, 64),
         (4, 18, 32, 32, 18, 3, 1, 1, 16), (4, 36, 32, 32, 18, 1, 1, 0, 12), (4, 18, 64, 64, 36, 3, 2, 1, 30), (2, 144, 8, 8, 72, 1, 1, 0, 6),
-        (2, 8, 8, 8, 8, 1, 1, 0, 2)]
+        (2, 8, 8, 8, 8, 1, 1, 0, 2), (4, 18, 64, 64, 18, 3, 2, 1, 20), (2, 36, 32, 32, 72, 3, 2, 1, 8), (2, 36, 14, 18, 72, 3, 2, 1, 10)]
     arena = torch.empty(256 << 20, dtype=torch.uint8, device=dev())
     off, keep, comp, red, want, dws = 0, [], {}, [], [], []
     for n, (B, Cin, H, W, Cout, k, stride, pad, share) in enumerate(layers):
@@ -611,8 +616,9 @@ def test_wgrad_group_equals_the_single_layer_launches(lib, dtype):
         _abi.check(lib.cp_conv2d_wgrad_item(C.byref(d), dy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr(), arena.data_ptr() + off, arena.numel() - off,
                                             share, C.byref(ci), C.byref(ri)), "wgrad item")
         assert ci.blocks == ci.gx * ci.gy and ci.blocks > 0
-        if dtype == CP_BF16 and k == 3 and stride == 1:
-            assert ci.kind == (1 if max(Cin, Cout) <= 32 else 0) and ci.blocks <= max(share, ci.gy)      # the share is respected
+        if dtype == CP_BF16 and k == 3 and W % 16 == 0:                      # all-taps kinds: 0 / 1 at stride 1, 4 at stride 2 (narrow layers only)
+            want_kind = (1 if max(Cin, Cout) <= 32 else 0) if stride == 1 else (4 if max(Cin, Cout) <= 32 else 2)
+            assert ci.kind == want_kind and ci.blocks <= max(share, ci.gy) * (9 if want_kind == 2 else 1)
         if ri.ws:
             off += (ri.S * ri.GY * ri.taps_in_block * 4096 * 4 + 255) // 256 * 256
             red.append(ri)
