@@ -249,3 +249,17 @@ def check(code, what=""):
     if code != 0:
         msg = load().cp_strerror(code).decode()
         raise RuntimeError("checkerpose_hip %s failed: %s (code %d)" % (what, msg, code))
+
+
+def device_table(items, blocks, device):
+    """The device-side form of a grouped launch: `items` (ctypes structs of ONE type, the kernels' parameter blocks) as a byte tensor
+    on `device` plus the exclusive prefix sum (len(items) + 1 uint32 entries) of `blocks` (workgroups per item) -- block b of the launch
+    belongs to item k with prefix[k] <= b < prefix[k + 1].  -> (items tensor, prefix tensor, total blocks); keep both tensors alive."""
+    import torch
+    arr = (type(items[0]) * len(items))(*items)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    pre = [0]
+    for nb in blocks:
+        pre.append(pre[-1] + int(nb))
+    prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(device)
+    return raw, prefix, pre[-1]

@@ -446,14 +446,9 @@ class Program:
 
         def argb(P):
             items = [b(P) for b in builders]
-            arr = (CpConvGroupItem * len(items))(*items)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            pre = [0]
-            for it in items:
-                pre.append(pre[-1] + int(it.blocks))
-            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+            raw, prefix, total = _abi.device_table(items, [it.blocks for it in items], self.device)
             self.keep += [raw, prefix]
-            return (dt, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1], max(int(it.lds_bytes) for it in items))
+            return (dt, raw.data_ptr(), prefix.data_ptr(), len(items), total, max(int(it.lds_bytes) for it in items))
         self._add(lib.cp_conv3x3_halo_group, argb, "conv3x3_halo_group:" + names[0] + "+%d" % (len(names) - 1), reads, writes)
         return outs
 

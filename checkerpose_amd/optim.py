@@ -8,8 +8,6 @@ The reference builds `optim.Adam(net.parameters(), lr=learning_rate)` or `optim.
 instead of torch's ~30 multi-tensor launches and ~10 ms of host work per step for the ~1 000 tensors of PoseNet_GNNskip -- the
 training step replays its forward / backward as hipGraphs and had become bound by how fast the host enqueues it
 (`tools/train_cpu_timeline.py`).  fp32 parameters on one GPU; anything else raises (no silent fallback)."""
-import ctypes as C
-
 import torch
 
 from . import _abi
@@ -26,7 +24,7 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
         if cache.get("sig") == sig:
             return cache
         dev = params[0].device
-        items, pre = [], [0]
+        items, nbs = [], []
         lib = _abi.load()
         for p in params:
             if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() \
@@ -40,11 +38,9 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
             it.p, it.g, it.n, it.step0 = p.data_ptr(), p.grad.data_ptr(), p.numel(), self._step0.get(p, 0)
             self._fill_state_ptrs(it, st)
             items.append(it)
-            pre.append(pre[-1] + int(lib.cp_opt_item_blocks(p.numel())))
-        arr = (CpOptItem * len(items))(*items)
-        cache.update(sig=sig, n=len(items), blocks=pre[-1],
-                     raw=torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev),
-                     prefix=torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(dev))
+            nbs.append(lib.cp_opt_item_blocks(p.numel()))
+        raw, prefix, total = _abi.device_table(items, nbs, dev)
+        cache.update(sig=sig, n=len(items), blocks=total, raw=raw, prefix=prefix)
         return cache
 
     def state_dict(self):

@@ -318,14 +318,9 @@ class TrainProgram(Program):
         """builders: callables P -> CpBnItem, run when the workspace is planned (pointers are final then)"""
         def argb(P):
             items = [b(P) for b in builders]
-            arr = (CpBnItem * len(items))(*items)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            pre = [0]
-            for it in items:
-                pre.append(pre[-1] + int(it.blocks))
-            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+            raw, prefix, total = _abi.device_table(items, [it.blocks for it in items], self.device)
             self.keep += [raw, prefix]
-            return (self.dtype, kind, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1], max(int(it.lds_bytes) for it in items))
+            return (self.dtype, kind, raw.data_ptr(), prefix.data_ptr(), len(items), total, max(int(it.lds_bytes) for it in items))
         self._add(self.lib.cp_bn_group, argb, name, reads, writes)
 
     def bn_train_group(self, members):
@@ -515,14 +510,9 @@ class TrainProgram(Program):
 
             def argb(P, builders=builders, kind=kind):
                 items = [b(P) for b in builders]
-                arr = (CpWgradItem * len(items))(*items)
-                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-                pre = [0]
-                for it in items:
-                    pre.append(pre[-1] + int(it.blocks))
-                prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+                raw, prefix, total = _abi.device_table(items, [it.blocks for it in items], self.device)
                 self.keep += [raw, prefix]
-                return (kind, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1])
+                return (kind, raw.data_ptr(), prefix.data_ptr(), len(items), total)
             k3 = all(m["k3s1"] for m in mem)
             self._add(lib.cp_wgrad_group, argb, "wgrad_group:%s x%d" % (" k3 s1 " if k3 else "mixed", len(mem)),
                       [t for m in mem for t in (m["dt"], m["xt"])], [])
@@ -533,13 +523,7 @@ class TrainProgram(Program):
     def _flush_wgrad_reduce(self):
         if self._wg_items:
             items = self._wg_items
-            arr = (CpWgradReduceItem * len(items))(*items)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            pre, acc = [0], 0
-            for it in items:
-                acc += int(self.lib.cp_wgrad_reduce_item_blocks(C.byref(it)))
-                pre.append(acc)
-            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+            raw, prefix, acc = _abi.device_table(items, [self.lib.cp_wgrad_reduce_item_blocks(C.byref(it)) for it in items], self.device)
             self.wg_tabs.append((raw, prefix))
             n = len(items)
             self._add(self.lib.cp_wgrad_reduce_batch, lambda P: (raw.data_ptr(), prefix.data_ptr(), n, acc), "wgrad_reduce_batch:%d" % n, [], [])
@@ -634,18 +618,16 @@ class TrainProgram(Program):
             mem = members[lo:lo + 64]
 
             def argb(P, mem=mem):
-                items, pre = [], [0]
+                items, nbs = [], []
                 for gout, out, gsrc, shift, relu in mem:
                     it, nb = CpFuseBwdItem(), C.c_uint32()
                     _abi.check(lib.cp_fuse_sum_act_bwd_item(dt, P(gout.tbuf), P(out.tbuf), P(gsrc.tbuf), gsrc.B, gsrc.H, gsrc.W, gsrc.Cphys,
                                                             int(shift), 1 if relu else 0, 1, C.byref(it), C.byref(nb)), "cp_fuse_sum_act_bwd_item")
                     items.append(it)
-                    pre.append(pre[-1] + nb.value)
-                arr = (CpFuseBwdItem * len(items))(*items)
-                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-                prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)
+                    nbs.append(nb.value)
+                raw, prefix, total = _abi.device_table(items, nbs, self.device)
                 self.keep += [raw, prefix]
-                return (dt, raw.data_ptr(), prefix.data_ptr(), len(items), pre[-1])
+                return (dt, raw.data_ptr(), prefix.data_ptr(), len(items), total)
             tbs = [t for gout, out, gsrc, _, _ in mem for t in (gout.tbuf, out.tbuf, gsrc.tbuf)]
             self._add(lib.cp_fuse_sum_act_bwd_group, argb, "fuse_sum_bwd_group:%d" % len(mem), tbs, [m[2].tbuf for m in mem])
 
@@ -710,13 +692,7 @@ class TrainProgram(Program):
         for key, items in self.items.items():
             if not items:
                 continue
-            arr = (CpPackItem * len(items))(*items)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            pre, acc = [0], 0
-            for it in items:
-                acc += (int(it.total) + 255) // 256
-                pre.append(acc)
-            prefix = torch.tensor(pre, dtype=torch.int64).to(torch.int32).to(self.device)      # uint32 on the device
+            raw, prefix, acc = _abi.device_table(items, [(int(it.total) + 255) // 256 for it in items], self.device)
             self.item_tabs[key] = (raw, prefix, len(items), acc)
         self.acc_arena = torch.zeros(max(self.acc_total, 2), dtype=torch.float64, device=self.device)
         total = sum(t.nbytes for t in self.arena)
