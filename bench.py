@@ -15,7 +15,8 @@ N=1 run (`--no-extras` skips them): `fp32_exact` (the path 
 batch), `by_batch` (bf16 at B = 1 / 8 / 32: the reference's test.py:198 runs batch 1, its configs train at 32),
 `b1_latency_ms`, `bf16_agreement` (the bf16 path's accuracy contract, checkerpose_amd/agreement.py, measured against the
 fp32 HIP path on the same crops) and `host_u8` (crops start as uint8 in pinned HOST memory and are double-buffered over
-PCIe on a copy stream: the PCIe-inclusive rate, never `value`).
+PCIe on a copy stream: the PCIe-inclusive rate, never `value`) and `device_crop` (the data loader's RoI crop + resize done on the
+device from full frames in HBM, row N3).
 
 Workloads (BASELINE.json configs):
   lmo_ape     (default) config #2: LM-O `ape`, one network, npt=512
@@ -256,6 +257,31 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
                      "h2d_gb_per_s": round(B * n * 256 * 256 * 3 / el / 1e9, 2),
                      "note": "PCIe-inclusive: uint8 crops from pinned host memory, H2D double-buffered on a copy stream, "
                              "normalised on the device (cp_u8hwc_to_nhwc_norm); not `value`"}
+    # ---- the loader's crop on the device (row N3, second half): 32 full 640 x 480 uint8 frames resident in HBM, 8 detections per
+    #      frame -> padding_Bbox / crop_square_resize / cv2-style bilinear resize in ONE launch (cp_crop_resize_u8) -> uint8 forward
+    from checkerpose_amd import preprocess as PP
+    g = torch.Generator().manual_seed(11)
+    frames = torch.randint(0, 256, (32, 480, 640, 3), dtype=torch.uint8, generator=g).to(dev)
+    boxes = [PP.padding_Bbox([int(torch.randint(0, 560, (1,), generator=g)), int(torch.randint(0, 400, (1,), generator=g)),
+                              int(torch.randint(40, 200, (1,), generator=g)), int(torch.randint(40, 200, (1,), generator=g))], 1.5)
+             for _ in range(B)]
+    fidx = [b % 32 for b in range(B)]
+    crops = torch.empty(B, 256, 256, 3, dtype=torch.uint8, device=dev)
+
+    def crop_step():
+        PP.get_roi_batch(frames, boxes, 256, PP.INTER_LINEAR, "crop_square_resize", img_index=fidx, out=crops)
+        net_bf16(crops, None)
+    el = timed_steps(crop_step, 10, 3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        PP.get_roi_batch(frames, boxes, 256, PP.INTER_LINEAR, "crop_square_resize", img_index=fidx, out=crops)
+    e1.record()
+    torch.cuda.synchronize()
+    ex["device_crop"] = {"crops_per_s": round(B * 10 / el, 1), "ms_per_step": round(el / 10 * 1e3, 3), "batch": B,
+                         "crop_kernel_ms": round(e0.elapsed_time(e1) / 10, 3),
+                         "note": "full uint8 frames in HBM -> RoI windows + 8-bit bilinear resize on the device (one launch per batch, "
+                                 "incl. the host-side window arithmetic and its 6 KB upload) -> uint8 forward; not `value`"}
     return ex
 
 

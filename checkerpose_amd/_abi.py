@@ -215,6 +215,7 @@ SIGNATURES = {
     "cp_index2feat_gather_bwd_t": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_nchw_to_nhwc": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I]),
     "cp_u8hwc_to_nhwc_norm": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cp_crop_resize_u8": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I]),
     "cp_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),
     "cp_graph_begin_capture": (_I, [_P]),
     "cp_graph_end_capture": (_I, [_P, C.POINTER(_P)]),

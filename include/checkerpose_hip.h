@@ -689,6 +689,15 @@ int cp_nhwc_to_nchw_f32(cp_stream_t stream, int dtype, const void* in, float* ou
 int cp_u8hwc_to_nhwc_norm(cp_stream_t stream, int dtype, const uint8_t* in, void* out, int B, int H, int W, int Cphys,
                           const float* mean3, const float* std3);
 
+/* Input side, second half of row N3: the data loader's RoI crops (bop_dataset_pytorch.py:132-145 get_roi with resize_method
+ * crop_square_resize :55-91 or crop_resize :94-108, i.e. zero-padded window + cv2.resize) for a whole batch from full uint8 images
+ * (n_img, H, W, C <= 4) resident in device memory.  windows (device, B x 6 int32): x1, y1, x2, y2, roi_w, roi_h -- roi pixel
+ * (ry, rx) = image pixel (y1 + ry, x1 + rx) inside [max(x1,0), min(x2,W)) x [max(y1,0), min(y2,H)), zero elsewhere; the roi is resized
+ * to crop x crop with cv2's 8-bit INTER_NEAREST (0) / INTER_LINEAR (1) arithmetic.  img_idx (device, B) or NULL when n_img is 1 or B.
+ * out: (B, crop, crop, C) uint8, the operand of cp_u8hwc_to_nhwc_norm.  An empty roi gives a zero crop. */
+int cp_crop_resize_u8(cp_stream_t stream, const uint8_t* images, int n_img, int H, int W, int C, const int32_t* windows,
+                      const int32_t* img_idx, uint8_t* out, int B, int crop, int interpolation);
+
 /* ---------------------------------------------------------------------------------------------
  * hipGraph helpers: capture the launch sequence of one forward (everything above is capture-safe:
  * no allocation, no synchronisation) and replay it with one call.
