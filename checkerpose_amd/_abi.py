@@ -147,6 +147,7 @@ SIGNATURES = {
     "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_bits_decode": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
     "cp_correspondences": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "cp_correspondences_bbox": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "cp_pnp_ransac_scratch_bytes": (C.c_size_t, [_I, _I]),
     "cp_pnp_ransac": (_I, [_P, _P, _L, _P, _P, _I, _P, _L, _I, _I, _F, _I, C.c_uint32, _P, _P, _P, _P]),
     "cp_edgeconv_bwd_workspace_bytes": (C.c_size_t, [_I, _I, _I]),

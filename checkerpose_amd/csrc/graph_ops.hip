@@ -214,8 +214,8 @@ extern "C" int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, 
 // Only B*N*(2 floats + 3 bytes) leave the GPU instead of logits, ids and two 64x64 masks.
 __global__ void correspondences_kernel(const float* __restrict__ bits, const float* __restrict__ seg,
                                        const int64_t* __restrict__ x_id, const int64_t* __restrict__ y_id,
-                                       const float* __restrict__ roi_xy, float* __restrict__ p2d, uint8_t* __restrict__ valid,
-                                       int32_t* __restrict__ count, int N, int Hh, int Ww, int bd, size_t total) {
+                                       const float* __restrict__ roi_xy, const int32_t* __restrict__ bbox, float* __restrict__ p2d,
+                                       uint8_t* __restrict__ valid, int32_t* __restrict__ count, int N, int Hh, int Ww, int bd, size_t total) {
   const int HW = Hh * Ww;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*N
   if (i >= total) return;
@@ -223,8 +223,14 @@ __global__ void correspondences_kernel(const float* __restrict__ bits, const flo
   const int n = (int)(i - b * N);
   const int x = (int)x_id[i], y = (int)y_id[i];
   const size_t pix = (size_t)y * Ww + x;
-  p2d[2 * i + 0] = roi_xy[(b * 2 + 0) * HW + pix];
-  p2d[2 * i + 1] = roi_xy[(b * 2 + 1) * HW + pix];
+  if (roi_xy) {
+    p2d[2 * i + 0] = roi_xy[(b * 2 + 0) * HW + pix];
+    p2d[2 * i + 1] = roi_xy[(b * 2 + 1) * HW + pix];
+  } else {          // the loader's grid, built here: mapping_pixel_position_to_original_position_2d (bop_dataset_pytorch.py:223-235) in fp64,
+    const int32_t* bb = bbox + 4 * b;                      // cast to fp32 as `torch.from_numpy(roi_xy_ori).type(torch.float)` does (:380)
+    p2d[2 * i + 0] = (float)((double)bb[2] / (double)Ww * (double)x + (double)bb[0]);
+    p2d[2 * i + 1] = (float)((double)bb[3] / (double)Hh * (double)y + (double)bb[1]);
+  }
   const bool inner = (x >= bd) & (x < Ww - bd) & (y >= bd) & (y < Hh - bd);     // bd_mask[d:H-d, d:W-d] = 1  (:61-62)
   const bool v0 = inner && cp_sigmoid_gt_half(bits[b * 13 * (size_t)N + n]);
   const bool v1 = v0 && cp_sigmoid_gt_half(seg[(b * 2 + 1) * HW + pix]);
@@ -236,16 +242,30 @@ __global__ void correspondences_kernel(const float* __restrict__ bits, const flo
   if (v2) atomicAdd(&count[b * 3 + 2], 1);
 }
 
-extern "C" int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id,
-                                  const int64_t* y_id, const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count,
-                                  int B, int N, int H, int W, int discard_bd_pixel) {
-  if (!bits || !seg || !x_id || !y_id || !roi_xy_ori || !p2d || !valid || !count || B <= 0 || N <= 0 || H <= 0 || W <= 0 ||
+static int correspondences_impl(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id, const int64_t* y_id,
+                                const float* roi_xy_ori, const int32_t* bbox, float* p2d, uint8_t* valid, int32_t* count, int B, int N,
+                                int H, int W, int discard_bd_pixel) {
+  if (!bits || !seg || !x_id || !y_id || (!roi_xy_ori && !bbox) || !p2d || !valid || !count || B <= 0 || N <= 0 || H <= 0 || W <= 0 ||
       discard_bd_pixel < 0)
     return CP_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(count, 0, (size_t)B * 3 * sizeof(int32_t), st) != hipSuccess) return CP_ERR_HIP;
   const size_t total = (size_t)B * N;
   CP_LAUNCH(correspondences_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bits, seg, x_id, y_id,
-                     roi_xy_ori, p2d, valid, count, N, H, W, discard_bd_pixel, total);
+                     roi_xy_ori, bbox, p2d, valid, count, N, H, W, discard_bd_pixel, total);
   return cp_check_launch();
+}
+
+extern "C" int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id,
+                                  const int64_t* y_id, const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count,
+                                  int B, int N, int H, int W, int discard_bd_pixel) {
+  if (!roi_xy_ori) return CP_ERR_INVALID;
+  return correspondences_impl(stream, bits, seg, x_id, y_id, roi_xy_ori, nullptr, p2d, valid, count, B, N, H, W, discard_bd_pixel);
+}
+
+extern "C" int cp_correspondences_bbox(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id,
+                                       const int64_t* y_id, const int32_t* final_bbox, float* p2d, uint8_t* valid, int32_t* count,
+                                       int B, int N, int H, int W, int discard_bd_pixel) {
+  if (!final_bbox) return CP_ERR_INVALID;
+  return correspondences_impl(stream, bits, seg, x_id, y_id, nullptr, final_bbox, p2d, valid, count, B, N, H, W, discard_bd_pixel);
 }

@@ -2,22 +2,27 @@
 host in test.py:294-329 / test_network_with_test_data.py:from_id_to_pose :50-66, computed by one HIP kernel so that
 only (B,N,2) floats + (B,N,3) validity bytes leave the GPU.  The reference's PnP (Progressive-X / cv2) stays untouched and can
 consume these; `solve_pnp_ransac` is the opt-in on-device twin of its cv2 branch (row N4), after which 12 doubles per crop leave."""
+import numpy as np
 import torch
 
 from . import _abi
 
 
-def correspondences(outputs, roi_xy_ori, discard_bd_pixel=0):
+def correspondences(outputs, roi_xy_ori=None, discard_bd_pixel=0, Bboxes=None):
     """outputs: the 6-tuple of PoseNet_GNNskip.forward (full 6+6 bits); roi_xy_ori: (B,2,H,W) fp32 CUDA tensor
-    (the dataset's original-image coordinate grid of the crop, bop_dataset_pytorch.py).  Returns
+    (the dataset's original-image coordinate grid of the crop, bop_dataset_pytorch.py) -- or, instead of it, Bboxes: the (B,4)
+    final boxes (x, y, w, h) of the crops (`get_final_Bbox`, :188-222; host array or int32 CUDA tensor), from which the kernel
+    builds the very same grid entries on the fly (16 bytes per crop travel instead of 32 KB).  Returns
     (p2d (B,N,2) f32, valid (B,N,3) uint8 [all | in full mask | in visible mask], count (B,3) int32).
     discard_bd_pixel: from_id_to_pose's border filter (test_network_with_test_data.py:60-63), 0 = off."""
     roi, xb, yb, seg, xid, yid = outputs
-    if not (roi.is_cuda and roi_xy_ori.is_cuda):
+    if not roi.is_cuda or (roi_xy_ori is not None and not roi_xy_ori.is_cuda):
         raise RuntimeError("checkerpose_amd.postprocess: CUDA/HIP tensors required (no CPU fallback)")
+    if (roi_xy_ori is None) == (Bboxes is None):
+        raise ValueError("give either roi_xy_ori or Bboxes")
     B, _, N = roi.shape
     H, W = seg.shape[2], seg.shape[3]
-    if tuple(roi_xy_ori.shape) != (B, 2, H, W):
+    if roi_xy_ori is not None and tuple(roi_xy_ori.shape) != (B, 2, H, W):
         raise ValueError("roi_xy_ori must be (B,2,%d,%d)" % (H, W))
     lib = _abi.load()
     # the three logit views are slices of one (B,13,N) block when they come from the module; rebuild it otherwise
@@ -26,11 +31,20 @@ def correspondences(outputs, roi_xy_ori, discard_bd_pixel=0):
     if bits.shape[1] != 13:
         raise ValueError("need the full 13-row logit block (all refinement stages active)")
     seg = seg.contiguous(); xid = xid.contiguous(); yid = yid.contiguous()
-    rxy = roi_xy_ori.contiguous().float()
     p2d = torch.empty(B, N, 2, dtype=torch.float32, device=roi.device)
     valid = torch.empty(B, N, 3, dtype=torch.uint8, device=roi.device)
     count = torch.empty(B, 3, dtype=torch.int32, device=roi.device)
     st = torch.cuda.current_stream(roi.device).cuda_stream
+    if Bboxes is not None:
+        bb = Bboxes if torch.is_tensor(Bboxes) else torch.as_tensor(np.asarray(Bboxes), dtype=torch.int32)
+        bb = bb.to(device=roi.device, dtype=torch.int32).contiguous()
+        if tuple(bb.shape) != (B, 4):
+            raise ValueError("Bboxes must be (B,4): x, y, w, h of every crop")
+        _abi.check(lib.cp_correspondences_bbox(st, bits.data_ptr(), seg.data_ptr(), xid.data_ptr(), yid.data_ptr(), bb.data_ptr(),
+                                               p2d.data_ptr(), valid.data_ptr(), count.data_ptr(), B, N, H, W, int(discard_bd_pixel)),
+                   "cp_correspondences_bbox")
+        return p2d, valid, count
+    rxy = roi_xy_ori.contiguous().float()
     _abi.check(lib.cp_correspondences(st, bits.data_ptr(), seg.data_ptr(), xid.data_ptr(), yid.data_ptr(), rxy.data_ptr(),
                                       p2d.data_ptr(), valid.data_ptr(), count.data_ptr(), B, N, H, W, int(discard_bd_pixel)),
                "cp_correspondences")

@@ -355,6 +355,12 @@ int cp_bits_decode(cp_stream_t stream, const float* bits, int stage, float* mask
 int cp_correspondences(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id, const int64_t* y_id,
                        const float* roi_xy_ori, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W,
                        int discard_bd_pixel);
+/* The same with the coordinate grid built on the fly from the crop's final box (device, B x 4 int32: x, y, w, h = get_final_Bbox,
+ * bop_dataset_pytorch.py:188-222) instead of a (B,2,H,W) roi_xy_ori tensor uploaded per batch: p2d = (float)(w / W * x_id + x) etc.
+ * in fp64 then fp32, exactly the entries of the loader's grid (mapping_pixel_position_to_original_position_2d :223-235, :380). */
+int cp_correspondences_bbox(cp_stream_t stream, const float* bits, const float* seg, const int64_t* x_id, const int64_t* y_id,
+                            const int32_t* final_bbox, float* p2d, uint8_t* valid, int32_t* count, int B, int N, int H, int W,
+                            int discard_bd_pixel);
 
 /* Pose from the correspondences, on the device (next-row N4; reference test_network_with_test_data.py:100-114: the call
  *   cv2.solvePnPRansac(valid_p3d, valid_disc_p2d, cam_K, None, reprojectionError, iterationsCount, flags=cv2.SOLVEPNP_EPNP)

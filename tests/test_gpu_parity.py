@@ -1428,6 +1428,31 @@ def test_postprocess_correspondences_on_device(lib):
         assert torch.equal(p2d.cpu(), rp2d) and torch.equal(valid.cpu(), rvalid) and torch.equal(count.cpu(), rcount)
 
 
+def test_postprocess_correspondences_from_final_bboxes(lib):
+    """cp_correspondences_bbox builds the loader's coordinate grid on the fly: same result as handing over the (B,2,H,W) roi_xy_ori
+    tensor the loader makes from the crop's final box (mapping_pixel_position_to_original_position_2d, bop_dataset_pytorch.py:223-235,
+    in float64, cast to float32 at :380), bit for bit -- boxes with negative corners, odd sizes and a degenerate one"""
+    from checkerpose_amd.postprocess import correspondences
+    net = build_net(seed=1).to(dev())
+    out = net(det_image(5, seed=5).to(dev()), None)
+    boxes = np.array([[-2, 4, 45, 45], [100, 37, 211, 211], [0, 0, 64, 64], [310, 200, 77, 77], [5, 5, 0, 0]])
+    S = 64
+    pix = np.linspace(0, S - 1, S)                                             # the loader's roi_xy (:266-269)
+    gx, gy = np.meshgrid(pix, pix)
+    grid = np.stack([np.stack([b[2] / S * gx + b[0], b[3] / S * gy + b[1]]) for b in boxes])          # float64
+    grid_t = torch.from_numpy(grid).type(torch.float)
+    for bd in (0, 3):
+        want = correspondences(out, grid_t.to(dev()), discard_bd_pixel=bd)
+        got = correspondences(out, None, discard_bd_pixel=bd, Bboxes=boxes)
+        got_t = correspondences(out, discard_bd_pixel=bd, Bboxes=torch.from_numpy(boxes).to(dev()))
+        for a, b, c in zip(want, got, got_t):
+            assert torch.equal(a, b) and torch.equal(a, c)
+    with pytest.raises(ValueError):
+        correspondences(out, grid_t.to(dev()), Bboxes=boxes)
+    with pytest.raises(ValueError):
+        correspondences(out)
+
+
 def test_postprocess_correspondences_vs_reference_from_id_to_pose(lib):
     """cp_correspondences on the golden's inputs == the lists the REFERENCE's from_id_to_pose handed to its (stubbed,
     recording) solver: check_seg in {False, full, visib} x discard_bd_pixel in {0, 2} (n2_from_id_to_pose.npz)."""
