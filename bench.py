@@ -15,8 +15,8 @@ N=1 run (`--no-extras` skips them): `fp32_exact` (the path 
 batch), `by_batch` (bf16 at B = 1 / 8 / 32: the reference's test.py:198 runs batch 1, its configs train at 32),
 `b1_latency_ms`, `bf16_agreement` (the bf16 path's accuracy contract, checkerpose_amd/agreement.py, measured against the
 fp32 HIP path on the same crops) and `host_u8` (crops start as uint8 in pinned HOST memory and are double-buffered over
-PCIe on a copy stream: the PCIe-inclusive rate, never `value`) and `device_crop` (the data loader's RoI crop + resize done on the
-device from full frames in HBM, row N3).
+PCIe on a copy stream: the PCIe-inclusive rate, never `value`) `device_crop` (the data loader's RoI crop + resize done on the
+device from full frames in HBM, row N3) and `end_to_end` (frames + boxes -> poses without leaving the GPU).
 
 Workloads (BASELINE.json configs):
   lmo_ape     (default) config #2: LM-O `ape`, one network, npt=512
@@ -282,6 +282,23 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
                          "crop_kernel_ms": round(e0.elapsed_time(e1) / 10, 3),
                          "note": "full uint8 frames in HBM -> RoI windows + 8-bit bilinear resize on the device (one launch per batch, "
                                  "incl. the host-side window arithmetic and its 6 KB upload) -> uint8 forward; not `value`"}
+    # ---- test.py's inner loop end to end on the device: detection boxes on frames in HBM -> crops -> forward -> correspondences from
+    #      the final boxes -> EPnP + RANSAC; 12 doubles + a status word per crop leave the GPU (rows N3 + path + N2 + N4)
+    try:
+        from checkerpose_amd import postprocess as Q
+        raw_boxes = [[int(b[0] + b[2] // 6), int(b[1] + b[3] // 6), max(int(b[2] * 2 // 3), 8), max(int(b[3] * 2 // 3), 8)] for b in boxes]
+        p3d_xyz = det_tensor("e2e_p3d", (npoint, 3), 60.0).to(dev)
+        K = torch.tensor([[572.4, 0.0, 325.3], [0.0, 573.6, 242.0], [0.0, 0.0, 1.0]])
+
+        def e2e_step():
+            return Q.estimate_poses(net_bf16, frames, raw_boxes, p3d_xyz, K, img_index=fidx)
+        el = timed_steps(e2e_step, 10, 3)
+        st_ = e2e_step()[3]
+        ex["end_to_end"] = {"crops_per_s": round(B * 10 / el, 1), "ms_per_step": round(el / 10 * 1e3, 3), "batch": B, "solved": int(st_.sum()),
+                            "note": "frames in HBM + detection boxes -> poses (crop, forward, correspondences, EPnP + RANSAC), random-init "
+                                    "weights: the correspondences are noise, RANSAC runs its full 150 hypotheses; not `value`"}
+    except Exception as e:                                   # an extra must never take the headline line down
+        ex["end_to_end"] = {"error": repr(e)[:200]}
     return ex
 
 

@@ -82,6 +82,29 @@ def solve_pnp_ransac(p3d_xyz, p2d, valid, cam_K, column=0, reproj_threshold=2.0,
     return pose[:, :9].view(B, 3, 3), pose[:, 9:].view(B, 3, 1), inl.bool(), status
 
 
+def estimate_poses(net, frames, Bboxes, p3d_xyz, cam_K, img_index=None, obj_ids=None, padding_ratio=1.5, crop_size=256,
+                   resize_method="crop_square_resize", check_seg=False, discard_bd_pixel=0, reproj_threshold=2.0, iterations=150, seed=0):
+    """The inner loop of the reference's test.py (:198-330) for a whole batch without leaving the GPU: detection boxes on full uint8
+    frames -> padded RoI crops (`padding_Bbox` + `get_roi`, bop_dataset_pytorch.py:344-354; preprocess.get_roi_batch) -> network forward
+    (uint8 input, normalised on the device) -> correspondences from the crops' final boxes (`get_final_Bbox`; N2) -> EPnP + RANSAC (N4).
+      frames: uint8 CUDA tensor (n_img, H, W, 3) or (H, W, 3); Bboxes: (B, 4) detection boxes (x, y, w, h), None = no detection;
+      p3d_xyz (N,3) / (B,N,3) model keypoints in original units; cam_K (3,3) / (B,3,3); obj_ids for the LM shared estimator.
+    -> (R (B,3,3) f64, t (B,3,1) f64, inliers (B,N) bool, status (B,) int32 (0: identity fallback), final boxes (B,4) int array)"""
+    from . import preprocess as PP
+    if frames.dim() == 3:
+        frames = frames.unsqueeze(0)
+    H, W = int(frames.shape[1]), int(frames.shape[2])
+    padded = [None if b is None else PP.padding_Bbox(b, padding_ratio) for b in Bboxes]
+    crops = PP.get_roi_batch(frames, padded, crop_size, PP.INTER_LINEAR, resize_method, img_index=img_index)
+    final = np.array([[0, 0, 0, 0] if b is None else PP.get_final_Bbox(b, resize_method, W, H) for b in padded], dtype=np.int32)
+    with torch.no_grad():
+        out = net(crops, None) if obj_ids is None else net(crops, None, obj_ids)
+    p2d, valid, _ = correspondences(out, discard_bd_pixel=discard_bd_pixel, Bboxes=final)
+    R, t, inl, status = solve_pnp_ransac(p3d_xyz, p2d, valid, cam_K, column=1 if check_seg else 0, reproj_threshold=reproj_threshold,
+                                         iterations=iterations, seed=seed)
+    return R, t, inl, status, final
+
+
 def from_id_to_pose(p3d_xyz, roi_xy_ori, cam_K, roi_mask_bit, pixel_x_id, pixel_y_id, check_seg=False, seg_mask=None,
                     use_progressivex=False, neighborhood_ball_radius=20, spatial_coherence_weight=0.1, prog_max_iters=400,
                     discard_bd_pixel=0, return_inliers=False, reprojErr_thresh=2, cv_max_iters=150, device="cuda:0", seed=0):

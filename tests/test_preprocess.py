@@ -115,3 +115,31 @@ def test_device_crops_at_full_size_and_into_the_model():
         bq = net(torch.from_numpy(c[:8]).cuda(), p3d)
     for u, v in zip(a, bq):
         assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_estimate_poses_is_the_composition_of_its_stages():
+    """postprocess.estimate_poses (test.py's inner loop on the device: boxes on full frames -> crops -> forward -> correspondences from
+    the final boxes -> EPnP + RANSAC) == the stages called one by one, incl. a missing detection (zero crop, degenerate box)"""
+    from checkerpose_amd.synthetic import build_net
+    from checkerpose_amd import postprocess as Q
+    rng = np.random.default_rng(9)
+    frames = torch.from_numpy(rng.integers(0, 256, (2, 480, 640, 3), dtype=np.uint8)).cuda()
+    boxes = [[100, 80, 120, 90], [300, 200, 60, 140], None, [-10, 400, 90, 90]]
+    idx = [0, 1, 0, 1]
+    net = build_net(npoint=512, seed=1).cuda().eval()
+    net.set_compute_dtype("bf16")
+    p3d = torch.from_numpy(rng.normal(size=(512, 3)).astype(np.float32) * 50).cuda()
+    K = np.array([[572.4, 0, 325.3], [0, 573.6, 242.0], [0, 0, 1]], dtype=np.float32)
+    R, t, inl, status, final = Q.estimate_poses(net, frames, boxes, p3d, K, img_index=idx)
+    padded = [None if b is None else PP.padding_Bbox(b, 1.5) for b in boxes]
+    crops = PP.get_roi_batch(frames, padded, 256, PP.INTER_LINEAR, "crop_square_resize", img_index=idx)
+    assert not crops[2].any()
+    want_final = np.array([[0, 0, 0, 0] if b is None else PP.get_final_Bbox(b, "crop_square_resize", 640, 480) for b in padded])
+    assert np.array_equal(final, want_final)
+    with torch.no_grad():
+        out = net(crops, None)
+    p2d, valid, _ = Q.correspondences(out, Bboxes=want_final)
+    R2, t2, inl2, st2 = Q.solve_pnp_ransac(p3d, p2d, valid, K)
+    assert torch.equal(R, R2) and torch.equal(t, t2) and torch.equal(inl, inl2) and torch.equal(status, st2)
+    assert tuple(R.shape) == (4, 3, 3) and tuple(t.shape) == (4, 3, 1) and status.dtype == torch.int32
