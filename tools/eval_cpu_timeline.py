@@ -9,7 +9,7 @@ from checkerpose_amd.synthetic import build_net, det_image
 dev = torch.device("cuda:0")
 net = build_net(npoint=512, seed=1).to(dev).eval()
 net.set_compute_dtype("bf16")
-for B in (1, 8, 32, 256):
+for B in ([int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 8, 32, 256)):
     img = det_image(B, seed=3).to(dev)
     with torch.no_grad():
         net(img, None)
