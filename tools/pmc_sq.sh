@@ -1,13 +1,15 @@
 #!/bin/bash
-# usage: bash tools/pmc_sq.sh [bench.py args, e.g. --workload lm13_n4096]
+# usage: bash tools/pmc_sq.sh [bench.py args, e.g. --workload lm13_n4096]      (SQ_SCRIPT=bench_train.py: the training step instead)
 # SQ counters of every kernel of the default forward (eager replay, 2 steps): MFMA busy share, LDS activity / bank conflicts, VALU per
 # MFMA instruction -> gpurun_out/sq_counters.csv (one row per kernel, averages per launch).  Two --pmc passes (counter groups).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/psq
-export CHECKERPOSE_AMD_GRAPH=0
+export CHECKERPOSE_AMD_GRAPH=0 CHECKERPOSE_AMD_TRAIN_GRAPH=none
+script=${SQ_SCRIPT:-bench.py}
+extra="--no-cpu-baseline --no-breakdown"; if [ "$script" = "bench.py" ]; then extra="$extra --no-extras"; fi
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS"; do
   d=gpurun_out/psq/$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-breakdown "$@" > gpurun_out/psq.log 2>&1 || { tail -5 gpurun_out/psq.log; echo "(counter set skipped: $set)"; }
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 $script --steps 2 --warmup 1 $extra "$@" > gpurun_out/psq.log 2>&1 || { tail -5 gpurun_out/psq.log; echo "(counter set skipped: $set)"; }
 done
 python3 - <<'PY'
 import csv, glob, collections
