@@ -818,6 +818,12 @@ extern "C" int cp_bn_stats_accumulate(cp_stream_t stream, int dtype, const void*
   return cp_check_launch();
 }
 
+// per-channel coefficient tables in LDS: a lane reads the 8 (bf16) / 4 (fp32) coefficients of its 16-byte piece with ds_read_b128; at a piece
+// stride of 8 floats the 16 lanes of a read phase fall on 16 x 4 banks of which only 8 x 4 are distinct (pieces g and g + 8 collide:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.82 in profiles/r03_sq_counters_train.csv) -- bf16 pieces are therefore 12 floats apart
+template <typename Tag> struct CoefPitch { static constexpr int PS = Tag::E == 8 ? 12 : Tag::E; };
+static inline size_t coef_floats(int dtype, int Cphys) { const int E = cp_chan_align(dtype); return (size_t)(Cphys / E) * (E == 8 ? 12 : E); }
+
 struct BnApplyParams {
   const void* x; int x_cs, x_coff;
   const void* res; int r_cs, r_coff;
@@ -855,8 +861,9 @@ __device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_c
         if (p.rvar) p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)(p.count > 1.0 ? var * p.count / (p.count - 1.0) : var);
       }
     }
-    s_coef[c] = sc;
-    s_coef[Cphys + c] = sh;
+    const int ci = (c / E) * CoefPitch<Tag>::PS + c % E;
+    s_coef[ci] = sc;
+    s_coef[p.G * CoefPitch<Tag>::PS + ci] = sh;
   }
 }
 
@@ -879,13 +886,12 @@ template <typename Tag>
 __device__ __forceinline__ void bn_apply_finish(const BnApplyParams& p, const float* s_coef, size_t i, const BnApplyOperands<Tag>& o) {
   constexpr int E = Tag::E;
   using T = typename Tag::elem;
-  const int Cphys = p.G * E;
   const int g = (int)(i % p.G);
   const size_t m = i / p.G;
   float v[E], r[E];
   Vec16<Tag>::unpack(o.x, v);
 #pragma unroll
-  for (int j = 0; j < E; ++j) v[j] = v[j] * s_coef[g * E + j] + s_coef[Cphys + g * E + j];
+  for (int j = 0; j < E; ++j) v[j] = v[j] * s_coef[g * CoefPitch<Tag>::PS + j] + s_coef[(p.G + g) * CoefPitch<Tag>::PS + j];
   if (p.res) {
     Vec16<Tag>::unpack(o.r, r);
 #pragma unroll
@@ -990,7 +996,7 @@ extern "C" int cp_bn_apply(cp_stream_t stream, int dtype, const void* x, int x_c
   const int rc = build_bn_apply(dtype, x, x_cstride, x_coff, acc, gamma, beta, running_mean, running_var, momentum, eps, res, res_cstride,
                                 res_coff, y, y_cstride, y_coff, M, C, act, slope, mean, rstd, &p, &blocks, &Cphys);
   if (rc) return rc;
-  const size_t lds = (size_t)2 * Cphys * sizeof(float);
+  const size_t lds = 2 * coef_floats(dtype, Cphys) * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
   else CP_LAUNCH(bn_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
   return cp_check_launch();
@@ -1060,7 +1066,8 @@ __device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s
         if (p.x && pp.dgamma) pp.dgamma[c] = (float)s2;
       }
     }
-    s_cf[c] = ca; s_cf[Cphys + c] = cb; s_cf[2 * Cphys + c] = cr; s_cf[3 * Cphys + c] = mu;
+    const int ci = (c / E) * CoefPitch<Tag>::PS + c % E, AS = p.G * CoefPitch<Tag>::PS;
+    s_cf[ci] = ca; s_cf[AS + ci] = cb; s_cf[2 * AS + ci] = cr; s_cf[3 * AS + ci] = mu;
   }
 }
 
@@ -1083,7 +1090,6 @@ template <typename Tag>
 __device__ __forceinline__ void bn_bwd_finish(const BnBwdParams& p, const float* s_cf, size_t i, const BnBwdOperands<Tag>& ops) {
   constexpr int E = Tag::E;
   using T = typename Tag::elem;
-  const int Cphys = p.G * E;
   const int g = (int)(i % p.G);
   const size_t m = i / p.G;
   float dz[E], t[E];
@@ -1111,8 +1117,8 @@ __device__ __forceinline__ void bn_bwd_finish(const BnBwdParams& p, const float*
     Vec16<Tag>::unpack(ops.x, xv);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-      const int c = g * E + j;
-      o[j] = s_cf[c] * (dz[j] - s_cf[Cphys + c] - (xv[j] - s_cf[3 * Cphys + c]) * s_cf[2 * Cphys + c]);
+      const int c = g * CoefPitch<Tag>::PS + j, AS = p.G * CoefPitch<Tag>::PS;
+      o[j] = s_cf[c] * (dz[j] - s_cf[AS + c] - (xv[j] - s_cf[3 * AS + c]) * s_cf[2 * AS + c]);
     }
   } else {
 #pragma unroll
@@ -1198,7 +1204,7 @@ extern "C" int cp_bn_bwd_apply(cp_stream_t stream, int dtype, const void* dy, in
                                     act, slope, dx, dx_cstride, dx_coff, dres, dres_cstride, dres_coff, dres_accumulate, dgamma, dbeta,
                                     &pp, &blocks, &Cphys);
   if (rc) return rc;
-  const size_t lds = (size_t)4 * Cphys * sizeof(float);
+  const size_t lds = 4 * coef_floats(dtype, Cphys) * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_bwd_apply_kernel<F32Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
   else CP_LAUNCH(bn_bwd_apply_kernel<BF16Tag>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pp);
   return cp_check_launch();
@@ -1261,7 +1267,7 @@ extern "C" int cp_bn_item_apply(int dtype, const void* x, int x_cstride, int x_c
                                 res_coff, y, y_cstride, y_coff, M, C, act, slope, mean, rstd, &u.ap, &blocks, &Cphys);
   if (rc) return rc;
   memcpy(item->params, &u, sizeof(u));
-  item->kind = CP_BN_ITEM_APPLY; item->dtype = dtype; item->blocks = blocks; item->lds_bytes = (uint32_t)(2 * Cphys * sizeof(float));
+  item->kind = CP_BN_ITEM_APPLY; item->dtype = dtype; item->blocks = blocks; item->lds_bytes = (uint32_t)(2 * coef_floats(dtype, Cphys) * sizeof(float));
   return CP_OK;
 }
 
@@ -1293,7 +1299,7 @@ extern "C" int cp_bn_item_bwd_apply(int dtype, const void* dy, int dy_cstride, i
                                     &u.bp, &blocks, &Cphys);
   if (rc) return rc;
   memcpy(item->params, &u, sizeof(u));
-  item->kind = CP_BN_ITEM_BWD_APPLY; item->dtype = dtype; item->blocks = blocks; item->lds_bytes = (uint32_t)(4 * Cphys * sizeof(float));
+  item->kind = CP_BN_ITEM_BWD_APPLY; item->dtype = dtype; item->blocks = blocks; item->lds_bytes = (uint32_t)(4 * coef_floats(dtype, Cphys) * sizeof(float));
   return CP_OK;
 }
 
@@ -1357,7 +1363,7 @@ extern "C" int cp_bn_train_fused(cp_stream_t stream, int dtype, const void* x, i
   p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = Cvec; p.C = C; p.count = (double)M;
   p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum; p.rmean = running_mean; p.rvar = running_var;
   p.mean = mean; p.rstd = rstd; p.G = Cphys / E; p.act = act; p.slope = slope; p.total = (size_t)M * p.G;
-  const size_t lds = (size_t)2 * Cphys * sizeof(float);
+  const size_t lds = 2 * coef_floats(dtype, Cphys) * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_fused_fwd_kernel<F32Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, p, counter);
   else CP_LAUNCH(bn_fused_fwd_kernel<BF16Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, p, counter);
   return cp_check_launch();
@@ -1390,7 +1396,7 @@ extern "C" int cp_bn_bwd_fused(cp_stream_t stream, int dtype, const void* dy, in
   q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
   q.coef = nullptr; q.Cvec = Cvec; q.G = Cphys / E; q.slope = act == CP_ACT_RELU ? 0.f : slope; q.total = (size_t)M * q.G;
   pp.acc = acc; pp.C = C; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
-  const size_t lds = (size_t)4 * Cphys * sizeof(float);
+  const size_t lds = 4 * coef_floats(dtype, Cphys) * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_fused_bwd_kernel<F32Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, pp, counter);
   else CP_LAUNCH(bn_fused_bwd_kernel<BF16Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, pp, counter);
   return cp_check_launch();
