@@ -2,6 +2,7 @@
 persistent I/O tensors, captures the hipGraph and replays it.  Fails loudly -- no CPU or PyTorch fallback.
 """
 import ctypes as C
+import operator
 import os
 
 import torch
@@ -11,6 +12,7 @@ from ..engine import DTYPES, Program, ProgramGroup, WeightStore
 from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
 
 
+_VERSION_OF = operator.attrgetter("_version")
 TRAIN_GRAPH = os.environ.get("CHECKERPOSE_AMD_TRAIN_GRAPH", "fwd,bwd").split(",")   # which halves replay as hipGraphs (A/B + debugging)
 
 
@@ -466,7 +468,7 @@ class HipForwardMixin:
             # (Edits through `p.data` do not move the counter -- torch gives `.data` a counter of its own: call invalidate().)
             if self._sig_tensors is None:
                 self._sig_tensors = list(self.parameters()) + list(self.buffers())
-            sig = sum(t._version for t in self._sig_tensors) + len(self._sig_tensors)
+            sig = sum(map(_VERSION_OF, self._sig_tensors)) + len(self._sig_tensors)      # ~2 000 tensors: the B = 1 forward is host-bound
             if self._programs and sig != getattr(self, "_eval_sig", None):
                 self._drop_eval_programs()
             self._eval_sig = sig
