@@ -358,17 +358,12 @@ extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, cons
   p.tiles_x = (d->W + BTW - 1) / BTW; p.tiles_y = (d->H + BTH - 1) / BTH;
   p.in_bytes = (uint32_t)in_bytes;
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx;
-  static int n_cu = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      return CP_ERR_HIP;
-    if (hipFuncSetAttribute((const void*)bottleneck_fused_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(8, false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)bottleneck_fused_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, true)) != hipSuccess)
-      return CP_ERR_HIP;
-    attr_set = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)bottleneck_fused_kernel<8, false>, lds_bytes(8, false)) &&
+                                  cp_set_max_lds((const void*)bottleneck_fused_kernel<2, true>, lds_bytes(2, true)));
+  const int n_cu = cp_num_cus();
+  if (n_cu <= 0) return CP_ERR_HIP;
   // one persistent block per CU, a multiple of 8 (XCD labels); never more blocks than tiles of the crops one XCD owns
   const long long per_xcd = (long long)((d->B + 7) / 8) * p.tiles_x * p.tiles_y;
   long long nbx = n_cu / 8 > 0 ? n_cu / 8 : 1;

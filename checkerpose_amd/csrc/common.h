@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/checkerpose_hip.h"
 
@@ -104,6 +105,42 @@ void cp_mark_kernel(const char* fmt, ...);
 static inline int cp_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+// Per-DEVICE launch prerequisites (hipFuncSetAttribute applies to the current device only; a process may drive several).
+// The library keeps no other state than these idempotent caches: a bit per device ordinal, set after the attribute calls of
+// that device succeeded; two threads racing here both set the same attributes (harmless) and OR the same bit.
+struct CpDeviceOnce {
+  std::atomic<unsigned long long> bits[4];      // device ordinals 0..255
+  bool needed(int dev) const { return !((bits[(dev >> 6) & 3].load(std::memory_order_acquire) >> (dev & 63)) & 1ull); }
+  void mark(int dev) { bits[(dev >> 6) & 3].fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
+static inline int cp_current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for `fn` on the current device, once per device; CP_OK / CP_ERR_HIP
+#define CP_LDS_ATTR_ONCE(once, dev, ...)                                                     \
+  do {                                                                                       \
+    if ((dev) < 0) return CP_ERR_HIP;                                                        \
+    if ((once).needed(dev)) {                                                                \
+      if (!(__VA_ARGS__)) return CP_ERR_HIP;                                                 \
+      (once).mark(dev);                                                                      \
+    }                                                                                        \
+  } while (0)
+static inline bool cp_set_max_lds(const void* fn, size_t bytes) {
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+// compute units of the CURRENT device (cached per device ordinal); 0 on error
+static inline int cp_num_cus() {
+  static std::atomic<int> cache[256];
+  const int dev = cp_current_device();
+  if (dev < 0) return 0;
+  int n = cache[dev & 255].load(std::memory_order_relaxed);
+  if (!n) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cache[dev & 255].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 static inline bool cp_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int cp_elem_size(int dtype) { return dtype == CP_BF16 ? 2 : 4; }

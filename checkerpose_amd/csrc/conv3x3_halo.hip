@@ -1628,12 +1628,8 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
   const size_t lds = 4 * FXPLANE + HBUF + (size_t)9 * NT * 1024;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_BF16 && NT == 2 && !cp_knob("CP_NO_BB_PERSIST")) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return CP_ERR_HIP;
-    }
+    const int n_cu = cp_num_cus();
+    if (n_cu <= 0) return CP_ERR_HIP;
     // two resident 4-wave blocks per CU, a multiple of 8 (XCD labels), never more than the tiles one XCD owns
     const long long per_xcd = (long long)((d->B + 7) / 8) * p.tiles_x * p.tiles_y;
     long long nbx = 2 * n_cu / 8 > 0 ? 2 * n_cu / 8 : 1;

@@ -225,13 +225,10 @@ extern "C" int cp_conv3x3_s2_small(cp_stream_t stream, const CpConvDesc* d, cons
   const size_t lds = (size_t)2 * 4 * p.plane_bytes;
   const long long grid = (long long)d->B * (d->H / S2_BAND);
   if (grid >= (1LL << 31)) return CP_ERR_RANGE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)conv3x3_s2_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_s2_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-      return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)conv3x3_s2_small_kernel<4>, 80 * 1024) &&
+                                  cp_set_max_lds((const void*)conv3x3_s2_small_kernel<2>, 80 * 1024));
   // band = 4 output rows x W / 2 pixels: 8 tiles at W = 64 (4 per wave), 4 at W = 32 (2 per wave)
   if (p.ntile == 8) CP_LAUNCH((conv3x3_s2_small_kernel<4>), dim3((unsigned)grid), dim3(384), lds, (hipStream_t)stream, p);
   else CP_LAUNCH((conv3x3_s2_small_kernel<2>), dim3((unsigned)grid), dim3(384), lds, (hipStream_t)stream, p);

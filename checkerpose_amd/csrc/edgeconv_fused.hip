@@ -292,13 +292,10 @@ extern "C" int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstri
   if (!cp_edgeconv_fused_supported(N, K, Cin, Cout)) return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + Cout > out_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(x) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift) || !cp_aligned16(out)) return CP_ERR_ALIGN;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)edgeconv_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS) != hipSuccess)
-      return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)edgeconv_fused_kernel<64>, EF_LDS) &&
+                                  cp_set_max_lds((const void*)edgeconv_fused_kernel<256>, EF_LDS));
   EdgeFusedParams p;
   p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.idx = idx; p.gids = graph_ids; p.out = out;
   p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.K = K; p.Cout = Cout; p.slope = slope;

@@ -17,6 +17,11 @@
 // (the round-1 path: [P'|Q'] 4 MB out and K = 20 row reads per keypoint = 42 MB through the L2).
 #include "common.h"
 
+// knock-out switches of tools/edge_tiled_bench.py (results wrong on purpose): only a `make KNOBS=1` build may define them
+#if (defined(ET_NODMA) || defined(ET_NOGATHER) || defined(ET_NOQ)) && !defined(CP_DEBUG_KNOBS)
+#error "ET_NODMA / ET_NOGATHER / ET_NOQ are knock-out builds: they need -DCP_DEBUG_KNOBS (make KNOBS=1)"
+#endif
+
 namespace {
 
 constexpr int ET_BLK = 512, ET_KMAX = 20;
@@ -440,18 +445,15 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
   const size_t lds1[2] = {(size_t)2 * 2 * 4 * 1024 + 1024, (size_t)2 * 8 * 4 * 1024 + 1024};      // Cin = 64 / 256
   const bool db = tiled_lds_db(Cin, HPAD) <= 160 * 1024;
   const size_t lds2 = db ? tiled_lds_db(Cin, HPAD) : tiled_lds(Cin, HPAD);
-  static bool attr_done = false;
-  if (!attr_done) {
-    const int want = 160 * 1024;
-    if (hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[0]) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_ptable_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1[1]) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edgeconv_tiled_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
-      return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  const size_t want = 160 * 1024;
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)edgeconv_ptable_kernel<64>, lds1[0]) &&
+                                  cp_set_max_lds((const void*)edgeconv_ptable_kernel<256>, lds1[1]) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, false>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, false>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, true>, want));
   EdgeTiledParams p;
   p.x = x; p.scale = scale; p.shift = shift; p.halo = halo; p.nbr = nbr; p.gids = graph_ids; p.ptab = key_table; p.out = out;
   p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.N = N; p.NB = N / ET_BLK; p.K = K;

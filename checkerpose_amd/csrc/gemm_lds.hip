@@ -449,16 +449,12 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
   const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_BF16 && !residual && p.nchunk <= 16 && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0, ncu = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return CP_ERR_HIP;
-      if (hipFuncSetAttribute((const void*)gemm_rows_ws_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_buf(8)) != hipSuccess ||
-          hipFuncSetAttribute((const void*)gemm_rows_ws_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_buf(16)) != hipSuccess)
-        return CP_ERR_HIP;
-      n_cu = ncu;
-    }
+    static CpDeviceOnce once;
+    const int dev = cp_current_device();
+    CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)gemm_rows_ws_kernel<8, 2>, 2 * ws_buf(8)) &&
+                                    cp_set_max_lds((const void*)gemm_rows_ws_kernel<16, 1>, 2 * ws_buf(16)));
+    const int n_cu = cp_num_cus();
+    if (n_cu <= 0) return CP_ERR_HIP;
     const bool deep = p.nchunk > 8;                           // 256 < K <= 512: 8-wave blocks, one per CU
     const int ncg = (p.ngroups + 7) / 8;                      // column groups of 256 channels
     const int n_rt = (int)((M + WS_ROWS - 1) / WS_ROWS);

@@ -377,12 +377,9 @@ __global__ void pack_chain_weight_kernel(const float* __restrict__ w, const floa
 
 template <typename Cfg>
 int launch_chain(hipStream_t st, const ChainParams& p) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)hr_chain_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
-      return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;                  // per template instance, per device
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)hr_chain_kernel<Cfg>, Cfg::LDS));
   const unsigned grid = (unsigned)((p.B + Cfg::CPW - 1) / Cfg::CPW);
   CP_LAUNCH((hr_chain_kernel<Cfg>), dim3(grid), dim3(Cfg::NTHR), Cfg::LDS, st, p);
   return cp_check_launch();

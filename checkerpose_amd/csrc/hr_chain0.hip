@@ -280,11 +280,9 @@ int cp_chain0_pack(hipStream_t st, const float* w, const float* scale, int conv_
 
 int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
                      const void* packed_w, const float* affine, void* out) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)hr_chain0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ZLDS) != hipSuccess) return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)hr_chain0_kernel, ZLDS));
   Chain0Params p;
   for (int k = 0; k < 4; ++k) { p.src[k] = k < nsrc ? srcs[k] : nullptr; p.shift[k] = k < nsrc ? shifts[k] : 0; }
   p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0; p.w = packed_w; p.aff = affine; p.out = out; p.B = B;

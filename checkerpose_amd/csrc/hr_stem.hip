@@ -234,11 +234,9 @@ extern "C" int cp_hr_stem(cp_stream_t stream, const float* img_nchw, int B, int 
   if (!img_nchw || !packed1 || !packed2 || !scale1 || !shift1 || !scale2 || !shift2 || !out || B <= 0) return CP_ERR_INVALID;
   if (Hin <= 0 || Win <= 0 || Hin % (4 * ST_TH) || Win % (4 * ST_TW)) return CP_ERR_INVALID;     // whole 8 x 16 output tiles
   if (!cp_aligned16(packed1) || !cp_aligned16(packed2) || !cp_aligned16(scale2) || !cp_aligned16(shift2) || !cp_aligned16(out)) return CP_ERR_ALIGN;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)hr_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess) return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)hr_stem_kernel, ST_LDS));
   StemParams p;
   p.img = img_nchw; p.w1 = packed1; p.w2 = packed2; p.s1 = scale1; p.t1 = shift1; p.s2 = scale2; p.t2 = shift2; p.out = out;
   p.B = B; p.Hin = Hin; p.Win = Win;

@@ -166,11 +166,9 @@ extern "C" int cp_index2feat_conv(cp_stream_t stream, const void* f, int in_cstr
   if (!cp_aligned16(f) || !cp_aligned16(packed_w) || !cp_aligned16(bias) || !cp_aligned16(out)) return CP_ERR_ALIGN;
   const long long in_bytes = (long long)B * H * W * in_cstride * 2;
   if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)patch_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS) != hipSuccess) return CP_ERR_HIP;
-    attr_done = true;
-  }
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)patch_gather_kernel, PG_LDS));
   PatchParams p;
   p.f = f; p.w = packed_w; p.bias = bias; p.xid = x_id; p.yid = y_id; p.mask = mask; p.out = out;
   p.B = B; p.N = N; p.H = H; p.W = W; p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.k = k;

@@ -816,13 +816,10 @@ extern "C" int cp_pnp_ransac(cp_stream_t stream, const float* p3d, long long p3d
   p.p3d_bs = p3d_bstride; p.K_bs = K_bstride; p.B = B; p.N = N; p.valid_stride = valid_stride; p.iters = iterations; p.thr = reproj_threshold;
   p.seed = seed;
   const size_t lds1 = (size_t)2 * 144 * 64 * 8 + (size_t)N * 2 + 16, lds2 = (size_t)N * (5 * 4 + 8 + 1) + 16;
-  static size_t attr = 0;
-  if (attr < lds2) {
-    if (hipFuncSetAttribute((const void*)pnp_hypotheses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 144 * 64 * 8 + PNP_NMAX * 2 + 16)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)pnp_select_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PNP_NMAX * 29 + 16)) != hipSuccess)
-      return CP_ERR_HIP;
-    attr = (size_t)PNP_NMAX * 29 + 16;
-  }
+  static CpDeviceOnce once;                  // both kernels are sized for PNP_NMAX keypoints, once per device
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)pnp_hypotheses_kernel, (size_t)2 * 144 * 64 * 8 + PNP_NMAX * 2 + 16) &&
+                                  cp_set_max_lds((const void*)pnp_select_refit_kernel, (size_t)PNP_NMAX * 29 + 16));
   hipStream_t st = (hipStream_t)stream;
   for (int r = 0; 64 * r < iterations; ++r) {
     p.round = r;

@@ -11,8 +11,10 @@
  *   - plain pointers + ints, no torch / HIP types in signatures; `cp_stream_t` is a hipStream_t
  *     passed as void* (NULL = default stream).
  *   - every buffer (activations, packed weights, outputs) is caller-owned DEVICE memory; the
- *     library allocates nothing, keeps no mutable global state (beyond the thread-local cp_last_kernel note),
- *     is re-entrant and stream-ordered.
+ *     library allocates nothing and is re-entrant and stream-ordered.  Its only process state: the thread-local
+ *     cp_last_kernel note, and idempotent per-DEVICE caches (an atomic bit per device ordinal = "the large-LDS
+ *     function attributes are set on this device", the device's CU count) -- calls are made on the caller's
+ *     current device (hipSetDevice), several devices and several threads per process are fine.
  *   - activations are channels-last: (B, H, W, Cphys) with Cphys a multiple of cp_chan_align(dtype);
  *     padded channels are zero.  Graph features are (B, N, Cphys), i.e. the same layout with H=1.
  *   - returns CP_OK (0) or a negative code; cp_strerror() names it.
