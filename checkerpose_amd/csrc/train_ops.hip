@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const CeLossArgs a, LossWs
     for (int c = 0; c < a.C; ++c) se += expf(p[(long long)c * a.N] - mx);
     const int y = (int)a.gt[e];
     const float m = a.mask[e];
-    s0 += (double)((mx + logf(se) - p[(long long)y * a.N]) * m);
+    // nn.CrossEntropyLoss: ignore_index (-100) contributes 0 loss; any other id outside [0, C) raises there -- a kernel cannot, so
+    // every out-of-range id is treated as ignored (never read: p[y * N] would be out of bounds even under mask = 0)
+    if (y >= 0 && y < a.C) s0 += (double)((mx + logf(se) - p[(long long)y * a.N]) * m);
     s1 += m;
   }
   loss_block_reduce(s0, s1, ws, loss, 1, (double)total, 1);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void ce_loss_grad_kernel(const CeLossArgs a, c
   float se = 0.f;
   for (int c = 0; c < a.C; ++c) se += expf(p[(long long)c * a.N] - mx);
   const int y = (int)a.gt[e];
-  const float w = a.mask[e] / ws->denom, inv = 1.f / se;
+  const float w = (y >= 0 && y < a.C) ? a.mask[e] / ws->denom : 0.f, inv = 1.f / se;      // ignored / out-of-range id: zero gradient
   for (int c = 0; c < a.C; ++c) d[(long long)c * a.N] = (expf(p[(long long)c * a.N] - mx) * inv - (c == y ? 1.f : 0.f)) * w;
 }
 

@@ -13,6 +13,27 @@ from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
 
 
 _VERSION_OF = operator.attrgetter("_version")
+# Any parameter / buffer / submodule (re)registration anywhere in the process moves this epoch: the cached tensor list of the eval
+# staleness check is rebuilt (and the programs dropped if the tensors are not the same objects any more) -- a reassigned
+# submodule or parameter must not leave stale tensors in the list.  One global counter: registrations are rare, a forward's check
+# is one integer compare.
+_STRUCT_EPOCH = [0]
+
+
+def _bump_epoch(*_a):
+    _STRUCT_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+
+
+def _version_sum(tensors):
+    try:
+        return sum(map(_VERSION_OF, tensors))
+    except RuntimeError:        # inference-mode tensors (built / loaded under torch.inference_mode) track no version: they cannot be
+        return sum(0 if t.is_inference() else t._version for t in tensors)   # edited in place outside inference mode either
 TRAIN_GRAPH = os.environ.get("CHECKERPOSE_AMD_TRAIN_GRAPH", "fwd,bwd").split(",")   # which halves replay as hipGraphs (A/B + debugging)
 
 
@@ -132,7 +153,7 @@ class HipForwardMixin:
         self.kernel_selection = os.environ.get("CHECKERPOSE_AMD_SELECTION", "auto")
         self.batch_buckets = os.environ.get("CHECKERPOSE_AMD_BUCKETS", "1") != "0"   # eval: pad ragged batches to a cached size
         self.check_weight_versions = os.environ.get("CHECKERPOSE_AMD_CHECK_VERSIONS", "1") != "0"   # eval: detect in-place weight edits
-        self._sig_tensors = None
+        self._sig_tensors, self._sig_epoch = None, -1
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
     # ---- cache control
@@ -466,9 +487,13 @@ class HipForwardMixin:
             # eval programs fold BatchNorm and pack weights at build time: an in-place edit of any parameter / buffer since then
             # (optimizer step, EMA `copy_` / `mul_` under no_grad, a child's load_state_dict) bumps its version counter -> rebuild.
             # (Edits through `p.data` do not move the counter -- torch gives `.data` a counter of its own: call invalidate().)
-            if self._sig_tensors is None:
-                self._sig_tensors = list(self.parameters()) + list(self.buffers())
-            sig = sum(map(_VERSION_OF, self._sig_tensors)) + len(self._sig_tensors)      # ~2 000 tensors: the B = 1 forward is host-bound
+            if self._sig_tensors is None or self._sig_epoch != _STRUCT_EPOCH[0]:
+                ts = list(self.parameters()) + list(self.buffers())
+                if self._sig_tensors is not None and (len(ts) != len(self._sig_tensors) or
+                                                      any(a is not b for a, b in zip(ts, self._sig_tensors))):
+                    self._eval_sig = None                    # other tensor objects than the programs folded: rebuild
+                self._sig_tensors, self._sig_epoch = ts, _STRUCT_EPOCH[0]
+            sig = _version_sum(self._sig_tensors) + len(self._sig_tensors)      # ~2 000 tensors: the B = 1 forward is host-bound
             if self._programs and sig != getattr(self, "_eval_sig", None):
                 self._drop_eval_programs()
             self._eval_sig = sig

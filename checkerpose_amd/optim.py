@@ -101,6 +101,7 @@ class Adam(_MultiTensorOptimizer):
             stream = torch.cuda.current_stream(params[0].device).cuda_stream
             _abi.check(lib.cp_adam_multi(stream, tab["raw"].data_ptr(), tab["prefix"].data_ptr(), tab["n"], tab["blocks"], float(group["lr"]),
                                          float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), t), "cp_adam_multi")
+            torch._C._increment_version(params)        # written through raw pointers: tell autograd / the eval staleness check
         return loss
 
 
@@ -138,4 +139,5 @@ class SGD(_MultiTensorOptimizer):
             stream = torch.cuda.current_stream(params[0].device).cuda_stream
             _abi.check(lib.cp_sgd_multi(stream, tab["raw"].data_ptr(), tab["prefix"].data_ptr(), tab["n"], tab["blocks"], float(group["lr"]),
                                         float(group["momentum"]), float(group["weight_decay"]), 0), "cp_sgd_multi")
+            torch._C._increment_version(params)
         return loss

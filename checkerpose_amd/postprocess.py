@@ -51,6 +51,9 @@ def correspondences(outputs, roi_xy_ori=None, discard_bd_pixel=0, Bboxes=None):
     return p2d, valid, count
 
 
+PNP_MAX_ITERS = 256        # csrc/pnp.hip: 4 rounds of 64 hypotheses
+
+
 def solve_pnp_ransac(p3d_xyz, p2d, valid, cam_K, column=0, reproj_threshold=2.0, iterations=150, seed=0):
     """On-device twin of from_id_to_pose's cv2 branch (test_network_with_test_data.py:100-114; defaults reprojErr_thresh=2,
     cv_max_iters=150): EPnP + RANSAC over the correspondences of `correspondences()`.
@@ -60,6 +63,8 @@ def solve_pnp_ransac(p3d_xyz, p2d, valid, cam_K, column=0, reproj_threshold=2.0,
     Returns (R (B,3,3) f64, t (B,3,1) f64, inliers (B,N) bool, status (B,) int32: 0 = the reference's identity fallback)."""
     if not (p2d.is_cuda and valid.is_cuda):
         raise RuntimeError("checkerpose_amd.postprocess: CUDA/HIP tensors required (no CPU fallback)")
+    if not 0 < int(iterations) <= PNP_MAX_ITERS:        # no silent clamp: cv2 would run them all
+        raise ValueError("iterations (cv_max_iters) must be in 1..%d for cp_pnp_ransac, got %r" % (PNP_MAX_ITERS, iterations))
     lib = _abi.load()
     dev = p2d.device
     B, N, _ = p2d.shape
@@ -137,7 +142,7 @@ def from_id_to_pose(p3d_xyz, roi_xy_ori, cam_K, roi_mask_bit, pixel_x_id, pixel_
         p2d = torch.from_numpy(np.ascontiguousarray(disc_p2d, dtype=np.float32)).to(dev)[None]
         R, t, inl, status = solve_pnp_ransac(torch.from_numpy(np.ascontiguousarray(p3d_xyz, dtype=np.float32)).to(dev), p2d, valid,
                                              torch.from_numpy(np.ascontiguousarray(cam_K, dtype=np.float32)).to(dev), column=0,
-                                             reproj_threshold=float(reprojErr_thresh), iterations=min(int(cv_max_iters), 256), seed=seed)
+                                             reproj_threshold=float(reprojErr_thresh), iterations=int(cv_max_iters), seed=seed)
         if int(status[0]) == 1:
             R_predict, t_predict = R[0].cpu().numpy(), t[0].cpu().numpy()
             inliers = np.nonzero(inl[0].cpu().numpy())[0]

@@ -84,6 +84,20 @@ class TrainWeightStore(WeightStore):
         return super().affine(name, scale, shift, rows)
 
 
+_WG_ARENAS = {}
+
+
+def _shared_wgrad_arena(device):
+    """The weight-gradient partial-sum arena of `device` + the current stream (CHECKERPOSE_AMD_WGRAD_ARENA_MB, default 4096)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    nbytes = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_ARENA_MB", "4096")) << 20
+    key = (idx, torch.cuda.current_stream(dev).cuda_stream, nbytes)
+    if key not in _WG_ARENAS:
+        _WG_ARENAS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return _WG_ARENAS[key]
+
+
 class TrainProgram(Program):
     training = True
 
@@ -98,7 +112,10 @@ class TrainProgram(Program):
         self._bn_ws = {}           # lane -> BatchNorm partial-sum workspace
         # weight-gradient pixel-slice partials: every layer gets its OWN region of this arena and its reduction is DEFERRED; when the
         # arena is full (and at the end of the backward) one cp_wgrad_reduce_batch launch settles every pending layer
-        self.wg_ws = torch.empty(int(os.environ.get("CHECKERPOSE_AMD_WGRAD_ARENA_MB", "4096")) << 20, dtype=torch.uint8, device=device)
+        # (ONE arena per device and stream, shared by every TrainProgram -- the stage schedule, a ragged last batch and a second module
+        # each build their own program, but the partials never outlive the backward that wrote them and backwards on one stream are
+        # ordered)
+        self.wg_ws = _shared_wgrad_arena(device)
         self._wg_off, self._wg_items, self._wg_keys, self.wg_tabs = 0, [], set(), []
         self.wg_defer = os.environ.get("CHECKERPOSE_AMD_WGRAD_DEFER", "1") != "0"        # A/B: one reduction launch per layer
         # grouped weight gradients: the partial-sum launches of up to wg_group_n layers wait for each other and go out as ONE launch
