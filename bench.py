@@ -2,8 +2,11 @@
 """bench.py -- forward throughput of the CheckerPose hot path on MI355X (BASELINE.json metric).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32] [--npoint 512]
-                  [--workload lmo_ape|ycbv_rr21|lm13_n4096] [--feed hbm|host_u8] [--no-extras]
-  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+                  [--workload lmo_ape|ycbv_rr21|lm13_n4096] [--no-extras] [--dry-run]
+  N>1: either way works -- under the driver's launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+       --master-addr 127.0.0.1 ... bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or plain
+       `python bench.py --gpus N`: with no WORLD_SIZE in the environment the process makes no GPU call, starts exactly that
+       launcher as a child and exits with its code.  The line carries `ranks_seen` (all-gather of the rank ids) and `per_rank_ms`.
 
 A "step" = one forward of PoseNet_GNNskip (HRNet-W18 + decoder + 3 progressive GNN stages,
 hr18GNN2_res6_gnn3Skip_mlpQuery, LM-O `ape` keypoints, npt=512) over one batch of B synthetic 256x256 crops
@@ -16,7 +19,9 @@ batch), `by_batch` (bf16 at B = 1 / 8 / 32: the reference's test.py:198 runs bat
 `b1_latency_ms`, `bf16_agreement` (the bf16 path's accuracy contract, checkerpose_amd/agreement.py, measured against the
 fp32 HIP path on the same crops) and `host_u8` (crops start as uint8 in pinned HOST memory and are double-buffered over
 PCIe on a copy stream: the PCIe-inclusive rate, never `value`) `device_crop` (the data loader's RoI crop + resize done on the
-device from full frames in HBM, row N3) and `end_to_end` (frames + boxes -> poses without leaving the GPU).
+device from full frames in HBM, row N3), `end_to_end` (frames + boxes -> poses without leaving the GPU) and `configs`: short
+sub-runs of BASELINE configs #4 (`ycbv_rr21`), #5 (`lm13_n4096`) and the training step (`train_step_b32`, bench_train.py), each with
+its own value / ms_per_step / batch / roofline.
 
 Workloads (BASELINE.json configs):
   lmo_ape     (default) config #2: LM-O `ape`, one network, npt=512
@@ -37,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+LM13_DEFAULT_BATCH = 256      # config #5 (`--workload lm13_n4096`): crops per GPU per step; measured 7 010 / 9 010 / 10 290 / 10 940 crops/s at 32 / 64 / 128 / 256
 MFMA_KERNELS = {"conv_igemm": "conv_igemm_kernel", "conv3x3_halo": "conv3x3_halo_kernel", "conv3x3_halo4": "conv3x3_halo4_kernel",
                 "conv3x3_halo_s": "conv3x3_halo_s_kernel", "conv3x3_s2_small": "conv3x3_s2_small_kernel", "gemm_rows": "gemm_rows_kernel|gemm_rows_ws_kernel",
                 "basicblock_fused": "basicblock_fused_kernel|basicblock_persist_kernel", "bottleneck_fused": "bottleneck_fused_kernel",
@@ -65,8 +71,10 @@ def host_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(npoint, seconds=12.0):
-    """The oracle (validated CPU restatement incl. its HRNet-W18) on the host cores: B=1 forwards for ~`seconds`."""
+def cpu_baseline(npoint, seconds=9.0):
+    """The oracle (validated CPU restatement incl. its HRNet-W18) on the host cores: B=1 forwards under no_grad for ~`seconds`
+    (`value`), then the two variants SURVEY.md 8(d) names -- the reference's own test mode (test.py:290 never enters no_grad, so
+    autograd records the graph) and B=8 -- one bounded sample each (~20 s of CPU work in total)."""
     from oracle import checkerpose_oracle as O
     from checkerpose_amd.synthetic import det_image
     oracle_kwargs = lambda: ORACLE_KW   # noqa: E731
@@ -74,17 +82,37 @@ def cpu_baseline(npoint, seconds=12.0):
     net = build(npoint)
     sd = net.state_dict()
     img = det_image(1, seed=0)
-    with torch.no_grad():
+
+    def sample(fn, budget, first_counts=False):
         t0 = time.perf_counter()
-        O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())      # warm-up
+        fn()                                                            # warm-up (counted when one call already exhausts the budget)
         first = time.perf_counter() - t0
+        if first_counts or first >= budget:
+            return 1, first
         n, t0 = 0, time.perf_counter()
-        while (time.perf_counter() - t0 < seconds and first < seconds) or n < 1:          # bounded: ~`seconds` of CPU work
-            O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs())
+        while time.perf_counter() - t0 < budget or n < 1:               # bounded: ~`budget` seconds of CPU work
+            fn()
             n += 1
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
+        return n, time.perf_counter() - t0
+
+    with torch.no_grad():
+        n, dt = sample(lambda: O.posenet_forward(sd, img, net.init_net.knn_idx, npoint, **oracle_kwargs()), seconds)
+    res = {"value": round(n / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d forwards at B=1 (fp32, eval, no_grad) of the oracle restatement incl. HRNet-W18, %.1f s" % (n, dt)}
+    try:
+        sd_g = dict(sd)
+        sd_g.update({k: p_ for k, p_ in net.named_parameters()})         # parameters that require grad: the graph is recorded
+        with torch.enable_grad():
+            n2, dt2 = sample(lambda: O.posenet_forward(sd_g, img, net.init_net.knn_idx, npoint, **oracle_kwargs()), 4.0)
+        img8 = det_image(8, seed=0)
+        with torch.no_grad():
+            n8, dt8 = sample(lambda: O.posenet_forward(sd, img8, net.init_net.knn_idx, npoint, **oracle_kwargs()), 4.0, first_counts=True)
+        res["variants"] = {"b1_autograd_recording": {"value": round(n2 / dt2, 3), "sample": "%d forwards at B=1 WITHOUT no_grad (the reference's "
+                                                     "test.py:290 mode), %.1f s" % (n2, dt2)},
+                           "b8_no_grad": {"value": round(8 * n8 / dt8, 3), "sample": "%d forward(s) at B=8 under no_grad, %.1f s" % (n8, dt8)}}
+    except Exception as e:
+        res["variants"] = {"error": repr(e)[:200]}
+    return res
 
 
 def profile_tag(workload, dtype, B):
@@ -353,6 +381,304 @@ def kernel_breakdown(net, B, steps, dump=None):
     return fams, symbols
 
 
+def self_launch(script, n):
+    """`python <script> --gpus N` outside a torchrun environment: this process makes NO GPU call; it starts a fresh child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... <script> <same arguments>` (a subprocess, never an exec:
+    the pool forbids replacing a process that may have touched the GPU), lets rank 0's JSON line through on the shared stdout and
+    exits with the child's code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(script)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+class Ranks:
+    """This process's place in the job: torchrun's environment, the process group, the device."""
+
+    def __init__(self, dry_run=False):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("CHECKERPOSE_BENCH_BACKEND", "nccl")    # "gloo": exercise the N>1 path on a 1-GPU box / on CPU
+        self.dist, self.dev = None, None
+        if not dry_run:
+            ndev = torch.cuda.device_count()
+            if self.world > 1 and self.backend == "nccl" and ndev < self.world:
+                raise SystemExit("bench: %d ranks over RCCL need %d GPUs, this node shows %d (CHECKERPOSE_BENCH_BACKEND=gloo rehearses "
+                                 "the N>1 path with several ranks per GPU)" % (self.world, self.world, ndev))
+            self.dev = torch.device("cuda", (self.local % max(ndev, 1)) if self.world > 1 else 0)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl" and not dry_run:                        # nccl == RCCL over xGMI on ROCm
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo" if dry_run else self.backend)
+            self.dist = dist
+        self.coll_dev = self.dev if (self.backend == "nccl" and not dry_run) else None     # where the tiny timing collectives live
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def timed(self, step, steps, sync):
+        """barrier + sync, EXACTLY `steps` steps, sync + barrier; returns (whole-job seconds = MAX over ranks, ranks seen, per-rank ms)"""
+        from checkerpose_amd.parallel import gather_over_ranks, max_over_ranks
+        sync()
+        self.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        el_local = time.perf_counter() - t0
+        self.barrier()
+        el = max_over_ranks(el_local, self.coll_dev)                           # slowest rank defines the whole-job step time
+        seen = [int(r) for r in gather_over_ranks(self.rank, self.coll_dev)]
+        per_rank = [round(v / steps * 1e3, 3) for v in gather_over_ranks(el_local, self.coll_dev)]
+        return el, seen, per_rank
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def make_workload(workload, npoint, B, dtype, dev, rank=0, streams=1):
+    """Networks + resident inputs + the step closure of one BASELINE config.  Returns dict(net, step, name, img, nets)."""
+    from checkerpose_amd.synthetic import LM_OBJ_IDS, det_image, ycbv_p3d
+    img = det_image(B, seed=100 + rank).to(dev)      # this rank's shard, resident in HBM before timing
+    if workload == "ycbv_rr21":
+        # 21 per-object networks (own weights seed, own kNN graph); every model gets its program + graph before timing
+        nets = [build(npoint, seed=o, p3d=ycbv_p3d(o, npoint)).to(dev).set_compute_dtype(dtype) for o in range(1, 22)]
+        for n_ in nets:
+            n_.clone_outputs = False
+            for _ in range(2):
+                n_(img, None)
+        bufs = []
+        for n_ in nets:
+            b_ = n_.input_buffer(B); b_.copy_(img); bufs.append(b_)
+        counter = [0]
+        # the 21 per-object networks are independent (own weights, graph, workspace, hipGraph): with --streams S > 1 consecutive
+        # steps go to S HIP streams in turn.  Measured on MI355X (B = 64): 14 960 / 15 700 / 15 330 / 15 430 crops/s at S = 1 / 2 / 4 /
+        # 6 -- ROCm does not overlap the replays of independent multi-lane hipGraphs, so the default stays 1
+        rr_streams = [torch.cuda.Stream(dev) for _ in range(max(streams, 1))] if streams > 1 else None
+        if rr_streams:
+            for s_ in rr_streams:
+                s_.wait_stream(torch.cuda.current_stream(dev))
+
+        def step():
+            k = counter[0] % 21
+            counter[0] += 1
+            if rr_streams is None:
+                return nets[k](bufs[k], None)
+            with torch.cuda.stream(rr_streams[counter[0] % len(rr_streams)]):
+                return nets[k](bufs[k], None)
+        name = "YCB-V all 21 objects, one hr18GNN2_res6_gnn3Skip_mlpQuery network per object (round-robin), npt=%d" % npoint
+        return {"net": nets[0], "nets": nets, "step": step, "name": name, "img": bufs[0]}
+    lm = workload == "lm13_n4096"
+    net = build(npoint, lm=lm).to(dev).set_compute_dtype(dtype)
+    net.clone_outputs = False            # outputs stay in the program's persistent buffers (no per-step clones)
+    obj = torch.tensor([LM_OBJ_IDS[(i + rank) % 13] for i in range(B)], device=dev) if lm else None
+    net(img, None, obj) if lm else net(img, None)      # builds the launch program for B
+    buf = net.input_buffer(B)            # zero-copy boundary: the crops live in the buffer the program reads
+    buf.copy_(img)
+
+    def step():
+        return net(buf, None, obj) if lm else net(buf, None)
+    name = ("LM 13-object shared estimator (pipeline_lm), npt=%d dense keypoints, obj_ids uniform over the 13 LM ids" % npoint
+            if lm else "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d" % npoint)
+    return {"net": net, "nets": [net], "step": step, "name": name, "img": buf}
+
+
+def roofline_report(out, net, B, dtype, workload, npoint, steps, dump=None):
+    """`roofline` (+ `roofline_gather`, `kernel_symbols`, `mfma_kernels`, ...) of one configuration into `out`: live HIP-event
+    timing of every launch (kernel_breakdown) priced with the launch program's algorithmic FLOPs / bytes."""
+    prog = net.program_for(B)
+    fam, symbols = kernel_breakdown(net, B, steps, dump)
+    # MFMA kernel families (host-side grouping) ...
+    fl_by, by_by = {}, {}
+    for wk, M, Cout, K, fl, kf, nby in prog.conv_log:
+        fl_by[kf] = fl_by.get(kf, 0) + fl
+        by_by[kf] = by_by.get(kf, 0) + nby
+    mf = {k: fam[k] for k in MFMA_KERNELS if k in fam}
+    per = {}
+    for k, v in mf.items():
+        t = v["ms_per_step"] * 1e-3
+        tf, gb = fl_by.get(k, 0) / t / 1e12, by_by.get(k, 0) / t / 1e9
+        per[k] = {"kernel": MFMA_KERNELS[k], "ms_per_step": round(v["ms_per_step"], 3), "launches": v["launches_per_step"],
+                  "tflops": round(tf, 1), "frac_mfma": round(tf / PEAK_TFLOPS[dtype], 4),
+                  "alg_gbs": round(gb, 0), "frac_hbm": round(gb / PEAK_HBM_GBS, 4)}
+    # ... and per kernel SYMBOL (the granularity of rocprofv3's kernel stats): `roofline` = the symbol with the
+    # most device time per step, priced against the roof it sits closer to
+    ksym = {}
+    for k, v in symbols.items():
+        if not v["flops"]:
+            continue
+        t = v["ms_per_step"] * 1e-3
+        tf, gb = v["flops"] / t / 1e12, v["bytes"] / t / 1e9
+        ksym[k] = {"ms_per_step": round(v["ms_per_step"], 3), "launches": v["launches_per_step"], "tflops": round(tf, 1),
+                   "frac_mfma": round(tf / PEAK_TFLOPS[dtype], 4), "alg_gbs": round(gb, 0),
+                   "frac_hbm": round(gb / PEAK_HBM_GBS, 4)}
+    dom = max(ksym, key=lambda k: ksym[k]["ms_per_step"])
+    pd, sv = ksym[dom], symbols[dom]
+    n = pd["launches"]
+    if pd["frac_hbm"] > pd["frac_mfma"]:
+        out["roofline"] = {"bound": "hbm", "kernel": "%s (%d launches per step)" % (dom, n),
+                           "achieved": pd["alg_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pd["frac_hbm"],
+                           "traffic": None, "algorithmic_mb_per_launch_avg": round(sv["bytes"] / n / 1e6, 2),
+                           "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
+    else:
+        out["roofline"] = {"bound": "mfma", "kernel": "%s (%d launches per step)" % (dom, n),
+                           "achieved": pd["tflops"], "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                           "frac": pd["frac_mfma"], "traffic": None,
+                           "algorithmic_gflop_per_launch_avg": round(sv["flops"] / n / 1e9, 3),
+                           "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
+    out["kernel_symbols"] = dict(sorted(ksym.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8])
+    out["roofline"]["timing"] = ("HIP events on the launch stream around every launch of an eager replay of the same launch "
+                                 "program, mean over %d steps (bench.py:kernel_breakdown)" % steps)
+    short = dom.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+    tr, us_prof, src = committed_profile(short, profile_tag(workload, dtype, B))
+    if src is not None:      # committed rocprofv3 evidence of this exact command (same workload, dtype and batch), if any
+        out["roofline"]["traffic"] = tr
+        out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch"
+        out["roofline"]["traffic_source"] = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                             "this command; not re-measured by this run)" % src)
+        if us_prof:          # the same fraction priced with rocprofv3's own average duration of that kernel
+            per_launch = (sv["bytes"] / n / 1e3 / us_prof / PEAK_HBM_GBS) if out["roofline"]["bound"] == "hbm" else \
+                         (sv["flops"] / n / 1e6 / us_prof / PEAK_TFLOPS[dtype])
+            out["roofline"]["rocprofv3_avg_launch_us"] = us_prof
+            out["roofline"]["frac_rocprofv3"] = round(per_launch, 4)
+    tot_s = sum(v["ms_per_step"] for v in mf.values()) * 1e-3
+    out["mfma_kernels"] = per
+    out["mfma_all"] = {"achieved": round(prog.flops / tot_s / 1e12, 2), "unit": "TFLOP/s",
+                       "frac": round(prog.flops / tot_s / 1e12 / PEAK_TFLOPS[dtype], 4)}
+    # the GNN gather (north_star: "achieved GB/s on the GNN gather"): algorithmic bytes per layer (SURVEY.md 8d) =
+    # N*K*C*e neighbour rows + N*C*e centre + N*C*e write + N*K*4 index, all 11 EdgeConv layers.  Three kernels can carry
+    # it: edgeconv_fused (N = 512: table in LDS), edgeconv_tiled (N = 4096: neighbour window in LDS), and the L2 gather.
+    e = 2 if dtype == "bf16" else 4
+    N, K = npoint, 20
+    LDS_PEAK = 256 * 256 * 2.4          # B/clk/CU x CUs x GHz = GB/s (MI355X_MICROARCH.md: ds_read_b128 256 B/clk/CU)
+    layers = {}                          # family -> [C' per launch]
+    for (fn_, args_, name_) in prog.calls:
+        f_ = name_.split(":")[0]
+        if f_ in ("edge_fused", "edge_tiled"):
+            layers.setdefault(f_, []).append(64 if name_.split(":")[1].startswith("init_net.") else 256)
+        elif f_ == "edge_gather":
+            layers.setdefault(f_, []).append(int(name_.split(":")[1]))
+    rg = {}
+    for f_, cs in layers.items():
+        t_ = fam[f_]["ms_per_step"] * 1e-3
+        by = B * sum(N * K * c * e + 2 * N * c * e + N * K * 4 for c in cs)
+        hbm_by = B * sum(2 * N * c * e for c in cs)            # compulsory: the layer's input rows in, its output out
+        lds = f_ != "edge_gather"
+        peak = LDS_PEAK if lds else 34500.0
+        sym_ = {"edge_fused": "edgeconv_fused_kernel", "edge_tiled": "edgeconv_tiled_kernel", "edge_gather": "edgeconv_gather_max_kernel"}[f_]
+        r_ = {"bound": "lds" if lds else "l2", "kernel": "%s (%d launches per step)" % (sym_, len(cs)),
+              "achieved": round(by / t_ / 1e9, 1), "peak": round(peak, 0), "unit": "GB/s", "frac": round(by / t_ / 1e9 / peak, 4),
+              "algorithmic_mb_per_step": round(by / 1e6, 1), "ms_per_step": round(t_ * 1e3, 3),
+              "compulsory_hbm_mb_per_step": round(hbm_by / 1e6, 1), "compulsory_hbm_gbs": round(hbm_by / t_ / 1e9, 1),
+              "traffic": None,
+              "note": ("gather bytes = K=20 neighbour rows + centre + write + idx (SURVEY.md 8d) over the WHOLE launch time; "
+                       + ("the launch also runs the layer's node GEMM on the MFMA pipe, so this is a lower bound of the gather "
+                          "rate; the neighbour rows are read from the LDS table (ds_read_b128: %.0f TB/s aggregate)" % (LDS_PEAK / 1e3)
+                          if lds else "the neighbour rows are served by the XCD L2 (~34.5 TB/s aggregate), not HBM"))}
+        tr, src = _profile_prefix_mb_per_step(sym_, profile_tag(workload, dtype, B))      # template instances: by prefix
+        if tr is not None:
+            r_["traffic"] = tr
+            r_["traffic_unit"] = "MB of HBM read+write per step, all launches of this kernel (PMC)"
+            r_["traffic_source"] = "from_committed_profile: %s" % src
+            r_["compulsory_hbm_fraction"] = round(hbm_by / 1e6 / tr, 3)
+        rg[f_] = r_
+    if rg:
+        main_f = max(rg, key=lambda k_: rg[k_]["ms_per_step"])
+        out["roofline_gather"] = rg[main_f]
+        for k_, v_ in rg.items():
+            if k_ != main_f:
+                out["roofline_gather_" + k_] = v_
+    out["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+    out["dense_gflop_per_crop"] = round(prog.flops / B / 1e9, 2)
+    out["workspace_mb"] = round(prog.workspace_bytes / 2 ** 20, 1)
+
+
+# the other BASELINE configs inside the DEFAULT line (N = 1): short runs of the same code paths `--workload` / bench_train.py time
+SUB_CONFIGS = (("ycbv_rr21", dict(workload="ycbv_rr21", npoint=512, batch=256, steps=42)),
+               ("lm13_n4096", dict(workload="lm13_n4096", npoint=4096, batch=LM13_DEFAULT_BATCH, steps=20)))
+
+
+def sub_configs(dtype, dev):
+    """configs #4 / #5 and the training step (row N1) as short sub-runs of the default line: each its own try / except (an extra
+    can never take the headline down), own `roofline` / `roofline_gather`, everything freed before the next."""
+    res = {}
+    for key, c in SUB_CONFIGS:
+        t_start = time.perf_counter()
+        try:
+            wl = make_workload(c["workload"], c["npoint"], c["batch"], dtype, dev)
+            el = timed_steps(wl["step"], c["steps"], 3)
+            r = {"metric": "crops/sec forward (256x256, npt=%d)" % c["npoint"], "value": round(c["batch"] * c["steps"] / el, 1), "unit": "crops/s",
+                 "ms_per_step": round(el / c["steps"] * 1e3, 3), "batch": c["batch"], "steps": c["steps"], "dtype": dtype,
+                 "workload": wl["name"], "command": "bench.py --workload %s --batch %d" % (c["workload"], c["batch"])}
+            roofline_report(r, wl["net"], c["batch"], dtype, c["workload"], c["npoint"], 2)
+            for k in ("mfma_kernels", "kernel_symbols"):
+                r.pop(k, None)                              # the full tables are in the `--workload` line; keep the sub-run compact
+            r["kernel_ms_per_step"] = dict(list(r["kernel_ms_per_step"].items())[:8])
+            del wl
+        except Exception as e:
+            r = {"error": repr(e)[:300]}
+        r["wall_s"] = round(time.perf_counter() - t_start, 1)
+        res[key] = r
+        torch.cuda.empty_cache()
+    t_start = time.perf_counter()
+    try:
+        import bench_train
+        torch.set_grad_enabled(True)
+        r = bench_train.run_step_bench(Ranks_single(dev), batch=32, npoint=512, dtype=dtype, steps=20, warmup=10, breakdown=True)
+        r = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "loss_first_last", "device_ms_fwd_bwd", "roofline") if k in r}
+        r["batch"], r["steps"], r["command"] = 32, 20, "bench_train.py --batch 32"
+    except Exception as e:
+        r = {"error": repr(e)[:300]}
+    finally:
+        torch.set_grad_enabled(False)
+    r["wall_s"] = round(time.perf_counter() - t_start, 1)
+    res["train_step_b32"] = r
+    torch.cuda.empty_cache()
+    return res
+
+
+class Ranks_single:
+    """the one-rank stand-in for `Ranks` inside a process that already owns its device (sub-runs of the default line)"""
+    world, rank, local, dist, backend, coll_dev = 1, 0, 0, None, "nccl", None
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    barrier = lambda self: None          # noqa: E731
+    timed = Ranks.timed
+    close = lambda self: None            # noqa: E731
+
+
+def dry_run(a):
+    """`--dry-run`: the launcher + rendezvous + timing collectives of the N-rank path with NO GPU call (CPU test of `--gpus N`):
+    a step is a 1 ms sleep."""
+    rk = Ranks(dry_run=True)
+    el, seen, per_rank = rk.timed(lambda: time.sleep(0.001), a.steps, lambda: None)
+    if rk.rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": round(rk.world * a.batch * a.steps / el, 1), "unit": "crops/s",
+                          "n_gpus": rk.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+                          "ranks_seen": seen, "per_rank_ms": per_rank, "dry_run": True, "backend": "gloo"}), flush=True)
+    rk.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,219 +691,56 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--dump-convs", default=None, help="write per-conv-launch timings (json) to this path")
     ap.add_argument("--workload", default="lmo_ape", choices=["lmo_ape", "ycbv_rr21", "lm13_n4096"])
-    ap.add_argument("--no-extras", action="store_true", help="skip fp32_exact / by_batch / bf16_agreement / host_u8")
+    ap.add_argument("--no-extras", action="store_true", help="skip fp32_exact / by_batch / bf16_agreement / host_u8 / the sub-configs")
     ap.add_argument("--streams", type=int, default=1, help="ycbv_rr21: HIP streams the independent per-object networks' steps rotate over")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing collectives only, no GPU call (CPU test of --gpus N)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # not under torchrun: launch the N ranks ourselves
+        sys.exit(self_launch(__file__, a.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher started %s ranks" % (a.gpus, os.environ["WORLD_SIZE"]))
+    if a.dry_run:
+        return dry_run(a)
     if a.workload == "lm13_n4096":
         a.npoint = 4096
         if "--batch" not in sys.argv:
-            a.batch = 32
+            a.batch = LM13_DEFAULT_BATCH
     # (ycbv_rr21 runs at the default 256 crops per network too: switching among the 21 networks costs nothing -- 22 290 crops/s
     #  against 22 470-23 300 for the single network; 14 880 at --batch 64 and 19 540 at 128: the per-crop launches need the crops)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("CHECKERPOSE_BENCH_BACKEND", "nccl")    # "gloo": exercise the N>1 path on a 1-GPU box
-    ndev = max(torch.cuda.device_count(), 1)
-    dev = torch.device("cuda", (local % ndev) if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":                                          # nccl == RCCL over xGMI on ROCm
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    rk = Ranks()
+    world, rank, dev = rk.world, rk.rank, rk.dev
     torch.set_grad_enabled(False)
-
-    from checkerpose_amd.synthetic import LM_OBJ_IDS, det_image, ycbv_p3d
     B = a.batch
-    img = det_image(B, seed=100 + rank).to(dev)      # this rank's shard, resident in HBM before timing
-    if a.workload == "ycbv_rr21":
-        # 21 per-object networks (own weights seed, own kNN graph); every model gets its program + graph before timing
-        nets = [build(a.npoint, seed=o, p3d=ycbv_p3d(o, a.npoint)).to(dev).set_compute_dtype(a.dtype) for o in range(1, 22)]
-        for n_ in nets:
-            n_.clone_outputs = False
-            for _ in range(2):
-                n_(img, None)
-        net = nets[0]
-        bufs = []
-        for n_ in nets:
-            b_ = n_.input_buffer(B); b_.copy_(img); bufs.append(b_)
-        counter = [0]
-        # the 21 per-object networks are independent (own weights, graph, workspace, hipGraph): with --streams S > 1 consecutive
-        # steps go to S HIP streams in turn.  Measured on MI355X (B = 64): 14 960 / 15 700 / 15 330 / 15 430 crops/s at S = 1 / 2 / 4 /
-        # 6 -- ROCm does not overlap the replays of independent multi-lane hipGraphs, so the default stays 1
-        rr_streams = [torch.cuda.Stream(dev) for _ in range(max(a.streams, 1))] if a.streams > 1 else None
-        if rr_streams:
-            for s_ in rr_streams:
-                s_.wait_stream(torch.cuda.current_stream(dev))
-
-        def step():
-            k = counter[0] % 21
-            counter[0] += 1
-            if rr_streams is None:
-                return nets[k](bufs[k], None)
-            with torch.cuda.stream(rr_streams[counter[0] % len(rr_streams)]):
-                return nets[k](bufs[k], None)
-        wl_name = "YCB-V all 21 objects, one hr18GNN2_res6_gnn3Skip_mlpQuery network per object (round-robin), npt=%d" % a.npoint
-    else:
-        lm = a.workload == "lm13_n4096"
-        net = build(a.npoint, lm=lm).to(dev).set_compute_dtype(a.dtype)
-        net.clone_outputs = False            # outputs stay in the program's persistent buffers (no per-step clones)
-        obj = torch.tensor([LM_OBJ_IDS[(i + rank) % 13] for i in range(B)], device=dev) if lm else None
-        net(img, None, obj) if lm else net(img, None)      # builds the launch program for B
-        buf = net.input_buffer(B)            # zero-copy boundary: the crops live in the buffer the program reads
-        buf.copy_(img)
-        img = buf
-
-        def step():
-            return net(img, None, obj) if lm else net(img, None)
-        wl_name = ("LM 13-object shared estimator (pipeline_lm), npt=%d dense keypoints, obj_ids uniform over the 13 LM ids" % a.npoint
-                   if lm else "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d" % a.npoint)
+    wl = make_workload(a.workload, a.npoint, B, a.dtype, dev, rank, a.streams)
+    net, step, img = wl["net"], wl["step"], wl["img"]
     for _ in range(max(a.warmup, 2)):    # >= 2: eager run, then hipGraph capture
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        from checkerpose_amd.parallel import max_over_ranks
-        el = max_over_ranks(el, dev if backend == "nccl" else None)   # slowest rank defines the whole-job step time
+    el, seen, per_rank = rk.timed(step, a.steps, torch.cuda.synchronize)
     ms_per_step = el / a.steps * 1e3
     value = world * B * a.steps / el
 
     out = {"metric": "crops/sec forward (256x256, npt=%d)" % a.npoint, "value": round(value, 1), "unit": "crops/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-           "config": {"workload": wl_name + ", PoseNet_GNNskip forward, deterministic random-init weights",
+           "config": {"workload": wl["name"] + ", PoseNet_GNNskip forward, deterministic random-init weights",
                       "crops_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d (no forward collective)" % world,
-                      "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls)}}
+                      "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls)},
+           "ranks_seen": seen, "per_rank_ms": per_rank, "backend": rk.backend if world > 1 else None}
     if a.workload == "ycbv_rr21":
         out["config"]["streams"] = max(a.streams, 1)
     if rank == 0:
-        prog = net.program_for(B)
         if not a.no_breakdown:
-            fam, symbols = kernel_breakdown(net, B, min(a.steps, 5), a.dump_convs)
-            # MFMA kernel families (host-side grouping) ...
-            fl_by, by_by = {}, {}
-            for wk, M, Cout, K, fl, kf, nby in prog.conv_log:
-                fl_by[kf] = fl_by.get(kf, 0) + fl
-                by_by[kf] = by_by.get(kf, 0) + nby
-            mf = {k: fam[k] for k in MFMA_KERNELS if k in fam}
-            per = {}
-            for k, v in mf.items():
-                t = v["ms_per_step"] * 1e-3
-                tf, gb = fl_by.get(k, 0) / t / 1e12, by_by.get(k, 0) / t / 1e9
-                per[k] = {"kernel": MFMA_KERNELS[k], "ms_per_step": round(v["ms_per_step"], 3), "launches": v["launches_per_step"],
-                          "tflops": round(tf, 1), "frac_mfma": round(tf / PEAK_TFLOPS[a.dtype], 4),
-                          "alg_gbs": round(gb, 0), "frac_hbm": round(gb / PEAK_HBM_GBS, 4)}
-            # ... and per kernel SYMBOL (the granularity of rocprofv3's kernel stats): `roofline` = the symbol with the
-            # most device time per step, priced against the roof it sits closer to
-            ksym = {}
-            for k, v in symbols.items():
-                if not v["flops"]:
-                    continue
-                t = v["ms_per_step"] * 1e-3
-                tf, gb = v["flops"] / t / 1e12, v["bytes"] / t / 1e9
-                ksym[k] = {"ms_per_step": round(v["ms_per_step"], 3), "launches": v["launches_per_step"], "tflops": round(tf, 1),
-                           "frac_mfma": round(tf / PEAK_TFLOPS[a.dtype], 4), "alg_gbs": round(gb, 0),
-                           "frac_hbm": round(gb / PEAK_HBM_GBS, 4)}
-            dom = max(ksym, key=lambda k: ksym[k]["ms_per_step"])
-            pd, sv = ksym[dom], symbols[dom]
-            n = pd["launches"]
-            if pd["frac_hbm"] > pd["frac_mfma"]:
-                out["roofline"] = {"bound": "hbm", "kernel": "%s (%d launches per step)" % (dom, n),
-                                   "achieved": pd["alg_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pd["frac_hbm"],
-                                   "traffic": None, "algorithmic_mb_per_launch_avg": round(sv["bytes"] / n / 1e6, 2),
-                                   "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
-            else:
-                out["roofline"] = {"bound": "mfma", "kernel": "%s (%d launches per step)" % (dom, n),
-                                   "achieved": pd["tflops"], "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                                   "frac": pd["frac_mfma"], "traffic": None,
-                                   "algorithmic_gflop_per_launch_avg": round(sv["flops"] / n / 1e9, 3),
-                                   "avg_launch_us": round(pd["ms_per_step"] * 1e3 / n, 2)}
-            out["kernel_symbols"] = dict(sorted(ksym.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8])
-            out["roofline"]["timing"] = ("HIP events on the launch stream around every launch of an eager replay of the same launch "
-                                         "program, mean over %d steps (bench.py:kernel_breakdown)" % min(a.steps, 5))
-            short = dom.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
-            tr, us_prof, src = committed_profile(short, profile_tag(a.workload, a.dtype, B))
-            if src is not None:      # committed rocprofv3 evidence of this exact command (same workload, dtype and batch), if any
-                out["roofline"]["traffic"] = tr
-                out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch"
-                out["roofline"]["traffic_source"] = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                                     "this command; not re-measured by this run)" % src)
-                if us_prof:          # the same fraction priced with rocprofv3's own average duration of that kernel
-                    per_launch = (sv["bytes"] / n / 1e3 / us_prof / PEAK_HBM_GBS) if out["roofline"]["bound"] == "hbm" else \
-                                 (sv["flops"] / n / 1e6 / us_prof / PEAK_TFLOPS[a.dtype])
-                    out["roofline"]["rocprofv3_avg_launch_us"] = us_prof
-                    out["roofline"]["frac_rocprofv3"] = round(per_launch, 4)
-            tot_s = sum(v["ms_per_step"] for v in mf.values()) * 1e-3
-            out["mfma_kernels"] = per
-            out["mfma_all"] = {"achieved": round(prog.flops / tot_s / 1e12, 2), "unit": "TFLOP/s",
-                               "frac": round(prog.flops / tot_s / 1e12 / PEAK_TFLOPS[a.dtype], 4)}
-            # the GNN gather (north_star: "achieved GB/s on the GNN gather"): algorithmic bytes per layer =
-            # N*K*C*e neighbour rows + N*C*e centre + N*C*e write + N*K*4 index, all 11 EdgeConv layers.  Three kernels can carry
-            # it: edgeconv_fused (N = 512: table in LDS), edgeconv_tiled (N = 4096: neighbour window in LDS), and the L2 gather.
-            e = 2 if a.dtype == "bf16" else 4
-            N, K = a.npoint, 20
-            LDS_PEAK = 256 * 256 * 2.4          # B/clk/CU x CUs x GHz = GB/s (MI355X_MICROARCH.md: ds_read_b128 256 B/clk/CU)
-            layers = {}                          # family -> [C' per launch]
-            for (fn_, args_, name_) in prog.calls:
-                f_ = name_.split(":")[0]
-                if f_ in ("edge_fused", "edge_tiled"):
-                    layers.setdefault(f_, []).append(64 if name_.split(":")[1].startswith("init_net.") else 256)
-                elif f_ == "edge_gather":
-                    layers.setdefault(f_, []).append(int(name_.split(":")[1]))
-            rg = {}
-            for f_, cs in layers.items():
-                t_ = fam[f_]["ms_per_step"] * 1e-3
-                by = B * sum(N * K * c * e + 2 * N * c * e + N * K * 4 for c in cs)
-                hbm_by = B * sum(2 * N * c * e for c in cs)            # compulsory: the layer's input rows in, its output out
-                lds = f_ != "edge_gather"
-                peak = LDS_PEAK if lds else 34500.0
-                sym_ = {"edge_fused": "edgeconv_fused_kernel", "edge_tiled": "edgeconv_tiled_kernel", "edge_gather": "edgeconv_gather_max_kernel"}[f_]
-                r_ = {"bound": "lds" if lds else "l2", "kernel": "%s (%d launches per step)" % (sym_, len(cs)),
-                      "achieved": round(by / t_ / 1e9, 1), "peak": round(peak, 0), "unit": "GB/s", "frac": round(by / t_ / 1e9 / peak, 4),
-                      "algorithmic_mb_per_step": round(by / 1e6, 1), "ms_per_step": round(t_ * 1e3, 3),
-                      "compulsory_hbm_mb_per_step": round(hbm_by / 1e6, 1), "compulsory_hbm_gbs": round(hbm_by / t_ / 1e9, 1),
-                      "traffic": None,
-                      "note": ("gather bytes = K=20 neighbour rows + centre + write + idx (SURVEY.md 8d) over the WHOLE launch time; "
-                               + ("the launch also runs the layer's node GEMM on the MFMA pipe, so this is a lower bound of the gather "
-                                  "rate; the neighbour rows are read from the LDS table (ds_read_b128: %.0f TB/s aggregate)" % (LDS_PEAK / 1e3)
-                                  if lds else "the neighbour rows are served by the XCD L2 (~34.5 TB/s aggregate), not HBM"))}
-                tr, src = _profile_prefix_mb_per_step(sym_, profile_tag(a.workload, a.dtype, B))      # template instances: by prefix
-                if tr is not None:
-                    r_["traffic"] = tr
-                    r_["traffic_unit"] = "MB of HBM read+write per step, all launches of this kernel (PMC)"
-                    r_["traffic_source"] = "from_committed_profile: %s" % src
-                    r_["compulsory_hbm_fraction"] = round(hbm_by / 1e6 / tr, 3)
-                rg[f_] = r_
-            if rg:
-                main_f = max(rg, key=lambda k_: rg[k_]["ms_per_step"])
-                out["roofline_gather"] = rg[main_f]
-                for k_, v_ in rg.items():
-                    if k_ != main_f:
-                        out["roofline_gather_" + k_] = v_
-            out["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
-            out["dense_gflop_per_crop"] = round(prog.flops / B / 1e9, 2)
-            out["workspace_mb"] = round(prog.workspace_bytes / 2 ** 20, 1)
+            roofline_report(out, net, B, a.dtype, a.workload, a.npoint, min(a.steps, 5), a.dump_convs)
         if world == 1 and not a.no_extras and a.workload == "lmo_ape" and a.dtype == "bf16":
             out.update(side_measurements(net, a.npoint, dev, B, img))
+            del wl, net, step, img
+            torch.cuda.empty_cache()
+            out["configs"] = sub_configs(a.dtype, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.npoint)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

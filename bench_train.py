@@ -61,41 +61,15 @@ def cpu_baseline(npoint, seconds=20.0, B=2):
                       "incl. HRNet-W18), %.1f s" % (n, B, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10,
-                    help="untimed steps: the first ~10 replays of freshly captured hipGraphs run slower (one-time, ~100 ms in total)")
-    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step (reference config: batch_size 32)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--npoint", type=int, default=512)
-    ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("CHECKERPOSE_BENCH_BACKEND", "nccl")
-    ndev = max(torch.cuda.device_count(), 1)
-    dev = torch.device("cuda", (local % ndev) if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
+def run_step_bench(rk, batch=32, npoint=512, dtype="bf16", steps=40, warmup=10, breakdown=True):
+    """The training step on this rank's device (rk: bench.Ranks); returns the result dict (complete on rank 0)."""
     from checkerpose_amd.losses.code_loss import MaskedCodeLoss, UnmaskedCodeLoss
     from checkerpose_amd.losses.mask_loss import MaskLoss_interpolate
     from checkerpose_amd.synthetic import build_net, det_image, det_tensor
-    B, N = a.batch, a.npoint
+    world, rank, dev = rk.world, rk.rank, rk.dev
+    B, N = batch, npoint
     net = build_net(npoint=N, seed=1).to(dev).train()
-    net.set_compute_dtype(a.dtype)
+    net.set_compute_dtype(dtype)
     img = det_image(B, seed=100 + rank).to(dev)
     roi_gt = (det_tensor("t_roi", (B, 1, N), seed=rank) > -0.5).float().to(dev)
     x_gt = (det_tensor("t_x", (B, 16, N), seed=rank) > 0).float().to(dev)
@@ -107,6 +81,7 @@ def main():
     opt = (torch.optim.Adam(net.parameters(), lr=2e-4, fused=True) if os.environ.get("CHECKERPOSE_BENCH_TORCH_ADAM") == "1"
            else Adam(net.parameters(), lr=2e-4))
     p3d = torch.zeros(1, 3, N, device=dev).expand(B, -1, -1)
+    last = [None, None]
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -116,36 +91,27 @@ def main():
             + seg_loss(seg[:, 0:1], m_vis) + seg_loss(seg[:, 1:2], m_full)
         loss.backward()
         opt.step()
+        last[1] = loss
         return loss
 
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         l0 = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        l1 = step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        from checkerpose_amd.parallel import max_over_ranks
-        el = max_over_ranks(el, dev if backend == "nccl" else None)
+    el, seen, per_rank = rk.timed(step, steps, torch.cuda.synchronize)
+    l1 = last[1]
     pr = list(net._train_programs.values())[0]
     prog = pr["prog"]
-    out = {"metric": "crops/sec training step (256x256, npt=%d)" % N, "value": round(world * B * a.steps / el, 1), "unit": "crops/s",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+    out = {"metric": "crops/sec training step (256x256, npt=%d)" % N, "value": round(world * B * steps / el, 1), "unit": "crops/s",
+           "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
            "config": {"workload": "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d: train.py step (forward in train mode, 5 losses, "
                                   "backward, gradient all-reduce, Adam)" % N,
                       "crops_per_gpu_per_step": B, "global_batch": world * B,
                       "parallelism": "dp%d, one all-reduce of the %.1f MB flat fp32 gradient buffer per step" % (world, pr["pgrad"].numel() * 4 / 1e6),
                       "launches": "%d forward + %d backward kernel launches per step" % (prog.n_fwd_ops, len(prog.calls) - prog.n_fwd_ops)},
+           "ranks_seen": seen, "per_rank_ms": per_rank, "backend": rk.backend if world > 1 else None,
            "loss_first_last": [round(float(l0), 4), round(float(l1), 4)],
            "workspace_mb": round(prog.workspace_bytes / 2 ** 20, 1)}
-    if rank == 0 and not a.no_breakdown:
+    if rank == 0 and breakdown:
         from checkerpose_amd import _abi
         lib = _abi.load()
         stream = torch.cuda.current_stream()
@@ -176,7 +142,7 @@ def main():
         out["device_ms_fwd_bwd"] = [round(sum(v[0] for k, v in agg.items() if k[0] == h), 3) for h in ("fwd", "bwd")]
         # roofline of the dominant dense training kernel: the all-taps weight gradient (MFMA-bound), algorithmic FLOPs
         # 2*M*9*Cin*Cout of its launches / their measured device time (HIP events on the launch stream)
-        peak = {"bf16": 2500.0, "fp32": 157.3}[a.dtype]
+        peak = {"bf16": 2500.0, "fp32": 157.3}[dtype]
         w3 = [(i, e0.elapsed_time(e1)) for i, ((fn, args, name), (e0, e1), sy) in enumerate(zip(prog.calls, evs, syms))
               if sy.startswith("wgrad") and i in prog.wgrad_flops and " k3 s1 " in name]
         if w3:
@@ -185,7 +151,7 @@ def main():
             big = max(w3, key=lambda it: prog.wgrad_flops[it[0]])
             from bench import _profile_prefix_mb_per_step
             n_single = sum(1 for i, _ in w3 if not prog.calls[i][2].startswith("wgrad_group"))
-            tr, trf = _profile_prefix_mb_per_step("wgrad", "train_%s_b%d" % (a.dtype, B))
+            tr, trf = _profile_prefix_mb_per_step("wgrad", "train_%s_b%d" % (dtype, B))
             out["roofline"] = {"bound": "mfma", "kernel": "all-taps 3x3 weight gradient: wgrad3x3_kernel (%d single launches per step, the layers above %g GFLOP) + "
                                                           "wgrad_group_kernel (%d grouped launches: the smaller layers, several per launch); the pixel-slice partials "
                                                           "are summed by the batched wgrad_reduce launches" % (n_single, prog.wg_group_flops / 1e9, len(w3) - n_single),
@@ -196,13 +162,33 @@ def main():
                                "largest_launch": {"name": prog.calls[big[0]][2], "gflop": round(prog.wgrad_flops[big[0]] / 1e9, 1),
                                                   "us": round(big[1] * 1e3, 1),
                                                   "tflops": round(prog.wgrad_flops[big[0]] / (big[1] * 1e-3) / 1e12, 1)}}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N)
-    if rank == 0:
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps: the first ~10 replays of freshly captured hipGraphs run slower (one-time, ~100 ms in total)")
+    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step (reference config: batch_size 32)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--npoint", type=int, default=512)
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    from bench import Ranks, self_launch
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # not under torchrun: launch the N ranks ourselves (no GPU call here)
+        sys.exit(self_launch(__file__, a.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit("bench_train: --gpus %d but the launcher started %s ranks" % (a.gpus, os.environ["WORLD_SIZE"]))
+    rk = Ranks()
+    out = run_step_bench(rk, a.batch, a.npoint, a.dtype, a.steps, a.warmup, not a.no_breakdown)
+    if rk.rank == 0 and rk.world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.npoint)
+    if rk.rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

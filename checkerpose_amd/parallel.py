@@ -24,6 +24,16 @@ def max_over_ranks(seconds, device=None, group=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, device=None, group=None):
+    """[rank 0's value, rank 1's value, ...] on every rank (a bench line checks itself with it: `ranks_seen`, `per_rank_ms`)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [float(o.item()) for o in out]
+
+
 def aggregate_crops_per_sec(local_crops, seconds, device=None, group=None):
     """Whole-job throughput: all crops processed by all ranks / slowest rank's time."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -117,3 +117,34 @@ def test_two_rank_gloo_bucketed_backward_allreduce():
     assert segs0 == segs1 and n0 == n1 == 3 and log0 == log1 == [(k, lo, hi) for k, (lo, hi, _, _) in enumerate(segs0)]
     assert vals0 == vals1 == [1.5 * (k + 1) for k in range(3)]                      # mean of (1, 2) * (k + 1)
     assert sum0 == sum1
+
+
+def test_bench_gpus_n_self_launches_n_ranks_dry_run():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts `torch.distributed.run --nproc-per-node 2` itself,
+    rank 0's line comes through and says who took part (no GPU call anywhere: --dry-run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CHECKERPOSE_BENCH_BACKEND"] = "gloo"
+    for script in ("bench.py",):           # bench_train.py uses the same launcher (bench.self_launch); its ranks need a GPU
+        p = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "1"],
+                           env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout                       # ONE JSON line, from rank 0
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["ranks_seen"] == [0, 1] and len(out["per_rank_ms"]) == 2
+        assert out["steps"] == 5 and out["dry_run"] is True
+        assert out["ms_per_step"] >= max(out["per_rank_ms"]) - 1e-6        # whole-job time = the slowest rank's
+
+
+def test_bench_rejects_world_size_mismatch():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=120, cwd=root)
+    assert p.returncode != 0 and "launcher started 2 ranks" in (p.stderr + p.stdout)
