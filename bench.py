@@ -216,16 +216,19 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
     img8 = det_image(8, seed=3).to(dev)
     ref = net32(img8, None)
     net_bf16.clone_outputs = True
-    free = logit_agreement(net_bf16(img8, None), ref)
     t = torch.zeros(8, 13, npoint, device=dev)
     t[:, 0:1], t[:, 1:7], t[:, 7:13] = ref[0], ref[1], ref[2]
     forced = logit_agreement(net_bf16.forward_teacher_forced(img8, t), ref)
+    free = logit_agreement(net_bf16(img8, None), ref, tau=forced["tau"], explain=True, knn_idx=net_bf16.init_net.knn_idx)
     net_bf16.clone_outputs = False
+    from checkerpose_amd.agreement import margin_contract_violations
     keep = ("bit_agreement_min_row", "bit_agreement_all_rows", "xy_id_equal", "id_abs_err_mean_px", "seg_agreement",
-            "max_abs_dlogit", "mean_abs_dlogit", "logit_rms")
+            "max_abs_dlogit", "mean_abs_dlogit", "logit_rms", "tau", "flips", "flips_above_margin", "max_flip_margin",
+            "flip_rate_by_margin", "id_mismatches", "id_mismatches_explained_frac", "id_mismatches_from_subtau_self_flip")
     ex["bf16_agreement"] = {"vs": "fp32 HIP path (oracle-pinned <= 1e-4) on 8 crops, random-init weights",
-                            "free_running": {k: free[k] for k in keep}, "free_running_rows": free["bit_agreement_per_row"],
-                            "teacher_forced": {k: forced[k] for k in keep}, "teacher_forced_rows": forced["bit_agreement_per_row"]}
+                            "margin_contract_violations": margin_contract_violations(forced, free),
+                            "free_running": {k: free[k] for k in keep if k in free}, "free_running_rows": free["bit_agreement_per_row"],
+                            "teacher_forced": {k: forced[k] for k in keep if k in forced}, "teacher_forced_rows": forced["bit_agreement_per_row"]}
     # ---- post-forward rows N2 + N4 on the device: correspondences + EPnP / RANSAC pose for the whole batch (opt-in path; the
     #      reference does both per image on the host, test_network_with_test_data.py:32-115).  Random-init weights: the poses are
     #      meaningless, the launch time is what is measured.

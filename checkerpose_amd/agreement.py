@@ -16,9 +16,12 @@ def _bit(z):
     return z > _Z0.to(z.device)
 
 
-def logit_agreement(out, ref):
+def logit_agreement(out, ref, tau=None, explain=False, knn_idx=None, graph_ids=None, init_bits=3):
     """out / ref: 6-tuples (roi (B,1,N), x_bits (B,nx,N), y_bits (B,ny,N), seg (B,2,h,w), x_id, y_id) of the same forward.
-    Returns a dict of plain floats (JSON-able)."""
+    Returns a dict of plain floats (JSON-able).  Margin-aware part: `tau` (default 4 x this run's mean |dlogit|; free-running runs
+    pass the TEACHER-FORCED run's tau, whose dlogit is arithmetic error only), `flip_rate_by_margin`, `flips_above_margin`;
+    `explain=True` (free-running runs; `knn_idx` (G,N,K) + `graph_ids` (B,) 0-based for the neighbourhood rule) adds
+    `id_mismatches_explained_frac`."""
     o = [t.detach().float().cpu() if t.dtype != torch.int64 else t.detach().cpu() for t in out]
     r = [t.detach().float().cpu() if t.dtype != torch.int64 else t.detach().cpu() for t in ref]
     zo, zr = torch.cat(o[:3], 1), torch.cat(r[:3], 1)                      # (B, 1+nx+ny, N)
@@ -42,4 +45,111 @@ def logit_agreement(out, ref):
         "mean_abs_dlogit_over_rms": round(float(d.mean()) / max(rms, 1e-30), 6),
         "max_abs_dseg": round(float((o[3] - r[3]).abs().max()), 5),
     }
+    res["tau"] = round(float(tau), 6) if tau is not None else round(4.0 * float(d.mean()), 6)
+    res.update(_margin_stats(zo, zr, res["tau"]))
+    if explain:
+        res.update(_explain_id_mismatches(zo, zr, o, r, res["tau"], knn_idx, graph_ids, init_bits))
     return res
+
+
+MARGIN_BUCKETS = ((0.0, 0.05), (0.05, 0.2), (0.2, 1.0), (1.0, float("inf")))       # of the REFERENCE logit's |z|: its decision margin
+
+
+def _margin_stats(zo, zr, tau):
+    """Where the flipped bits sit relative to the reference's decision margin |z_ref| (a flip at |z| = 2 is an error, a flip at
+    |z| = 1e-3 is a coin the reference itself barely decided): flip rate per margin bucket, the largest margin any flip has, and
+    the flips whose margin exceeds tau (= 4 x the mean |dlogit| of the run unless given)."""
+    flip = _bit(zo) != _bit(zr)
+    m = (zr - _Z0).abs()
+    buckets = {}
+    for lo, hi in MARGIN_BUCKETS:
+        sel = (m >= lo) & (m < hi)
+        n = int(sel.sum())
+        f = int((flip & sel).sum())
+        per_row = [(float((flip[:, i] & sel[:, i]).sum()) / max(int(sel[:, i].sum()), 1)) for i in range(zr.shape[1])]
+        buckets["%g-%s" % (lo, ("%g" % hi) if hi != float("inf") else "inf")] = {
+            "n": n, "flips": f, "flip_rate": round(f / max(n, 1), 6), "worst_row_flip_rate": round(max(per_row), 6)}
+    above = flip & (m > tau)
+    return {"flip_rate_by_margin": buckets,
+            "flips": int(flip.sum()),
+            "flips_above_margin": int(above.sum()),
+            "max_flip_margin": round(float(m[flip].max()) if bool(flip.any()) else 0.0, 6),
+            "flip_margin_over_dlogit_max": round(float((m[flip] / (zo - zr).abs()[flip].clamp_min(1e-30)).max()) if bool(flip.any()) else 0.0, 4)}
+
+
+def row_stages(nx, ny, init_bits=3):
+    """refinement stage that PRODUCES each logit row (roi | x bits MSB first | y bits MSB first): InitNet (stage 0) gives roi and the
+    `init_bits` most significant bits of each coordinate, every Refine stage one more (pipeline.py:367-381)"""
+    return [0] + [max(0, i - (init_bits - 1)) for i in range(nx)] + [max(0, i - (init_bits - 1)) for i in range(ny)]
+
+
+def _explain_id_mismatches(zo, zr, o, r, tau, knn_idx, graph_ids, init_bits):
+    """Free-running runs: the bits of stage s pick the pixels stage s + 1 gathers from (discrete feedback, pipeline.py:367-381), and the
+    EdgeConv layers mix a keypoint with its graph neighbours, so ONE near-tie flipped early legitimately changes later logits of
+    that keypoint and of its neighbourhood by O(1).  A final (x_id, y_id) mismatch of keypoint n is EXPLAINED when the first stage
+    at which n's bits differ has, at n, a flipped bit whose reference margin is below tau (a near-tie: either answer is within the
+    arithmetic's error), or when an earlier-stage flip sits within n's 3-hop graph neighbourhood (the three EdgeConv layers of a
+    stage: n's input was already perturbed by the feedback).  Unexplained mismatches would be arithmetic errors."""
+    B, R, N = zr.shape
+    nx, ny = o[1].shape[1], o[2].shape[1]
+    st = torch.tensor(row_stages(nx, ny, init_bits))
+    flip = _bit(zo) != _bit(zr)                                        # (B, R, N)
+    m = (zr - _Z0).abs()
+    nst = int(st.max()) + 1
+    flip_s = torch.stack([flip[:, st == s_].any(1) for s_ in range(nst)], 1)                      # (B, S, N) any flip at stage s
+    sub_s = torch.stack([(flip[:, st == s_] & (m[:, st == s_] < tau)).any(1) for s_ in range(nst)], 1)    # ... with a sub-tau one
+    mism = (o[4] != r[4]) | (o[5] != r[5])                            # (B, N)
+    if knn_idx is not None:
+        idx = torch.as_tensor(knn_idx).long().cpu()
+        if idx.dim() == 2:
+            idx = idx[None]
+        g = (torch.as_tensor(graph_ids).long().cpu() if graph_ids is not None else torch.zeros(B, dtype=torch.long))
+        if idx.shape[0] == 1:
+            g = torch.zeros(B, dtype=torch.long)
+        nb = idx[g]                                                    # (B, N, K)
+    else:
+        nb = None
+
+    def dilate(mask):                                                  # one hop: n or any of its K neighbours
+        if nb is None:
+            return mask
+        return mask | torch.gather(mask[:, None, :].expand(-1, N, -1), 2, nb).any(2)
+
+    perturbed = torch.zeros(B, N, dtype=torch.bool)                    # some flip at an EARLIER stage within 3 hops
+    explained = torch.zeros(B, N, dtype=torch.bool)
+    decided = torch.zeros(B, N, dtype=torch.bool)
+    for s_ in range(nst):
+        first = flip_s[:, s_] & ~decided                               # keypoints whose first differing stage is s_
+        explained |= first & (sub_s[:, s_] | perturbed)
+        decided |= flip_s[:, s_]
+        reach = flip_s[:, s_]
+        for _ in range(3):
+            reach = dilate(reach)
+        perturbed |= reach
+    n_m = int(mism.sum())
+    n_e = int((mism & explained).sum())
+    return {"id_mismatches": n_m, "id_mismatches_explained": n_e,
+            "id_mismatches_explained_frac": round(n_e / n_m, 5) if n_m else 1.0,
+            "id_mismatches_from_subtau_self_flip": int((mism & torch.stack([flip_s[:, s_] & sub_s[:, s_] for s_ in range(nst)], 0).any(0)).sum())}
+
+
+def margin_contract_violations(forced, free=None):
+    """The margin-aware part of the bf16 contract, as a list of violated clauses (empty = holds).
+    teacher-forced (dlogit = arithmetic error only): (a) no flipped bit whose reference margin |z| is 0.2 or more; (b) the largest
+    margin of any flip <= 6 x the run's mean |dlogit|; (c) flips above tau = 4 x mean |dlogit| are stragglers: <= max(2, 1 %) of
+    the flips (a flip needs |dlogit| > margin, so their number follows the tail of the error distribution; measured 0-2).
+    free-running (tau taken from the teacher-forced run): (d) >= 95 % of the final id mismatches are explained by an upstream
+    near-tie (see _explain_id_mismatches)."""
+    bad = []
+    fb = forced["flip_rate_by_margin"]
+    for k in ("0.2-1", "1-inf"):
+        if fb[k]["flips"] != 0:
+            bad.append("teacher-forced: %d flips at reference margin %s" % (fb[k]["flips"], k))
+    if forced["max_flip_margin"] > 6.0 * forced["mean_abs_dlogit"]:
+        bad.append("teacher-forced: a flip at margin %.4f > 6 x mean |dlogit| = %.4f" % (forced["max_flip_margin"], 6 * forced["mean_abs_dlogit"]))
+    if forced["flips_above_margin"] > max(2, 0.01 * forced["flips"]):
+        bad.append("teacher-forced: %d of %d flips above tau = %.4f" % (forced["flips_above_margin"], forced["flips"], forced["tau"]))
+    if free is not None and "id_mismatches_explained_frac" in free and free["id_mismatches_explained_frac"] < 0.95:
+        bad.append("free-running: only %.1f %% of %d id mismatches explained by an upstream sub-tau flip"
+                   % (100 * free["id_mismatches_explained_frac"], free["id_mismatches"]))
+    return bad

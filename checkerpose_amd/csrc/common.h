@@ -27,6 +27,42 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cp_s16x2, v), cp_s16x2{0, 0}));
 }
 
+// ---- EdgeConv gather keys (edgeconv_fused.hip / edgeconv_tiled.hip): P' = s * (W1 x) is tabled as packed IEEE HALF pairs so that
+// the K-way neighbour max is gfx950's three-input packed maximum (v_pk_maximum3_f16: two neighbours x two channels per
+// instruction; int16 order keys of the bf16 value needed v_pk_max_i16 = one neighbour per instruction plus the key transform on
+// both sides).  f16 keeps 3 more mantissa bits than the bf16 storage type, values are clamped to its finite range (+-65504).
+typedef _Float16 cp_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float a, float b) {
+  cp_h2 r;
+  r.x = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+  r.y = (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);          // the pair: one v_cvt_pk_f16_f32
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pkmax3_f16(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(cp_h2, a),
+                            __builtin_elementwise_maximum(__builtin_bit_cast(cp_h2, b), __builtin_bit_cast(cp_h2, c))));
+}
+// m[j] = max(m[j], a[j], b[j], c[j], d[j]) for the four dwords of a 16-byte table piece, as exactly EIGHT v_pk_maximum3_f16
+// (hipcc re-associates nested maxima into balanced trees: max(a, b), max(c, d), max(m, .., ..) = three instructions per dword
+// instead of two, with an s_nop between dependent packed instructions).  One asm block, the two rounds interleaved over the four
+// dwords: a dependent instruction is four issue slots behind its producer (gfx940+ packed / dst_sel forwarding needs one).
+__device__ __forceinline__ void pkmax5x4_f16(uint32_t* m, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& d) {
+  asm("v_pk_maximum3_f16 %0, %0, %4, %8\n\t"
+      "v_pk_maximum3_f16 %1, %1, %5, %9\n\t"
+      "v_pk_maximum3_f16 %2, %2, %6, %10\n\t"
+      "v_pk_maximum3_f16 %3, %3, %7, %11\n\t"
+      "v_pk_maximum3_f16 %0, %0, %12, %16\n\t"
+      "v_pk_maximum3_f16 %1, %1, %13, %17\n\t"
+      "v_pk_maximum3_f16 %2, %2, %14, %18\n\t"
+      "v_pk_maximum3_f16 %3, %3, %15, %19"
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3])
+      : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w),
+        "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+}
+__device__ __forceinline__ float f16_lo(uint32_t w) { return (float)__builtin_bit_cast(cp_h2, w).x; }
+__device__ __forceinline__ float f16_hi(uint32_t w) { return (float)__builtin_bit_cast(cp_h2, w).y; }
+constexpr uint32_t CP_F16X2_NEG_INF = 0xFC00FC00u;
+
 // element type tags
 struct F32Tag { using elem = float; static constexpr int E = 4; static constexpr int dtype = CP_F32; };
 struct BF16Tag { using elem = uint16_t; static constexpr int E = 8; static constexpr int dtype = CP_BF16; };

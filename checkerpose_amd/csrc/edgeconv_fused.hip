@@ -8,15 +8,15 @@
 //   * the crop's x rows (512 x Cin bf16) live in REGISTERS for the whole layer (the B operand of every MFMA: 128 VGPRs at
 //     Cin = 256), loaded once;
 //   * per 64-channel slice: the P and the Q half of the weights (32 KB each) stream L2 -> LDS by LDS-DMA, double-buffered
-//     under the other half's MFMAs; P' = s * (W1 x) is written to the LDS table as ORDER-PRESERVING int16 keys of its bf16
-//     value (so the K-way max is v_pk_max_i16, two channels per instruction), Q' = s * ((W2 - W1) x) + t stays in the fp32
+//     under the other half's MFMAs; P' = s * (W1 x) is written to the LDS table as packed f16 pairs
+//     (so the K-way max is v_pk_maximum3_f16: two neighbours x two channels per instruction; common.h), Q' = s * ((W2 - W1) x) + t stays in the fp32
 //     accumulators;
 //   * gather: a lane owns 16 channels of a keypoint: 2 ds_read_b128 per neighbour row.  The table is [8-channel plane][row][16 B]:
 //     the 16 lanes of a ds_read_b128 group are 16 different keypoints reading 16 different rows, bank slot = row mod 16, and the
 //     host hands in every keypoint's list ORDERED so that the rows of a step have different residues (graph_sched.py: the max
 //     does not care; bank-conflict share of the kernel's LDS cycles 54 % -> 27 %, LDS cycles per launch 18.8 M -> 11.8 M).  Index lists staged once per layer as int16;
 //     out = leaky(max_k P'_j(k) + Q'_i) leaves as 32 B per lane.
-// Two barriers per slice.  Numerics: P' rounded to bf16 as before, Q' no longer rounded to bf16 (one rounding less).
+// Two barriers per slice.  Numerics: P' rounded to f16 (3 more mantissa bits than the bf16 of the two-launch form), Q' stays fp32.
 #include "common.h"
 
 namespace {
@@ -36,14 +36,6 @@ struct EdgeFusedParams {
   float slope;
 };
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t sortable(uint32_t w) {         // two bf16 -> two int16 keys, monotone in the float value
-  return w ^ (((w >> 15) & 0x00010001u) * 0x7fffu);                // (involution: the same call maps keys back)
-}
-__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
 
 template <int CIN>
 __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedParams p) {
@@ -121,7 +113,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
     }
   };
   for (int s = 0; s < nslice; ++s) {
-    // ---- P' = s * (W1 x) -> bf16 -> sortable keys -> LDS table
+    // ---- P' = s * (W1 x) -> packed f16 -> LDS table
     w_issue(2 * s + 1);                                       // Q half into the other buffer: its last readers passed the previous barrier
     gemm_half(2 * s);
     {
@@ -137,14 +129,14 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         u32x4 lo, hi;
-        lo.x = sortable(pack_bf16x2(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
-        lo.y = sortable(pack_bf16x2(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
-        lo.z = sortable(pack_bf16x2(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
-        lo.w = sortable(pack_bf16x2(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
-        hi.x = sortable(pack_bf16x2(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
-        hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
-        hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
-        hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+        lo.x = (pack_f16x2_sat(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+        lo.y = (pack_f16x2_sat(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+        lo.z = (pack_f16x2_sat(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+        lo.w = (pack_f16x2_sat(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+        hi.x = (pack_f16x2_sat(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+        hi.y = (pack_f16x2_sat(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+        hi.z = (pack_f16x2_sat(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+        hi.w = (pack_f16x2_sat(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
         unsigned char* dst = sP + (2 * q) * EF_PLANE + (wave * 64 + f * 16 + x) * 16;       // 16 consecutive rows: 16 slots
         *(u32x4*)dst = lo;
         *(u32x4*)(dst + EF_PLANE) = hi;
@@ -160,7 +152,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[f][j] = 0x80008000u;         // int16 minimum
+      for (int j = 0; j < 8; ++j) m[f][j] = CP_F16X2_NEG_INF;
     {
       const unsigned char* const pq = sP + (2 * q) * EF_PLANE;
       const int16_t* const my = sIdx + (wave * 64 + x) * EF_KMAX;
@@ -183,14 +175,8 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             uint32_t* mm = m[fp + h];
-            mm[0] = pkmax(pkmax(mm[0], a0[h].x), pkmax(c0_[h].x, pkmax(d0[h].x, e0[h].x)));
-            mm[1] = pkmax(pkmax(mm[1], a0[h].y), pkmax(c0_[h].y, pkmax(d0[h].y, e0[h].y)));
-            mm[2] = pkmax(pkmax(mm[2], a0[h].z), pkmax(c0_[h].z, pkmax(d0[h].z, e0[h].z)));
-            mm[3] = pkmax(pkmax(mm[3], a0[h].w), pkmax(c0_[h].w, pkmax(d0[h].w, e0[h].w)));
-            mm[4] = pkmax(pkmax(mm[4], a1[h].x), pkmax(c1[h].x, pkmax(d1[h].x, e1[h].x)));
-            mm[5] = pkmax(pkmax(mm[5], a1[h].y), pkmax(c1[h].y, pkmax(d1[h].y, e1[h].y)));
-            mm[6] = pkmax(pkmax(mm[6], a1[h].z), pkmax(c1[h].z, pkmax(d1[h].z, e1[h].z)));
-            mm[7] = pkmax(pkmax(mm[7], a1[h].w), pkmax(c1[h].w, pkmax(d1[h].w, e1[h].w)));
+            pkmax5x4_f16(mm, a0[h], c0_[h], d0[h], e0[h]);
+            pkmax5x4_f16(mm + 4, a1[h], c1[h], d1[h], e1[h]);
           }
         }
       }
@@ -232,11 +218,11 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
           float v[16];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const uint32_t w2 = sortable(m[f][j]);
+            const uint32_t w2 = m[f][j];
             const int nt = j >> 1, r = (j & 1) * 2;
             const float q0 = aq[h][nt][r] * sScale[c0 + 4 * nt + r] + sShift[c0 + 4 * nt + r];
             const float q1 = aq[h][nt][r + 1] * sScale[c0 + 4 * nt + r + 1] + sShift[c0 + 4 * nt + r + 1];
-            const float y0 = __uint_as_float(w2 << 16) + q0, y1 = __uint_as_float(w2 & 0xffff0000u) + q1;
+            const float y0 = f16_lo(w2) + q0, y1 = f16_hi(w2) + q1;
             v[2 * j] = y0 > 0.f ? y0 : y0 * p.slope;
             v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
           }

@@ -5,12 +5,12 @@
 // and a patch's neighbour rows are its own 512 rows plus a thin rim ("halo", 170-370 rows on the LM objects).  Two launches per
 // layer, both one 8-wave workgroup per (crop, patch) with the patch's 512 x rows in REGISTERS (the MFMA B operand):
 //
-//   edgeconv_ptable_kernel   P' = s * (W1 x) for every row, exactly once, written as ORDER-PRESERVING int16 keys of its bf16 value
+//   edgeconv_ptable_kernel   P' = s * (W1 x) for every row, exactly once, written as packed f16 pairs (common.h: the gather's max is v_pk_maximum3_f16)
 //                            in plane-major order [crop][8-channel plane][row][16 B] (the LDS table's own layout, so staging a
 //                            patch's rows is a stream of full 1 KB segments and staging its halo rows 16-byte pieces);
 //   edgeconv_tiled_kernel    per 32-channel slice: the table (512 own + HPAD halo rows, 4 planes) arrives by LDS-DMA with per-lane
 //                            source rows (no registers, no VALU); gather-max over the K neighbours out of LDS (one ds_read_b128 per
-//                            neighbour and lane, v_pk_max_i16, neighbour lists as table SLOTS, scheduled against bank conflicts);
+//                            neighbour and lane, v_pk_maximum3_f16, neighbour lists as table SLOTS, scheduled against bank conflicts);
 //                            Q' = s * ((W2 - W1) x) + t on the MFMA pipe from the register-resident rows while the NEXT slice's
 //                            table streams in; out = leaky(max_k P'_j(k) + Q'_i), 16 B per lane.
 // HBM / Infinity-Cache traffic per crop and layer at N = 4096, C = C' = 256: x 2 x 2 MB in, keys 2 MB out + 2.8 MB back in, out 2 MB
@@ -35,14 +35,6 @@ struct EdgeTiledParams {
   float slope;
 };
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t sortable(uint32_t w) {         // two bf16 -> two int16 keys, monotone in the float value
-  return w ^ (((w >> 15) & 0x00010001u) * 0x7fffu);                // (involution: the same call maps keys back)
-}
-__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
 
 // blockIdx -> (crop, patch): all patches of a crop on ONE XCD (blockIdx % 8), so the halo pieces they share are hits in its L2
 __device__ __forceinline__ void crop_patch(int NB, int B, int& b, int& t) {
@@ -127,14 +119,14 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       u32x4 lo, hi;
-      lo.x = sortable(pack_bf16x2(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
-      lo.y = sortable(pack_bf16x2(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
-      lo.z = sortable(pack_bf16x2(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
-      lo.w = sortable(pack_bf16x2(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
-      hi.x = sortable(pack_bf16x2(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
-      hi.y = sortable(pack_bf16x2(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
-      hi.z = sortable(pack_bf16x2(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
-      hi.w = sortable(pack_bf16x2(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+      lo.x = (pack_f16x2_sat(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+      lo.y = (pack_f16x2_sat(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+      lo.z = (pack_f16x2_sat(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+      lo.w = (pack_f16x2_sat(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+      hi.x = (pack_f16x2_sat(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+      hi.y = (pack_f16x2_sat(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+      hi.z = (pack_f16x2_sat(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+      hi.w = (pack_f16x2_sat(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
       const size_t r = (size_t)t * ET_BLK + wave * 64 + f * 16 + x;
       unsigned char* dst = tab + ((size_t)(8 * s + 2 * q) * p.N + r) * 16;
       *(u32x4*)dst = lo;
@@ -161,6 +153,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
   int16_t* const sIdx = (int16_t*)(sW + (DB ? 1 : 2) * WQ);
   float* const sScale = (float*)((unsigned char*)sIdx + ET_IDX);    // [Cout] then shift [Cout] at + 256
   float* const sShift = sScale + 256;
+  int32_t* const sHalo = (int32_t*)((unsigned char*)sScale + ET_AFF);   // [HPAD] table rows of the halo slots (byte offsets: row * 16)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -184,7 +177,8 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
     for (int c = wave; c < 4 * nchunk; c += 8) {
       const int pl = c / nchunk, ch = c - pl * nchunk;
       const int slot = ch * 64 + lane;
-      const int row = ch < 8 ? t * ET_BLK + slot : halo[slot - ET_BLK];
+      // (halo rows come from the LDS copy: a global load per piece in front of its DMA put ~1 us of latency on every halo piece)
+      const int row = ch < 8 ? t * ET_BLK + slot : sHalo[slot - ET_BLK];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N + row) * 16),
                                        (__attribute__((address_space(3))) void*)(dstb + pl * PLANE + ch * 1024), 16, 0, 0);
     }
@@ -200,6 +194,8 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
                                          (__attribute__((address_space(3))) void*)(sW + (DB ? 0 : (s & 1) * WQ) + i0 * 16), 16, 0, 0);
     }
   };
+  for (int i = tid; i < p.HPAD; i += 512) sHalo[i] = halo[i];
+  __syncthreads();
   table_issue(0);
   w_issue(0);
   {
@@ -243,7 +239,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m[f][j] = 0x80008000u;             // int16 minimum
+      for (int j = 0; j < 4; ++j) m[f][j] = CP_F16X2_NEG_INF;
     {
       const unsigned char* const pq = sP + (DB ? (s & 1) * 4 * PLANE : 0) + q * PLANE;
       const uint16_t* const my = (const uint16_t*)sIdx + (wave * 64 + x) * ET_KMAX;
@@ -251,12 +247,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
         r[0] = *(const u32x4*)(pq + (i4.x & 0xffffu)); r[1] = *(const u32x4*)(pq + (i4.x >> 16));
         r[2] = *(const u32x4*)(pq + (i4.y & 0xffffu)); r[3] = *(const u32x4*)(pq + (i4.y >> 16));
       };
-      auto mx4 = [&](uint32_t* mm, const u32x4* r) {
-        mm[0] = pkmax(pkmax(mm[0], r[0].x), pkmax(r[1].x, pkmax(r[2].x, r[3].x)));
-        mm[1] = pkmax(pkmax(mm[1], r[0].y), pkmax(r[1].y, pkmax(r[2].y, r[3].y)));
-        mm[2] = pkmax(pkmax(mm[2], r[0].z), pkmax(r[1].z, pkmax(r[2].z, r[3].z)));
-        mm[3] = pkmax(pkmax(mm[3], r[0].w), pkmax(r[1].w, pkmax(r[2].w, r[3].w)));
-      };
+      auto mx4 = [&](uint32_t* mm, const u32x4* r) { pkmax5x4_f16(mm, r[0], r[1], r[2], r[3]); };
 #ifdef ET_NOGATHER                                                    // knock-out builds (tools/edge_tiled_bench.py): results wrong on purpose
       if (false) {
 #else
@@ -344,12 +335,12 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       float v[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t w2 = sortable(m[f][j]);                       // channels 2 j, 2 j + 1 of this lane's 8
+        const uint32_t w2 = m[f][j];                                 // channels 2 j, 2 j + 1 of this lane's 8 (f16 pair)
         const int nt = j >> 1, r = (j & 1) * 2;
         const float sa = nt ? s1[r] : s0[r], sb = nt ? s1[r + 1] : s0[r + 1];
         const float ta = nt ? t1[r] : t0[r], tb = nt ? t1[r + 1] : t0[r + 1];
-        const float y0 = __uint_as_float(w2 << 16) + (acc[f][nt][r] * sa + ta);
-        const float y1 = __uint_as_float(w2 & 0xffff0000u) + (acc[f][nt][r + 1] * sb + tb);
+        const float y0 = f16_lo(w2) + (acc[f][nt][r] * sa + ta);
+        const float y1 = f16_hi(w2) + (acc[f][nt][r + 1] * sb + tb);
         v[2 * j] = fmaxf(y0, y0 * p.slope);                            // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
         v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
       }
@@ -363,6 +354,181 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
     }
     __syncthreads();                                                // DB: table(s + 1) landed, weights(s) / table(s) free.  !DB: both landed
     if (DB && s + 1 < nslice) w_issue(s + 1);                       // awaited at the next mid-slice barrier, a whole gather away
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launch 2, interleaved form
+// The same slice loop with the Q' GEMM INSIDE the gather (both tables of consecutive slices resident): knock-outs of the form above
+// put 46 of 82 us on the gather, 15 on the Q' MFMA loop and 15 on the table DMA, one after the other -- gather (LDS port + VALU) and
+// Q' (matrix pipe) use different units and do not depend on each other, so each wave now walks its four row fragments as two PAIRS;
+// a pair's pass = 10 steps (list quad k4, fragment h), and step st carries: the list read of step st + 2, the 4 table reads of step
+// st + 1, the weight fragments of K chunk st + 1, the 4 MFMAs of chunk st (2 fragments x 2 channel tiles) and the 8 packed maxima
+// of step st.  A pair's epilogue (scale / shift, + max, LeakyReLU, pack, 32-byte stores on odd slices) follows its pass, so only one
+// pair's maxima and accumulators are live (220 VGPRs beside the 128 that hold the wave's x rows).
+// Q' weights travel in K HALVES through a ring of three LDS slots (8 KB each at Cin = 256): halves 2 s and 2 s + 1 are resident
+// during slice s, half 2 s + 2 streams in from the slice's start and half 2 s + 3 from the moment every wave has passed chunk
+// KC / 2 - 1 of its second pass (an LDS-only barrier: the table DMA and the stores stay in flight).  One full barrier per slice.
+__device__ __forceinline__ void lds_only_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int CIN>
+__global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledParams p) {
+  constexpr int KC = CIN / 32;
+  constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
+  constexpr int WH = WQ / 2, KH = KC / 2;                           // one K half: bytes, chunks
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int T = ET_BLK + p.HPAD;
+  const int PLANE = T * 16;                                         // a multiple of 256 B: bank slot = row mod 16
+  unsigned char* const sP = smem;                                   // 2 x [4 planes][T rows][16 B]
+  unsigned char* const sW = smem + 2 * 4 * PLANE;                   // ring of 3 K halves
+  int16_t* const sIdx = (int16_t*)(sW + 3 * WH);
+  float* const sScale = (float*)((unsigned char*)sIdx + ET_IDX);    // [Cout] then shift [Cout] at + 256
+  float* const sShift = sScale + 256;
+  int32_t* const sHalo = (int32_t*)((unsigned char*)sScale + ET_AFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  int b, t;
+  crop_patch(p.NB, p.B, b, t);
+  if (b >= p.B) return;
+  const int nslice = p.Cout / 32;
+  const int g = p.gids ? p.gids[b] : 0;
+  const int32_t* const halo = p.halo + ((size_t)g * p.NB + t) * p.HPAD;
+  const unsigned char* const tab = (const unsigned char*)p.ptab + (size_t)b * (p.Cout / 8) * p.N * 16;
+
+  // this wave's 64 x rows -> registers (first: the MFMAs of slice 0 need them; they travel while the lists are staged)
+  u32x4 xa[4][KC];
+  const size_t row0 = (size_t)b * p.N + (size_t)t * ET_BLK + wave * 64;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
+
+  const int nchunk = 8 + p.HPAD / 64;
+  auto table_issue = [&](int s) {                                   // see edgeconv_tiled_kernel: slice s -> buffer s & 1
+    unsigned char* const dstb = sP + (s & 1) * 4 * PLANE;
+    for (int c = wave; c < 4 * nchunk; c += 8) {
+      const int pl = c / nchunk, ch = c - pl * nchunk;
+      const int slot = ch * 64 + lane;
+      const int row = ch < 8 ? t * ET_BLK + slot : sHalo[slot - ET_BLK];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N + row) * 16),
+                                       (__attribute__((address_space(3))) void*)(dstb + pl * PLANE + ch * 1024), 16, 0, 0);
+    }
+  };
+  const u32x4* const wg = (const u32x4*)p.w;
+  auto wh_issue = [&](int u) {                                      // K half u = 2 s + kh -> ring slot u % 3
+    constexpr int PIECES = WH / 16;                                 // 512 (Cin = 256) / 128 (Cin = 64)
+    const int i0 = wave * 64;
+    if (i0 < PIECES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)u * PIECES + i0 + lane),
+                                       (__attribute__((address_space(3))) void*)(sW + (u % 3) * WH + i0 * 16), 16, 0, 0);
+  };
+  for (int i = tid; i < p.HPAD; i += 512) sHalo[i] = halo[i];
+  __syncthreads();
+  table_issue(0);
+  wh_issue(0);
+  wh_issue(1);
+  {
+    const int16_t* gi = p.nbr + ((size_t)g * p.NB + t) * ET_BLK * p.K;      // K == ET_KMAX (checked by the entry point): 16-byte copies
+    for (int i = tid; i < ET_BLK * ET_KMAX / 8; i += 512) {          // staged as BYTE offsets into a table plane
+      u32x4 v = ((const u32x4*)gi)[i];
+      v.x = (v.x & 0x0fff0fffu) << 4; v.y = (v.y & 0x0fff0fffu) << 4; v.z = (v.z & 0x0fff0fffu) << 4; v.w = (v.w & 0x0fff0fffu) << 4;
+      ((u32x4*)sIdx)[i] = v;
+    }
+  }
+  for (int i = tid; i < p.Cout; i += 512) { sScale[i] = p.scale[p.Cout + i]; sShift[i] = p.shift[p.Cout + i]; }
+  __syncthreads();                                                  // table(0), halves 0 and 1, lists, affine, x rows: all landed
+
+  const uint16_t* const my = (const uint16_t*)sIdx + (wave * 64 + x) * ET_KMAX;
+  for (int s = 0; s < nslice; ++s) {
+    if (s + 1 < nslice) { table_issue(s + 1); wh_issue(2 * s + 2); }
+    const unsigned char* const pq = sP + (s & 1) * 4 * PLANE + q * PLANE;
+    const unsigned char* const wlo = sW + ((2 * s) % 3) * WH + lane * 16;           // chunks [0, KH)
+    const unsigned char* const whi = sW + ((2 * s + 1) % 3) * WH + lane * 16;       // chunks [KH, KC)
+    const int c0 = (s >> 1) * 64 + q * 16 + (s & 1) * 8;
+    auto rd4 = [&](const u32x2& i4, u32x4* r) {                      // the 4 neighbour rows of one list quad
+      r[0] = *(const u32x4*)(pq + (i4.x & 0xffffu)); r[1] = *(const u32x4*)(pq + (i4.x >> 16));
+      r[2] = *(const u32x4*)(pq + (i4.y & 0xffffu)); r[3] = *(const u32x4*)(pq + (i4.y >> 16));
+    };
+    auto wfrag = [&](int kc, u32x4* w2) {                            // the two channel tiles' fragments of K chunk kc
+      const unsigned char* const wb = (kc < KH ? wlo + kc * 2048 : whi + (kc - KH) * 2048);
+      w2[0] = *(const u32x4*)wb; w2[1] = *(const u32x4*)(wb + 1024);
+    };
+#pragma unroll
+    for (int fp = 0; fp < 2; ++fp) {
+      uint32_t m[2][4];
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[h][j] = CP_F16X2_NEG_INF;
+        acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      u32x4 r[4], wf[2][2];
+      u32x2 il[2];
+      // step st = 2 k4 + h: list quad k4 of fragment 2 fp + h.  ONE set of table-read registers (a second set spilled the x rows):
+      // a step consumes its four rows, then sends out the next step's reads and runs its MFMAs under their latency; the other wave
+      // of the SIMD fills what is left of it.
+      il[0] = *(const u32x2*)(my + (2 * fp) * 16 * ET_KMAX);
+      il[1] = *(const u32x2*)(my + (2 * fp + 1) * 16 * ET_KMAX);
+      wfrag(0, wf[0]);
+      rd4(il[0], r);
+#pragma unroll
+      for (int st = 0; st < 10; ++st) {
+        const int h = st & 1;
+        {
+          pkmax5x4_f16(m[h], r[0], r[1], r[2], r[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (LDS results return in order: the list quad of step st + 2 goes out BEFORE the table reads of step st + 1, the weight
+        // fragments of chunk st + 1 behind them)
+        if (st + 2 < 10) il[h] = *(const u32x2*)(my + (2 * fp + h) * 16 * ET_KMAX + 4 * ((st + 2) >> 1));
+        if (st + 1 < 10) rd4(il[h ^ 1], r);
+        if (st + 1 < KC) wfrag(st + 1, wf[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st < KC) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[h2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[st & 1][nt]),
+                                                                    __builtin_bit_cast(bf16x8, xa[2 * fp + h2][st]), acc[h2][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fp == 1 && st == (KH > 0 ? KH - 1 : 0)) {
+          // every wave is past its last read of K half 2 s: that ring slot takes half 2 s + 3 (LDS-only barrier)
+          lds_only_barrier();
+          if (s + 1 < nslice) wh_issue(2 * s + 3);
+        }
+      }
+      // ---- epilogue of this fragment pair: 16 bytes per lane and slice (the 32-byte form held the even slice's result in 16
+      // registers per lane, which this kernel does not have; the odd slice's store completes the 128-byte line in L2)
+      const f32x4 s0 = *(const f32x4*)(sScale + c0), s1 = *(const f32x4*)(sScale + c0 + 4);
+      const f32x4 t0 = *(const f32x4*)(sShift + c0), t1 = *(const f32x4*)(sShift + c0 + 4);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int f = 2 * fp + h;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w2 = m[h][j];                               // channels 2 j, 2 j + 1 of this lane's 8 (f16 pair)
+          const int nt = j >> 1, rg = (j & 1) * 2;
+          const float sa = nt ? s1[rg] : s0[rg], sb = nt ? s1[rg + 1] : s0[rg + 1];
+          const float ta = nt ? t1[rg] : t0[rg], tb = nt ? t1[rg + 1] : t0[rg + 1];
+          const float y0 = f16_lo(w2) + (acc[h][nt][rg] * sa + ta);
+          const float y1 = f16_hi(w2) + (acc[h][nt][rg + 1] * sb + tb);
+          v[2 * j] = fmaxf(y0, y0 * p.slope);                          // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
+          v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
+        }
+        *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = Vec16<BF16Tag>::pack(v);
+      }
+    }
+    __syncthreads();                                                // table(s + 1), halves 2 s + 2 and 2 s + 3 landed; every gather of slice s done
   }
 }
 
@@ -410,9 +576,11 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const T* __restrict__
   else out[i] = in[br * N + pn];
 }
 
-size_t tiled_lds(int Cin, int HPAD) { return (size_t)4 * (ET_BLK + HPAD) * 16 + (size_t)2 * (Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF; }
+size_t tiled_lds(int Cin, int HPAD) { return (size_t)4 * (ET_BLK + HPAD) * 16 + (size_t)2 * (Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF + (size_t)HPAD * 4; }
 // both tables of consecutive slices resident (the next one streams in a whole slice ahead), one weight buffer
-size_t tiled_lds_db(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)(Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF; }
+size_t tiled_lds_db(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)(Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF + (size_t)HPAD * 4; }
+// interleaved form: both tables + the ring of three weight K halves
+size_t tiled2_lds(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)3 * (Cin / 32) * 1024 + ET_IDX + ET_AFF + (size_t)HPAD * 4; }
 
 }  // namespace
 
@@ -443,8 +611,9 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
       !cp_aligned16(out) || !cp_aligned16(key_table) || !cp_aligned16(nbr))
     return CP_ERR_ALIGN;
   const size_t lds1[2] = {(size_t)2 * 2 * 4 * 1024 + 1024, (size_t)2 * 8 * 4 * 1024 + 1024};      // Cin = 64 / 256
+  const bool il = K == ET_KMAX && tiled2_lds(Cin, HPAD) <= 160 * 1024 && !cp_knob("CP_NO_TILED2");      // the interleaved form
   const bool db = tiled_lds_db(Cin, HPAD) <= 160 * 1024;
-  const size_t lds2 = db ? tiled_lds_db(Cin, HPAD) : tiled_lds(Cin, HPAD);
+  const size_t lds2 = il ? tiled2_lds(Cin, HPAD) : db ? tiled_lds_db(Cin, HPAD) : tiled_lds(Cin, HPAD);
   static CpDeviceOnce once;
   const int dev = cp_current_device();
   const size_t want = 160 * 1024;
@@ -453,7 +622,9 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
                                   cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, false>, want) &&
                                   cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, false>, want) &&
                                   cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, true>, want) &&
-                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, true>, want));
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled2_kernel<64>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled2_kernel<256>, want));
   EdgeTiledParams p;
   p.x = x; p.scale = scale; p.shift = shift; p.halo = halo; p.nbr = nbr; p.gids = graph_ids; p.ptab = key_table; p.out = out;
   p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.N = N; p.NB = N / ET_BLK; p.K = K;
@@ -464,7 +635,9 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
   if (Cin == 64) CP_LAUNCH((edgeconv_ptable_kernel<64>), dim3(grid), dim3(512), lds1[0], st, p);
   else CP_LAUNCH((edgeconv_ptable_kernel<256>), dim3(grid), dim3(512), lds1[1], st, p);
   p.w = packed_w_q;
-  if (Cin == 64 && db) CP_LAUNCH((edgeconv_tiled_kernel<64, true>), dim3(grid), dim3(512), lds2, st, p);
+  if (il && Cin == 64) CP_LAUNCH((edgeconv_tiled2_kernel<64>), dim3(grid), dim3(512), lds2, st, p);
+  else if (il) CP_LAUNCH((edgeconv_tiled2_kernel<256>), dim3(grid), dim3(512), lds2, st, p);
+  else if (Cin == 64 && db) CP_LAUNCH((edgeconv_tiled_kernel<64, true>), dim3(grid), dim3(512), lds2, st, p);
   else if (Cin == 64) CP_LAUNCH((edgeconv_tiled_kernel<64, false>), dim3(grid), dim3(512), lds2, st, p);
   else if (db) CP_LAUNCH((edgeconv_tiled_kernel<256, true>), dim3(grid), dim3(512), lds2, st, p);
   else CP_LAUNCH((edgeconv_tiled_kernel<256, false>), dim3(grid), dim3(512), lds2, st, p);
