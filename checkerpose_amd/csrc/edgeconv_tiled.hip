@@ -357,6 +357,18 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
   }
 }
 
+#ifdef CP_DEBUG_KNOBS
+// phase clock of workgroup 0 (make KNOBS=1 builds only; tools/edge_tiled_stamps.py): per wave, shader-clock cycles summed over the slices
+__device__ unsigned long long et_stamps[8][12];
+#define ET_T0() unsigned long long et_t = __builtin_amdgcn_s_memtime(), et_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ET_MARK(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); et_acc[k] += n_ - et_t; et_t = n_; } while (0)
+#define ET_DUMP() do { if (blockIdx.x == 0 && lane == 0) for (int k_ = 0; k_ < 12; ++k_) et_stamps[wave][k_] = et_acc[k_]; } while (0)
+#else
+#define ET_T0() do {} while (0)
+#define ET_MARK(k) do {} while (0)
+#define ET_DUMP() do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ launch 2, interleaved form
 // The same slice loop with the Q' GEMM INSIDE the gather (both tables of consecutive slices resident): knock-outs of the form above
 // put 46 of 82 us on the gather, 15 on the Q' MFMA loop and 15 on the table DMA, one after the other -- gather (LDS port + VALU) and
@@ -387,7 +399,6 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
   int16_t* const sIdx = (int16_t*)(sW + 3 * WH);
   float* const sScale = (float*)((unsigned char*)sIdx + ET_IDX);    // [Cout] then shift [Cout] at + 256
   float* const sShift = sScale + 256;
-  int32_t* const sHalo = (int32_t*)((unsigned char*)sScale + ET_AFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,6 +411,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
   const int32_t* const halo = p.halo + ((size_t)g * p.NB + t) * p.HPAD;
   const unsigned char* const tab = (const unsigned char*)p.ptab + (size_t)b * (p.Cout / 8) * p.N * 16;
 
+  ET_T0();
   // this wave's 64 x rows -> registers (first: the MFMAs of slice 0 need them; they travel while the lists are staged)
   u32x4 xa[4][KC];
   const size_t row0 = (size_t)b * p.N + (size_t)t * ET_BLK + wave * 64;
@@ -409,15 +421,28 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
     for (int kc = 0; kc < KC; ++kc)
       xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
 
+  // table of slice s -> buffer s & 1: 4 planes x (8 own + HPAD / 64 halo) chunks of 64 rows, dealt round-robin to the 8 waves
+  // (piece i of this wave = chunk wave + 8 i).  Which rows a piece moves does not depend on the slice, so every lane keeps its
+  // source row offsets (bytes inside a plane) in registers and a piece costs one 64-bit add + the DMA; the pieces of slice s + 1 go
+  // out ONE PER STEP of slice s's first pass: issued in one burst at the slice's start they took 19 % of the launch (all eight
+  // waves stalled on the texture path's queue at once, nothing else running; in-kernel clock, tools/edge_tiled_stamps.py).
+  constexpr int NPC = 7;                                            // pieces per wave: ceil(4 * 14 / 8) at HPAD <= 384
   const int nchunk = 8 + p.HPAD / 64;
-  auto table_issue = [&](int s) {                                   // see edgeconv_tiled_kernel: slice s -> buffer s & 1
-    unsigned char* const dstb = sP + (s & 1) * 4 * PLANE;
-    for (int c = wave; c < 4 * nchunk; c += 8) {
+  uint32_t srcoff[NPC];
+  auto piece_rows = [&](const int32_t* hsrc) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int c = wave + 8 * i;
+      const int ch = c % nchunk, slot = ch * 64 + lane;
+      srcoff[i] = c < 4 * nchunk ? (uint32_t)(ch < 8 ? t * ET_BLK + slot : hsrc[slot - ET_BLK]) * 16u : 0u;
+    }
+  };
+  auto table_piece = [&](int s, int i) {
+    const int c = wave + 8 * i;
+    if (c < 4 * nchunk) {
       const int pl = c / nchunk, ch = c - pl * nchunk;
-      const int slot = ch * 64 + lane;
-      const int row = ch < 8 ? t * ET_BLK + slot : sHalo[slot - ET_BLK];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N + row) * 16),
-                                       (__attribute__((address_space(3))) void*)(dstb + pl * PLANE + ch * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + (size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N * 16 + srcoff[i]),
+                                       (__attribute__((address_space(3))) void*)(sP + (s & 1) * 4 * PLANE + pl * PLANE + ch * 1024), 16, 0, 0);
     }
   };
   const u32x4* const wg = (const u32x4*)p.w;
@@ -428,9 +453,9 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)u * PIECES + i0 + lane),
                                        (__attribute__((address_space(3))) void*)(sW + (u % 3) * WH + i0 * 16), 16, 0, 0);
   };
-  for (int i = tid; i < p.HPAD; i += 512) sHalo[i] = halo[i];
-  __syncthreads();
-  table_issue(0);
+  piece_rows(halo);                                                  // (halo row ids straight from global memory: one round trip)
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) table_piece(0, i);
   wh_issue(0);
   wh_issue(1);
   {
@@ -442,11 +467,14 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
     }
   }
   for (int i = tid; i < p.Cout; i += 512) { sScale[i] = p.scale[p.Cout + i]; sShift[i] = p.shift[p.Cout + i]; }
+  ET_MARK(0);                                                       // prologue issue
   __syncthreads();                                                  // table(0), halves 0 and 1, lists, affine, x rows: all landed
+  ET_MARK(1);                                                       // prologue wait
 
   const uint16_t* const my = (const uint16_t*)sIdx + (wave * 64 + x) * ET_KMAX;
   for (int s = 0; s < nslice; ++s) {
-    if (s + 1 < nslice) { table_issue(s + 1); wh_issue(2 * s + 2); }
+    if (s + 1 < nslice) wh_issue(2 * s + 2);
+    ET_MARK(2);                                                     // DMA issue
     const unsigned char* const pq = sP + (s & 1) * 4 * PLANE + q * PLANE;
     const unsigned char* const wlo = sW + ((2 * s) % 3) * WH + lane * 16;           // chunks [0, KH)
     const unsigned char* const whi = sW + ((2 * s + 1) % 3) * WH + lane * 16;       // chunks [KH, KC)
@@ -469,28 +497,26 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
         for (int j = 0; j < 4; ++j) m[h][j] = CP_F16X2_NEG_INF;
         acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      u32x4 r[4], wf[2][2];
+      u32x4 r[2][4], wf[2][2];
       u32x2 il[2];
-      // step st = 2 k4 + h: list quad k4 of fragment 2 fp + h.  ONE set of table-read registers (a second set spilled the x rows):
-      // a step consumes its four rows, then sends out the next step's reads and runs its MFMAs under their latency; the other wave
-      // of the SIMD fills what is left of it.
+      // step st = 2 k4 + h: list quad k4 of fragment 2 fp + h.  Two sets of table-read registers: step st sends out the reads of
+      // step st + 1 (and the list quad of step st + 2, the weight fragments of chunk st + 1), runs its MFMAs and then folds ITS
+      // four rows, which were requested a whole step earlier.
       il[0] = *(const u32x2*)(my + (2 * fp) * 16 * ET_KMAX);
       il[1] = *(const u32x2*)(my + (2 * fp + 1) * 16 * ET_KMAX);
       wfrag(0, wf[0]);
-      rd4(il[0], r);
+      rd4(il[0], r[0]);
 #pragma unroll
       for (int st = 0; st < 10; ++st) {
         const int h = st & 1;
-        {
-          pkmax5x4_f16(m[h], r[0], r[1], r[2], r[3]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         // (LDS results return in order: the list quad of step st + 2 goes out BEFORE the table reads of step st + 1, the weight
         // fragments of chunk st + 1 behind them)
-        if (st + 2 < 10) il[h] = *(const u32x2*)(my + (2 * fp + h) * 16 * ET_KMAX + 4 * ((st + 2) >> 1));
-        if (st + 1 < 10) rd4(il[h ^ 1], r);
+        u32x2 inext = il[h];
+        if (st + 2 < 10) inext = *(const u32x2*)(my + (2 * fp + h) * 16 * ET_KMAX + 4 * ((st + 2) >> 1));
+        if (st + 1 < 10) rd4(il[h ^ 1], r[h ^ 1]);
         if (st + 1 < KC) wfrag(st + 1, wf[(st + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
+        if (fp == 0 && st < NPC && s + 1 < nslice) table_piece(s + 1, st);
         if (st < KC) {
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2)
@@ -500,12 +526,18 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
                                                                     __builtin_bit_cast(bf16x8, xa[2 * fp + h2][st]), acc[h2][nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        pkmax5x4_f16(m[h], r[h][0], r[h][1], r[h][2], r[h][3]);
+        il[h] = inext;
+        __builtin_amdgcn_sched_barrier(0);
         if (fp == 1 && st == (KH > 0 ? KH - 1 : 0)) {
           // every wave is past its last read of K half 2 s: that ring slot takes half 2 s + 3 (LDS-only barrier)
+          ET_MARK(5);                                                 // pass 1 up to the mid barrier
           lds_only_barrier();
+          ET_MARK(6);                                                 // mid barrier wait
           if (s + 1 < nslice) wh_issue(2 * s + 3);
         }
       }
+      if (fp == 0) ET_MARK(3); else ET_MARK(7);                       // pass 0 steps / rest of pass 1
       // ---- epilogue of this fragment pair: 16 bytes per lane and slice (the 32-byte form held the even slice's result in 16
       // registers per lane, which this kernel does not have; the odd slice's store completes the 128-byte line in L2)
       const f32x4 s0 = *(const f32x4*)(sScale + c0), s1 = *(const f32x4*)(sScale + c0 + 4);
@@ -527,9 +559,12 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
         }
         *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = Vec16<BF16Tag>::pack(v);
       }
+      if (fp == 0) ET_MARK(4); else ET_MARK(8);                       // epilogues
     }
     __syncthreads();                                                // table(s + 1), halves 2 s + 2 and 2 s + 3 landed; every gather of slice s done
+    ET_MARK(9);                                                     // end-of-slice barrier wait
   }
+  ET_DUMP();
 }
 
 // Q halves, 32-channel slices (see the kernel's header comment)
@@ -580,9 +615,15 @@ size_t tiled_lds(int Cin, int HPAD) { return (size_t)4 * (ET_BLK + HPAD) * 16 + 
 // both tables of consecutive slices resident (the next one streams in a whole slice ahead), one weight buffer
 size_t tiled_lds_db(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)(Cin / 32) * 2 * 1024 + ET_IDX + ET_AFF + (size_t)HPAD * 4; }
 // interleaved form: both tables + the ring of three weight K halves
-size_t tiled2_lds(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)3 * (Cin / 32) * 1024 + ET_IDX + ET_AFF + (size_t)HPAD * 4; }
+size_t tiled2_lds(int Cin, int HPAD) { return (size_t)8 * (ET_BLK + HPAD) * 16 + (size_t)3 * (Cin / 32) * 1024 + ET_IDX + ET_AFF; }
 
 }  // namespace
+
+#ifdef CP_DEBUG_KNOBS
+extern "C" int cp_debug_edge_tiled_stamps(unsigned long long* out96) {      // 8 waves x 12 phase sums of workgroup 0's last launch
+  return hipMemcpyFromSymbol(out96, HIP_SYMBOL(et_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+#endif
 
 extern "C" int cp_edgeconv_tiled_supported(int N, int K, int Cin, int Cout, int HPAD) {
   return (N > ET_BLK && N % ET_BLK == 0 && N <= 32768 && K > 0 && K <= ET_KMAX && K % 4 == 0 && (Cin == 64 || Cin == 256) && Cout >= 64 &&
@@ -611,7 +652,7 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
       !cp_aligned16(out) || !cp_aligned16(key_table) || !cp_aligned16(nbr))
     return CP_ERR_ALIGN;
   const size_t lds1[2] = {(size_t)2 * 2 * 4 * 1024 + 1024, (size_t)2 * 8 * 4 * 1024 + 1024};      // Cin = 64 / 256
-  const bool il = K == ET_KMAX && tiled2_lds(Cin, HPAD) <= 160 * 1024 && !cp_knob("CP_NO_TILED2");      // the interleaved form
+  const bool il = K == ET_KMAX && HPAD <= 384 && tiled2_lds(Cin, HPAD) <= 160 * 1024 && !cp_knob("CP_NO_TILED2");      // the interleaved form
   const bool db = tiled_lds_db(Cin, HPAD) <= 160 * 1024;
   const size_t lds2 = il ? tiled2_lds(Cin, HPAD) : db ? tiled_lds_db(Cin, HPAD) : tiled_lds(Cin, HPAD);
   static CpDeviceOnce once;
