@@ -251,6 +251,140 @@ __device__ void procrustes_rotation(const double* m, double* R) {
   if (det < 0.0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
 }
 
+// ---- exactly four valid correspondences: OpenCV's solvePnPRansac runs no RANSAC there (calib3d solvepnp.cpp: model_points ==
+// npoints) but solvePnP with its P3P kernel -- P3P on the first three points, the fourth picks among the up-to-four poses by its
+// reprojection error; all four are reported as inliers.  P3P here: Grunert's quartic in v = s3 / s1 (Haralick et al., IJCV 1994),
+// roots by Durand-Kerner + Newton, the three distances polished by Newton steps on the law-of-cosines system, pose by absolute
+// orientation (procrustes_rotation: rank 2 with three points).  oracle/pnp_oracle.py:solve_four_points is the same arithmetic.
+__device__ int quartic_real_roots(const double* A, double* roots) {
+  double mx = 0.0;
+  for (int i = 0; i < 5; ++i) mx = fmax(mx, fabs(A[i]));
+  if (!(mx > 0.0) || fabs(A[0]) < 1e-14 * mx) return 0;       // (a vanishing leading coefficient: a measure-zero configuration)
+  double c[4];                                                // monic: v^4 + c0 v^3 + c1 v^2 + c2 v + c3
+  double bound = 0.0;
+  for (int i = 0; i < 4; ++i) { c[i] = A[i + 1] / A[0]; bound = fmax(bound, fabs(c[i])); }
+  bound += 1.0;
+  double zr[4], zi[4];
+  {
+    double pr = 1.0, pi = 0.0;                                // (0.4 + 0.9 i)^k * bound
+    for (int k = 0; k < 4; ++k) {
+      zr[k] = pr * bound; zi[k] = pi * bound;
+      const double nr = pr * 0.4 - pi * 0.9, ni = pr * 0.9 + pi * 0.4;
+      pr = nr; pi = ni;
+    }
+  }
+  for (int it = 0; it < 200; ++it) {
+    double change = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      double pr = 1.0, pi = 0.0;                              // p(z_k) by Horner
+      for (int i = 0; i < 4; ++i) {
+        const double nr = pr * zr[k] - pi * zi[k] + c[i], ni = pr * zi[k] + pi * zr[k];
+        pr = nr; pi = ni;
+      }
+      double dr = 1.0, di = 0.0;                              // prod_{j != k} (z_k - z_j)
+      for (int j = 0; j < 4; ++j) {
+        if (j == k) continue;
+        const double er = zr[k] - zr[j], ei = zi[k] - zi[j];
+        const double nr = dr * er - di * ei, ni = dr * ei + di * er;
+        dr = nr; di = ni;
+      }
+      const double dn = dr * dr + di * di;
+      if (!(dn > 0.0)) continue;
+      const double qr = (pr * dr + pi * di) / dn, qi = (pi * dr - pr * di) / dn;
+      zr[k] -= qr; zi[k] -= qi;
+      change = fmax(change, fabs(qr) + fabs(qi));
+    }
+    if (change < 1e-15 * bound) break;
+  }
+  int n = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (fabs(zi[k]) > 1e-6 * (1.0 + fabs(zr[k]))) continue;
+    double v = zr[k];
+    for (int it = 0; it < 2; ++it) {                          // Newton on the real polynomial
+      const double f = (((A[0] * v + A[1]) * v + A[2]) * v + A[3]) * v + A[4];
+      const double d = ((4.0 * A[0] * v + 3.0 * A[1]) * v + 2.0 * A[2]) * v + A[3];
+      if (d != 0.0) v -= f / d;
+    }
+    roots[n++] = v;
+  }
+  return n;
+}
+
+// pose from exactly four correspondences (pw (4,3) float, uv (4,2) float): true + R (row-major), t; false: no admissible solution
+__device__ bool solve_four_points(const float* pw, const float* uv, double fu, double fv, double uc, double vc, double* Rout, double* tout) {
+  double f[3][3], X[4][3];
+  for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < 3; ++c) X[i][c] = (double)pw[3 * i + c];
+  for (int i = 0; i < 3; ++i) {
+    const double a = ((double)uv[2 * i] - uc) / fu, b = ((double)uv[2 * i + 1] - vc) / fv;
+    const double inv = 1.0 / sqrt(a * a + b * b + 1.0);
+    f[i][0] = a * inv; f[i][1] = b * inv; f[i][2] = inv;
+  }
+  auto d2 = [&](int i, int j) { double s = 0.0; for (int c = 0; c < 3; ++c) s += (X[i][c] - X[j][c]) * (X[i][c] - X[j][c]); return s; };
+  auto dot = [&](int i, int j) { return f[i][0] * f[j][0] + f[i][1] * f[j][1] + f[i][2] * f[j][2]; };
+  const double a2 = d2(1, 2), b2 = d2(0, 2), c2 = d2(0, 1);
+  if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return false;
+  const double ca = dot(1, 2), cb = dot(0, 2), cg = dot(0, 1);
+  const double q = (a2 - c2) / b2;
+  const double A[5] = {(q - 1.0) * (q - 1.0) - 4.0 * c2 / b2 * ca * ca,
+                       4.0 * (q * (1.0 - q) * cb - (1.0 - (a2 + c2) / b2) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb),
+                       2.0 * (q * q - 1.0 + 2.0 * q * q * cb * cb + 2.0 * (b2 - c2) / b2 * ca * ca - 4.0 * (a2 + c2) / b2 * ca * cb * cg +
+                              2.0 * (b2 - a2) / b2 * cg * cg),
+                       4.0 * (-q * (1.0 + q) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - (a2 + c2) / b2) * ca * cg),
+                       (1.0 + q) * (1.0 + q) - 4.0 * a2 / b2 * cg * cg};
+  double roots[4];
+  const int nr = quartic_real_roots(A, roots);
+  bool have = false;
+  double best = INFINITY;
+  for (int r = 0; r < nr; ++r) {
+    const double v = roots[r];
+    if (!(v > 0.0)) continue;
+    const double den = 2.0 * (cg - v * ca), w = 1.0 + v * v - 2.0 * v * cb;
+    if (fabs(den) < 1e-12 || !(w > 0.0)) continue;
+    const double u = ((q - 1.0) * v * v - 2.0 * q * cb * v + 1.0 + q) / den;
+    if (!(u > 0.0)) continue;
+    double sd[3];
+    sd[0] = sqrt(b2 / w); sd[1] = u * sd[0]; sd[2] = v * sd[0];
+    for (int it = 0; it < 3; ++it) {                          // Newton polish of (s1, s2, s3)
+      const double F0 = sd[1] * sd[1] + sd[2] * sd[2] - 2.0 * sd[1] * sd[2] * ca - a2;
+      const double F1 = sd[0] * sd[0] + sd[2] * sd[2] - 2.0 * sd[0] * sd[2] * cb - b2;
+      const double F2 = sd[0] * sd[0] + sd[1] * sd[1] - 2.0 * sd[0] * sd[1] * cg - c2;
+      const double J01 = 2.0 * sd[1] - 2.0 * sd[2] * ca, J02 = 2.0 * sd[2] - 2.0 * sd[1] * ca;
+      const double J10 = 2.0 * sd[0] - 2.0 * sd[2] * cb, J12 = 2.0 * sd[2] - 2.0 * sd[0] * cb;
+      const double J20 = 2.0 * sd[0] - 2.0 * sd[1] * cg, J21 = 2.0 * sd[1] - 2.0 * sd[0] * cg;
+      // J = [[0, J01, J02], [J10, 0, J12], [J20, J21, 0]]: Cramer
+      const double det = -J01 * (0.0 - J12 * J20) + J02 * (J10 * J21);
+      if (!(fabs(det) > 1e-30)) break;
+      const double x0 = (F0 * (0.0 - J12 * J21) - J01 * (0.0 - J12 * F2) + J02 * (F1 * J21)) / det;
+      const double x1 = (0.0 - F0 * (0.0 - J12 * J20) + J02 * (J10 * F2 - F1 * J20)) / det;
+      const double x2 = (J01 * (0.0 - (J10 * F2 - F1 * J20)) + F0 * (J10 * J21)) / det;
+      sd[0] -= x0; sd[1] -= x1; sd[2] -= x2;
+    }
+    if (!(sd[0] > 0.0) || !(sd[1] > 0.0) || !(sd[2] > 0.0)) continue;
+    double pc[3][3], c0[3] = {0, 0, 0}, w0[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+      for (int c = 0; c < 3; ++c) { pc[i][c] = sd[i] * f[i][c]; c0[c] += pc[i][c] / 3.0; w0[c] += X[i][c] / 3.0; }
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) H[3 * a + c] += (pc[i][a] - c0[a]) * (X[i][c] - w0[c]);
+    double R[9], t[3];
+    procrustes_rotation(H, R);
+    for (int a = 0; a < 3; ++a) t[a] = c0[a] - (R[3 * a] * w0[0] + R[3 * a + 1] * w0[1] + R[3 * a + 2] * w0[2]);
+    const double Z = R[6] * X[3][0] + R[7] * X[3][1] + R[8] * X[3][2] + t[2];
+    if (!(Z > 0.0)) continue;
+    const double du = uc + fu * (R[0] * X[3][0] + R[1] * X[3][1] + R[2] * X[3][2] + t[0]) / Z - (double)uv[6];
+    const double dv = vc + fv * (R[3] * X[3][0] + R[4] * X[3][1] + R[5] * X[3][2] + t[1]) / Z - (double)uv[7];
+    const double e = sqrt(du * du + dv * dv);
+    if (e < best) {
+      best = e; have = true;
+      for (int i = 0; i < 9; ++i) Rout[i] = R[i];
+      for (int i = 0; i < 3; ++i) tout[i] = t[i];
+    }
+  }
+  return have;
+}
+
 constexpr int PNP_THREADS = 256, PNP_MAX_ITERS = 256, PNP_NMAX = 4096, PNP_HYP = 14;      // doubles per hypothesis record: count, -, 12 pose
 
 struct Points {            // the correspondences of one EPnP call: idx[0 .. n) into this crop's (N, 3) / (N, 2) arrays
@@ -550,8 +684,8 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const PnpParams p, d
   const int vs = p.valid_stride;
   const int nv = block_compact<64>([&](int i) { return valid[(size_t)i * vs] != 0; }, p.N, vidx, wsum, tid);
   const int h = p.round * 64 + tid;
-  if (nv < 4) return;
-  if (p.round > 0 && hypotheses_run(hyp + (size_t)b * p.iters * PNP_HYP, nv, nv >= 5 ? 5 : 4, p.iters, p.round) <= 64 * p.round)
+  if (nv < 5) return;                                        // < 4: identity; exactly 4: P3P in the selection launch, no hypotheses
+  if (p.round > 0 && hypotheses_run(hyp + (size_t)b * p.iters * PNP_HYP, nv, 5, p.iters, p.round) <= 64 * p.round)
     return;                                                  // the rule was satisfied by the earlier rounds: whole workgroup, uniform
   if (h >= p.iters) return;
   Points P;                                                  // straight from global memory: the scoring loop reads the SAME point on
@@ -560,7 +694,7 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const PnpParams p, d
   const float* K = p.K + (size_t)b * p.K_bs;
   P.fu = K[0]; P.fv = K[4]; P.uc = K[2]; P.vc = K[5];
   const double thr2 = (double)p.thr * (double)p.thr;
-  const int m = nv >= 5 ? 5 : 4;
+  const int m = 5;
   int32_t sel[5];
   int got = 0;
   uint32_t tries = 0;
@@ -648,11 +782,33 @@ __global__ __launch_bounds__(PNP_THREADS) void pnp_select_refit_kernel(const Pnp
     }
   };
   if (nv < 4) { identity(); return; }
-  const int m = nv >= 5 ? 5 : 4;
+  const int m = 5;
   Points P;
   P.p3d = s3; P.p2d = s2;
   const float* K = p.K + (size_t)b * p.K_bs;
   P.fu = K[0]; P.fv = K[4]; P.uc = K[2]; P.vc = K[5];
+  if (nv == 4) {                                             // OpenCV: no RANSAC, P3P + the fourth point; all four are inliers
+    if (tid == 0) {
+      float pw4[12], uv4[8];
+      for (int i = 0; i < 4; ++i) {
+        const int k = vidx[i];
+        for (int c = 0; c < 3; ++c) pw4[3 * i + c] = s3[3 * k + c];
+        uv4[2 * i] = s2[2 * k]; uv4[2 * i + 1] = s2[2 * k + 1];
+      }
+      double R4[9], t4[3];
+      if (solve_four_points(pw4, uv4, P.fu, P.fv, P.uc, P.vc, R4, t4)) {
+        for (int i = 0; i < 9; ++i) pose[i] = R4[i];
+        for (int i = 0; i < 3; ++i) pose[9 + i] = t4[i];
+        for (int i = 0; i < 4; ++i) p.inliers[(size_t)b * p.N + vidx[i]] = 1;
+        p.status[b] = 1;
+      } else {
+        for (int i = 0; i < 9; ++i) pose[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        pose[9] = pose[10] = pose[11] = 0.0;
+        p.status[b] = 0;
+      }
+    }
+    return;
+  }
   const double thr2 = (double)p.thr * (double)p.thr;
   const double* hb = hyp + (size_t)b * p.iters * PNP_HYP;
   if (tid == 0) {                                            // most inliers, first on ties, at least a full sample

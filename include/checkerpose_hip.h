@@ -370,9 +370,10 @@ int cp_correspondences_bbox(cp_stream_t stream, const float* bits, const float* 
  *   p3d fp32 (N,3) model keypoints in their ORIGINAL units (batch stride p3d_bstride elements; 0 = one object for all crops);
  *   p2d fp32 (B,N,2) and valid uint8 with `valid_stride` bytes between keypoints = cp_correspondences' outputs (valid + column c,
  *   stride 3: c = 0 all | 1 in full mask | 2 in visible mask);  cam_K fp32 row-major 3x3 (batch stride K_bstride; 0 = shared);
- *   RANSAC over `iterations` (<= 256) EPnP hypotheses of 5 correspondences (4 when only 4 are valid) drawn by a counter-based
+ *   RANSAC over `iterations` (<= 256) EPnP hypotheses of 5 correspondences drawn by a counter-based
  *   hash of (seed, crop, hypothesis), inlier test squared reprojection error <= reproj_threshold^2, the hypothesis with the most
- *   inliers (>= the sample size; first on ties), final EPnP over its inliers.
+ *   inliers (>= the sample size; first on ties), final EPnP over its inliers.  Exactly 4 valid correspondences: no RANSAC, as in
+ *   OpenCV (model_points == npoints) -- P3P on the first three, the fourth picks among the up-to-four poses, all four are inliers.
  * Outputs: pose fp64 (B,12) = [R row-major | t], inliers uint8 (B,N), status int32 (B): 1 = solved, 0 = identity fallback.
  * scratch: cp_pnp_ransac_scratch_bytes(B, N).  opencv-python is not part of the reference's tree: the algorithm is restated from
  * the publication / OpenCV's structure (oracle/pnp_oracle.py lists the deliberate differences); parity with cv2 is UNPINNED. */

@@ -13,15 +13,16 @@ output.  What is restated here is the PUBLISHED algorithm:
     M^T M, the three beta approximations (N = 4, 2, 3 unknown-products variants) each refined by 5 Gauss-Newton steps, camera-frame
     control points -> absolute orientation (SVD of the 3x3 cross-covariance, row-flip on a reflection), best of the three by mean
     reprojection error;
-  * the RANSAC frame of OpenCV's solvePnPRansac: minimal sets of 5 correspondences (4 when only 4 are valid), squared reprojection
+  * the RANSAC frame of OpenCV's solvePnPRansac: minimal sets of 5 correspondences, squared reprojection
     error <= threshold^2 as the inlier test, the hypothesis with the most inliers (first one on ties, at least the sample size),
     a final EPnP over its inliers; the returned inlier list is that hypothesis' set.
 Deliberate differences (no way to pin them, and nothing downstream depends on them): the sample sequence comes from a counter-based
 hash (`sample_indices`, shared bit for bit with the device kernel) instead of OpenCV's MWC generator; OpenCV's stopping rule
 (RANSACUpdateNumIters at confidence 0.99) is applied between rounds of 64 hypotheses, not after every better model, so at least as
 many hypotheses are evaluated as OpenCV would; small linear systems are
-solved through the normal equations instead of an SVD; with exactly 4 valid correspondences EPnP runs on the 4 (OpenCV switches to
-a P3P kernel there).  Known-answer anchoring instead of golden vectors: synthetic poses with
+solved through the normal equations instead of an SVD.  With exactly 4 valid correspondences OpenCV runs no RANSAC but its P3P
+kernel on the first three points and lets the fourth choose among the solutions: restated here (round 4) with Grunert's quartic
+(OpenCV's p3p.cpp follows Gao et al.: another derivation of the same up-to-four solutions).  Known-answer anchoring instead of golden vectors: synthetic poses with
 exact and outlier-contaminated correspondences must be recovered (tests/test_pnp.py).
 """
 import numpy as np
@@ -180,6 +181,73 @@ def needed_iterations(best, nv, m, iterations, confidence=0.99):
     return int(np.rint(num / denom))
 
 
+def _absolute_orientation(pc, pw):
+    """R, t with pc ~ R pw + t (SVD of the 3x3 cross-covariance, proper rotation also for 3 points / rank 2)"""
+    c0, w0 = pc.mean(0), pw.mean(0)
+    U, _, Vt = np.linalg.svd((pc - c0).T @ (pw - w0))
+    R = U @ np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))]) @ Vt
+    return R, c0 - R @ w0
+
+
+def p3p_distances(pw, uv, K):
+    """Grunert's quartic for the three camera distances (as reviewed by Haralick et al., IJCV 1994): up to four (s1, s2, s3), each
+    polished by Newton steps on the three law-of-cosines equations.  pw (3,3), uv (3,2).  Returns (bearings (3,3), [distances])."""
+    f = np.stack([(uv[:, 0] - K[0, 2]) / K[0, 0], (uv[:, 1] - K[1, 2]) / K[1, 1], np.ones(3)], 1)
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    a2, b2, c2 = ((pw[1] - pw[2]) ** 2).sum(), ((pw[0] - pw[2]) ** 2).sum(), ((pw[0] - pw[1]) ** 2).sum()
+    ca, cb, cg = f[1] @ f[2], f[0] @ f[2], f[0] @ f[1]
+    if min(a2, b2, c2) <= 0:
+        return f, []
+    q = (a2 - c2) / b2
+    A = [(q - 1) ** 2 - 4 * c2 / b2 * ca ** 2,
+         4 * (q * (1 - q) * cb - (1 - (a2 + c2) / b2) * ca * cg + 2 * c2 / b2 * ca ** 2 * cb),
+         2 * (q ** 2 - 1 + 2 * q ** 2 * cb ** 2 + 2 * (b2 - c2) / b2 * ca ** 2 - 4 * (a2 + c2) / b2 * ca * cb * cg + 2 * (b2 - a2) / b2 * cg ** 2),
+         4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg ** 2 * cb - (1 - (a2 + c2) / b2) * ca * cg),
+         (1 + q) ** 2 - 4 * a2 / b2 * cg ** 2]
+    out = []
+    for v in np.roots(A):
+        if abs(v.imag) > 1e-6 * (1 + abs(v.real)) or v.real <= 0:
+            continue
+        v = float(v.real)
+        den = 2 * (cg - v * ca)
+        if abs(den) < 1e-12:
+            continue
+        u = ((q - 1) * v * v - 2 * q * cb * v + 1 + q) / den
+        if u <= 0 or 1 + v * v - 2 * v * cb <= 0:
+            continue
+        s1 = np.sqrt(b2 / (1 + v * v - 2 * v * cb))
+        sd = np.array([s1, u * s1, v * s1])
+        for _ in range(3):                                  # Newton polish
+            F = np.array([sd[1] ** 2 + sd[2] ** 2 - 2 * sd[1] * sd[2] * ca - a2, sd[0] ** 2 + sd[2] ** 2 - 2 * sd[0] * sd[2] * cb - b2,
+                          sd[0] ** 2 + sd[1] ** 2 - 2 * sd[0] * sd[1] * cg - c2])
+            J = np.array([[0, 2 * sd[1] - 2 * sd[2] * ca, 2 * sd[2] - 2 * sd[1] * ca],
+                          [2 * sd[0] - 2 * sd[2] * cb, 0, 2 * sd[2] - 2 * sd[0] * cb],
+                          [2 * sd[0] - 2 * sd[1] * cg, 2 * sd[1] - 2 * sd[0] * cg, 0]])
+            if abs(np.linalg.det(J)) < 1e-30:
+                break
+            sd = sd - np.linalg.solve(J, F)
+        if (sd > 0).all():
+            out.append(sd)
+    return f, out
+
+
+def solve_four_points(pw4, uv4, K):
+    """What OpenCV's solvePnPRansac does with exactly 4 correspondences (calib3d solvepnp.cpp: model_points == npoints -> no RANSAC,
+    solvePnP with the P3P kernel): P3P on the first three, the fourth picks among the up-to-four poses (smallest reprojection error).
+    Returns (R, t) or None."""
+    f, dists = p3p_distances(pw4[:3], uv4[:3], K)
+    best = None
+    for sd in dists:
+        R, t = _absolute_orientation(sd[:, None] * f, pw4[:3])
+        pc = R @ pw4[3] + t
+        if pc[2] <= 0:
+            continue
+        e = np.hypot(K[0, 2] + K[0, 0] * pc[0] / pc[2] - uv4[3, 0], K[1, 2] + K[1, 1] * pc[1] / pc[2] - uv4[3, 1])
+        if best is None or e < best[0]:
+            best = (e, R, t)
+    return None if best is None else (best[1], best[2])
+
+
 def solve_pnp_ransac(p3d, p2d, valid, K, threshold=2.0, iterations=150, seed=0, crop=0):
     """p3d (N,3), p2d (N,2), valid (N,) bool, K (3,3).  Returns (R, t, inlier mask (N,) bool, status): status 0 = the
     reference's identity fallback (fewer than 4 valid points, or no hypothesis with a full sample of inliers)."""
@@ -189,7 +257,14 @@ def solve_pnp_ransac(p3d, p2d, valid, K, threshold=2.0, iterations=150, seed=0, 
     ident = (np.eye(3), np.zeros(3), np.zeros(len(p3d), bool), 0)
     if nv < 4:
         return ident
-    m = 5 if nv >= 5 else 4
+    if nv == 4:                                                # no RANSAC on exactly 4 points: P3P + the 4th point, all four "inliers"
+        rt = solve_four_points(p3d[vid], p2d[vid], np.asarray(K, np.float64))
+        if rt is None:
+            return ident
+        mask = np.zeros(len(p3d), bool)
+        mask[vid] = True
+        return rt[0], rt[1], mask, 1
+    m = 5
     best_cnt, best_mask = m - 1, None
     counts = []
     for h in range(iterations):

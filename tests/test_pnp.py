@@ -58,7 +58,7 @@ def test_epnp_recovers_exact_poses():
             if n >= 5:
                 assert err < 1e-8 and np.abs(Re - R).max() < 1e-8 and np.abs(te - t).max() < 1e-6, (n, err)
             else:        # 4 points leave a 4-dimensional null space: EPnP's linearisation + 5 Gauss-Newton steps need not reach the
-                assert np.isfinite(err) and np.isfinite(Re).all()      # pose (cv2 switches to a P3P kernel for 4 points; not built)
+                assert np.isfinite(err) and np.isfinite(Re).all()      # pose (4 valid points go to P3P instead: solve_four_points)
             assert abs(np.linalg.det(Re) - 1) < 1e-12
 
 
@@ -84,9 +84,61 @@ def test_reference_fallbacks():
         Re, te, mask, status = P.solve_pnp_ransac(xyz, uv, valid, K_LMO)
         assert status == 0 and np.array_equal(Re, np.eye(3)) and not te.any() and not mask.any()
     valid = np.zeros(16, bool)
-    valid[[1, 4, 9, 12]] = True                             # exactly 4: solved from the 4 (cv2 switches to a 4-point kernel there)
+    valid[[1, 4, 9, 12]] = True                             # exactly 4: no RANSAC, P3P + the 4th point (as cv2 does); all 4 are inliers
     Re, te, mask, status = P.solve_pnp_ransac(xyz, uv, valid, K_LMO)
-    assert status in (0, 1) and abs(np.linalg.det(Re) - 1) < 1e-9          # a pose or the fallback, never garbage
+    assert status == 1 and np.array_equal(mask, valid)
+    assert np.abs(Re - R).max() < 1e-8 and np.abs(te - t).max() < 1e-6
+
+
+def test_four_points_p3p_known_answers():
+    """exactly 4 correspondences (test_network_with_test_data.py:100: `num_valid >= 4` reaches cv2.solvePnPRansac, which then runs its
+    P3P kernel): the true pose is recovered from exact data for random poses and random 4-subsets of the model; every P3P solution
+    reproduces the three points it was solved from"""
+    rng = np.random.default_rng(11)
+    xyz = _model(512)
+    for trial in range(60):
+        R, t = _pose(rng)
+        sel = rng.choice(512, 4, replace=False)
+        uv = P.project(xyz[sel], K_LMO, R, t)
+        f, dists = P.p3p_distances(xyz[sel[:3]], uv[:3], K_LMO)
+        assert 1 <= len(dists) <= 4
+        for sd in dists:
+            Rk, tk = P._absolute_orientation(sd[:, None] * f, xyz[sel[:3]])
+            assert np.abs(P.project(xyz[sel[:3]], K_LMO, Rk, tk) - uv[:3]).max() < 1e-6          # a valid pose of the 3 points
+        rt = P.solve_four_points(xyz[sel], uv, K_LMO)
+        assert rt is not None
+        assert np.abs(rt[0] - R).max() < 1e-7 and np.abs(rt[1] - t).max() < 1e-5, trial
+
+
+@pytest.mark.gpu
+def test_device_four_points_p3p():
+    """cp_pnp_ransac with exactly 4 valid correspondences per crop: P3P on the device == the oracle == the true pose; the 4 valid
+    keypoints are the inliers; 4 collinear points (no solution) -> the identity fallback."""
+    from checkerpose_amd.postprocess import solve_pnp_ransac
+    rng = np.random.default_rng(12)
+    B, N = 8, 512
+    xyz = _model(N)
+    p2d = np.zeros((B, N, 2))
+    valid = np.zeros((B, N, 3), np.uint8)
+    poses = []
+    for b in range(B):
+        R, t = _pose(rng)
+        poses.append((R, t))
+        p2d[b] = P.project(xyz, K_LMO, R, t)
+        valid[b, rng.choice(N, 4, replace=False), 0] = 1
+    dev = torch.device("cuda:0")
+    Kf = K_LMO.astype(np.float32).astype(np.float64)
+    p2f = p2d.astype(np.float32)
+    Rd, td, inl, status = solve_pnp_ransac(torch.from_numpy(xyz).float().to(dev), torch.from_numpy(p2f).to(dev), torch.from_numpy(valid).to(dev),
+                                           torch.from_numpy(K_LMO).float().to(dev), column=0, reproj_threshold=2.0, iterations=150, seed=1)
+    torch.cuda.synchronize()
+    Rd, td, inl, status = Rd.cpu().numpy(), td.cpu().numpy()[:, :, 0], inl.cpu().numpy(), status.cpu().numpy()
+    for b in range(B):
+        Ro, to, mo, so = P.solve_pnp_ransac(xyz, p2f[b].astype(np.float64), valid[b, :, 0].astype(bool), Kf, 2.0, 150, seed=1, crop=b)
+        assert status[b] == so == 1, b
+        assert np.array_equal(inl[b].astype(bool), mo) and int(mo.sum()) == 4
+        assert np.abs(Rd[b] - Ro).max() < 1e-6 and np.abs(td[b] - to).max() < 1e-5 * max(1.0, np.linalg.norm(to)), b
+        assert np.abs(Rd[b] - poses[b][0]).max() < 2e-3 and np.linalg.norm(td[b] - poses[b][1]) < 5e-3 * np.linalg.norm(poses[b][1])   # fp32 pixels
 
 
 @pytest.mark.gpu
