@@ -1,0 +1,208 @@
+// MLP_QueryNet (reference pipeline.py:168-180: Linear(256 -> 256) + LeakyReLU, Linear(256 -> 64) + LeakyReLU, Linear(64 -> 2)) as ONE
+// launch over the (B * N) keypoint rows (bf16 operands, fp32 accumulation).
+//
+// As three launches the stack moved, per row: 512 B in, 512 B out + in again, 128 B out + in again, 8 B out -- 2.3 KB for a
+// 512-byte input, every launch bound by that traffic (the weight-stationary row GEMM of gemm_lds.hip reaches 2.7 TB/s; at config
+// #5's 1 M rows per stage the three launches took ~0.65 ms).  Here the rows are read once and only the two logits leave the chip:
+// a persistent 8-wave workgroup per CU walks tiles of 64 rows as a two-stage pipeline.
+//   waves 0-3 (layer 1, weight-stationary): wave w keeps the 256 x 64 slice W1[64 w .. 64 w + 63] in registers (8 K chunks x 4
+//     tiles = 128 VGPRs), multiplies the tile's rows (staged in LDS in full 512-byte row segments, double-buffered, the next
+//     tile's loads in flight under the MFMAs) and writes its 64 hidden channels of the tile -- LeakyReLU, bf16 -- into an LDS tile
+//     in MFMA operand order ([16-byte channel piece][row][16 B], double-buffered);
+//   waves 4-7 (layers 2 + 3): wave v owns rows 16 v .. 16 v + 15 of the PREVIOUS tile: 256 -> 64 from the hidden tile with W2
+//     resident in registers (128 VGPRs), LeakyReLU in fp32 (never rounded to bf16), then the 64 -> 2 head as per-lane partial dot
+//     products met by two cross-lane adds; 8 bytes per row leave, in the caller's (row, channel) strides (the logit block).
+// One barrier per tile.  The layer-1 image is cp_pack_gemm_weight's (gemm_lds.hip), as is the layer-2 image.
+#include "common.h"
+
+namespace {
+
+constexpr int MQ_ROWS = 64;
+constexpr int MQ_PITCH = MQ_ROWS * 16 + 16;                  // plane [row][16 B]; +16: consecutive planes shift one bank slot
+constexpr int MQ_BUF = 32 * MQ_PITCH;                        // 32 pieces of 8 channels = 256 channels: 33 280 B
+constexpr int MQ_LDS = 4 * MQ_BUF + 512;                     // x tile x 2, hidden tile x 2, layer-3 weights
+
+struct MlpQueryParams {
+  const void* in; const void* w1; const float* s1; const float* t1;
+  const void* w2; const float* s2; const float* t2;
+  const float* w3; const float* b3;                          // (2, 64) fp32 row-major, (2,)
+  float* out;
+  int M, Nrow, in_cs, in_coff, n_rt;
+  uint32_t in_bytes;
+  float slope1, slope2;
+  long long o_base, o_sb, o_sn, o_sc;                        // logit (m = b * Nrow + n, c) at o_base + b * o_sb + n * o_sn + c * o_sc
+};
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+__global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sX = smem;                             // 2 x MQ_BUF
+  unsigned char* const sH = smem + 2 * MQ_BUF;                // 2 x MQ_BUF
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const bool l1 = wave < 4;
+
+  // ---- resident weights: [32-channel group][chunk][nt][lane][16 B] (cp_pack_gemm_weight); layer 1: groups 2 w, 2 w + 1 of 8;
+  // layer 2: groups 0, 1 of 2 (every layer-2 wave holds all 64 output channels)
+  u32x4 W[8][4];
+  {
+    const u32x4* const wsrc = (const u32x4*)(l1 ? p.w1 : p.w2);
+    const int g0 = l1 ? 2 * wave : 0;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) W[kc][t] = wsrc[((size_t)((g0 + (t >> 1)) * 8 + kc) * 2 + (t & 1)) * 64 + lane];
+  }
+  float* const sW3 = (float*)(smem + 4 * MQ_BUF);            // [2][64]: layer-3 rows (kept out of the layer-1 waves' registers)
+  if (tid < 128) sW3[tid] = p.w3[tid];
+  const float b3a = p.b3[0], b3b = p.b3[1];
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  // staging by the 256 threads of the layer-2 waves (they carry a quarter of the MFMA work; the layer-1 waves have no registers
+  // to spare for the eight in-flight pieces): piece i = (tid - 256) + 256 k (k = 0..7): row = i / 32, piece-in-row = i % 32
+  const int s_pr = tid & 31, s_row = (tid & 255) >> 5;        // rows s_row + 8 k
+  auto stage_load = [&](u32x4* v, int rt) {
+    const int m0 = rt * MQ_ROWS;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int m = m0 + s_row + 8 * k;
+      const uint32_t off = (rt < p.n_rt && m < p.M) ? (uint32_t)(m * p.in_cs + p.in_coff + s_pr * 8) * 2u : 0x80000000u;
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+  auto stage_write = [&](const u32x4* v, int buf) {
+    unsigned char* dst = sX + buf * MQ_BUF + s_pr * MQ_PITCH + s_row * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(u32x4*)(dst + k * 8 * 16) = v[k];
+  };
+
+  const int step = gridDim.x;
+  u32x4 sv[8];
+  if (!l1) {
+    stage_load(sv, blockIdx.x);
+    stage_write(sv, 0);
+  }
+  __syncthreads();
+  // iteration it: layer 1 works on tile rt (x in sX[it & 1] -> hidden in sH[it & 1]), layers 2 + 3 on tile rt - step (sH[(it - 1) & 1])
+  int it = 0;
+  for (int rt = blockIdx.x; rt - step < p.n_rt; rt += step, ++it) {
+    if (l1) {
+      if (rt < p.n_rt) {
+#pragma unroll 1
+        for (int mh = 0; mh < 2; ++mh) {                      // two passes of 32 rows: bounds the live accumulators (32 VGPRs)
+          f32x4 acc[2][4];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const unsigned char* ab = sX + (it & 1) * MQ_BUF + q * MQ_PITCH + (mh * 32 + x) * 16;
+#pragma unroll
+          for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const u32x4 a = *(const u32x4*)(ab + kc * 4 * MQ_PITCH + mt * 256);
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc][t]), __builtin_bit_cast(bf16x8, a), acc[mt][t], 0, 0, 0);
+            }
+          // lane (x, q): rows 32 mh + 16 mt + x, hidden channels (2 wave + h) * 32 + 8 q + {0..7} = piece (2 wave + h) * 4 + q
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int ch = (2 * wave + h) * 32 + q * 8;
+            const f32x4 s0 = *(const f32x4*)(p.s1 + ch), t0 = *(const f32x4*)(p.t1 + ch);
+            const f32x4 s1 = *(const f32x4*)(p.s1 + ch + 4), t1 = *(const f32x4*)(p.t1 + ch + 4);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                v[j] = leaky(acc[mt][2 * h][j] * s0[j] + t0[j], p.slope1);
+                v[4 + j] = leaky(acc[mt][2 * h + 1][j] * s1[j] + t1[j], p.slope1);
+              }
+              *(u32x4*)(sH + (it & 1) * MQ_BUF + ((2 * wave + h) * 4 + q) * MQ_PITCH + (mh * 32 + mt * 16 + x) * 16) = Vec16<BF16Tag>::pack(v);
+            }
+          }
+        }
+      }
+    } else {
+      stage_load(sv, rt + step);                              // the tile layer 1 takes next; past the end: zeros, never consumed
+      if (it > 0) {
+      const int v4 = wave - 4;                                // rows 16 v4 .. 16 v4 + 15 of tile rt - step
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned char* ab = sH + ((it - 1) & 1) * MQ_BUF + q * MQ_PITCH + (v4 * 16 + x) * 16;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const u32x4 a = *(const u32x4*)(ab + kc * 4 * MQ_PITCH);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc][t]), __builtin_bit_cast(bf16x8, a), acc[t], 0, 0, 0);
+      }
+      // lane (x, q): row 16 v4 + x, hidden-2 channels 32 h + 8 q + {0..7}; layer 3 on the fp32 values
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ch = h * 32 + q * 8;
+        const f32x4 s0 = *(const f32x4*)(p.s2 + ch), t0 = *(const f32x4*)(p.t2 + ch);
+        const f32x4 s1 = *(const f32x4*)(p.s2 + ch + 4), t1 = *(const f32x4*)(p.t2 + ch + 4);
+        const f32x4 a0 = *(const f32x4*)(sW3 + ch), a1 = *(const f32x4*)(sW3 + ch + 4);
+        const f32x4 c0 = *(const f32x4*)(sW3 + 64 + ch), c1 = *(const f32x4*)(sW3 + 64 + ch + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u0 = leaky(acc[2 * h][j] * s0[j] + t0[j], p.slope2), u1 = leaky(acc[2 * h + 1][j] * s1[j] + t1[j], p.slope2);
+          d0 += u0 * a0[j] + u1 * a1[j];
+          d1 += u0 * c0[j] + u1 * c1[j];
+        }
+      }
+      d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
+      d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
+      const int m = (rt - step) * MQ_ROWS + v4 * 16 + x;
+      if (q == 0 && m < p.M) {
+        const int b = m / p.Nrow, n = m - b * p.Nrow;
+        float* o = p.out + p.o_base + (long long)b * p.o_sb + (long long)n * p.o_sn;
+        o[0] = d0 + b3a;
+        o[p.o_sc] = d1 + b3b;
+      }
+      }
+      stage_write(sv, (it + 1) & 1);                          // sX[(it + 1) & 1]: its readers (layer 1, iteration it - 1) passed the last barrier
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int cp_mlp_query_fused_supported(int C0, int C1, int C2, int C3) { return (C0 == 256 && C1 == 256 && C2 == 64 && C3 == 2) ? 1 : 0; }
+
+extern "C" int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int B, int N,
+                                  const void* packed_w1, const float* scale1, const float* shift1, float slope1,
+                                  const void* packed_w2, const float* scale2, const float* shift2, float slope2,
+                                  const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn,
+                                  long long o_sc) {
+  if (!in || !packed_w1 || !scale1 || !shift1 || !packed_w2 || !scale2 || !shift2 || !w3 || !b3 || !out || B <= 0 || N <= 0)
+    return CP_ERR_INVALID;
+  if (in_cstride % 8 || in_coff % 8 || in_coff + 256 > in_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(scale1) || !cp_aligned16(shift1) ||
+      !cp_aligned16(scale2) || !cp_aligned16(shift2))
+    return CP_ERR_ALIGN;
+  const long long M = (long long)B * N;
+  const long long in_bytes = M * in_cstride * 2;
+  if (in_bytes >= (1LL << 32) || M >= (1LL << 31)) return CP_ERR_RANGE;
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)mlp_query_fused_kernel, MQ_LDS));
+  const int n_cu = cp_num_cus();
+  if (n_cu <= 0) return CP_ERR_HIP;
+  MlpQueryParams p;
+  p.in = in; p.w1 = packed_w1; p.s1 = scale1; p.t1 = shift1; p.w2 = packed_w2; p.s2 = scale2; p.t2 = shift2; p.w3 = w3; p.b3 = b3; p.out = out;
+  p.M = (int)M; p.Nrow = N; p.in_cs = in_cstride; p.in_coff = in_coff; p.n_rt = (int)((M + MQ_ROWS - 1) / MQ_ROWS);
+  p.in_bytes = (uint32_t)in_bytes; p.slope1 = slope1; p.slope2 = slope2;
+  p.o_base = o_base; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sc = o_sc;
+  const int grid = p.n_rt < n_cu ? p.n_rt : n_cu;
+  CP_LAUNCH(mlp_query_fused_kernel, dim3((unsigned)grid), dim3(512), MQ_LDS, (hipStream_t)stream, p);
+  return cp_check_launch();
+}

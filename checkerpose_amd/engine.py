@@ -24,6 +24,8 @@ USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decode
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
+USE_MLP_FUSED = os.environ.get("CHECKERPOSE_AMD_MLP_FUSED", "1") != "0"   # MLP_QueryNet's three Linears as one launch (bf16)
+MLP_FUSED_MIN_ROWS = int(os.environ.get("CHECKERPOSE_AMD_MLP_FUSED_MIN_ROWS", "32768"))   # one persistent workgroup per CU walks 64-row tiles
 EDGE_SCHED = os.environ.get("CHECKERPOSE_AMD_EDGE_SCHED", "1") != "0"   # A/B: bank-conflict-aware neighbour order for edge_fused
 USE_CONV_GROUP = os.environ.get("CHECKERPOSE_AMD_CONV_GROUP", "0") == "1"    # training: independent small 3x3 convs in one launch (measured: no gain)
 CONV_GROUP_MAX_C = int(os.environ.get("CHECKERPOSE_AMD_CONV_GROUP_MAXC", "48"))
@@ -214,6 +216,7 @@ class Program:
         # launch selection by batch size (module globals = the measured crossovers); HipForwardMixin.set_kernel_selection pins one
         # selection for every batch size, so a crop's bf16 bits do not depend on the size of the batch it arrives in
         self.chain_min, self.stem_min, self.edge_min, self.splitk = CHAIN_MIN_BATCH, STEM_MIN_BATCH, EDGE_FUSED_MIN_BATCH, USE_SPLITK
+        self.mlp_min_rows = MLP_FUSED_MIN_ROWS
         self._raw = {}         # (ptr, nbytes) -> TBuf of a raw-pointer operand (see raw())
 
     # ---- tensors
@@ -832,6 +835,35 @@ class Program:
         self.flops += fl
         self.conv_log.append((wkey, self.B * N, Co2, Cin, fl, "edge_tiled", self.B * N * (Cin + Co) * self.es + Co2 * Cin * self.es))
         return out
+
+    def can_fuse_query_mlp(self, x: Act, dims):
+        return (USE_MLP_FUSED and self.dtype == CP_BF16 and x.H == 1 and self.B * x.W >= self.mlp_min_rows
+                and len(dims) == 4 and bool(self.lib.cp_mlp_query_fused_supported(*[int(d) for d in dims])) and x.C == dims[0])
+
+    def mlp_query_fused(self, x: Act, keys, ws, bs, slope, out_tbuf, ostr):
+        """MLP_QueryNet (pipeline.py:168-180) in one launch: ws = the three nn.Linear weights, bs their biases; the two logits of
+        row (b, n) go to out_tbuf[ostr[0] + b * ostr[1] + n * ostr[3] + c * ostr[4]] (fp32)"""
+        N = x.W
+        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(ws[0].shape[0], ws[0].shape[1], 1, 1), 256, 256, 256)
+        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(ws[1].shape[0], ws[1].shape[1], 1, 1), 64, 256, 256)
+        ck = ("mlp_query", keys[0])
+        if ck not in self.ws.cache:
+            dev = self.device
+            self.ws.cache[ck] = (torch.ones(256, dtype=torch.float32, device=dev), bs[0].float().contiguous(),
+                                 torch.ones(64, dtype=torch.float32, device=dev), bs[1].float().contiguous(),
+                                 ws[2].float().reshape(2, 64).contiguous(), bs[2].float().contiguous())
+        s1, t1, s2, t2, w3, b3 = self.ws.cache[ck]
+        self.keep += [pw1, pw2, s1, t1, s2, t2, w3, b3]
+        xt = x.tbuf
+        a1 = (pw1.data_ptr(), s1.data_ptr(), t1.data_ptr(), float(slope), pw2.data_ptr(), s2.data_ptr(), t2.data_ptr(), float(slope),
+              w3.data_ptr(), b3.data_ptr())
+        o = (int(ostr[0]), int(ostr[1]), int(ostr[3]), int(ostr[4]))
+        self._add(self.lib.cp_mlp_query_fused, lambda P: (P(xt), x.cstride, x.coff, self.B, N) + a1 + (P(out_tbuf),) + o,
+                  "mlp_fused:" + keys[0], [xt], [out_tbuf])
+        M = self.B * N
+        fl = 2 * M * (256 * 256 + 256 * 64 + 64 * 2)
+        self.flops += fl
+        self.conv_log.append((keys[0], M, 256 + 64 + 2, 256, fl, "mlp_fused", M * (256 * self.es + 8) + (256 * 256 + 64 * 256) * self.es))
 
     def permute_rows(self, x: Act, out: Act, perm_t, gids_t):
         """out[b, i, :] = x[b, perm[g_b, i], :] over whole (B, N, cstride) rows (cp_permute_rows)"""

@@ -806,11 +806,21 @@ def emit_posenet(em: NetEmitter, cfg, io):
                             out=Lnext.slice(qd[0], qd[0]) if (last and Lnext is not None) else None)
         if ngs[i] == 0 and Lnext is not None:
             raise RuntimeError("num_graph_module == 0 is not supported by the fused program")
-        q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope)
-        q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope)
         # Linear(64 -> 2): channel 0 = new x bit -> row 4+i, channel 1 = new y bit -> row 10+i  (pipeline.py:375-378)
         qk = rp + ".query_block.mlps.4"
-        if tp is None:
+        qkeys = [rp + ".query_block.mlps.%d" % j for j in (0, 2, 4)]
+        qws = [em.W(k_ + ".weight") for k_ in qkeys]
+        if tp is None and p.can_fuse_query_mlp(h, [qws[0].shape[1], qws[0].shape[0], qws[1].shape[0], qws[2].shape[0]]):
+            # MLP_QueryNet as one launch: both hidden layers stay on chip, only the logits leave (csrc/mlp_fused.hip)
+            p.mlp_query_fused(h, qkeys, qws, [em.W(k_ + ".bias") for k_ in qkeys], slope, io["bits_tb"],
+                              ((4 + i) * N, 13 * N, 0, 1, 6 * N))
+            q = None
+        else:
+            q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope)
+            q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope)
+        if q is None:
+            pass
+        elif tp is None:
             em.linear(q, qk, ACT_NONE, 0.0, out_f32=True, ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
         else:
             wq = em.W(qk + ".weight")

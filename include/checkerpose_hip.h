@@ -195,6 +195,18 @@ int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w, int Cout,
 int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                  const float* scale, const float* shift, const void* residual, void* out);
 
+/* MLP_QueryNet.forward (pipeline.py:168-180: Linear(256 -> 256) + LeakyReLU, Linear(256 -> 64) + LeakyReLU, Linear(64 -> 2); the
+ * `pts` argument is unused there) as ONE launch over the B * N keypoint rows, bf16: rows read once, both hidden layers stay on chip
+ * (LDS / registers), only the two logits per row leave.  in (B, N, in_cstride) bf16 channels [in_coff, in_coff + 256);
+ * packed_w1 / packed_w2: cp_pack_gemm_weight images of the (256, 256) and (64, 256) weights, scale / shift fp32 per output channel
+ * (nn.Linear: scale 1, shift = bias); w3 fp32 (2, 64) row-major as nn.Linear stores it, b3 fp32 (2).
+ * out fp32: logit c of row (b, n) at out[o_base + b * o_sb + n * o_sn + c * o_sc] (the (B, 13, N) logit block: pipeline.py:375-378). */
+int cp_mlp_query_fused_supported(int C0, int C1, int C2, int C3);
+int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int B, int N,
+                       const void* packed_w1, const float* scale1, const float* shift1, float slope1,
+                       const void* packed_w2, const float* scale2, const float* shift2, float slope2,
+                       const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn, long long o_sc);
+
 /* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
  * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
 int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,

@@ -813,6 +813,7 @@ def test_edgeconv_fused_vs_reference_form(lib, monkeypatch, Cc, pfx):
     from checkerpose_amd.engine import Program, WeightStore
     from checkerpose_amd.netbuilder import NetEmitter
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1)
     dtype = CP_BF16
     net = build_net(seed=0)
     sd_cpu = net.state_dict()
@@ -899,6 +900,42 @@ def test_edgeconv_tiled_vs_reference_form(lib, N, Cc, pfx):
     _abi.check(lib.cp_permute_cols(st(), src.data_ptr(), out_f.data_ptr(), perm.data_ptr(), gids.data_ptr(), B, Cc, N, 4, 1))
     torch.cuda.synchronize()
     close(out_f.cpu(), ref, 4e-2)
+
+
+@pytest.mark.parametrize("B,N", [(3, 512), (2, 100), (1, 4096)])
+def test_mlp_query_fused_vs_torch(lib, B, N):
+    """cp_mlp_query_fused (MLP_QueryNet, pipeline.py:168-180, as one launch) == the three nn.Linear layers in torch with the bf16
+    roundings the kernel makes (input rows, layer-1 activations) and fp32 from there on; a channel-sliced input, rows that do not
+    fill the last 64-row tile, logits written into their two rows of a (B, 13, N) block and nothing else touched."""
+    net = build_net(seed=0)
+    sd = net.state_dict()
+    pfx = "refine_net.1.query_block.mlps."
+    w = [sd[pfx + "%d.weight" % j].float() for j in (0, 2, 4)]
+    b = [sd[pfx + "%d.bias" % j].float() for j in (0, 2, 4)]
+    x = rnd(det_tensor("mlpq%d_%d" % (B, N), (B, N, 256)), CP_BF16)
+    h1 = rnd(F.leaky_relu(x @ rnd(w[0], CP_BF16).t() + b[0], 0.01), CP_BF16)
+    h2 = F.leaky_relu(h1 @ rnd(w[1], CP_BF16).t() + b[1], 0.01)
+    ref = h2 @ w[2].t() + b[2]                                          # (B, N, 2)
+    wide = torch.zeros(B, N, 320, dtype=torch.bfloat16, device=dev())
+    wide[..., 64:] = x.to(torch.bfloat16).to(dev())
+    pk = []
+    for wi, (co, ci) in zip(w[:2], ((256, 256), (64, 256))):
+        buf = torch.empty(lib.cp_packed_gemm_weight_bytes(CP_BF16, co, ci), dtype=torch.uint8, device=dev())
+        wd = wi.contiguous().to(dev())
+        _abi.check(lib.cp_pack_gemm_weight(st(), CP_BF16, wd.data_ptr(), co, ci, ci, buf.data_ptr()))
+        pk.append(buf)
+    ones = [torch.ones(256, device=dev()), torch.ones(64, device=dev())]
+    bd = [t.contiguous().to(dev()) for t in b]
+    w3 = w[2].contiguous().to(dev())
+    bits = torch.full((B, 13, N), 7.0, device=dev())
+    _abi.check(lib.cp_mlp_query_fused(st(), wide.data_ptr(), 320, 64, B, N, pk[0].data_ptr(), ones[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                      pk[1].data_ptr(), ones[1].data_ptr(), bd[1].data_ptr(), 0.01, w3.data_ptr(), bd[2].data_ptr(),
+                                      bits.data_ptr(), 5 * N, 13 * N, 1, 6 * N))
+    torch.cuda.synchronize()
+    got = bits.cpu()
+    keep = [r for r in range(13) if r not in (5, 11)]
+    assert float((got[:, keep] - 7.0).abs().max()) == 0.0               # only rows 5 and 11 of the logit block are written
+    close(torch.stack([got[:, 5], got[:, 11]], -1), ref, 2e-3)          # fp32 accumulation order only (inputs rounded identically)
 
 
 def test_edgeconv_per_sample_graphs_lm(lib):
@@ -1212,6 +1249,7 @@ def test_e2e_bf16_accuracy_contract(lib, monkeypatch, chain):
     monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1 if chain else 1 << 30)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1 if chain else 1 << 30)
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if chain else 1 << 30)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1 if chain else 1 << 30)
     net = build_net(seed=1)
     img = det_image(4, seed=3)
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
@@ -1241,6 +1279,7 @@ def test_e2e_bf16_accuracy_contract_n4096_lm(lib, monkeypatch, tiled):
     from checkerpose_amd.agreement import logit_agreement, margin_contract_violations
     from tests.common import LM_OBJ_IDS
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if tiled else 1 << 30)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1 if tiled else 1 << 30)
     obj, net, img, ref = _lm4096_case()
     net = net.to(dev()).set_compute_dtype("bf16")
     tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()), obj_ids=obj.to(dev())), ref)
@@ -1357,6 +1396,7 @@ def test_batch_slices_concurrent_graphs_bitwise(lib, monkeypatch):
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)      # slices and the unsplit batch must pick the same kernels
     monkeypatch.setattr(engine, "USE_SPLITK", False)       # (the split-K conv variant is chosen by output pixels = batch size)
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1)
     img = det_image(16, seed=3).to(dev())
     net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
     net.batch_splits = 2
@@ -1379,6 +1419,7 @@ def test_dataflow_graph_capture_bitwise(lib, monkeypatch):
     monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1)
     img = det_image(16, seed=3).to(dev())
     net = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
     net.use_dag = True
@@ -1401,6 +1442,7 @@ def test_edge_neighbour_schedule_bitwise(lib, monkeypatch):
     scheduled lists == forward with the kNN order, bit for bit (the max over a keypoint's neighbours ignores their order)."""
     from checkerpose_amd import engine
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1)
     img = det_image(4, seed=3).to(dev())
     a = build_net(seed=1).to(dev()).set_compute_dtype("bf16")
     o1 = [t.clone() for t in a(img, None)]
@@ -1502,6 +1544,7 @@ def test_full_batch_size_property_batch_independence(lib, dt, monkeypatch):
     test_e2e_* pins to the oracle (fp32) and test_e2e_bf16_accuracy_contract bounds (bf16)."""
     from checkerpose_amd import engine
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1)
+    monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1)
     monkeypatch.setattr(engine, "STEM_MIN_BATCH", 1)
     monkeypatch.setattr(engine, "USE_SPLITK", False)     # ... and no batch-size-dependent split-K conv variant
     monkeypatch.setattr(engine, "CHAIN_MIN_BATCH", 1)    # same kernel selection at B=4 and B=256 (below 16 crops the engine
