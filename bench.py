@@ -46,7 +46,7 @@ LM13_DEFAULT_BATCH = 256      # config #5 (`--workload lm13_n4096`): crops per G
 MFMA_KERNELS = {"conv_igemm": "conv_igemm_kernel", "conv3x3_halo": "conv3x3_halo_kernel", "conv3x3_halo4": "conv3x3_halo4_kernel",
                 "conv3x3_halo_s": "conv3x3_halo_s_kernel", "conv3x3_s2_small": "conv3x3_s2_small_kernel", "gemm_rows": "gemm_rows_kernel|gemm_rows_ws_kernel",
                 "basicblock_fused": "basicblock_fused_kernel|basicblock_persist_kernel", "bottleneck_fused": "bottleneck_fused_kernel",
-                "hr_chain": "hr_chain_kernel|hr_chain0_kernel", "hr_fuse_out": "hr_fuse_out_kernel", "edge_fused": "edgeconv_fused_kernel", "edge_tiled": "edgeconv_ptable_kernel + edgeconv_tiled_kernel", "hr_stem": "hr_stem_kernel", "patch_gather": "patch_gather_kernel", "mlp_fused": "mlp_query_fused_kernel"}
+                "hr_chain": "hr_chain_kernel|hr_chain0_kernel", "hr_fuse_out": "hr_fuse_out_kernel", "edge_fused": "edgeconv_fused_kernel", "edge_tiled": "edgeconv_ptable_kernel + edgeconv_tiled_kernel", "hr_stem": "hr_stem_kernel", "patch_gather": "patch_gather_kernel", "mlp_fused": "mlp_query_fused_kernel|mlp_pair_fused_kernel"}
 
 
 ORACLE_KW = dict(backbone="hrnet_w18", res_log2=6, init_n_graph=2, n_graph=3, local_k=2, slope=0.01, graph_slope=0.2,

@@ -114,6 +114,8 @@ SIGNATURES = {
     "cp_gemm_rows": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
     "cp_mlp_query_fused_supported": (_I, [_I, _I, _I, _I]),
     "cp_mlp_query_fused": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P, _P, _L, _L, _L, _L]),
+    "cp_mlp_pair_fused_supported": (_I, [_I, _I, _I]),
+    "cp_mlp_pair_fused": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
     "cp_hr_stem_weight_bytes": (C.c_size_t, [_I]),
     "cp_pack_hr_stem_weights": (_I, [_P, _P, _P, _P, _P]),
     "cp_hr_stem": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -206,3 +206,212 @@ extern "C" int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cst
   CP_LAUNCH(mlp_query_fused_kernel, dim3((unsigned)grid), dim3(512), MQ_LDS, (hipStream_t)stream, p);
   return cp_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// pre_graph_module (reference pipeline.py:237-240, :283-286: Linear(256 + g -> 256) + LeakyReLU, Linear(256 -> 256) + LeakyReLU over
+// the concatenated [local feature | previous graph feature] rows) as ONE launch: the 256-channel hidden rows never leave the chip.
+// A persistent 12-wave workgroup per CU walks tiles of 32 rows as a two-stage pipeline:
+//   waves 0-7 (layer 1, K <= 512): wave w keeps W1's 32-channel group w in registers (16 K chunks x 2 tiles = 128 VGPRs); the
+//     tile's rows arrive by LDS-DMA (no staging registers: the budget is 168 VGPRs at three waves per SIMD), two tiles ahead, into a
+//     ring of three row-major images whose 16-byte pieces are XOR-swizzled with the row number inside each 256-byte block -- a
+//     fragment read (16 consecutive rows, one piece each) then covers all 64 banks, and a DMA instruction still moves whole
+//     256-byte blocks of a row; LeakyReLU, bf16, into the hidden tile (same swizzle, double-buffered);
+//   waves 8-11 (layer 2): wave v keeps W2's channels 64 v .. 64 v + 63 in registers (8 chunks x 4 tiles) and works on the PREVIOUS
+//     tile's hidden rows; LeakyReLU, bf16, 16-byte stores (a row's 64 channels of a wave = 128 contiguous bytes).
+// One barrier per tile; the layer-1 waves wait with a COUNTED vmcnt (their only vector-memory operations inside the loop are the
+// DMA pieces, the same number every iteration), so the tile that streams in two iterations ahead is not waited for.
+constexpr int MP_ROWS = 32;
+constexpr int MP_HP = 32;                                    // pieces per hidden row (256 channels)
+constexpr int MP_HBUF = MP_ROWS * MP_HP * 16;                // 16 384 B
+
+struct MlpPairParams {
+  const void* in; const void* w1; const float* t1;
+  const void* w2; const float* t2;
+  void* out;
+  int M, in_cs, in_coff, nchunk1, n_rt, out_cs, out_coff;
+  float slope1, slope2;
+};
+
+// slot (in 16-byte pieces) of piece `pc` of tile row `r` in an image of P pieces per row
+__device__ __forceinline__ int mp_slot(int r, int pc, int P) { return r * P + (pc & ~15) + ((pc ^ r) & 15); }
+
+template <int NI>                                            // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
+__global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int P = 16 * NI;                                  // pieces per row image: 64 (K <= 512) / 48 (K <= 384) / 32 (K <= 256)
+  constexpr int XBUF = MP_ROWS * P * 16;
+  unsigned char* const sX = smem;                             // 3 x XBUF
+  unsigned char* const sH = smem + 3 * XBUF;                  // 2 x MP_HBUF
+  float* const sAff = (float*)(sH + 2 * MP_HBUF);             // bias 1 | bias 2, 256 floats each
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int qx = q ^ x;
+  const bool l1 = wave < 8;
+
+  u32x4 W[32];                                                // layer 1: [kc 0..15][t 0..1]; layer 2: [kc 0..7][t 0..3]
+  if (l1) {
+#pragma unroll
+    for (int kc = 0; kc < 16; ++kc)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {                             // chunks past the layer's K: zero weights (no branches: the loop below runs 4 NI chunks)
+        const bool live = kc < p.nchunk1;
+        const u32x4 w_ = ((const u32x4*)p.w1)[((size_t)(wave * p.nchunk1 + (live ? kc : 0)) * 2 + t) * 64 + lane];
+        W[kc * 2 + t] = live ? w_ : u32x4{0u, 0u, 0u, 0u};
+      }
+  } else {
+    const int g0 = 2 * (wave - 8);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) W[kc * 4 + t] = ((const u32x4*)p.w2)[((size_t)((g0 + (t >> 1)) * 8 + kc) * 2 + (t & 1)) * 64 + lane];
+  }
+  for (int i = tid; i < 256; i += 768) { sAff[i] = p.t1[i]; sAff[256 + i] = p.t2[i]; }
+
+  // DMA piece j (0 .. NI - 1) of layer-1 wave w: LDS slots (w * NI + j) * 64 + lane of the image, i.e. row = slot / P, stored piece
+  // index s = slot % P holds the row's piece (s & ~15) + ((s ^ row) & 15) (the swizzle is an involution); pieces past the row's
+  // real width re-read its piece 0 (their weights are zero)
+  const int step = gridDim.x;
+  const int npiece = p.nchunk1 * 4;
+  auto dma_tile = [&](int rt, int buf) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int slot = (wave * NI + j) * 64 + lane;
+      const int r = slot / P, s_ = slot - r * P;
+      int pc = (s_ & ~15) + ((s_ ^ r) & 15);
+      if (pc >= npiece) pc = 0;
+      long long m = (long long)rt * MP_ROWS + r;
+      if (m >= p.M) m = p.M - 1;                              // rows past the end: a valid row, never stored
+      const unsigned char* src = (const unsigned char*)p.in + ((size_t)m * p.in_cs + p.in_coff) * 2 + (size_t)pc * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sX + buf * XBUF + (wave * NI + j) * 1024), 16, 0, 0);
+    }
+  };
+  __syncthreads();                                            // weights in registers (vmcnt 0), affine table written
+  if (l1) {
+    dma_tile(blockIdx.x, 0);
+    if (blockIdx.x + step < p.n_rt) dma_tile(blockIdx.x + step, 1); else dma_tile(blockIdx.x, 1);
+    __builtin_amdgcn_s_waitcnt(0x0070 | NI);                  // vmcnt(NI): tile 0 has landed
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+
+  // iteration it: layer 1 on tile rt (sX[it % 3] -> sH[it & 1]) while tile rt + 2 step streams into sX[(it + 2) % 3]; layer 2 on
+  // tile rt - step (sH[(it - 1) & 1])
+  int it = 0, xb = 0;
+  for (int rt = blockIdx.x; rt - step < p.n_rt; rt += step, ++it) {
+    if (l1) {
+      const int nb = xb >= 1 ? xb - 1 : 2;                    // (it + 2) % 3
+      dma_tile(rt + 2 * step < p.n_rt ? rt + 2 * step : blockIdx.x, nb);       // always NI pieces: the vmcnt arithmetic below counts them
+      if (rt < p.n_rt) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // piece 4 kc + q of row 16 f + x sits at slot (kc >> 2) * 16 + ((4 (kc & 3)) ^ q ^ x) of its row (mp_slot): a lane constant
+        // XOR one of four compile-time values
+        const unsigned char* const xbp = sX + xb * XBUF + x * (P * 16);
+#pragma unroll
+        for (int kc = 0; kc < 16; ++kc) {
+          if (kc < NI * 4) {                                  // compile-time
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+              const u32x4 a = *(const u32x4*)(xbp + f * (16 * P * 16) + (kc >> 2) * 256 + (((4 * (kc & 3)) ^ qx) << 4));
+              acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2]), __builtin_bit_cast(bf16x8, a), acc[f][0], 0, 0, 0);
+              acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2 + 1]), __builtin_bit_cast(bf16x8, a), acc[f][1], 0, 0, 0);
+            }
+          }
+        }
+        // lane (x, q): rows 16 f + x, hidden channels 32 wave + 8 q + {0..7} = piece 4 wave + q
+        const int ch = wave * 32 + q * 8;
+        const f32x4 t0 = *(const f32x4*)(sAff + ch), t1 = *(const f32x4*)(sAff + ch + 4);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = leaky(acc[f][0][j] + t0[j], p.slope1);
+            v[4 + j] = leaky(acc[f][1][j] + t1[j], p.slope1);
+          }
+          *(u32x4*)(sH + (it & 1) * MP_HBUF + (f * 16 + x) * (MP_HP * 16) + (wave >> 2) * 256 + (((4 * (wave & 3)) ^ qx) << 4)) = Vec16<BF16Tag>::pack(v);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0070 | NI);                // vmcnt(NI), lgkmcnt(0): the tile of the NEXT iteration has landed
+    } else {
+      if (it > 0) {
+        const int wv = wave - 8;
+        const unsigned char* const hb = sH + ((it - 1) & 1) * MP_HBUF + x * (MP_HP * 16);
+        const int ch = wv * 64 + q * 8;
+#pragma unroll 1
+        for (int f = 0; f < 2; ++f) {
+          f32x4 acc[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kc = 0; kc < 8; ++kc) {
+            const u32x4 a = *(const u32x4*)(hb + f * (16 * MP_HP * 16) + (kc >> 2) * 256 + (((4 * (kc & 3)) ^ qx) << 4));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 4 + t]), __builtin_bit_cast(bf16x8, a), acc[t], 0, 0, 0);
+          }
+          const long long m = (long long)(rt - step) * MP_ROWS + f * 16 + x;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = ch + 32 * h;
+            const f32x4 t0 = *(const f32x4*)(sAff + 256 + c), t1 = *(const f32x4*)(sAff + 256 + c + 4);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = leaky(acc[2 * h][j] + t0[j], p.slope2);
+              v[4 + j] = leaky(acc[2 * h + 1][j] + t1[j], p.slope2);
+            }
+            if (m < p.M) *(u32x4*)((uint16_t*)p.out + (size_t)m * p.out_cs + p.out_coff + c) = Vec16<BF16Tag>::pack(v);
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0) only: this wave's stores stay in flight
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    xb = xb == 2 ? 0 : xb + 1;
+  }
+}
+
+static size_t mlp_pair_lds(int P) { return (size_t)3 * MP_ROWS * P * 16 + 2 * MP_HBUF + 2 * 256 * 4; }
+
+extern "C" int cp_mlp_pair_fused_supported(int Cin, int C1, int C2) {
+  return (Cin >= 64 && Cin <= 512 && Cin % 32 == 0 && C1 == 256 && C2 == 256) ? 1 : 0;
+}
+
+extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
+                                 const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
+                                 float slope2, void* out, int out_cstride, int out_coff) {
+  if (!in || !packed_w1 || !bias1 || !packed_w2 || !bias2 || !out || B <= 0 || N <= 0) return CP_ERR_INVALID;
+  if (!cp_mlp_pair_fused_supported(Cin, 256, 256)) return CP_ERR_INVALID;
+  if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + 256 > out_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(in) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(out)) return CP_ERR_ALIGN;
+  const long long M = (long long)B * N;
+  if (M >= (1LL << 31) / MP_ROWS * MP_ROWS) return CP_ERR_RANGE;
+  const int nchunk = Cin / 32;
+  const int P = (nchunk * 4 + 15) / 16 * 16;                  // 32 / 48 / 64 pieces per row image
+  const size_t lds = mlp_pair_lds(P);
+  static CpDeviceOnce once;
+  const int dev = cp_current_device();
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)mlp_pair_fused_kernel<2>, mlp_pair_lds(32)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<3>, mlp_pair_lds(48)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4>, mlp_pair_lds(64)));
+  const int n_cu = cp_num_cus();
+  if (n_cu <= 0) return CP_ERR_HIP;
+  MlpPairParams p;
+  p.in = in; p.w1 = packed_w1; p.t1 = bias1; p.w2 = packed_w2; p.t2 = bias2; p.out = out;
+  p.M = (int)M; p.in_cs = in_cstride; p.in_coff = in_coff; p.nchunk1 = nchunk; p.n_rt = (int)((M + MP_ROWS - 1) / MP_ROWS);
+  p.out_cs = out_cstride; p.out_coff = out_coff; p.slope1 = slope1; p.slope2 = slope2;
+  const int grid = p.n_rt < n_cu ? p.n_rt : n_cu;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 32) CP_LAUNCH((mlp_pair_fused_kernel<2>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  else if (P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  else CP_LAUNCH((mlp_pair_fused_kernel<4>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  return cp_check_launch();
+}

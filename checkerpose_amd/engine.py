@@ -865,6 +865,33 @@ class Program:
         self.flops += fl
         self.conv_log.append((keys[0], M, 256 + 64 + 2, 256, fl, "mlp_fused", M * (256 * self.es + 8) + (256 * 256 + 64 * 256) * self.es))
 
+    def can_fuse_mlp_pair(self, x: Act, w1, w2):
+        return (USE_MLP_FUSED and self.dtype == CP_BF16 and x.H == 1 and self.B * x.W >= self.mlp_min_rows and x.C == w1.shape[1]
+                and x.C == x.Cphys and bool(self.lib.cp_mlp_pair_fused_supported(int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])))
+                and w2.shape[1] == w1.shape[0])
+
+    def mlp_pair_fused(self, x: Act, keys, ws, bs, slope, out: Act = None):
+        """pre_graph_module (two nn.Linear + LeakyReLU) in one launch: the 256-channel hidden rows stay on chip"""
+        N, Cin = x.W, x.C
+        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(256, Cin, 1, 1), 256, Cin, Cin)
+        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(256, 256, 1, 1), 256, 256, 256)
+        ck = ("mlp_pair", keys[0])
+        if ck not in self.ws.cache:
+            self.ws.cache[ck] = (bs[0].float().contiguous(), bs[1].float().contiguous())
+        b1, b2 = self.ws.cache[ck]
+        self.keep += [pw1, pw2, b1, b2]
+        if out is None:
+            out = self.act(1, N, 256)
+        xt, ot = x.tbuf, out.tbuf
+        a1 = (pw1.data_ptr(), b1.data_ptr(), float(slope), pw2.data_ptr(), b2.data_ptr(), float(slope))
+        self._add(self.lib.cp_mlp_pair_fused, lambda P: (P(xt), x.cstride, x.coff, Cin, self.B, N) + a1 + (P(ot), out.cstride, out.coff),
+                  "mlp_fused:" + keys[0], [xt], [ot])
+        M = self.B * N
+        fl = 2 * M * (Cin * 256 + 256 * 256)
+        self.flops += fl
+        self.conv_log.append((keys[0], M, 512, Cin, fl, "mlp_fused", M * (Cin + 256) * self.es + (Cin * 256 + 256 * 256) * self.es))
+        return out
+
     def permute_rows(self, x: Act, out: Act, perm_t, gids_t):
         """out[b, i, :] = x[b, perm[g_b, i], :] over whole (B, N, cstride) rows (cp_permute_rows)"""
         assert x.coff == 0 and out.coff == 0 and x.cstride == out.cstride and (x.cstride * self.es) % 16 == 0

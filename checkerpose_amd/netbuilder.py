@@ -797,8 +797,13 @@ def emit_posenet(em: NetEmitter, cfg, io):
                 ids_i[nm] = torch.empty_like(io[nm])
                 tp.memcpy(ids_i[nm].data_ptr(), io[nm].data_ptr(), io[nm].numel() * 4, "save_ids")
             _patch_tape(em, pgk, wpg, f, patches, L.slice(0, 4 * Ech), ids_i, N, Ech, k)
-        h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)
-        h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope)
+        pkeys = [rp + ".pre_graph_module.0", rp + ".pre_graph_module.2"]
+        pws = [em.W(k_ + ".weight") for k_ in pkeys]
+        if tp is None and p.can_fuse_mlp_pair(L, pws[0], pws[1]):
+            h = p.mlp_pair_fused(L, pkeys, pws, [em.W(k_ + ".bias") for k_ in pkeys], slope)     # csrc/mlp_fused.hip
+        else:
+            h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)
+            h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope)
         Lnext = local_buf(i + 1) if i + 1 < active else None
         for gi in range(ngs[i]):
             last = gi == ngs[i] - 1

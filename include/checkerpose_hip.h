@@ -207,6 +207,15 @@ int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cstride, int i
                        const void* packed_w2, const float* scale2, const float* shift2, float slope2,
                        const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn, long long o_sc);
 
+/* Refine_moduleGNN.pre_graph_module (pipeline.py:237-240, applied at :283-286: Linear(Cin -> 256) + LeakyReLU, Linear(256 -> 256) +
+ * LeakyReLU over the concatenated [local | previous graph] feature rows) as ONE launch, bf16: the hidden rows stay in LDS.
+ * in (B, N, in_cstride) channels [in_coff, in_coff + Cin), Cin a multiple of 32, <= 512; packed_w1 / packed_w2: cp_pack_gemm_weight
+ * images of the (256, Cin) and (256, 256) weights; bias fp32 (256) each; out (B, N, out_cstride) channels [out_coff, out_coff + 256). */
+int cp_mlp_pair_fused_supported(int Cin, int C1, int C2);
+int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
+                      const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2, float slope2,
+                      void* out, int out_cstride, int out_coff);
+
 /* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
  * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
 int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,

@@ -938,6 +938,38 @@ def test_mlp_query_fused_vs_torch(lib, B, N):
     close(torch.stack([got[:, 5], got[:, 11]], -1), ref, 2e-3)          # fp32 accumulation order only (inputs rounded identically)
 
 
+@pytest.mark.parametrize("B,N,stage", [(3, 512, 1), (2, 100, 0), (1, 4096, 2), (5, 33, 0)])
+def test_mlp_pair_fused_vs_torch(lib, B, N, stage):
+    """cp_mlp_pair_fused (Refine_moduleGNN.pre_graph_module, pipeline.py:237-240 / :283-286, as one launch) == the two nn.Linear +
+    LeakyReLU in torch with the kernel's bf16 roundings (input rows, hidden rows, output); Cin = 320 (stage 0: 256 + 64) and 512,
+    a channel-sliced output, row counts that do not fill the last 32-row tile, fewer tiles than workgroups."""
+    net = build_net(seed=0)
+    sd = net.state_dict()
+    pfx = "refine_net.%d.pre_graph_module." % stage
+    w = [sd[pfx + "%d.weight" % j].float() for j in (0, 2)]
+    b = [sd[pfx + "%d.bias" % j].float() for j in (0, 2)]
+    Cin = w[0].shape[1]
+    assert Cin == (320 if stage == 0 else 512)
+    x = rnd(det_tensor("mlpp%d_%d" % (B, N), (B, N, Cin)), CP_BF16)
+    h1 = rnd(F.leaky_relu(x @ rnd(w[0], CP_BF16).t() + b[0], 0.01), CP_BF16)
+    ref = F.leaky_relu(h1 @ rnd(w[1], CP_BF16).t() + b[1], 0.01)          # (B, N, 256)
+    xin = x.to(torch.bfloat16).to(dev())
+    pk = []
+    for wi, ci in zip(w, (Cin, 256)):
+        buf = torch.empty(lib.cp_packed_gemm_weight_bytes(CP_BF16, 256, ci), dtype=torch.uint8, device=dev())
+        wd = wi.contiguous().to(dev())
+        _abi.check(lib.cp_pack_gemm_weight(st(), CP_BF16, wd.data_ptr(), 256, ci, ci, buf.data_ptr()))
+        pk.append(buf)
+    bd = [t.contiguous().to(dev()) for t in b]
+    wide = torch.full((B, N, 320), 7.0, dtype=torch.bfloat16, device=dev())
+    _abi.check(lib.cp_mlp_pair_fused(st(), xin.data_ptr(), Cin, 0, Cin, B, N, pk[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                     pk[1].data_ptr(), bd[1].data_ptr(), 0.01, wide.data_ptr(), 320, 64))
+    torch.cuda.synchronize()
+    got = wide.float().cpu()
+    assert float((got[..., :64] - 7.0).abs().max()) == 0.0               # channels outside the slice untouched
+    close(got[..., 64:], ref, 2e-2)                                      # bf16 output rounding + one-ulp hidden flips
+
+
 def test_edgeconv_per_sample_graphs_lm(lib):
     """LM twin: each sample gathers along its own object's graph (pipeline_lm.py:55-57), 1-based obj_ids."""
     B, N, K, Cc = 4, 512, 20, 64
