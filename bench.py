@@ -587,7 +587,8 @@ def roofline_report(out, net, B, dtype, workload, npoint, steps, dump=None):
         lds = f_ != "edge_gather"
         peak = LDS_PEAK if lds else 34500.0
         sym_ = {"edge_fused": "edgeconv_fused_kernel", "edge_tiled": "edgeconv_tiled_kernel", "edge_gather": "edgeconv_gather_max_kernel"}[f_]
-        r_ = {"bound": "lds" if lds else "l2", "kernel": "%s (%d launches per step)" % (sym_, len(cs)),
+        shown = "edgeconv_ptable_kernel + edgeconv_tiled2_kernel (key table + LDS-staged gather launch)" if f_ == "edge_tiled" else sym_
+        r_ = {"bound": "lds" if lds else "l2", "kernel": "%s (%d launches per step)" % (shown, len(cs)),
               "achieved": round(by / t_ / 1e9, 1), "peak": round(peak, 0), "unit": "GB/s", "frac": round(by / t_ / 1e9 / peak, 4),
               "algorithmic_mb_per_step": round(by / 1e6, 1), "ms_per_step": round(t_ * 1e3, 3),
               "compulsory_hbm_mb_per_step": round(hbm_by / 1e6, 1), "compulsory_hbm_gbs": round(hbm_by / t_ / 1e9, 1),
