@@ -597,7 +597,8 @@ def roofline_report(out, net, B, dtype, workload, npoint, steps, dump=None):
                        + ("the launch also runs the layer's node GEMM on the MFMA pipe, so this is a lower bound of the gather "
                           "rate; the neighbour rows are read from the LDS table (ds_read_b128: %.0f TB/s aggregate)" % (LDS_PEAK / 1e3)
                           if lds else "the neighbour rows are served by the XCD L2 (~34.5 TB/s aggregate), not HBM"))}
-        tr, src = _profile_prefix_mb_per_step(sym_, profile_tag(workload, dtype, B))      # template instances: by prefix
+        # template instances: by prefix (the tiled family = key-table launch + gather launch: edgeconv_ptable_kernel, edgeconv_tiled2_kernel)
+        tr, src = _profile_prefix_mb_per_step("edgeconv_" if f_ == "edge_tiled" else sym_, profile_tag(workload, dtype, B))
         if tr is not None:
             r_["traffic"] = tr
             r_["traffic_unit"] = "MB of HBM read+write per step, all launches of this kernel (PMC)"
