@@ -137,9 +137,9 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 }
 
 // ------------------------------------------------------------------------------------------------ launch 2: gather + Q'
-// weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt of slice s = 2 j + h
-// = output channel 64 j + (r >> 2) * 16 + 8 h + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels
-// 64 j + 16 q + 8 h + 4 nt + reg
+// weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt of slice s
+// = output channel 32 s + (r >> 2) * 8 + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels
+// 32 s + 8 q + 4 nt + reg
 template <int CIN, bool DB>
 __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledParams p) {
   constexpr int KC = CIN / 32;
@@ -166,10 +166,11 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
   const int32_t* const halo = p.halo + ((size_t)g * p.NB + t) * p.HPAD;
   const unsigned char* const tab = (const unsigned char*)p.ptab + (size_t)b * (p.Cout / 8) * p.N * 16;
 
-  // slice s = 2 j + h holds channels 64 j + 16 q + 8 h + (0..7) for lane group q (not 32 consecutive ones): after an even / odd
-  // slice pair a lane owns 16 CONSECUTIVE channels of its keypoint and stores 32 bytes -- the four q lanes a full 128-byte line
-  // (16-byte stores per slice wrote every line in two halves, slices apart: 92 MB of HBM writes for a 67 MB output).
-  // table of slice s: plane pl <- global plane 8 j + 2 pl + h; 64-row chunks: own rows are one contiguous 1 KB segment, halo rows
+  // slice s holds channels 32 s + 8 q + (0..7) for lane group q: the four q lanes of a keypoint store 64 CONTIGUOUS bytes per slice
+  // (two whole 32-byte sectors).  (Round 3 interleaved the slices -- 64 j + 16 q + 8 h -- and held the even slice's 16 bytes in
+  // registers until the odd slice completed 32 bytes per lane; the interleaved form without the hold wrote half SECTORS: 1 016 MB of
+  // HBM writes per launch for a 537 MB output at B = 256.)
+  // table of slice s: plane pl <- global plane 4 s + pl; 64-row chunks: own rows are one contiguous 1 KB segment, halo rows
   // 16-byte pieces at per-lane rows.  (4 planes x (8 + HPAD / 64) chunks, dealt round-robin to the 8 waves.)
   const int nchunk = 8 + p.HPAD / 64;
   auto table_issue = [&](int s) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       const int slot = ch * 64 + lane;
       // (halo rows come from the LDS copy: a global load per piece in front of its DMA put ~1 us of latency on every halo piece)
       const int row = ch < 8 ? t * ET_BLK + slot : sHalo[slot - ET_BLK];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N + row) * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + ((size_t)(4 * s + pl) * p.N + row) * 16),
                                        (__attribute__((address_space(3))) void*)(dstb + pl * PLANE + ch * 1024), 16, 0, 0);
     }
   };
@@ -223,7 +224,6 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
     for (int kc = 0; kc < KC; ++kc)
       xa[f][kc] = *(const u32x4*)((const uint16_t*)p.x + (row0 + f * 16 + x) * p.in_cs + p.in_coff + kc * 32 + q * 8);
 
-  u32x4 held[4];
   for (int s = 0; s < nslice; ++s) {
     // DB: the NEXT slice's table streams into the other buffer (its readers, gather(s - 1), passed the last barrier) under this
     // whole slice; the single weight buffer was refilled behind the last barrier and is awaited at the mid-slice barrier.
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
                                                                acc[f][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int c0 = (s >> 1) * 64 + q * 16 + (s & 1) * 8;
+    const int c0 = s * 32 + q * 8;                                   // slice s = channels 32 s .. 32 s + 31, lane group q its 8 q .. 8 q + 7
     const f32x4 s0 = *(const f32x4*)(sScale + c0), s1 = *(const f32x4*)(sScale + c0 + 4);
     const f32x4 t0 = *(const f32x4*)(sShift + c0), t1 = *(const f32x4*)(sShift + c0 + 4);
 #pragma unroll
@@ -344,13 +344,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
         v[2 * j] = fmaxf(y0, y0 * p.slope);                            // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
         v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
       }
-      const u32x4 pk = Vec16<BF16Tag>::pack(v);
-      if ((s & 1) == 0) held[f] = pk;                                // even slice: channels c0 .. c0 + 7 wait for their upper neighbours
-      else {
-        uint16_t* dst = (uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0 - 8;
-        *(u32x4*)dst = held[f];
-        *(u32x4*)(dst + 8) = pk;
-      }
+      *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = Vec16<BF16Tag>::pack(v);
     }
     __syncthreads();                                                // DB: table(s + 1) landed, weights(s) / table(s) free.  !DB: both landed
     if (DB && s + 1 < nslice) w_issue(s + 1);                       // awaited at the next mid-slice barrier, a whole gather away
@@ -441,7 +435,9 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
     const int c = wave + 8 * i;
     if (c < 4 * nchunk) {
       const int pl = c / nchunk, ch = c - pl * nchunk;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + (size_t)(8 * (s >> 1) + 2 * pl + (s & 1)) * p.N * 16 + srcoff[i]),
+      uint32_t so = srcoff[i];
+      asm volatile("" : "+v"(so));                                   // (keeps `tab + srcoff[i]` from being hoisted out of the slice loop as a 64-bit pair per piece)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tab + (size_t)(4 * s + pl) * p.N * 16 + so),
                                        (__attribute__((address_space(3))) void*)(sP + (s & 1) * 4 * PLANE + pl * PLANE + ch * 1024), 16, 0, 0);
     }
   };
@@ -478,7 +474,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
     const unsigned char* const pq = sP + (s & 1) * 4 * PLANE + q * PLANE;
     const unsigned char* const wlo = sW + ((2 * s) % 3) * WH + lane * 16;           // chunks [0, KH)
     const unsigned char* const whi = sW + ((2 * s + 1) % 3) * WH + lane * 16;       // chunks [KH, KC)
-    const int c0 = (s >> 1) * 64 + q * 16 + (s & 1) * 8;
+    const int c0 = s * 32 + q * 8;                                   // slice s = channels 32 s .. 32 s + 31, lane group q its 8 q .. 8 q + 7
     auto rd4 = [&](const u32x2& i4, u32x4* r) {                      // the 4 neighbour rows of one list quad
       r[0] = *(const u32x4*)(pq + (i4.x & 0xffffu)); r[1] = *(const u32x4*)(pq + (i4.x >> 16));
       r[2] = *(const u32x4*)(pq + (i4.y & 0xffffu)); r[3] = *(const u32x4*)(pq + (i4.y >> 16));
@@ -538,8 +534,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
         }
       }
       if (fp == 0) ET_MARK(3); else ET_MARK(7);                       // pass 0 steps / rest of pass 1
-      // ---- epilogue of this fragment pair: 16 bytes per lane and slice (the 32-byte form held the even slice's result in 16
-      // registers per lane, which this kernel does not have; the odd slice's store completes the 128-byte line in L2)
+      // ---- epilogue of this fragment pair: 16 bytes per lane and slice, 64 contiguous bytes per keypoint (whole sectors)
       const f32x4 s0 = *(const f32x4*)(sScale + c0), s1 = *(const f32x4*)(sScale + c0 + 4);
       const f32x4 t0 = *(const f32x4*)(sShift + c0), t1 = *(const f32x4*)(sShift + c0 + 4);
 #pragma unroll
@@ -579,7 +574,7 @@ __global__ void pack_edgeconv_tiled_q_kernel(const float* __restrict__ wpq, uint
   const int kc = (int)(blk % KC);
   const int s = (int)(blk / KC);
   const int r = lane & 15, q = lane >> 4;
-  const int c = (s >> 1) * 64 + (r >> 2) * 16 + (s & 1) * 8 + nt * 4 + (r & 3);
+  const int c = s * 32 + (r >> 2) * 8 + nt * 4 + (r & 3);
   const int cin = kc * 32 + q * 8 + e;
   out[i] = (uint16_t)f32_to_bf16_bits(wpq[((size_t)(Cout + c)) * Cin + cin]);
 }
