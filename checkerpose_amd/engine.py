@@ -25,7 +25,9 @@ USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet 
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
 USE_MLP_FUSED = os.environ.get("CHECKERPOSE_AMD_MLP_FUSED", "1") != "0"   # MLP_QueryNet's three Linears as one launch (bf16)
-MLP_FUSED_MIN_ROWS = int(os.environ.get("CHECKERPOSE_AMD_MLP_FUSED_MIN_ROWS", "32768"))   # one persistent workgroup per CU walks 64-row tiles
+# (no lower bound: measured with the fused launches at every batch size against a 32 768-row threshold, ms per forward: B = 1 1.60 vs 1.77,
+#  B = 8 1.84 vs 1.94, B = 32 3.11 vs 3.17 -- below 64 crops a forward is bound by its ~350 dependent graph nodes, and the stacks are 9 fewer)
+MLP_FUSED_MIN_ROWS = int(os.environ.get("CHECKERPOSE_AMD_MLP_FUSED_MIN_ROWS", "1"))
 EDGE_SCHED = os.environ.get("CHECKERPOSE_AMD_EDGE_SCHED", "1") != "0"   # A/B: bank-conflict-aware neighbour order for edge_fused
 USE_CONV_GROUP = os.environ.get("CHECKERPOSE_AMD_CONV_GROUP", "0") == "1"    # training: independent small 3x3 convs in one launch (measured: no gain)
 CONV_GROUP_MAX_C = int(os.environ.get("CHECKERPOSE_AMD_CONV_GROUP_MAXC", "48"))
