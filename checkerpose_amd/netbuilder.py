@@ -19,7 +19,19 @@ FUSE_OUT_DEEP = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_DEEP", "1") != "0"   # 
 
 DECODER_SPLITK = os.environ.get("CHECKERPOSE_AMD_DECODER_SPLITK", "1") != "0"   # A/B: decoder convs as split-K convs at batch 1-4
 HEAD_ON_REFINE_LANE = os.environ.get("CHECKERPOSE_AMD_HEAD_LANE", "1") != "0"   # A/B: InitNet head beside up_net[0]
+# opt-in (measured +-0: 11.02 / 11.02 vs 11.09 / 10.73 ms at B = 256, alternating on one box): the 2nd / 3rd convs of the long stride-2
+# fuse chains run in the NEXT module's region, on their target's lane, instead of behind the 64 x 64 branch's lane in front of the join
+FUSE_DEFER = os.environ.get("CHECKERPOSE_AMD_FUSE_DEFER", "0") == "1"
 FUSE_SAME_LANE = os.environ.get("CHECKERPOSE_AMD_FUSE_SAME_LANE", "1") != "0"   # A/B: a fuse chain's later convs on its source's lane (no second region)
+
+
+class _PendingTerm:
+    """A fuse term whose stride-2 chain is only started: `act` = the output of its first conv, `convs` = [(conv key, bn key, relu)]
+    still to run.  The next module resolves it on the lane of the branch that consumes it (NetEmitter._resolve)."""
+    __slots__ = ("act", "convs")
+
+    def __init__(self, act, convs):
+        self.act, self.convs = act, convs
 
 
 class NetEmitter:
@@ -248,6 +260,18 @@ class NetEmitter:
         return self.conv_bn(y, pfx + ".conv3", pfx + ".bn3", 1, 1, 0, relu=True, residual=sc, out=out)
 
     # ---- HRNet-W18 features (timm HighResolutionNetFeatures)
+    def _resolve(self, t):
+        """run what is left of a deferred fuse chain (on the CURRENT lane) -> its Act"""
+        if not isinstance(t, _PendingTerm):
+            return t
+        a = t.act
+        for ck, bk, relu in t.convs:
+            if FUSE_OUT_DEEP and self.p.can_fuse_out(a):
+                a = self.p.hr_fuse_out(a, [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (3, relu)])[0]
+            else:
+                a = self.conv_bn(a, ck, bk, 3, 2, 1, relu=relu)
+        return a
+
     def _materialize(self, x, out=None):
         """a module output that is still the un-summed list of fuse terms -> one activation (cp_fuse_sum_act), optionally
         written into the channel slice `out` of a wider buffer"""
@@ -255,6 +279,7 @@ class NetEmitter:
             assert out is None
             return x
         terms, shifts = x
+        terms = [self._resolve(t) for t in terms]
         if out is None:
             out = self.p.act(terms[0].H << shifts[0], terms[0].W << shifts[0], terms[0].C)
         return self.p.fuse_sum(terms, shifts, out, relu=True)
@@ -277,7 +302,7 @@ class NetEmitter:
         wm, shift = self.ws.cache[ck]
         return self.p.conv(cat, ck, wm, self._unit(wm.shape[0]), shift, 1, 1, 1, 0, wm.shape[0], ACT_RELU, out=out)
 
-    def hr_module(self, pfx, xs, lazy=False):
+    def hr_module(self, pfx, xs, lazy=False, defer=False):
         """One timm HighResolutionModule.  xs[j]: an Act, or (terms, shifts) = the previous module's fuse terms of branch j
         still un-summed.  With lazy=True the outputs are returned in that un-summed form too: a branch that runs as ONE
         chain launch (engine.hr_chain, bf16) sums + ReLUs them while staging its map into LDS, other consumers
@@ -295,6 +320,8 @@ class NetEmitter:
         p.par_begin(nb)
         for j in range(nb):
             p.set_lane(j)
+            if not isinstance(xs[j], Act):       # deferred tails of the previous module's stride-2 fuse chains INTO branch j: on this lane,
+                xs[j] = ([self._resolve(t) for t in xs[j][0]], xs[j][1])     # in front of its chain (branches 0 / 1 have none and start at once)
             if isinstance(xs[j], Act):
                 C_, H, W = xs[j].C, xs[j].H, xs[j].W
             else:
@@ -355,13 +382,13 @@ class NetEmitter:
             p.set_lane(ln)
             q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
             if (i, j) in first:
-                t = first[(i, j)]
-                for k in range(1, i - j):
-                    ck, bk, relu = "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), k != i - j - 1
-                    if FUSE_OUT_DEEP and p.can_fuse_out(t):        # the rest of a long stride-2 chain: same kernel, one conv per launch
-                        t = p.hr_fuse_out(t, [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (3, relu)])[0]
-                    else:
-                        t = self.conv_bn(t, ck, bk, 3, 2, 1, relu=relu)
+                # the rest of a long stride-2 chain (same kernel, one conv per launch): now, on its source's lane -- or, when the
+                # consumer is the next module of the stage, deferred to that module's region and its TARGET's lane: the 64 x 64
+                # branch's lane is the module's critical path (chain + the grouped first-level launch), and its three small tail convs
+                # used to run behind it, in front of the join
+                t = _PendingTerm(first[(i, j)], [("%s.%d.0" % (q, k), "%s.%d.1" % (q, k), k != i - j - 1) for k in range(1, i - j)])
+                if not (self.tp is None and defer and lazy and same_lane and t.convs):
+                    t = self._resolve(t)
             elif j > i:
                 t = self.conv_bn(xs[j], q + ".0", q + ".1", 1, 1, 0, relu=False)
             else:
@@ -417,7 +444,8 @@ class NetEmitter:
                 xs = xs + [self.conv_bn(xs[-1], t + ".0", t + ".1", 3, 2, 1)]
             last_stage = si == len(HR_STAGES) - 1
             for m in range(nmod):           # inside a stage the fuse sums stay un-summed for the next module's chain launches
-                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs, lazy=(m + 1 < nmod) or (last_stage and self.tp is None))
+                xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs, lazy=(m + 1 < nmod) or (last_stage and self.tp is None),
+                                    defer=FUSE_DEFER and m + 1 < nmod)
         feats = []
         self.p.par_begin(len(xs))            # the four incre bottlenecks are independent
         for i, f in enumerate(xs):
