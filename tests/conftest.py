@@ -41,9 +41,13 @@ def pytest_sessionstart(session):
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     log = tempfile.NamedTemporaryFile(prefix="dp_child_", suffix=".log", delete=False)
     env = dict(os.environ, CHECKERPOSE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    proc = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_step_child.py")],
-                            stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    # one child shell, two jobs one after the other (never more than two extra processes on the GPU): the 2-rank training step, then
+    # `python bench.py --gpus 2` launching its OWN two ranks (no torchrun environment: bench.self_launch), a tiny batch
+    env_clean = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = ("%s -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port %d %s; rc=$?; "
+           "%s %s --gpus 2 --batch 8 --steps 3 --warmup 2 --no-extras --no-cpu-baseline --no-breakdown; echo BENCH_SELF_LAUNCH_RC=$?; exit $rc"
+           % (sys.executable, port, os.path.join(ROOT, "tests", "dp_step_child.py"), sys.executable, os.path.join(ROOT, "bench.py")))
+    proc = subprocess.Popen(["bash", "-c", cmd], stdout=log, stderr=subprocess.STDOUT, env=env_clean, cwd=ROOT)
     cfg._dp_child = (proc, log.name)
 
 

@@ -21,3 +21,22 @@ def test_two_rank_dp_training_step_on_one_gpu(request):
     out = open(log).read()
     assert rc == 0, out[-4000:]
     assert "DP_STEP_OK world=2" in out, out[-4000:]
+
+
+def test_bench_gpus_2_launches_its_own_ranks_on_the_gpu(request):
+    """`python bench.py --gpus 2` with no torchrun environment on the GPU box (gloo: both ranks share the one GPU): the parent starts
+    `torch.distributed.run --nproc-per-node 2` itself, rank 0's line says n_gpus 2 and names both ranks (the child job of
+    tests/conftest.py runs it behind the training-step job; this test reads its output)."""
+    import json
+    job = getattr(request.config, "_dp_child", None)
+    if job is None:
+        pytest.skip("the child job is only started for `-m gpu` sessions on a box with a GPU")
+    proc, log = job
+    proc.wait(timeout=900)
+    out = open(log).read()
+    assert "BENCH_SELF_LAUNCH_RC=0" in out, out[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"ranks_seen"' in ln]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and len(d["per_rank_ms"]) == 2 and d["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 16 and d["value"] > 0
