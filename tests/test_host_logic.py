@@ -81,3 +81,42 @@ def test_optimizers_refuse_cpu_tensors_and_keep_torch_defaults():
     assert {k: gs[k] for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")} == {k: gu[k] for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")}
     with pytest.raises(ValueError):
         O.Adam([p], lr=-1.0)
+
+
+def test_margin_aware_agreement_statistics():
+    """checkerpose_amd/agreement.py on synthetic logits: flips are bucketed by the REFERENCE's margin, flips above tau are counted,
+    and a free-running id mismatch is explained by (a) the keypoint's own near-tie flip or (b) an earlier flip in its graph
+    neighbourhood -- an unexplained one (a confident bit flipped with no upstream cause) makes the contract fail."""
+    import torch
+    from checkerpose_amd.agreement import logit_agreement, margin_contract_violations, row_stages
+    assert row_stages(6, 6) == [0, 0, 0, 0, 1, 2, 3, 0, 0, 0, 1, 2, 3]
+    B, N = 1, 32
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(B, 13, N, generator=g) * 2.0
+    z[z.abs() < 0.5] = 1.0                                   # confident reference decisions everywhere ...
+    z[0, 2, 5] = 0.01                                        # ... except one near-tie: stage-0 bit x4 of keypoint 5
+    ref = (z[:, 0:1].clone(), z[:, 1:7].clone(), z[:, 7:13].clone(), torch.randn(B, 2, 8, 8, generator=g),
+           torch.zeros(B, N, dtype=torch.int64), torch.zeros(B, N, dtype=torch.int64))
+    knn = torch.stack([torch.arange(N).roll(-k) for k in range(1, 4)], 1)[None]          # ring graph: neighbours n + 1 .. n + 3
+    # (1) the near-tie flips; keypoint 5's later bit and its neighbour 3's stage-2 bit follow (3 -> 4 -> 5 within 3 hops)
+    o = z.clone()
+    o[0, 2, 5] = -0.01
+    o[0, 4, 5] = -z[0, 4, 5]                                 # keypoint 5, stage 1: its own input moved
+    o[0, 5, 3] = -z[0, 5, 3]                                 # keypoint 3, stage 2: neighbour of 5 within 2 hops
+    xid = ref[4].clone(); xid[0, 5] = 7; xid[0, 3] = 9
+    out = (o[:, 0:1], o[:, 1:7], o[:, 7:13], ref[3], xid, ref[5])
+    tf = logit_agreement(out, ref, tau=0.05)
+    assert tf["flips"] == 3 and tf["flips_above_margin"] == 2 and tf["flip_rate_by_margin"]["0-0.05"]["flips"] == 1
+    fr = logit_agreement(out, ref, tau=0.05, explain=True, knn_idx=knn)
+    assert fr["id_mismatches"] == 2 and fr["id_mismatches_explained"] == 2 and fr["id_mismatches_from_subtau_self_flip"] == 1
+    # (2) a confident stage-0 bit of a far-away keypoint flips with nothing upstream: unexplained
+    o2 = z.clone()
+    o2[0, 1, 20] = -z[0, 1, 20]
+    xid2 = ref[4].clone(); xid2[0, 20] = 3
+    fr2 = logit_agreement((o2[:, 0:1], o2[:, 1:7], o2[:, 7:13], ref[3], xid2, ref[5]), ref, tau=0.05, explain=True, knn_idx=knn)
+    assert fr2["id_mismatches"] == 1 and fr2["id_mismatches_explained"] == 0
+    clean = logit_agreement(ref, ref)
+    assert margin_contract_violations(clean, clean) == []
+    assert any("explained" in v for v in margin_contract_violations(clean, fr2))
+    bad_tf = logit_agreement((o2[:, 0:1], o2[:, 1:7], o2[:, 7:13], ref[3], ref[4], ref[5]), ref)
+    assert any("reference margin" in v for v in margin_contract_violations(bad_tf))
