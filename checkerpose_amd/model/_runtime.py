@@ -147,6 +147,7 @@ class HipForwardMixin:
         self.compute_dtype = os.environ.get("CHECKERPOSE_AMD_DTYPE", "fp32")
         self.use_graph = os.environ.get("CHECKERPOSE_AMD_GRAPH", "1") != "0"
         self.use_lanes = os.environ.get("CHECKERPOSE_AMD_LANES", "1") != "0"   # parallel graph branches
+        self.max_lanes = int(os.environ.get("CHECKERPOSE_AMD_MAX_LANES", "0"))    # 0 = as many streams as the program has lanes (A/B knob)
         self.use_dag = os.environ.get("CHECKERPOSE_AMD_DAG", "0") == "1"       # dataflow capture (Program.run_dag) instead of fork/join lanes
         self.batch_splits = int(os.environ.get("CHECKERPOSE_AMD_SPLITS", "1"))   # concurrent batch slices per forward (measured: 1 is fastest; 2 and 4 lose 8 % / 30 % at B=128)
         self.clone_outputs = True
@@ -525,6 +526,8 @@ class HipForwardMixin:
                     graphs, keep = [], []
                     for sub in prog.progs:
                         lanes = [torch.cuda.Stream(device) for _ in range(sub.nlanes if self.use_lanes and not self.use_dag else 1)]
+                        if self.max_lanes and len(lanes) > self.max_lanes:      # lane k -> stream k mod max_lanes (fewer queues in the graph)
+                            lanes = [lanes[k % self.max_lanes] for k in range(len(lanes))]
                         lanes[0].wait_stream(cur)
                         _abi.check(lib.cp_graph_begin_capture(lanes[0].cuda_stream), "graph capture begin")
                         try:
