@@ -24,6 +24,8 @@ USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decode
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
+FUSE_OUT_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_MIN_BATCH", "1"))   # grouped first-level fuse-layer launches: at every batch
+#   (after per-conv branches too; 350 -> 317 graph nodes below 40 crops: B = 1 1.60 -> 1.58 ms, B = 8 1.88 -> 1.68, B = 32 3.10 -> 2.99; -1: with the chains)
 USE_MLP_FUSED = os.environ.get("CHECKERPOSE_AMD_MLP_FUSED", "1") != "0"   # MLP_QueryNet's three Linears as one launch (bf16)
 # (no lower bound: measured with the fused launches at every batch size against a 32 768-row threshold, ms per forward: B = 1 1.60 vs 1.77,
 #  B = 8 1.84 vs 1.94, B = 32 3.11 vs 3.17 -- below 64 crops a forward is bound by its ~350 dependent graph nodes, and the stacks are 9 fewer)
@@ -219,6 +221,7 @@ class Program:
         # selection for every batch size, so a crop's bf16 bits do not depend on the size of the batch it arrives in
         self.chain_min, self.stem_min, self.edge_min, self.splitk = CHAIN_MIN_BATCH, STEM_MIN_BATCH, EDGE_FUSED_MIN_BATCH, USE_SPLITK
         self.mlp_min_rows = MLP_FUSED_MIN_ROWS
+        self.fuse_out_min = FUSE_OUT_MIN_BATCH if FUSE_OUT_MIN_BATCH >= 0 else CHAIN_MIN_BATCH
         self._raw = {}         # (ptr, nbytes) -> TBuf of a raw-pointer operand (see raw())
 
     # ---- tensors
@@ -625,7 +628,7 @@ class Program:
         return out
 
     def can_fuse_out(self, x: Act):
-        return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= self.chain_min and x.coff == 0 and x.cstride == x.Cphys
+        return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= self.fuse_out_min and x.coff == 0 and x.cstride == x.Cphys
                 and bool(self.lib.cp_hr_fuse_out_supported(x.H, x.W, x.Cphys)))
 
     def hr_fuse_out(self, x: Act, convs):

@@ -268,10 +268,10 @@ class HipForwardMixin:
             sio = {k: (v[sl] if torch.is_tensor(v) else ([t[sl] for t in v] if isinstance(v, list) else v)) for k, v in io.items()}
             prog = Program(lib, ws, dtype, Bs, device)
             if self.kernel_selection == "per_crop":
-                prog.chain_min = prog.stem_min = prog.edge_min = prog.mlp_min_rows = 1
+                prog.chain_min = prog.stem_min = prog.edge_min = prog.mlp_min_rows = prog.fuse_out_min = 1
                 prog.splitk = False
             elif self.kernel_selection == "tiled":
-                prog.chain_min = prog.stem_min = prog.edge_min = prog.mlp_min_rows = 1 << 30
+                prog.chain_min = prog.stem_min = prog.edge_min = prog.mlp_min_rows = prog.fuse_out_min = 1 << 30
                 prog.splitk = False
             sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
             ext = None

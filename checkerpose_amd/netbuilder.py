@@ -333,24 +333,24 @@ class NetEmitter:
                 ws = [self.W("%s.%d.conv%d.weight" % (bp, k, c)) for k in range(4) for c in (1, 2)]
                 affs = [self.ws.bn_fold("%s.%d.bn%d" % (bp, k, c)) for k in range(4) for c in (1, 2)]
                 xs[j] = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W)
-                if nb > 1 and p.can_fuse_out(xs[j]):
-                    # the same lane goes on with ONE launch for every first-level fuse conv that reads branch j (its map staged
-                    # in LDS once); the second region keeps only the 2nd / 3rd convs of the long stride-2 chains
-                    lst = []
-                    for i in range(nb):
-                        q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
-                        if j > i:
-                            lst.append((i, q + ".0", q + ".1", 1, False))
-                        elif j < i:
-                            lst.append((i, q + ".0.0", q + ".0.1", 3, i - j > 1))
-                    outs = p.hr_fuse_out(xs[j], [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (k, relu)
-                                                 for (_, ck, bk, k, relu) in lst])
-                    for (i, _, _, _, _), o in zip(lst, outs):
-                        first[(i, j)] = o
             else:
                 xs[j] = self._materialize(xs[j])
                 for k in range(4):
                     xs[j] = self.basic_block("%s.branches.%d.%d" % (pfx, j, k), xs[j])
+            if self.tp is None and nb > 1 and p.can_fuse_out(xs[j]):
+                # the same lane goes on with ONE launch for every first-level fuse conv that reads branch j (its map staged
+                # in LDS once); the second region keeps only the 2nd / 3rd convs of the long stride-2 chains
+                lst = []
+                for i in range(nb):
+                    q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+                    if j > i:
+                        lst.append((i, q + ".0", q + ".1", 1, False))
+                    elif j < i:
+                        lst.append((i, q + ".0.0", q + ".0.1", 3, i - j > 1))
+                outs = p.hr_fuse_out(xs[j], [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (k, relu)
+                                             for (_, ck, bk, k, relu) in lst])
+                for (i, _, _, _, _), o in zip(lst, outs):
+                    first[(i, j)] = o
         if self.tp is not None:              # training program: lane j also runs the fuse chains fed by branch j (program order)
             sched = [(j, i, j) for j in range(nb) for i in range(nb) if i != j]
         else:
