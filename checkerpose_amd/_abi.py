@@ -25,6 +25,11 @@ class CpConvDesc(C.Structure):
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 
+class CpChainTail(C.Structure):       # the stride-2 fuse-layer convs computed in the 64x64 chain's tail (cp_hr_branch_chain_tail)
+    _fields_ = [("packed_w", C.c_void_p), ("shift", C.c_void_p), ("out", C.c_void_p * 3), ("nconv", C.c_int32),
+                ("Cout", C.c_int32 * 3), ("out_cphys", C.c_int32 * 3), ("relu", C.c_int32 * 3)]
+
+
 class CpFuseConv(C.Structure):
     _fields_ = [("packed_w", C.c_void_p), ("affine", C.c_void_p), ("out", C.c_void_p),
                 ("kind", C.c_int32), ("Cout", C.c_int32), ("out_cphys", C.c_int32), ("relu", C.c_int32)]
@@ -124,6 +129,11 @@ SIGNATURES = {
     "cp_hr_chain_affine_floats": (_I, [_I, _I, _I]),
     "cp_pack_hr_chain_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cp_hr_branch_chain": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P]),
+    "cp_hr_chain_tail_supported": (_I, [_I, _I, _I]),
+    "cp_hr_chain_tail_weight_bytes": (C.c_size_t, []),
+    "cp_hr_chain_tail_channels": (_I, []),
+    "cp_pack_hr_chain_tail_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cp_hr_branch_chain_tail": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P, C.POINTER(CpChainTail)]),
     "cp_upsample2x_bilinear_ac": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_maxpool3x3s2": (_I, [_P, _I, _P, _P, _I, _I, _I, _I]),

@@ -30,7 +30,10 @@ size_t cp_chain0_conv_bytes();
 int cp_chain0_aff();
 int cp_chain0_pack(hipStream_t st, const float* w, const float* scale, int conv_index, void* blob);
 int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
-                     const void* packed_w, const float* affine, void* out);
+                     const void* packed_w, const float* affine, void* out, const CpChainTail* tail);
+size_t cp_chain0_tail_bytes();
+int cp_chain0_tail_channels();
+int cp_chain0_tail_pack(hipStream_t st, const float* w, const float* scale, int Cout, int first_piece, int out_cphys, void* blob);
 
 namespace {
 
@@ -423,8 +426,31 @@ extern "C" int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, const
   return cp_check_launch();
 }
 
+extern "C" int cp_hr_chain_tail_supported(int C, int H, int W) { return (C == 18 && H == 64 && W == 64) ? 1 : 0; }
+extern "C" size_t cp_hr_chain_tail_weight_bytes(void) { return cp_chain0_tail_bytes(); }
+extern "C" int cp_hr_chain_tail_channels(void) { return cp_chain0_tail_channels(); }
+extern "C" int cp_pack_hr_chain_tail_weight(cp_stream_t stream, const float* w, const float* scale, int Cout, int first_piece, int out_cphys,
+                                            void* blob) {
+  return cp_chain0_tail_pack((hipStream_t)stream, w, scale, Cout, first_piece, out_cphys, blob);
+}
+
+static int branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
+                        const void* packed_w, const float* affine, void* out, const CpChainTail* tail);
+
 extern "C" int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
                                   const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out) {
+  return branch_chain(stream, B, C, H, W, nsrc, srcs, shifts, relu_in, packed_w, affine, out, nullptr);
+}
+
+extern "C" int cp_hr_branch_chain_tail(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
+                                       const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out,
+                                       const CpChainTail* tail) {
+  if (!tail || !cp_hr_chain_tail_supported(C, H, W)) return CP_ERR_INVALID;
+  return branch_chain(stream, B, C, H, W, nsrc, srcs, shifts, relu_in, packed_w, affine, out, tail);
+}
+
+static int branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
+                        const void* packed_w, const float* affine, void* out, const CpChainTail* tail) {
   ChainInfo ci;
   if (B <= 0 || !srcs || !shifts || nsrc < 1 || nsrc > 4 || !packed_w || !affine || !out) return CP_ERR_INVALID;
   if (!chain_info(C, H, W, &ci)) return CP_ERR_INVALID;
@@ -437,7 +463,7 @@ extern "C" int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W
     if (srcs[k] == out) return CP_ERR_INVALID;
     p.src[k] = srcs[k]; p.shift[k] = shifts[k];
   }
-  if (C == 18) return cp_chain0_launch((hipStream_t)stream, B, nsrc, srcs, shifts, relu_in, packed_w, affine, out);
+  if (C == 18) return cp_chain0_launch((hipStream_t)stream, B, nsrc, srcs, shifts, relu_in, packed_w, affine, out, tail);
   p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0;
   p.w = packed_w; p.aff = affine; p.out = out; p.B = B;
   p.dbg = cp_knob("CP_CHAIN_DBG") ? atoi(cp_knob("CP_CHAIN_DBG")) : 0;

@@ -35,7 +35,15 @@ struct Chain0Params {
   const float* aff;       // [8][2][32]
   void* out;              // (B, 64, 64, 24) bf16: block outputs (residual of the next block), finally the result
   int B;
+  // tail (cp_hr_branch_chain_tail): the stride-2 fuse-layer convs that read this branch's output, run off the finished map in LDS.
+  // Their output channels sit side by side in 16-byte pieces (conv i owns pieces [tps[i], tps[i] + tcph[i] / 8)), 4 pieces = one slab.
+  int tnp;                // pieces in all (0 = no tail)
+  int tps[3], tcph[3], trelu[3];
+  const void* tw;         // [slab][7][2][64][16 B], BN scale folded in, zero rows beyond a conv's channels
+  const float* tshift;    // [ZTAIL_CH] folded-BN shift per combined channel
+  void* tout[3];          // (B, 32, 32, tcph[i]) bf16
 };
+constexpr int ZTAIL_CH = 96;
 
 __device__ __forceinline__ void mma16z(const u32x4& w, const u32x4& a, f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
@@ -155,6 +163,23 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
     }
   };
 
+  auto load_frags_at = [&](u32x4* a, int kc, const uint32_t* pbs) {   // the tail's fragments: one window-top-left ring pixel per fragment
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint32_t px = pbs[f];
+      if (kc < 4) a[f] = *(const u32x4*)(smem + o16[kc] + px * 16);
+      else if (kc == 4) {
+        u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
+        const uint32_t sm = *(const uint32_t*)(smem + o4[0] + px * 4);
+        big.x = small4 ? sm : big.x;
+        a[f] = big;
+      } else {
+        const uint32_t sm = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);
+        a[f] = u32x4{sm, 0u, 0u, 0u};
+      }
+    }
+  };
+
   u32x4 hold[4];                               // wave 7: the band's last row, written one band later
 #pragma unroll
   for (int f = 0; f < 4; ++f) hold[f] = u32x4{0u, 0u, 0u, 0u};
@@ -194,9 +219,10 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (band == 7 && cv + 1 < 8) {                             // next conv's fragments behind the last use of this conv's
-          Wf[kc][0] = wg[(((cv + 1) * ZKC + kc) * 2 + 0) * 64 + lane];
-          Wf[kc][1] = wg[(((cv + 1) * ZKC + kc) * 2 + 1) * 64 + lane];
+        if (band == 7 && (cv + 1 < 8 || p.tnp)) {                  // next conv's (or the tail's first slab's) fragments behind the last use of this conv's
+          const u32x4* const wn = cv + 1 < 8 ? wg + (size_t)(cv + 1) * ZKC * 2 * 64 : (const u32x4*)p.tw;
+          Wf[kc][0] = wn[(kc * 2 + 0) * 64 + lane];
+          Wf[kc][1] = wn[(kc * 2 + 1) * 64 + lane];
         }
       }
       // ---- epilogue: lane (x, q) holds channels 8q .. 8q+7 of pixel (row, 16 f + x)
@@ -242,6 +268,69 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
     if (tid < 2 * ZAFF) sAff[((cv + 1) & 1) * 2 * ZAFF + tid] = affv;
     __syncthreads();                   // the conv's output map is complete
   }
+
+  // ---- tail: 3x3 / stride 2 / pad 1 convs of the finished map (read-only from here on: no barriers).  Output 32 x 32: wave w owns
+  //      output rows 4w .. 4w+3 = 8 fragments of 16 pixels, four at a time; a fragment's lanes read input pixels 2 apart, its window's
+  //      top-left ring pixel being (2 oy, 2 ox).  Slab sl = combined channels 32 sl .. 32 sl + 31 (two tiles, Wf as in a chain conv).
+  if (p.tnp) {
+    const int nslab = (p.tnp + 3) >> 2;
+#pragma unroll 1
+    for (int sl = 0; sl < nslab; ++sl) {
+      const int piece = sl * 4 + q;
+      const int cvi = piece >= p.tps[2] ? 2 : (piece >= p.tps[1] ? 1 : 0);
+      const bool live = piece < p.tnp;
+      const f32x4 t0 = live ? *(const f32x4*)(p.tshift + piece * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 t1 = live ? *(const f32x4*)(p.tshift + piece * 8 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int cph = p.tcph[cvi];
+      const bool relu = p.trelu[cvi] != 0;
+      unsigned char* const ob = (unsigned char*)p.tout[cvi] + ((size_t)b * 1024 * cph + (size_t)(piece - p.tps[cvi]) * 8) * 2;
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        uint32_t pbt[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int orow = 4 * wave + 2 * half + (f >> 1), xo = 16 * (f & 1) + x;
+          pbt[f] = (uint32_t)(2 * orow * ZWP + 2 * xo);
+        }
+        f32x4 acc[4][2];
+        u32x4 af[2][4];
+        load_frags_at(af[0], 0, pbt);
+#pragma unroll
+        for (int kc = 0; kc < ZKC; ++kc) {
+          if (kc + 1 < ZKC) load_frags_at(af[(kc + 1) & 1], kc + 1, pbt);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            if (kc == 0) {
+              acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][0]), __builtin_bit_cast(bf16x8, af[0][f]), t0, 0, 0, 0);
+              acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][1]), __builtin_bit_cast(bf16x8, af[0][f]), t1, 0, 0, 0);
+            } else {
+              mma16z(Wf[kc][0], af[kc & 1][f], acc[f][0]);
+              mma16z(Wf[kc][1], af[kc & 1][f], acc[f][1]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (half == 1 && sl + 1 < nslab) {                         // next slab's fragments behind the last use of this slab's
+            const u32x4* const wn = (const u32x4*)p.tw + (size_t)(sl + 1) * ZKC * 2 * 64;
+            Wf[kc][0] = wn[(kc * 2 + 0) * 64 + lane];
+            Wf[kc][1] = wn[(kc * 2 + 1) * 64 + lane];
+          }
+        }
+        if (live) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j]; e[4 + j] = acc[f][1][j]; }
+            u32x4 pk = Vec16<BF16Tag>::pack(e);
+            if (relu) { pk.x = relu_bf16x2(pk.x); pk.y = relu_bf16x2(pk.y); pk.z = relu_bf16x2(pk.z); pk.w = relu_bf16x2(pk.w); }
+            const int orow = 4 * wave + 2 * half + (f >> 1), xo = 16 * (f & 1) + x;
+            *(u32x4*)(ob + (size_t)(orow * 32 + xo) * cph * 2) = pk;
+          }
+        }
+      }
+    }
+  }
 }
 
 // [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
@@ -265,6 +354,29 @@ __global__ void pack_chain0_weight_kernel(const float* __restrict__ w, const flo
   out[i] = (uint16_t)f32_to_bf16_bits(v);
 }
 
+// tail weights of ONE conv into the shared blob [slab][chunk][tile][lane][8 bf16] (K order as above): combined channel
+// 32 slab + (row >> 2) * 8 + 4 nt + (row & 3) belongs to this conv if it lies in [8 ps, 8 ps + cphys); the rest of the blob is not touched
+__global__ void pack_chain0_tail_kernel(const float* __restrict__ w, const float* __restrict__ scale, uint16_t* __restrict__ out, int Cout,
+                                        int ps, int cphys, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % 8);
+  const int lane = (int)((i / 8) % 64);
+  const int nt = (int)((i / 512) % 2);
+  const int kc = (int)((i / 1024) % ZKC);
+  const int slab = (int)(i / (1024 * ZKC));
+  const int row = lane & 15, q = lane >> 4;
+  const int G = kc * 4 + q;
+  int tap = -1, cin = 0;
+  if (G < 18) { tap = G >> 1; cin = (G & 1) * 8 + e; }
+  else if (G < 27 && e < 2) { tap = G - 18; cin = 16 + e; }
+  const int c = slab * 32 + (row >> 2) * 8 + nt * 4 + (row & 3) - ps * 8;
+  if (c < 0 || c >= cphys) return;
+  float v = 0.f;
+  if (tap >= 0 && c < Cout && cin < ZC) v = w[((size_t)c * ZC + cin) * 9 + tap] * (scale ? scale[c] : 1.f);
+  out[i] = (uint16_t)f32_to_bf16_bits(v);
+}
+
 }  // namespace
 
 // entry points used by hr_chain.hip's dispatcher for (C, H, W) = (18, 64, 64)
@@ -279,13 +391,39 @@ int cp_chain0_pack(hipStream_t st, const float* w, const float* scale, int conv_
 }
 
 int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
-                     const void* packed_w, const float* affine, void* out) {
+                     const void* packed_w, const float* affine, void* out, const CpChainTail* tail) {
   static CpDeviceOnce once;
   const int dev = cp_current_device();
   CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)hr_chain0_kernel, ZLDS));
-  Chain0Params p;
+  Chain0Params p = {};
   for (int k = 0; k < 4; ++k) { p.src[k] = k < nsrc ? srcs[k] : nullptr; p.shift[k] = k < nsrc ? shifts[k] : 0; }
   p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0; p.w = packed_w; p.aff = affine; p.out = out; p.B = B;
+  if (tail) {
+    if (tail->nconv < 1 || tail->nconv > 3 || !tail->packed_w || !tail->shift) return CP_ERR_INVALID;
+    if (!cp_aligned16(tail->packed_w) || !cp_aligned16(tail->shift)) return CP_ERR_ALIGN;
+    int ps = 0;
+    for (int i = 0; i < 3; ++i) { p.tps[i] = 1 << 20; p.tcph[i] = 8; p.trelu[i] = 0; p.tout[i] = nullptr; }
+    for (int i = 0; i < tail->nconv; ++i) {
+      const int cph = tail->out_cphys[i];
+      if (cph <= 0 || cph % 8 || tail->Cout[i] <= 0 || tail->Cout[i] > cph || !tail->out[i] || tail->out[i] == out) return CP_ERR_INVALID;
+      if (!cp_aligned16(tail->out[i])) return CP_ERR_ALIGN;
+      p.tps[i] = ps; p.tcph[i] = cph; p.trelu[i] = tail->relu[i] ? 1 : 0; p.tout[i] = tail->out[i];
+      ps += cph / 8;
+    }
+    if (ps * 8 > ZTAIL_CH) return CP_ERR_INVALID;
+    p.tnp = ps; p.tw = tail->packed_w; p.tshift = tail->shift;
+  }
   CP_LAUNCH(hr_chain0_kernel, dim3((unsigned)B), dim3(512), ZLDS, st, p);
+  return cp_check_launch();
+}
+
+size_t cp_chain0_tail_bytes() { return (size_t)(ZTAIL_CH / 32) * ZCONV_W; }
+int cp_chain0_tail_channels() { return ZTAIL_CH; }
+
+int cp_chain0_tail_pack(hipStream_t st, const float* w, const float* scale, int Cout, int first_piece, int out_cphys, void* blob) {
+  if (!w || !blob || Cout <= 0 || out_cphys % 8 || Cout > out_cphys || first_piece < 0 || first_piece * 8 + out_cphys > ZTAIL_CH) return CP_ERR_INVALID;
+  if (!cp_aligned16(blob)) return CP_ERR_ALIGN;
+  const size_t total = cp_chain0_tail_bytes() / 2;
+  CP_LAUNCH(pack_chain0_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, scale, (uint16_t*)blob, Cout, first_piece, out_cphys, total);
   return cp_check_launch();
 }

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpConvDesc, CpConvGroupItem, CpFuseConv
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpChainTail, CpConvDesc, CpConvGroupItem, CpFuseConv
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
@@ -24,6 +24,7 @@ USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decode
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
+USE_CHAIN_TAIL = os.environ.get("CHECKERPOSE_AMD_CHAIN_TAIL", "1") != "0"   # the 64x64 chain launch also runs the stride-2 fuse convs that read its output
 FUSE_OUT_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_MIN_BATCH", "1"))   # grouped first-level fuse-layer launches: at every batch
 #   (after per-conv branches too; 350 -> 317 graph nodes below 40 crops: B = 1 1.60 -> 1.58 ms, B = 8 1.88 -> 1.68, B = 32 3.10 -> 2.99; -1: with the chains)
 USE_MLP_FUSED = os.environ.get("CHECKERPOSE_AMD_MLP_FUSED", "1") != "0"   # MLP_QueryNet's three Linears as one launch (bf16)
@@ -599,11 +600,20 @@ class Program:
     def can_chain(self, C_, H, W):
         return (USE_CHAIN and self.dtype == CP_BF16 and self.B >= self.chain_min and bool(self.lib.cp_hr_chain_supported(C_, H, W)))
 
-    def hr_chain(self, name, srcs, shifts, relu_in, ws, affs, C_, H, W):
+    def can_chain_tail(self, C_, H, W, convs):
+        """the stride-2 fuse convs that read this branch's output fit the chain launch's tail (cp_hr_branch_chain_tail)"""
+        return (USE_CHAIN_TAIL and self.can_chain(C_, H, W) and 1 <= len(convs) <= 3 and bool(self.lib.cp_hr_chain_tail_supported(C_, H, W))
+                and sum(_rup(c[1].shape[0], self.E) for c in convs) <= self.lib.cp_hr_chain_tail_channels())
+
+    def hr_chain(self, name, srcs, shifts, relu_in, ws, affs, C_, H, W, tail=None):
         """4 BasicBlocks of an HRNet branch on relu(sum of `srcs` (nearest-upsampled by 2^shift)) in ONE launch
-        (cp_hr_branch_chain): ws / affs = the 8 fp32 conv weights and folded-BN (scale, shift) pairs in execution order."""
+        (cp_hr_branch_chain): ws / affs = the 8 fp32 conv weights and folded-BN (scale, shift) pairs in execution order.
+        tail: [(wkey, w fp32 (Cout, C, 3, 3), scale, shift, relu)] -- the 3x3 / stride 2 fuse-layer convs reading the branch output, run in
+        the same launch off the map in LDS (can_chain_tail); returns (out, [their outputs]) then."""
         blob, aff = self.ws.pack_chain(name, ws, affs, C_, H, W)
         out = self.act(H, W, C_)
+        if tail is not None:
+            return self._hr_chain_tail(name, srcs, shifts, relu_in, blob, aff, out, C_, H, W, tail)
         n = len(srcs)
         arr_p = (C.c_void_p * 4)()
         arr_s = (C.c_int32 * 4)(*([int(v) for v in shifts] + [0] * (4 - n)))
@@ -626,6 +636,56 @@ class Program:
         nb = self.B * H * W * C_ * self.es
         self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es))
         return out
+
+    def _hr_chain_tail(self, name, srcs, shifts, relu_in, blob, aff, out, C_, H, W, tail):
+        lib = self.lib
+        ck = ("chain_tail", name)
+        if ck not in self.ws.cache:
+            tb = torch.zeros(lib.cp_hr_chain_tail_weight_bytes(), dtype=torch.uint8, device=self.device)
+            tsh = torch.zeros(lib.cp_hr_chain_tail_channels(), dtype=torch.float32, device=self.device)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            piece = 0
+            for wkey, w, scale, shift, relu in tail:
+                Cout = w.shape[0]
+                cph = _rup(Cout, self.E)
+                wc = w.contiguous()
+                sc = scale.to(device=self.device, dtype=torch.float32).contiguous()
+                self.ws.keep += [wc, sc]
+                _abi.check(lib.cp_pack_hr_chain_tail_weight(st, wc.data_ptr(), sc.data_ptr(), Cout, piece, cph, tb.data_ptr()),
+                           "cp_pack_hr_chain_tail_weight(%s)" % wkey)
+                tsh[piece * 8: piece * 8 + Cout] = shift
+                piece += cph // 8
+            self.ws.cache[ck] = (tb, tsh)
+        tb, tsh = self.ws.cache[ck]
+        touts = [self.act(H >> 1, W >> 1, w.shape[0]) for _, w, *_ in tail]
+        tl = CpChainTail()
+        tl.packed_w, tl.shift, tl.nconv = tb.data_ptr(), tsh.data_ptr(), len(tail)
+        for i, ((wkey, w, scale, shift, relu), o) in enumerate(zip(tail, touts)):
+            assert o.coff == 0 and o.cstride == o.Cphys
+            tl.Cout[i], tl.out_cphys[i], tl.relu[i] = w.shape[0], o.Cphys, 1 if relu else 0
+        n = len(srcs)
+        arr_p = (C.c_void_p * 4)()
+        arr_s = (C.c_int32 * 4)(*([int(v) for v in shifts] + [0] * (4 - n)))
+        self.keep += [arr_p, arr_s, blob, aff, tb, tsh, tl]
+        for s_, sh in zip(srcs, shifts):
+            assert s_.coff == 0 and s_.cstride == s_.Cphys == out.Cphys and (s_.H << sh, s_.W << sh) == (H, W)
+        tbs, ot, tts = [s_.tbuf for s_ in srcs], out.tbuf, [o.tbuf for o in touts]
+        bp, ap = blob.data_ptr(), aff.data_ptr()
+
+        def argb(P):
+            for i, t in enumerate(tbs):
+                arr_p[i] = P(t)
+            for i, t in enumerate(tts):
+                tl.out[i] = P(t)
+            return (self.B, C_, H, W, n, arr_p, arr_s, 1 if relu_in else 0, bp, ap, P(ot), C.byref(tl))
+
+        self._add(lib.cp_hr_branch_chain_tail, argb, "hr_chain:" + name, tbs, [ot] + tts)
+        fl = 8 * 2 * self.B * H * W * 9 * C_ * C_ + sum(2 * self.B * (H >> 1) * (W >> 1) * 9 * C_ * w.shape[0] for _, w, *_ in tail)
+        self.flops += fl
+        nb = self.B * H * W * C_ * self.es
+        nbt = sum(self.B * (H >> 1) * (W >> 1) * w.shape[0] * self.es + 9 * C_ * w.shape[0] * self.es for _, w, *_ in tail)
+        self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es + nbt))
+        return out, touts
 
     def can_fuse_out(self, x: Act):
         return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= self.fuse_out_min and x.coff == 0 and x.cstride == x.Cphys

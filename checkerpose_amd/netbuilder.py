@@ -332,6 +332,15 @@ class NetEmitter:
                 bp = "%s.branches.%d" % (pfx, j)
                 ws = [self.W("%s.%d.conv%d.weight" % (bp, k, c)) for k in range(4) for c in (1, 2)]
                 affs = [self.ws.bn_fold("%s.%d.bn%d" % (bp, k, c)) for k in range(4) for c in (1, 2)]
+                tl = [("%s.fuse_layers.%d.%d.0.0" % (pfx, i, j), "%s.fuse_layers.%d.%d.0.1" % (pfx, i, j), i - j > 1) for i in range(j + 1, nb)]
+                tconvs = [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (relu,) for ck, bk, relu in tl]
+                if tl and all(i > j for i in range(nb) if i != j) and p.can_chain_tail(C_, H, W, tconvs):
+                    # every first-level fuse conv fed by this branch is a stride-2 one (branch 0): the chain launch runs them off its
+                    # finished map in LDS -- the grouped launch behind the module's longest chain and its re-read of the map go away
+                    xs[j], touts = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W, tail=tconvs)
+                    for i, o in zip(range(j + 1, nb), touts):
+                        first[(i, j)] = o
+                    continue
                 xs[j] = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W)
             else:
                 xs[j] = self._materialize(xs[j])

@@ -280,6 +280,32 @@ int cp_pack_hr_chain_weight(cp_stream_t stream, const float* w, const float* sca
 int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
                        const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out);
 
+/* cp_hr_branch_chain of the 64 x 64 x 18 branch WITH the stride-2 fuse-layer convs that read its output (kind 1 of cp_hr_fuse_out
+ * below: fuse_layers[i][0][0], i = 1..3, 3x3 / stride 2 / pad 1 + folded BN (+ ReLU where the down-sampling chain goes on)) computed
+ * off the finished map while it is still in LDS: the separate launch behind the module's longest chain and its re-read of the map
+ * disappear.  Up to 3 convs whose padded channel counts (out_cphys, multiples of 8) add up to <= cp_hr_chain_tail_channels() (96:
+ * HRNet-W18 has 40 + 24 + 24); conv i owns the 16-byte channel pieces [first_piece_i, first_piece_i + out_cphys_i / 8) with
+ * first_piece_0 = 0 and first_piece_{i+1} = first_piece_i + out_cphys_i / 8.
+ *   packed_w: one ZERO-FILLED blob of cp_hr_chain_tail_weight_bytes() bytes into which cp_pack_hr_chain_tail_weight() has written every
+ *             conv (fp32 (Cout, 18, 3, 3) weights TIMES the folded-BN scale of their output channel);
+ *   shift:    fp32 [96], the folded-BN shift at combined channel 8 * first_piece_i + c, zero elsewhere;
+ *   out[i]:   (B, 32, 32, out_cphys[i]) bf16, channels [Cout, out_cphys) exactly zero.
+ * Same arithmetic as the chain's own convs (bf16 operands with the scale folded in, fp32 accumulate starting from the shift). */
+typedef struct CpChainTail {
+  const void* packed_w;
+  const float* shift;
+  void* out[3];
+  int32_t nconv;
+  int32_t Cout[3], out_cphys[3], relu[3];
+} CpChainTail;
+int cp_hr_chain_tail_supported(int C, int H, int W);
+size_t cp_hr_chain_tail_weight_bytes(void);
+int cp_hr_chain_tail_channels(void);
+int cp_pack_hr_chain_tail_weight(cp_stream_t stream, const float* w, const float* scale, int Cout, int first_piece, int out_cphys, void* blob);
+int cp_hr_branch_chain_tail(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
+                            const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out,
+                            const CpChainTail* tail);
+
 /* The first-level fuse-layer convs of a timm HighResolutionModule that read ONE branch's output `src` (B, H, W, cin_phys) bf16
  * (timm HighResolutionModule.fuse_layers inside backbone.py:35): up to 4 convs per launch, each
  *   kind 0: 1x1 conv + folded BN at the source resolution (the term towards a higher-resolution branch, before its nearest

@@ -590,6 +590,79 @@ def test_hr_branch_chain_vs_torch_cpu(lib, cfg, nsrc):
     assert lib.cp_hr_branch_chain(st(), B, Cc, H, W, nsrc, arr_p, arr_s, 0, blob.data_ptr(), aff.data_ptr(), out.data_ptr()) == -1
 
 
+@pytest.mark.parametrize("tconvs", [[(36, False)], [(36, False), (18, True)], [(36, False), (18, True), (18, True)]])
+def test_hr_branch_chain_tail_vs_fuse_out_and_torch(lib, tconvs):
+    """cp_hr_branch_chain_tail: the 64 x 64 x 18 chain launch also produces the stride-2 fuse-layer convs that read its output
+    (timm HighResolutionModule.fuse_layers[i][0][0], i = 1..3).  The chain output is bit-identical to cp_hr_branch_chain's; every
+    tail output matches torch's conv3x3 / stride 2 over that (bf16) output + folded BN (+ ReLU), pad channels exactly zero -- the same
+    reference cp_hr_fuse_out is held to; bad tails are refused."""
+    from checkerpose_amd._abi import CpChainTail
+    Cc, H, W, B, dtype = 18, 64, 64, 3, CP_BF16
+    assert lib.cp_hr_chain_tail_supported(18, 64, 64) == 1 and lib.cp_hr_chain_tail_supported(36, 32, 32) == 0
+    terms = [det_tensor("tt0", (B, Cc, H, W)), det_tensor("tt1", (B, Cc, H // 2, W // 2))]
+    shifts = [0, 1]
+    ws = [det_tensor("tw%d" % i, (Cc, Cc, 3, 3), (2.0 / (Cc * 9)) ** 0.5 * 1.5) for i in range(8)]
+    affs = [(1.0 + 0.3 * det_tensor("ts%d" % i, (Cc,)), 0.2 * det_tensor("tb%d" % i, (Cc,))) for i in range(8)]
+    for i in range(1, 8, 2):
+        affs[i] = (affs[i][0] * 0.4, affs[i][1])
+    blob = torch.empty(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev())
+    for i, w in enumerate(ws):
+        wd, sd_ = w.contiguous().to(dev()), affs[i][0].contiguous().to(dev())
+        _abi.check(lib.cp_pack_hr_chain_weight(st(), wd.data_ptr(), sd_.data_ptr(), Cc, H, W, i, blob.data_ptr()))
+        torch.cuda.synchronize()
+    n = lib.cp_hr_chain_affine_floats(Cc, H, W)
+    aff = torch.zeros(8, 2, n)
+    for i, (s_, t_) in enumerate(affs):
+        aff[i, 0, :Cc], aff[i, 1, :Cc] = s_, t_
+    aff = aff.to(dev())
+    srcs = [to_cl(t, dtype) for t in terms]
+    cp = srcs[0].shape[-1]
+    arr_p = (C.c_void_p * 4)(*([s_.data_ptr() for s_ in srcs] + [None] * 2))
+    arr_s = (C.c_int32 * 4)(*(shifts + [0, 0]))
+    plain = torch.full((B, H, W, cp), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_hr_branch_chain(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), plain.data_ptr()), "hr chain")
+    # ---- tail
+    tb = torch.zeros(lib.cp_hr_chain_tail_weight_bytes(), dtype=torch.uint8, device=dev())
+    tsh = torch.zeros(lib.cp_hr_chain_tail_channels(), dtype=torch.float32, device=dev())
+    tl = CpChainTail()
+    keep, touts, tw, piece = [], [], [], 0
+    for i, (Cout, relu) in enumerate(tconvs):
+        w = det_tensor("ttw%d" % i, (Cout, Cc, 3, 3), (2.0 / (Cc * 9)) ** 0.5 * 1.7)
+        scale, shift = 1.0 + 0.3 * det_tensor("tts%d" % i, (Cout,)), 0.2 * det_tensor("ttt%d" % i, (Cout,))
+        ocp = rup(Cout, 8)
+        wd, sd_ = w.contiguous().to(dev()), scale.contiguous().to(dev())
+        _abi.check(lib.cp_pack_hr_chain_tail_weight(st(), wd.data_ptr(), sd_.data_ptr(), Cout, piece, ocp, tb.data_ptr()), "tail pack")
+        tsh[piece * 8: piece * 8 + Cout] = shift.to(dev())
+        o = torch.full((B, H // 2, W // 2, ocp), float("nan"), dtype=DT[dtype], device=dev())
+        tl.out[i], tl.Cout[i], tl.out_cphys[i], tl.relu[i] = o.data_ptr(), Cout, ocp, 1 if relu else 0
+        touts.append(o)
+        tw.append((w, scale, shift, relu))
+        keep += [wd, sd_]
+        piece += ocp // 8
+    tl.packed_w, tl.shift, tl.nconv = tb.data_ptr(), tsh.data_ptr(), len(tconvs)
+    out = torch.full((B, H, W, cp), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_hr_branch_chain_tail(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), C.byref(tl)),
+               "hr chain tail")
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16)), "the chain's own output must not change"
+    x = from_cl(out, Cc)                                       # exactly the (bf16) map the tail read from LDS
+    for (w, scale, shift, relu), o in zip(tw, touts):
+        Cout = w.shape[0]
+        r = F.conv2d(x, rnd(w * scale.view(-1, 1, 1, 1), dtype), None, 2, 1) + shift.view(1, -1, 1, 1)     # the scale lives in the bf16 weights
+        r = F.relu(r) if relu else r
+        assert bool(torch.isfinite(o.float()).all()), "every output element must be written"
+        if o.shape[-1] > Cout:
+            assert float(o[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+        close(from_cl(o, Cout), r, TOL[dtype])
+    tl.nconv = 4
+    assert lib.cp_hr_branch_chain_tail(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), C.byref(tl)) == -1
+    tl.nconv = len(tconvs)
+    if len(tconvs) > 1:                                        # padded channel counts beyond the 96 the tail holds (refused before any launch)
+        tl.out_cphys[0] = 96
+        assert lib.cp_hr_branch_chain_tail(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), C.byref(tl)) == -1
+    assert lib.cp_pack_hr_chain_tail_weight(st(), keep[0].data_ptr(), keep[1].data_ptr(), 36, 9, 40, tb.data_ptr()) == -1     # past 96 channels
+
+
 @pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 13, 21), (9, 8, 16), (3, 64, 64)])
 def test_bottleneck_fused_vs_torch_cpu(lib, shape, ds):
