@@ -25,6 +25,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(cp_f32x2{lo, hi}, cp_bf16x2));
 }
 
+// (Leaky)ReLU / identity without per-element branches: with a run-time `act` the unrolled epilogues compiled to a scalar compare + branch
+// per VALUE (25 static instructions per output in the decoder conv's epilogue).  s = 0 / slope / 1, then max(v, v * s + 0): the "+ 0"
+// turns the -0 of a negative v times 0 into +0, so ReLU is exactly fmaxf(v, 0); slopes in [0, 1] only.
+__device__ __forceinline__ float cp_act_slope(int act, float slope) { return act == 1 ? 0.f : (act == 2 ? slope : 1.f); }   // CP_ACT_RELU, CP_ACT_LEAKY
+__device__ __forceinline__ float cp_act_apply(float v, float s) { return fmaxf(v, fmaf(v, s, 0.f)); }
+
 // relu of two packed bf16 values: the sign bit is the int16 sign bit, so max(int16, 0) per half (-0.0 -> +0.0 as fmaxf does)
 typedef short cp_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {

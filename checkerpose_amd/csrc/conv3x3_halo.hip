@@ -236,8 +236,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-      else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
     }
     if (E == 4) {
       *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -539,8 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const HaloParams 
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
       }
       if (E == 4) {
         if (xok) {
@@ -760,8 +758,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
       }
       if (E == 4) *(f32x4*)((float*)p.out + obase[mt] + nt * 4) = f32x4{v[0], v[1], v[2], v[3]};
       else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + obase[mt] + nt * 4) = pk; }
@@ -920,8 +917,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_group_kernel(const HaloGro
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
       }
       if (E == 4) *(f32x4*)((float*)p.out + obase[mt] + nt * 4) = f32x4{v[0], v[1], v[2], v[3]};
       else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + obase[mt] + nt * 4) = pk; }

@@ -156,8 +156,7 @@ __global__ __launch_bounds__(64 * 2 * S2_MAXMT, 2) void conv3x3_s2_small_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[j] = acc[t][j] * sc[j] + sh[j];
-          if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-          else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
         }
         u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
         *(u32x2*)((uint16_t*)p.out + p.o_base + (long long)b * p.o_sb + (long long)((r0 >> 1) + oy) * p.o_sy + (long long)ox * p.o_sx + co) = pk;

@@ -242,8 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
       }
       if (f32o) *(f32x4*)((float*)p.out + ofs[ps]) = f32x4{v[0], v[1], v[2], v[3]};
       else *(u32x4*)((uint16_t*)p.out + ofs[ps]) = Vec16<BF16Tag>::pack(v);
@@ -308,8 +307,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-          else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
         }
         if (f32io) {
           *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -324,8 +322,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
           const long long o = pix[mt] + (long long)(n + j) * p.o_sc;
           float y = v[j];
           if (p.res) y += f32io ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
-          if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
-          else if (p.act == CP_ACT_LEAKY) y = y > 0.f ? y : y * p.slope;
+          y = cp_act_apply(y, cp_act_slope(p.act, p.slope));
           if (f32io) ((float*)p.out)[o] = y;
           else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
         }
@@ -459,8 +456,7 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-        else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+        v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
       }
       if (f32io) {
         *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -475,8 +471,7 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
         const long long o = pix + (long long)(n + j) * p.o_sc;
         float y = v[j];
         if (p.res) y += f32io ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
-        if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
-        else if (p.act == CP_ACT_LEAKY) y = y > 0.f ? y : y * p.slope;
+        y = cp_act_apply(y, cp_act_slope(p.act, p.slope));
         if (f32io) ((float*)p.out)[o] = y;
         else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
       }

@@ -205,8 +205,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-      else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+      v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
     }
     if (E == 4) {
       *(f32x4*)((float*)p.out + o[mt]) = f32x4{v[0], v[1], v[2], v[3]};
@@ -342,8 +341,7 @@ __global__ __launch_bounds__(512 / NG, NG) void gemm_rows_ws_kernel(const GemmPa
         for (int j = 0; j < 4; ++j) { v[j] = acc[mt][2 * h][j] * s0[j] + t0[j]; v[4 + j] = acc[mt][2 * h + 1][j] * s1[j] + t1[j]; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (p.act == CP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-          else if (p.act == CP_ACT_LEAKY) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
         }
         if (hi_ok) {
           u32x4 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
