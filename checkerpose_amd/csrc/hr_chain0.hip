@@ -157,9 +157,8 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
         big.x = small4 ? sm : big.x;
         a[f] = big;
       } else {
-        const uint32_t sm = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);
-        a[f] = u32x4{sm, 0u, 0u, 0u};
-      }
+        a[f].x = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);     // K slots 2..7 of the group meet zero weights: the quad's other three
+      }                                                              // registers keep the (finite) activations of two chunks ago -- no 3 moves per fragment
     }
   };
 
@@ -174,9 +173,8 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
         big.x = small4 ? sm : big.x;
         a[f] = big;
       } else {
-        const uint32_t sm = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);
-        a[f] = u32x4{sm, 0u, 0u, 0u};
-      }
+        a[f].x = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);     // K slots 2..7 of the group meet zero weights: the quad's other three
+      }                                                              // registers keep the (finite) activations of two chunks ago -- no 3 moves per fragment
     }
   };
 
