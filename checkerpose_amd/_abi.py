@@ -101,6 +101,10 @@ SIGNATURES = {
     "cp_pack_conv3x3_halo_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "cp_conv3x3_halo": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
     "cp_conv3x3_halo_group_supported": (_I, [_I, _I, _I, _I]),
+    "cp_conv2x2_halo_supported": (_I, [_I, _I, _I, _I]),
+    "cp_packed_conv2x2_halo_weight_bytes": (C.c_size_t, [_I, _I, _I]),
+    "cp_pack_conv2x2_halo_weight": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "cp_conv2x2_halo": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
     "cp_conv3x3_halo_item": (_I, [C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P, C.POINTER(CpConvGroupItem)]),
     "cp_conv3x3_halo_group": (_I, [_P, _I, _P, _P, _I, C.c_uint32, C.c_uint32]),
     "cp_conv3x3_s2_small_supported": (_I, [_I, _I, _I, _I]),

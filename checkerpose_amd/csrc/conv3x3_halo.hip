@@ -622,12 +622,16 @@ static inline bool halo_wide(int Cout) { return Cout >= 256 && Cout % 256 == 0 &
 //     of the packed image), so the texture path only sees each byte once per block;
 //   * packed rows are permuted so lane q ends with channels [4*NT*q, 4*NT*(q+1)): the four q lanes of a pixel write
 //     its whole channel vector contiguously and the 16 pixels of a fragment are adjacent in memory.
-template <typename Tag, int NT>
+// KS = 2: the k = 2 / stride 1 / pad 1 conv of Index2Feat_module's patch_generator (pipeline.py:223-240; output (H + 1) x (W + 1)) --
+// the same tile walk over the larger output grid, four taps of the same staged halo (its last row / column is input row H / column W:
+// zero padding); the generic kernel read every pixel row four times through the texture path (10 % of any roof at N = 4096).
+template <typename Tag, int NT, int KS = 3>
 __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p) {
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
   constexpr int ES = 16 / E;
-  constexpr int WPIECES = 9 * NT * 64;                 // 16-byte pieces of one chunk's weights
+  constexpr int NTAP = KS * KS;
+  constexpr int WPIECES = NTAP * NT * 64;              // 16-byte pieces of one chunk's weights
   constexpr int WITER = (WPIECES + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [A: HBUF][W: 9*NT KiB]
   unsigned char* const sA = smem;
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
   // residual prefetch: issued BEFORE the main loop so its HBM latency overlaps the staging + MFMA work instead of
   // adding a second serial memory round trip in the epilogue (these layers are latency-bound).  Also satisfies the
   // "all residual loads before the first store" rule (res may alias out).
+  const int OH = p.H + (3 - KS), OW = p.W + (3 - KS);             // output extent (k = 2, pad 1: one more row / column than the input)
   const int ox = x0 + x;
   const int chq = q * 4 * NT;
   long long obase[2];
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int oy = y0 + 2 * wave + mt;
-    rok[mt] = (oy < p.H) & (ox < p.W);
+    rok[mt] = (oy < OH) & (ox < OW);
     obase[mt] = p.o_base + (long long)b * p.o_sb + (long long)oy * p.o_sy + (long long)ox * p.o_sx + chq;
   }
   f32x4 rv[2][NT];
@@ -725,8 +730,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
     }
     __syncthreads();
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, s2 = tap - 3 * r;
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int r = tap / KS, s2 = tap - KS * r;
       const unsigned char* ab = sA + a_lane + (r * HPW + s2) * 16;
       const u32x4 a0 = *(const u32x4*)(ab);
       const u32x4 a1 = *(const u32x4*)(ab + HPW * 16);
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
   }
 
   // ---- epilogue: lane (x, q): pixel (y0 + 2*wave + mt, x0 + x), channels 4*NT*q + 4*nt + {0..3}
-  if (ox >= p.W) return;
+  if (ox >= OW) return;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     if (!rok[mt]) continue;
@@ -1308,7 +1313,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_persist_kernel(const HaloPa
 // channel 4*NT*qr + 4*nt + reg.
 template <typename Tag>
 __global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int NT,
-                                          int perm, size_t total) {
+                                          int perm, size_t total, int ntap = 9) {
   constexpr int E = Tag::E;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -1316,13 +1321,13 @@ __global__ void pack_halo_s_weight_kernel(const float* __restrict__ w, void* __r
   const int lane = (int)((i / E) % 64);
   size_t blk = i / (E * 64);
   const int nt = (int)(blk % NT); blk /= NT;
-  const int tap = (int)(blk % 9);
-  const int c = (int)(blk / 9);
+  const int tap = (int)(blk % ntap);
+  const int c = (int)(blk / ntap);
   const int row = lane & 15, kq = lane >> 4;
   const int n = perm ? (row >> 2) * 4 * NT + nt * 4 + (row & 3) : nt * 16 + row;
   const int cin = c * (4 * E) + kq * E + e;
   float v = 0.f;
-  if (n < Cout && cin < Cin) v = w[((size_t)n * Cin + cin) * 9 + tap];
+  if (n < Cout && cin < Cin) v = w[((size_t)n * Cin + cin) * ntap + tap];
   store_elem<Tag>(out, i, v);
 }
 
@@ -1640,6 +1645,62 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
     if (NT == 1) CP_LAUNCH((basicblock_fused_kernel<BF16Tag, 1>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
     else CP_LAUNCH((basicblock_fused_kernel<BF16Tag, 2>), dim3((unsigned)tt), dim3(256), lds, st, p, packed_w2, scale2, shift2);
   }
+  return cp_check_launch();
+}
+
+// ---- k = 2 / stride 1 / pad 1 conv with <= 80 output channels (conv3x3_halo_s_kernel<.., KS = 2>)
+extern "C" int cp_conv2x2_halo_supported(int dtype, int H, int W, int Cout_phys) {
+  return ((dtype == CP_F32 || dtype == CP_BF16) && H >= 7 && W >= 15 && Cout_phys > 0 && Cout_phys % 4 == 0 && Cout_phys <= 80) ? 1 : 0;
+}
+
+extern "C" size_t cp_packed_conv2x2_halo_weight_bytes(int dtype, int Cout, int Cin_phys) {
+  const int E = cp_chan_align(dtype);
+  const size_t nchunk = ((size_t)Cin_phys + 4 * E - 1) / (4 * E);
+  return nchunk * 4 * (((size_t)Cout + 15) / 16) * 1024;           // [chunk][tap][nt][lane][16 B]
+}
+
+extern "C" int cp_pack_conv2x2_halo_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed) {
+  if (!w || !packed || Cout <= 0 || Cout > 80 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  const int E = cp_chan_align(dtype);
+  if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const size_t total = cp_packed_conv2x2_halo_weight_bytes(dtype, Cout, cin_phys) / cp_elem_size(dtype);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  const int NT = (Cout + 15) / 16;
+  if (dtype == CP_F32)
+    CP_LAUNCH(pack_halo_s_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total, 4);
+  else
+    CP_LAUNCH(pack_halo_s_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, NT, 1, total, 4);
+  return cp_check_launch();
+}
+
+extern "C" int cp_conv2x2_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
+                               const float* shift, const void* residual, void* out) {
+  if (!d || d->R != 2 || d->S != 2 || d->stride != 1 || d->pad != 1 || d->Ho != d->H + 1 || d->Wo != d->W + 1) return CP_ERR_INVALID;
+  if (!cp_conv2x2_halo_supported(d->dtype, d->H, d->W, d->Cout)) return CP_ERR_INVALID;
+  CpConvDesc d3 = *d;                      // the shared checks are the 3x3 kernel's; extents and weight size are set here
+  d3.R = d3.S = 3; d3.Ho = d->H; d3.Wo = d->W;
+  HaloParams p;
+  long long tt;
+  const int rcb = build_halo_params(&d3, in, packed_w, scale, shift, residual, out, &p, &tt);
+  if (rcb) return rcb;
+  p.tiles_x = (d->Wo + HTW - 1) / HTW; p.tiles_y = (d->Ho + HTH - 1) / HTH;
+  tt = (long long)d->B * p.tiles_x * p.tiles_y;
+  if (tt >= (1LL << 28)) return CP_ERR_RANGE;
+  p.total_tiles = (int)tt;
+  p.w_bytes = (uint32_t)cp_packed_conv2x2_halo_weight_bytes(d->dtype, d->Cout, d->Cin);
+  const int NT = (d->Cout + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = HBUF + (size_t)4 * NT * 1024;
+#define CP_HS2(TAG, N) CP_LAUNCH((conv3x3_halo_s_kernel<TAG, N, 2>), dim3((unsigned)tt), dim3(256), lds, st, p)
+  if (d->dtype == CP_F32) {
+    switch (NT) { case 1: CP_HS2(F32Tag, 1); break; case 2: CP_HS2(F32Tag, 2); break; case 3: CP_HS2(F32Tag, 3); break;
+                  case 4: CP_HS2(F32Tag, 4); break; default: CP_HS2(F32Tag, 5); break; }
+  } else {
+    switch (NT) { case 1: CP_HS2(BF16Tag, 1); break; case 2: CP_HS2(BF16Tag, 2); break; case 3: CP_HS2(BF16Tag, 3); break;
+                  case 4: CP_HS2(BF16Tag, 4); break; default: CP_HS2(BF16Tag, 5); break; }
+  }
+#undef CP_HS2
   return cp_check_launch();
 }
 

@@ -24,6 +24,8 @@ USE_UP_FUSED = os.environ.get("CHECKERPOSE_AMD_UP_FUSED", "1") != "0"   # decode
 USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet fuse layers: first-level convs grouped by source branch
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
+USE_HALO2 = os.environ.get("CHECKERPOSE_AMD_HALO2", "1") != "0"     # k = 2 / pad 1 convs on the LDS-staged halo kernel (A/B: the generic kernel)
+HALO2_MIN_PIXELS = int(os.environ.get("CHECKERPOSE_AMD_HALO2_MIN_PIXELS", "16384"))   # below: the generic kernel (split-K at small batch)
 USE_CHAIN_TAIL = os.environ.get("CHECKERPOSE_AMD_CHAIN_TAIL", "1") != "0"   # the 64x64 chain launch also runs the stride-2 fuse convs that read its output
 FUSE_OUT_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_MIN_BATCH", "1"))   # grouped first-level fuse-layer launches: at every batch
 #   (after per-conv branches too; 350 -> 317 graph nodes below 40 crops: B = 1 1.60 -> 1.58 ms, B = 8 1.88 -> 1.68, B = 32 3.10 -> 2.99; -1: with the chains)
@@ -326,6 +328,11 @@ class Program:
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
                    and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= self.chain_min
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
+        # k = 2 / pad 1 (Index2Feat's patch_generator over the whole map): the small-Cout halo kernel with four taps
+        halo2 = (USE_HALO2 and self.dtype == CP_BF16 and R == 2 and S == 2 and stride == 1 and pad == 1 and ostr is None and not out_f32
+                 and not transposed and row_map is None and x.B * x.H * x.W >= HALO2_MIN_PIXELS and not hasattr(self.ws, "passthrough")   # (eval
+                 # programs: the training program repacks its weights every step through the pack-item tables)
+                 and bool(self.lib.cp_conv2x2_halo_supported(self.dtype, x.H, x.W, _rup(wCout, self.E))))
         if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small)
                 and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
                                                     R * S * x.Cphys, _rup(wCout, self.E))):
@@ -342,6 +349,17 @@ class Program:
                 self.ws.cache[ck] = buf
             packed = self.ws.cache[ck]
             halo = gemm = False
+        elif halo2:
+            ck = ("halo2", wkey, x.Cphys)
+            if ck not in self.ws.cache:
+                buf = torch.empty(self.lib.cp_packed_conv2x2_halo_weight_bytes(self.dtype, wCout, x.Cphys), dtype=torch.uint8, device=self.device)
+                wc = w.contiguous()
+                self.ws.keep.append(wc)
+                st_ = torch.cuda.current_stream(self.device).cuda_stream
+                _abi.check(self.lib.cp_pack_conv2x2_halo_weight(st_, self.dtype, wc.data_ptr(), wCout, wCin, x.Cphys, buf.data_ptr()),
+                           "cp_pack_conv2x2_halo_weight(%s)" % wkey)
+                self.ws.cache[ck] = buf
+            packed = self.ws.cache[ck]
         elif halo:
             packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
         elif gemm:
@@ -373,6 +391,8 @@ class Program:
             assert (residual.cstride, residual.coff, residual.H, residual.W) == (out.cstride, out.coff, out.H, out.W), \
                 "residual must share the output layout"
         fn = self.lib.cp_conv3x3_halo if halo else (self.lib.cp_gemm_rows if gemm else self.lib.cp_conv2d_igemm)
+        if halo2:
+            fn = self.lib.cp_conv2x2_halo
         dref = C.byref(d)
         pw, ps, pt = packed.data_ptr(), sc.data_ptr(), sh.data_ptr()
         xtb = x.tbuf
@@ -380,6 +400,8 @@ class Program:
             fam = "conv3x3_halo_s" if wCout <= 80 else ("conv3x3_halo4" if wCout % 256 == 0 else "conv3x3_halo")
         else:
             fam = "gemm_rows" if gemm else "conv_igemm"
+        if halo2:
+            fam = "conv3x3_halo_s"
         if s2small:
             fam = "conv3x3_s2_small"
             self._add(self.lib.cp_conv3x3_s2_small, lambda P: (dref, P(xtb), pw, ps, pt, P(otb)), fam + ":" + wkey, [xtb], [otb])

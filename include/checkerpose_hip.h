@@ -123,6 +123,16 @@ int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, con
  * and packed on the host (weights packed as for cp_conv3x3_halo); cp_conv3x3_halo_group: items in device memory, prefix = exclusive
  * prefix sum (n_items + 1) of item.blocks, lds_bytes = the largest item.lds_bytes.  Results are bit-identical to the single launches.
  * A residual may alias the output (in-place accumulation) but no two items may write the same tensor. */
+/* k = 2 / stride 1 / pad 1 conv with <= 80 output channels off the same LDS-staged halo tile (Index2Feat_module.patch_generator,
+ * pipeline.py:223-240, where it runs over the whole map: N = 4096 keypoints, the low-resolution stages at N = 512): descriptor as
+ * cp_conv2d_igemm with R = S = 2, stride 1, pad 1, Ho = H + 1, Wo = W + 1, o_sc = 1; weights by cp_pack_conv2x2_halo_weight from the
+ * fp32 (Cout, Cin, 2, 2) tensor; scale / shift / residual / activation as cp_conv3x3_halo. */
+int cp_conv2x2_halo_supported(int dtype, int H, int W, int Cout_phys);
+size_t cp_packed_conv2x2_halo_weight_bytes(int dtype, int Cout, int Cin_phys);
+int cp_pack_conv2x2_halo_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed);
+int cp_conv2x2_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
+                    const float* shift, const void* residual, void* out);
+
 typedef struct CpConvGroupItem {
   int32_t NT; uint32_t blocks, lds_bytes, pad;
   unsigned long long params[25];       /* opaque: the kernel's parameter block */

@@ -195,6 +195,47 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
+@pytest.mark.parametrize("case", [(2, 256, 16, 16, 64, ACT_NONE), (1, 64, 13, 21, 64, ACT_RELU), (3, 40, 32, 32, 24, ACT_LEAKY), (1, 256, 64, 64, 64, ACT_NONE)])
+def test_conv2x2_halo_vs_torch_cpu(lib, dtype, case):
+    """cp_conv2x2_halo (k = 2 / stride 1 / pad 1 on the LDS-staged halo tile: Index2Feat_module.patch_generator, pipeline.py:223-240)
+    == F.conv2d(x, w, padding=1) * scale + shift (+ act): the (H + 1) x (W + 1) output incl. its last row / column (which see only
+    zero padding below / right), ragged tiles, a channel count that is not a multiple of the chunk, pad channels zero."""
+    B, Cin, H, W, Cout, act = case
+    E = 8 if dtype == CP_BF16 else 4
+    x = det_tensor("c2x%s" % (case[:5],), (B, Cin, H, W))
+    w = det_tensor("c2w%s" % (case[:5],), (Cout, Cin, 2, 2), (2.0 / (Cin * 4)) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("c2s%s" % (case[:5],), (Cout,))
+    shift = 0.2 * det_tensor("c2t%s" % (case[:5],), (Cout,))
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref) if act == ACT_RELU else (F.leaky_relu(ref, 0.2) if act == ACT_LEAKY else ref)
+    xin = to_cl(x, dtype)
+    cip, cop = xin.shape[-1], rup(Cout, E)
+    assert lib.cp_conv2x2_halo_supported(dtype, H, W, cop) == 1 and lib.cp_conv2x2_halo_supported(dtype, H, W, 96) == 0
+    pw = torch.empty(lib.cp_packed_conv2x2_halo_weight_bytes(dtype, Cout, cip), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv2x2_halo_weight(st(), dtype, wd.data_ptr(), Cout, Cin, cip, pw.data_ptr()), "pack 2x2")
+    n16 = rup(Cout, 16)
+    sc = torch.zeros(n16); sc[:Cout] = scale
+    sh = torch.zeros(n16); sh[:Cout] = shift
+    sc, sh = sc.to(dev()), sh.to(dev())
+    Ho, Wo = H + 1, W + 1
+    d = CpConvDesc()
+    d.dtype, d.out_f32, d.B, d.H, d.W = dtype, 0, B, H, W
+    d.Cin, d.in_cstride, d.in_coff = cip, cip, 0
+    d.R, d.S, d.stride, d.pad, d.Ho, d.Wo, d.Cout, d.act, d.slope = 2, 2, 1, 1, Ho, Wo, cop, act, 0.2
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, Ho * Wo * cop, Wo * cop, cop, 1
+    out = torch.full((B, Ho, Wo, cop), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_conv2x2_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()), "conv 2x2")
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any(), "every output element must be written"
+    if cop > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+    close(from_cl(out, Cout), ref, TOL[dtype])
+    d.Ho = H                                              # wrong output extent -> loud error
+    assert lib.cp_conv2x2_halo(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()) == -1
+
+
+@pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 def test_conv3x3_halo_group_bitwise_equals_single_launches(lib, dtype):
     """cp_conv3x3_halo_group (several independent small 3x3 convs in ONE launch: the branches of an HRNet module at equal depth,
     training forward and data-gradient) == cp_conv3x3_halo layer by layer, bit for bit: 18 / 36 / 72 / 64 / 80-channel layers on
