@@ -31,6 +31,19 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float cp_act_slope(int act, float slope) { return act == 1 ? 0.f : (act == 2 ? slope : 1.f); }   // CP_ACT_RELU, CP_ACT_LEAKY
 __device__ __forceinline__ float cp_act_apply(float v, float s) { return fmaxf(v, fmaf(v, s, 0.f)); }
 
+// ---- LDS-DMA (global memory -> LDS without registers) in its BUFFER form, 16 bytes per lane: lane l writes LDS bytes [dst + 16 l, + 16).
+// The global form (global_load_lds_dwordx4) is FLAT-encoded, and hipcc's waitcnt insertion treats a pending FLAT access that may touch
+// LDS as unordered with the wave's ds_reads: from the first DMA on every LDS wait of the kernel is lgkmcnt(0).  With the buffer form the
+// counted waits come back -- worth 4-8 % on edgeconv_fused (72.6 -> 69.5 us), nothing on hr_chain, and a loss on edgeconv_tiled2
+// (the compiler then also guards ds_reads behind the DMA with vmcnt(0), and spills): each kernel picks its form by measurement.
+// `off` = byte offset from the descriptor's base (< 4 GB); completion is tracked by vmcnt either way.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cp_dma_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void cp_lds_dma16(__amdgpu_buffer_rsrc_t rs, uint32_t off, void* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
+}
+
 // relu of two packed bf16 values: the sign bit is the int16 sign bit, so max(int16, 0) per half (-0.0 -> +0.0 as fmaxf does)
 typedef short cp_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {

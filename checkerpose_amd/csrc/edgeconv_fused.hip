@@ -55,15 +55,14 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
   const int b = blockIdx.x;
   const int nslice = p.Cout / 64;
 
-  const u32x4* const wg = (const u32x4*)p.w;
+  const __amdgpu_buffer_rsrc_t wrs = cp_dma_rsrc(p.w);          // buffer-form DMA: keeps the gather's LDS waits counted (common.h)
   auto w_issue = [&](int u) {                               // u = 2 slice + half -> buffer u & 1
     constexpr int PIECES = HALF / 16;
 #pragma unroll
     for (int k = 0; k < (PIECES + 511) / 512; ++k) {
       const int i0 = wave * 64 + 512 * k;
       if (i0 < PIECES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)u * PIECES + i0 + lane),
-                                         (__attribute__((address_space(3))) void*)(sW + (u & 1) * EF_WBUF + i0 * 16), 16, 0, 0);
+        cp_lds_dma16(wrs, (uint32_t)(((size_t)u * PIECES + i0 + lane) * 16), sW + (u & 1) * EF_WBUF + i0 * 16);
     }
   };
   w_issue(0);
