@@ -93,6 +93,7 @@ class WeightStore:
         self.E = lib.cp_chan_align(dtype)
         self.cache = {}
         self.keep = []   # keep temporaries alive until packing kernels ran
+        self.repacks_every_step = False      # trainer.TrainWeightStore: True
 
     def _w(self, key):
         t = self.sd[key]
@@ -330,8 +331,8 @@ class Program:
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
         # k = 2 / pad 1 (Index2Feat's patch_generator over the whole map): the small-Cout halo kernel with four taps
         halo2 = (USE_HALO2 and self.dtype == CP_BF16 and R == 2 and S == 2 and stride == 1 and pad == 1 and ostr is None and not out_f32
-                 and not transposed and row_map is None and x.B * x.H * x.W >= HALO2_MIN_PIXELS and not hasattr(self.ws, "passthrough")   # (eval
-                 # programs: the training program repacks its weights every step through the pack-item tables)
+                 and not transposed and row_map is None and x.B * x.H * x.W >= HALO2_MIN_PIXELS and not self.ws.repacks_every_step   # (eval programs:
+                 # the training program repacks its weights every step through the pack-item tables, which have no entry for this image)
                  and bool(self.lib.cp_conv2x2_halo_supported(self.dtype, x.H, x.W, _rup(wCout, self.E))))
         if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small)
                 and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),

@@ -33,6 +33,7 @@ class TrainWeightStore(WeightStore):
         super().__init__(lib, sd, dtype, device)
         self.prog = None
         self.passthrough = set()
+        self.repacks_every_step = True
 
     def _item(self, rc, item, what):
         _abi.check(rc, what)
