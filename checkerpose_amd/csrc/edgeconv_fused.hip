@@ -58,11 +58,13 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
   const __amdgpu_buffer_rsrc_t wrs = cp_dma_rsrc(p.w);          // buffer-form DMA: keeps the gather's LDS waits counted (common.h)
   auto w_issue = [&](int u) {                               // u = 2 slice + half -> buffer u & 1
     constexpr int PIECES = HALF / 16;
+    int ln = lane;                                          // opaque per call: hoisted out of the slice loop, the lane's piece offsets were
+    asm volatile("" : "+v"(ln));                            // spilled and their scratch reloads (VMEM) put a vmcnt(0) in front of every DMA
 #pragma unroll
     for (int k = 0; k < (PIECES + 511) / 512; ++k) {
       const int i0 = wave * 64 + 512 * k;
       if (i0 < PIECES)
-        cp_lds_dma16(wrs, (uint32_t)(((size_t)u * PIECES + i0 + lane) * 16), sW + (u & 1) * EF_WBUF + i0 * 16);
+        cp_lds_dma16(wrs, (uint32_t)(((size_t)u * PIECES + i0 + ln) * 16), sW + (u & 1) * EF_WBUF + i0 * 16);
     }
   };
   w_issue(0);

@@ -235,6 +235,21 @@ struct MlpPairParams {
 // slot (in 16-byte pieces) of piece `pc` of tile row `r` in an image of P pieces per row
 __device__ __forceinline__ int mp_slot(int r, int pc, int P) { return r * P + (pc & ~15) + ((pc ^ r) & 15); }
 
+#ifdef CP_DEBUG_KNOBS          // phase clock of workgroup 0 (tools/mlp_stamps.py): s_memtime sums per wave, `make KNOBS=1` builds only
+__device__ unsigned long long mp_stamps[12][8];
+#define MP_T0() unsigned long long mp_t = __builtin_amdgcn_s_memtime(), mp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MP_MARK(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); mp_acc[k] += n_ - mp_t; mp_t = n_; } while (0)
+#define MP_DUMP() do { if (blockIdx.x == 0 && lane == 0) for (int k_ = 0; k_ < 8; ++k_) mp_stamps[wave][k_] = mp_acc[k_]; } while (0)
+#else
+#define MP_T0() do {} while (0)
+#define MP_MARK(k) do {} while (0)
+#define MP_DUMP() do {} while (0)
+#endif
+
+#ifndef MP_L2B
+#define MP_L2B 2
+#endif
+constexpr int L2B = MP_L2B;
 template <int NI>                                            // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
 __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -246,8 +261,6 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x = lane & 15, q = lane >> 4;
-  const int qx = q ^ x;
   const bool l1 = wave < 8;
 
   u32x4 W[32];                                                // layer 1: [kc 0..15][t 0..1]; layer 2: [kc 0..7][t 0..3]
@@ -275,9 +288,15 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
   const int step = gridDim.x;
   const int npiece = p.nchunk1 * 4;
   auto dma_tile = [&](int rt, int buf) {
+    // The lane's piece offsets are loop invariants: hipcc hoisted them out of the tile loop as NI 64-bit pairs, spilled them (the
+    // layer-1 waves hold 128 weight registers) and reloaded them in front of every DMA -- and a scratch reload is a VMEM load:
+    // using it needs vmcnt(0), i.e. it waited for the tile DMA'd one iteration ago (38 % of a layer-1 wave's time by the phase
+    // clock, tools/mlp_stamps.py).  An opaque copy of the lane id keeps the arithmetic (a dozen VALU instructions per piece) inside.
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int slot = (wave * NI + j) * 64 + lane;
+      const int slot = (wave * NI + j) * 64 + ln;
       const int r = slot / P, s_ = slot - r * P;
       int pc = (s_ & ~15) + ((s_ ^ r) & 15);
       if (pc >= npiece) pc = 0;
@@ -301,28 +320,49 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
   // iteration it: layer 1 on tile rt (sX[it % 3] -> sH[it & 1]) while tile rt + 2 step streams into sX[(it + 2) % 3]; layer 2 on
   // tile rt - step (sH[(it - 1) & 1])
   int it = 0, xb = 0;
+  MP_T0();
   for (int rt = blockIdx.x; rt - step < p.n_rt; rt += step, ++it) {
     if (l1) {
       const int nb = xb >= 1 ? xb - 1 : 2;                    // (it + 2) % 3
       dma_tile(rt + 2 * step < p.n_rt ? rt + 2 * step : blockIdx.x, nb);       // always NI pieces: the vmcnt arithmetic below counts them
+      MP_MARK(0);                                             // DMA issue
       if (rt < p.n_rt) {
+        // (lane geometry from an opaque copy of the lane id, per iteration: hoisted out of the loop these few values were spilled
+        //  beside the 128 weight registers, and their scratch reloads -- VMEM loads -- each cost a vmcnt(0) on the tile DMA in flight)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int x = ln & 15, q = ln >> 4, qx = q ^ x;
         f32x4 acc[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // piece 4 kc + q of row 16 f + x sits at slot (kc >> 2) * 16 + ((4 (kc & 3)) ^ q ^ x) of its row (mp_slot): a lane constant
         // XOR one of four compile-time values
         const unsigned char* const xbp = sX + xb * XBUF + x * (P * 16);
+        // two K chunks per step: four fragment reads, then eight MFMAs.  (Every LDS wait in this kernel is lgkmcnt(0) -- the FLAT-encoded
+        // LDS-DMA makes hipcc's wait insertion conservative, common.h -- so a step pays one LDS round trip whatever it reads; the phase
+        // clock, tools/mlp_stamps.py, had the chunk-at-a-time form at 16 exposed round trips per tile.)
 #pragma unroll
-        for (int kc = 0; kc < 16; ++kc) {
-          if (kc < NI * 4) {                                  // compile-time
+        for (int k2 = 0; k2 < NI * 2; ++k2) {
+          u32x4 a[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-              const u32x4 a = *(const u32x4*)(xbp + f * (16 * P * 16) + (kc >> 2) * 256 + (((4 * (kc & 3)) ^ qx) << 4));
-              acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2]), __builtin_bit_cast(bf16x8, a), acc[f][0], 0, 0, 0);
-              acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2 + 1]), __builtin_bit_cast(bf16x8, a), acc[f][1], 0, 0, 0);
+              const int kc = 2 * k2 + h;
+              a[h][f] = *(const u32x4*)(xbp + f * (16 * P * 16) + (kc >> 2) * 256 + (((4 * (kc & 3)) ^ qx) << 4));
             }
-          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+              const int kc = 2 * k2 + h;
+              acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2]), __builtin_bit_cast(bf16x8, a[h][f]), acc[f][0], 0, 0, 0);
+              acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2 + 1]), __builtin_bit_cast(bf16x8, a[h][f]), acc[f][1], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
         }
+        MP_MARK(1);                                           // layer-1 MFMA loop
         // lane (x, q): rows 16 f + x, hidden channels 32 wave + 8 q + {0..7} = piece 4 wave + q
         const int ch = wave * 32 + q * 8;
         const f32x4 t0 = *(const f32x4*)(sAff + ch), t1 = *(const f32x4*)(sAff + ch + 4);
@@ -337,9 +377,14 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
           *(u32x4*)(sH + (it & 1) * MP_HBUF + (f * 16 + x) * (MP_HP * 16) + (wave >> 2) * 256 + (((4 * (wave & 3)) ^ qx) << 4)) = Vec16<BF16Tag>::pack(v);
         }
       }
+      MP_MARK(2);                                             // layer-1 epilogue
       __builtin_amdgcn_s_waitcnt(0x0070 | NI);                // vmcnt(NI), lgkmcnt(0): the tile of the NEXT iteration has landed
+      MP_MARK(3);                                             // DMA wait
     } else {
       if (it > 0) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int x = ln & 15, q = ln >> 4, qx = q ^ x;
         const int wv = wave - 8;
         const unsigned char* const hb = sH + ((it - 1) & 1) * MP_HBUF + x * (MP_HP * 16);
         const int ch = wv * 64 + q * 8;
@@ -349,11 +394,20 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kc = 0; kc < 8; ++kc) {
-            const u32x4 a = *(const u32x4*)(hb + f * (16 * MP_HP * 16) + (kc >> 2) * 256 + (((4 * (kc & 3)) ^ qx) << 4));
+          for (int k4 = 0; k4 < 8 / L2B; ++k4) {                // L2B K chunks per step (see layer 1): 8 / L2B LDS round trips per fragment
+            u32x4 a[L2B];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 4 + t]), __builtin_bit_cast(bf16x8, a), acc[t], 0, 0, 0);
+            for (int h = 0; h < L2B; ++h) {
+              const int kc = L2B * k4 + h;
+              a[h] = *(const u32x4*)(hb + f * (16 * MP_HP * 16) + (kc >> 2) * 256 + (((4 * (kc & 3)) ^ qx) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < L2B; ++h)
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[(L2B * k4 + h) * 4 + t]), __builtin_bit_cast(bf16x8, a[h]), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
           const long long m = (long long)(rt - step) * MP_ROWS + f * 16 + x;
 #pragma unroll
@@ -370,14 +424,24 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
           }
         }
       }
+      MP_MARK(5);                                             // layer 2 (both fragments, stores issued)
       __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0) only: this wave's stores stay in flight
+      MP_MARK(6);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    MP_MARK(4);                                               // barrier
     xb = xb == 2 ? 0 : xb + 1;
   }
+  MP_DUMP();
 }
+
+#ifdef CP_DEBUG_KNOBS
+extern "C" int cp_debug_mlp_pair_stamps(unsigned long long* out96) {       // 12 waves x 8 phase sums of workgroup 0's last launch
+  return hipMemcpyFromSymbol(out96, HIP_SYMBOL(mp_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+#endif
 
 static size_t mlp_pair_lds(int P) { return (size_t)3 * MP_ROWS * P * 16 + 2 * MP_HBUF + 2 * 256 * 4; }
 
