@@ -250,6 +250,9 @@ __device__ unsigned long long mp_stamps[12][8];
 #define MP_L2B 2
 #endif
 constexpr int L2B = MP_L2B;
+#ifndef MP_L2PRIO
+#define MP_L2PRIO 3
+#endif
 template <int NI>                                            // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
 __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -319,7 +322,8 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
 
   // iteration it: layer 1 on tile rt (sX[it % 3] -> sH[it & 1]) while tile rt + 2 step streams into sX[(it + 2) % 3]; layer 2 on
   // tile rt - step (sH[(it - 1) & 1])
-  int it = 0, xb = 0;
+  if (!l1) __builtin_amdgcn_s_setprio(MP_L2PRIO);             // the four layer-2 waves are the tile loop's critical path (phase clock: 91 % busy
+  int it = 0, xb = 0;                                         // against 70 % of the layer-1 waves they share the SIMDs with): they issue first
   MP_T0();
   for (int rt = blockIdx.x; rt - step < p.n_rt; rt += step, ++it) {
     if (l1) {
