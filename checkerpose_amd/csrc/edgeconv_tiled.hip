@@ -424,11 +424,21 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
   const int nchunk = 8 + p.HPAD / 64;
   uint32_t srcoff[NPC];
   auto piece_rows = [&](const int32_t* hsrc) {
+    // every piece reads a halo id UNCONDITIONALLY (own-row pieces: entry 0) and selects afterwards: with the load inside the
+    // `ch < 8 ? own : halo` branch each piece became a basic block of its own -- load, vmcnt(0), use -- seven global round trips
+    // one after the other at the head of every workgroup (the "prologue" of the in-kernel clock)
+    int hv[NPC];
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       const int c = wave + 8 * i;
       const int ch = c % nchunk, slot = ch * 64 + lane;
-      srcoff[i] = c < 4 * nchunk ? (uint32_t)(ch < 8 ? t * ET_BLK + slot : hsrc[slot - ET_BLK]) * 16u : 0u;
+      hv[i] = hsrc[(c < 4 * nchunk && ch >= 8) ? slot - ET_BLK : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int c = wave + 8 * i;
+      const int ch = c % nchunk, slot = ch * 64 + lane;
+      srcoff[i] = c < 4 * nchunk ? (uint32_t)(ch < 8 ? t * ET_BLK + slot : hv[i]) * 16u : 0u;
     }
   };
   auto table_piece = [&](int s, int i) {
@@ -455,11 +465,23 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
   wh_issue(0);
   wh_issue(1);
   {
-    const int16_t* gi = p.nbr + ((size_t)g * p.NB + t) * ET_BLK * p.K;      // K == ET_KMAX (checked by the entry point): 16-byte copies
-    for (int i = tid; i < ET_BLK * ET_KMAX / 8; i += 512) {          // staged as BYTE offsets into a table plane
-      u32x4 v = ((const u32x4*)gi)[i];
+    // K == ET_KMAX (checked by the entry point): 16-byte copies, staged as BYTE offsets into a table plane.  All of a thread's pieces are
+    // loaded before the first is written (the copy loop compiled to load - vmcnt(0) - write per piece, and -- from an int16_t pointer --
+    // to four dword loads per piece: three to six global round trips in a row at the head of every workgroup)
+    const u32x4* const gi4 = (const u32x4*)__builtin_assume_aligned(p.nbr + ((size_t)g * p.NB + t) * ET_BLK * p.K, 16);
+    constexpr int NLP = (ET_BLK * ET_KMAX / 8 + 511) / 512;
+    u32x4 lv[NLP];
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int i = tid + 512 * k;
+      lv[k] = gi4[i < ET_BLK * ET_KMAX / 8 ? i : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int i = tid + 512 * k;
+      u32x4 v = lv[k];
       v.x = (v.x & 0x0fff0fffu) << 4; v.y = (v.y & 0x0fff0fffu) << 4; v.z = (v.z & 0x0fff0fffu) << 4; v.w = (v.w & 0x0fff0fffu) << 4;
-      ((u32x4*)sIdx)[i] = v;
+      if (i < ET_BLK * ET_KMAX / 8) ((u32x4*)sIdx)[i] = v;
     }
   }
   for (int i = tid; i < p.Cout; i += 512) { sScale[i] = p.scale[p.Cout + i]; sShift[i] = p.shift[p.Cout + i]; }
