@@ -92,6 +92,17 @@ __device__ __forceinline__ void stage0(const Chain0Params& p, unsigned char* sme
   }
 }
 
+#ifdef CP_DEBUG_KNOBS          // phase clock of workgroup 0 (tools/chain0_stamps.py): s_memtime sums per wave, `make KNOBS=1` builds only
+__device__ unsigned long long z_stamps[8][8];
+#define Z_T0() unsigned long long z_t = __builtin_amdgcn_s_memtime(), z_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define Z_MARK(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); z_acc[k] += n_ - z_t; z_t = n_; } while (0)
+#define Z_DUMP() do { if (blockIdx.x == 0 && lane == 0) for (int k_ = 0; k_ < 8; ++k_) z_stamps[wave][k_] = z_acc[k_]; } while (0)
+#else
+#define Z_T0() do {} while (0)
+#define Z_MARK(k) do {} while (0)
+#define Z_DUMP() do {} while (0)
+#endif
+
 __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const sAff = (float*)(smem + 2 * ZPL16 + ZPL4);          // [2][2][32]
@@ -178,11 +189,13 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
     }
   };
 
+  Z_T0();
   u32x4 hold[4];                               // wave 7: the band's last row, written one band later
 #pragma unroll
   for (int f = 0; f < 4; ++f) hold[f] = u32x4{0u, 0u, 0u, 0u};
   const size_t gpix0 = (size_t)b * ZH * ZW;
 
+  Z_MARK(0);                                   // prologue: weights, ring, staging
 #pragma unroll 1
   for (int cv = 0; cv < 8; ++cv) {
     float affv = 0.f;
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
           Wf[kc][1] = wn[(kc * 2 + 1) * 64 + lane];
         }
       }
+      Z_MARK(1);                       // band: fragment reads + MFMAs
       // ---- epilogue: lane (x, q) holds channels 8q .. 8q+7 of pixel (row, 16 f + x)
       u32x4 v[4];
       if (q < 3) {                     // (+ residual), round, ReLU on the packed pairs (bf16 keeps the sign bit: max(int16, 0))
@@ -243,7 +257,9 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
           if (second) ((u32x4*)p.out)[(gpix0 + row * ZW + f * 16 + x) * 3 + q] = v[f];
         }
       }
+      Z_MARK(2);                       // band epilogue
       __syncthreads();                 // every wave has read this band's input rows (8 band - 1 .. 8 band + 8)
+      Z_MARK(3);                       // band barrier
       // ---- lagged write-back: rows 8 band .. 8 band + 6 now; row 8 band + 7 (wave 7) one band later
       auto put = [&](const u32x4* vv, int r) {
         if (q < 3) {
@@ -264,7 +280,9 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
       }
     }
     if (tid < 2 * ZAFF) sAff[((cv + 1) & 1) * 2 * ZAFF + tid] = affv;
+    Z_MARK(4);                         // write-back
     __syncthreads();                   // the conv's output map is complete
+    Z_MARK(5);                         // conv barrier
   }
 
   // ---- tail: 3x3 / stride 2 / pad 1 convs of the finished map (read-only from here on: no barriers).  Output 32 x 32: wave w owns
@@ -329,6 +347,8 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
       }
     }
   }
+  Z_MARK(6);                           // tail (stride-2 fuse convs)
+  Z_DUMP();
 }
 
 // [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
@@ -376,6 +396,13 @@ __global__ void pack_chain0_tail_kernel(const float* __restrict__ w, const float
 }
 
 }  // namespace
+
+#ifdef CP_DEBUG_KNOBS
+extern "C" int cp_debug_chain0_stamps(unsigned long long* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(z_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+#endif
+
 
 // entry points used by hr_chain.hip's dispatcher for (C, H, W) = (18, 64, 64)
 size_t cp_chain0_conv_bytes() { return ZCONV_W; }
