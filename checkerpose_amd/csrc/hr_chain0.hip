@@ -10,8 +10,10 @@
 // result for the last block) and the next block's second conv reads its residual back from there, pixel for pixel by the
 // lane that then overwrites it (prefetched at the start of the band, consumed in its epilogue).
 // LDS image: channel groups as planes -- [ch 0-7][px][16 B], [ch 8-15][px][16 B], [ch 16-17][px][4 B] -- so a crop costs
-// 36 B per pixel.  GEMM K order: the 18 (tap, 8-channel group) slots first, then the 9 (tap, 2 channels) slots: chunks 0-3 are
-// pure ds_read_b128, chunk 4 is mixed, chunks 5-6 read 4 bytes per lane (216 K slots -> 7 chunks instead of 9 x 32 -> 9).
+// 36 B per pixel.  GEMM K order: the 18 (tap, 8-channel group) slots first, then the 2-channel plane FOUR TAPS TO A GROUP (taps
+// 0-3, 4-7, 8): 21 groups of 8 -> 6 chunks (round 4; one group per tap made 27 -> 7 chunks, a seventh of the MFMAs and fragment
+// reads spent on zero weights).  Chunks 0-3 are pure ds_read_b128; chunk 4: lane groups q = 0, 1 read b128, q = 2, 3 four dwords
+// (four taps' 2-channel pairs) into the four registers of their operand quad; chunk 5: q = 0 one dword (tap 8), the rest zero weights.
 // Both tiles' weight fragments of a conv (14 KB) live in registers; the next conv's are loaded chunk by chunk during the
 // last band, each behind the last use of the fragment it replaces.
 #include "common.h"
@@ -23,7 +25,7 @@ constexpr int ZPLPX = (ZHP * ZWP + 15) / 16 * 16;        // 4368 ring pixels per
 constexpr int ZPL16 = ZPLPX * 16, ZPL4 = ZPLPX * 4;
 constexpr int ZAFF = 32;                                 // floats per scale / shift vector
 constexpr int ZLDS = 2 * ZPL16 + ZPL4 + 2 * 2 * ZAFF * 4;
-constexpr int ZKC = 7;
+constexpr int ZKC = 6;
 constexpr size_t ZCONV_W = (size_t)ZKC * 2 * 1024;
 static_assert(ZLDS <= 160 * 1024, "LDS budget");
 
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
 
   // ---- per-lane K-group geometry per chunk: byte offsets relative to the fragment's window-top-left pixel index pb
   //      (16-byte planes: + pb * 16; 4-byte plane: + pb * 4)
-  uint32_t o16[5], o4[3];                      // chunks 0..4 (b128 lanes), chunks 4..6 (b32 lanes)
+  uint32_t o16[5], o4[4], o4l;                 // chunks 0..4 (b128 lanes); chunk 4's four dword taps (q = 2: taps 0-3, q = 3: 4-7); chunk 5 (tap 8)
 #pragma unroll
   for (int kc = 0; kc < 5; ++kc) {
     const int G = 4 * kc + q;
@@ -149,12 +151,12 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
     o16[kc] = G < 18 ? (uint32_t)(cg * ZPL16 + (r * ZWP + s) * 16) : 0u;
   }
 #pragma unroll
-  for (int kc = 4; kc < 7; ++kc) {
-    const int G = 4 * kc + q;
-    const int tap = G - 18;
+  for (int e = 0; e < 4; ++e) {
+    const int tap = (q == 3 ? 4 : 0) + e;
     const int r = (tap * 11) >> 5, s = tap - 3 * r;
-    o4[kc - 4] = (G >= 18 && G < 27) ? (uint32_t)(2 * ZPL16 + (r * ZWP + s) * 4) : (uint32_t)(2 * ZPL16);
+    o4[e] = (uint32_t)(2 * ZPL16 + (r * ZWP + s) * 4);                  // (lanes q < 2 read them too -- valid addresses -- and keep their b128)
   }
+  o4l = (uint32_t)(2 * ZPL16 + (2 * ZWP + 2) * 4);                      // tap 8
   const bool small4 = q >= 2;                  // chunk 4: lanes q = 2, 3 read the 2-channel plane
 
   auto load_frags = [&](u32x4* a, int kc, uint32_t pb) {           // pb: window-top-left ring pixel index of fragment 0, this lane
@@ -162,14 +164,14 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
     for (int f = 0; f < 4; ++f) {
       const uint32_t px = pb + f * 16;
       if (kc < 4) a[f] = *(const u32x4*)(smem + o16[kc] + px * 16);
-      else if (kc == 4) {              // lanes q = 2, 3: K slots 1..7 of their group meet zero weights -- any finite data does (one select)
-        u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
-        const uint32_t sm = *(const uint32_t*)(smem + o4[0] + px * 4);
-        big.x = small4 ? sm : big.x;
-        a[f] = big;
+      else if (kc == 4) {              // lanes q = 2, 3: four taps' (2-channel) dwords; lanes q = 0, 1: channel groups 16, 17 of tap 8
+        const u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
+        const uint32_t s0 = *(const uint32_t*)(smem + o4[0] + px * 4), s1 = *(const uint32_t*)(smem + o4[1] + px * 4);
+        const uint32_t s2 = *(const uint32_t*)(smem + o4[2] + px * 4), s3 = *(const uint32_t*)(smem + o4[3] + px * 4);
+        a[f] = u32x4{small4 ? s0 : big.x, small4 ? s1 : big.y, small4 ? s2 : big.z, small4 ? s3 : big.w};
       } else {
-        a[f].x = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);     // K slots 2..7 of the group meet zero weights: the quad's other three
-      }                                                              // registers keep the (finite) activations of two chunks ago -- no 3 moves per fragment
+        a[f].x = *(const uint32_t*)(smem + o4l + px * 4);             // tap 8's pair (q = 0; the other lane groups and K slots 2..7 meet zero
+      }                                                              // weights: the quad keeps the finite activations of two chunks ago)
     }
   };
 
@@ -179,13 +181,13 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
       const uint32_t px = pbs[f];
       if (kc < 4) a[f] = *(const u32x4*)(smem + o16[kc] + px * 16);
       else if (kc == 4) {
-        u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
-        const uint32_t sm = *(const uint32_t*)(smem + o4[0] + px * 4);
-        big.x = small4 ? sm : big.x;
-        a[f] = big;
+        const u32x4 big = *(const u32x4*)(smem + o16[4] + px * 16);
+        const uint32_t s0 = *(const uint32_t*)(smem + o4[0] + px * 4), s1 = *(const uint32_t*)(smem + o4[1] + px * 4);
+        const uint32_t s2 = *(const uint32_t*)(smem + o4[2] + px * 4), s3 = *(const uint32_t*)(smem + o4[3] + px * 4);
+        a[f] = u32x4{small4 ? s0 : big.x, small4 ? s1 : big.y, small4 ? s2 : big.z, small4 ? s3 : big.w};
       } else {
-        a[f].x = *(const uint32_t*)(smem + o4[kc - 4] + px * 4);     // K slots 2..7 of the group meet zero weights: the quad's other three
-      }                                                              // registers keep the (finite) activations of two chunks ago -- no 3 moves per fragment
+        a[f].x = *(const uint32_t*)(smem + o4l + px * 4);             // tap 8's pair (q = 0; the other lane groups and K slots 2..7 meet zero
+      }                                                              // weights: the quad keeps the finite activations of two chunks ago)
     }
   };
 
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
 }
 
 // [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
-//   G < 18: tap G >> 1, input channel 8 (G & 1) + e;   18 <= G < 27: tap G - 18, input channel 16 + e (e < 2);   else zero.
+//   G < 18: tap G >> 1, input channel 8 (G & 1) + e;   18 <= G < 21: tap 4 (G - 18) + e / 2 (< 9), input channel 16 + (e & 1);   else zero.
 // tile row `row` of tile nt is output channel (row >> 2) * 8 + 4 nt + (row & 3).
 __global__ void pack_chain0_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, uint16_t* __restrict__ out, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,7 +367,7 @@ __global__ void pack_chain0_weight_kernel(const float* __restrict__ w, const flo
   const int G = kc * 4 + q;
   int tap = -1, cin = 0;
   if (G < 18) { tap = G >> 1; cin = (G & 1) * 8 + e; }
-  else if (G < 27 && e < 2) { tap = G - 18; cin = 16 + e; }
+  else if (G < 21 && (G - 18) * 4 + (e >> 1) < 9) { tap = (G - 18) * 4 + (e >> 1); cin = 16 + (e & 1); }
   const int n = (row >> 2) * 8 + nt * 4 + (row & 3);
   float v = 0.f;
   if (tap >= 0 && n < ZC && cin < ZC) v = w[((size_t)n * ZC + cin) * 9 + tap] * (scale ? scale[n] : 1.f);   // folded BN scale
@@ -387,7 +389,7 @@ __global__ void pack_chain0_tail_kernel(const float* __restrict__ w, const float
   const int G = kc * 4 + q;
   int tap = -1, cin = 0;
   if (G < 18) { tap = G >> 1; cin = (G & 1) * 8 + e; }
-  else if (G < 27 && e < 2) { tap = G - 18; cin = 16 + e; }
+  else if (G < 21 && (G - 18) * 4 + (e >> 1) < 9) { tap = (G - 18) * 4 + (e >> 1); cin = 16 + (e & 1); }
   const int c = slab * 32 + (row >> 2) * 8 + nt * 4 + (row & 3) - ps * 8;
   if (c < 0 || c >= cphys) return;
   float v = 0.f;
