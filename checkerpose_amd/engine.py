@@ -25,7 +25,6 @@ USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet 
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
 USE_HALO2 = os.environ.get("CHECKERPOSE_AMD_HALO2", "1") != "0"     # k = 2 / pad 1 convs on the LDS-staged halo kernel (A/B: the generic kernel)
-HALO2_MIN_PIXELS = int(os.environ.get("CHECKERPOSE_AMD_HALO2_MIN_PIXELS", "16384"))   # below: the generic kernel (split-K at small batch)
 USE_CHAIN_TAIL = os.environ.get("CHECKERPOSE_AMD_CHAIN_TAIL", "1") != "0"   # the 64x64 chain launch also runs the stride-2 fuse convs that read its output
 FUSE_OUT_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_MIN_BATCH", "1"))   # grouped first-level fuse-layer launches: at every batch
 #   (after per-conv branches too; 350 -> 317 graph nodes below 40 crops: B = 1 1.60 -> 1.58 ms, B = 8 1.88 -> 1.68, B = 32 3.10 -> 2.99; -1: with the chains)
@@ -331,13 +330,13 @@ class Program:
                    and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
         # k = 2 / pad 1 (Index2Feat's patch_generator over the whole map): the small-Cout halo kernel with four taps
         halo2 = (USE_HALO2 and self.dtype == CP_BF16 and R == 2 and S == 2 and stride == 1 and pad == 1 and ostr is None and not out_f32
-                 and not transposed and row_map is None and x.B * x.H * x.W >= HALO2_MIN_PIXELS and not self.ws.repacks_every_step   # (eval programs:
+                 and not transposed and row_map is None and not self.ws.repacks_every_step   # (eval programs:
                  # the training program repacks its weights every step through the pack-item tables, which have no entry for this image)
                  and bool(self.lib.cp_conv2x2_halo_supported(self.dtype, x.H, x.W, _rup(wCout, self.E))))
-        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small)
+        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small or halo2)
                 and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
                                                     R * S * x.Cphys, _rup(wCout, self.E))):
-            halo = gemm = s2small = False      # small batch: the generic kernel's split-K variant beats the tiled specialists
+            halo = gemm = s2small = halo2 = False      # small batch: the generic kernel's split-K variant beats the tiled specialists
         if s2small:
             ck = ("s2small", wkey, x.Cphys)
             if ck not in self.ws.cache:
