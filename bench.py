@@ -119,6 +119,15 @@ def profile_tag(workload, dtype, B):
     return ("%s_b%d" % (dtype, B)) if workload == "lmo_ape" else ("%s_%s_b%d" % (workload, dtype, B))
 
 
+def _summary_files(tag):
+    """profiles/rNN_<tag>_kernel_summary.csv, oldest round first -- the tag must follow the round prefix directly (a plain glob on
+    `r*_bf16_b256_*` also matched the `ycbv_rr21_bf16_b256` / `lm13_n4096_bf16_b256` summaries and the default line quoted theirs)"""
+    import glob
+    import re
+    pat = re.compile(r"^r\d+[a-z]?_%s_kernel_summary\.csv$" % re.escape(tag))
+    return sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary.csv")) if pat.match(os.path.basename(f)))
+
+
 def committed_profile(kernel_prefix, tag):
     """What the committed rocprofv3 evidence of this same bench command says about one kernel symbol
     (profiles/r*_<tag>_kernel_summary.csv, made by profiles/summarize.py from a `--kernel-trace --stats` run and two separate
@@ -127,7 +136,7 @@ def committed_profile(kernel_prefix, tag):
     figures are NOT re-measured by this run: they go stale when the kernel changes, hence the file name beside them."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_summary.csv" % tag)))
+    files = _summary_files(tag)
     if not files:
         return None, None, None
     tot, calls, dur, dcalls = 0.0, 0, 0.0, 0
@@ -148,7 +157,7 @@ def _profile_prefix_mb_per_step(prefix, tag):
     """sum over the rows of the committed summary whose kernel name starts with `prefix` (template instances): HBM MB per STEP"""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_summary.csv" % tag)))
+    files = _summary_files(tag)
     if not files:
         return None, None
     rows = [r for r in csv.DictReader(open(files[-1])) if r["kernel"].startswith(prefix) and r["avg_hbm_read_MB(FETCH_SIZE*2)"]]
