@@ -20,7 +20,7 @@ namespace {
 constexpr int MQ_ROWS = 64;
 constexpr int MQ_PITCH = MQ_ROWS * 16 + 16;                  // plane [row][16 B]; +16: consecutive planes shift one bank slot
 constexpr int MQ_BUF = 32 * MQ_PITCH;                        // 32 pieces of 8 channels = 256 channels: 33 280 B
-constexpr int MQ_LDS = 4 * MQ_BUF + 512;                     // x tile x 2, hidden tile x 2, layer-3 weights
+constexpr int MQ_LDS = 4 * MQ_BUF + 512 + 2560;              // x tile x 2, hidden tile x 2, layer-3 weights, folded-BN vectors of layers 1 / 2
 
 struct MlpQueryParams {
   const void* in; const void* w1; const float* s1; const float* t1;
@@ -57,7 +57,13 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
       for (int t = 0; t < 4; ++t) W[kc][t] = wsrc[((size_t)((g0 + (t >> 1)) * 8 + kc) * 2 + (t & 1)) * 64 + lane];
   }
   float* const sW3 = (float*)(smem + 4 * MQ_BUF);            // [2][64]: layer-3 rows (kept out of the layer-1 waves' registers)
+  // folded-BN scale / shift of layers 1 and 2 in LDS: read from global memory in the tile loop, the layer-2 waves' loads queued behind
+  // the eight tile-prefetch loads they had just issued (vmcnt is in order: waiting for the vectors meant waiting for the prefetch)
+  float* const sA1 = sW3 + 128;                               // s1 | t1 [256 each]
+  float* const sA2 = sA1 + 512;                               // s2 | t2 [64 each]
   if (tid < 128) sW3[tid] = p.w3[tid];
+  if (tid < 256) { sA1[tid] = p.s1[tid]; sA1[256 + tid] = p.t1[tid]; }
+  if (tid >= 256 && tid < 320) { sA2[tid - 256] = p.s2[tid - 256]; sA2[64 + tid - 256] = p.t2[tid - 256]; }
   const float b3a = p.b3[0], b3b = p.b3[1];
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int ch = (2 * wave + h) * 32 + q * 8;
-            const f32x4 s0 = *(const f32x4*)(p.s1 + ch), t0 = *(const f32x4*)(p.t1 + ch);
-            const f32x4 s1 = *(const f32x4*)(p.s1 + ch + 4), t1 = *(const f32x4*)(p.t1 + ch + 4);
+            const f32x4 s0 = *(const f32x4*)(sA1 + ch), t0 = *(const f32x4*)(sA1 + 256 + ch);
+            const f32x4 s1 = *(const f32x4*)(sA1 + ch + 4), t1 = *(const f32x4*)(sA1 + 256 + ch + 4);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
               float v[8];
@@ -147,8 +153,8 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int ch = h * 32 + q * 8;
-        const f32x4 s0 = *(const f32x4*)(p.s2 + ch), t0 = *(const f32x4*)(p.t2 + ch);
-        const f32x4 s1 = *(const f32x4*)(p.s2 + ch + 4), t1 = *(const f32x4*)(p.t2 + ch + 4);
+        const f32x4 s0 = *(const f32x4*)(sA2 + ch), t0 = *(const f32x4*)(sA2 + 64 + ch);
+        const f32x4 s1 = *(const f32x4*)(sA2 + ch + 4), t1 = *(const f32x4*)(sA2 + 64 + ch + 4);
         const f32x4 a0 = *(const f32x4*)(sW3 + ch), a1 = *(const f32x4*)(sW3 + ch + 4);
         const f32x4 c0 = *(const f32x4*)(sW3 + 64 + ch), c1 = *(const f32x4*)(sW3 + 64 + ch + 4);
 #pragma unroll
