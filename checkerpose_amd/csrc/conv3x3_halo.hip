@@ -622,7 +622,7 @@ static inline bool halo_wide(int Cout) { return Cout >= 256 && Cout % 256 == 0 &
 //     of the packed image), so the texture path only sees each byte once per block;
 //   * packed rows are permuted so lane q ends with channels [4*NT*q, 4*NT*(q+1)): the four q lanes of a pixel write
 //     its whole channel vector contiguously and the 16 pixels of a fragment are adjacent in memory.
-// KS = 2: the k = 2 / stride 1 / pad 1 conv of Index2Feat_module's patch_generator (pipeline.py:223-240; output (H + 1) x (W + 1)) --
+// KS = 2: the k = 2 / stride 1 / pad 1 conv of Index2Feat_module's patch_generator (pipeline.py:144-145,156; output (H + 1) x (W + 1)) --
 // the same tile walk over the larger output grid, four taps of the same staged halo (its last row / column is input row H / column W:
 // zero padding); the generic kernel read every pixel row four times through the texture path (10 % of any roof at N = 4096).
 template <typename Tag, int NT, int KS = 3>

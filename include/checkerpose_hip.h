@@ -124,7 +124,7 @@ int cp_conv3x3_halo(cp_stream_t stream, const CpConvDesc* d, const void* in, con
  * prefix sum (n_items + 1) of item.blocks, lds_bytes = the largest item.lds_bytes.  Results are bit-identical to the single launches.
  * A residual may alias the output (in-place accumulation) but no two items may write the same tensor. */
 /* k = 2 / stride 1 / pad 1 conv with <= 80 output channels off the same LDS-staged halo tile (Index2Feat_module.patch_generator,
- * pipeline.py:223-240, where it runs over the whole map: N = 4096 keypoints, the low-resolution stages at N = 512): descriptor as
+ * pipeline.py:144-145,156, where it runs over the whole map: N = 4096 keypoints, the low-resolution stages at N = 512): descriptor as
  * cp_conv2d_igemm with R = S = 2, stride 1, pad 1, Ho = H + 1, Wo = W + 1, o_sc = 1; weights by cp_pack_conv2x2_halo_weight from the
  * fp32 (Cout, Cin, 2, 2) tensor; scale / shift / residual / activation as cp_conv3x3_halo. */
 int cp_conv2x2_halo_supported(int dtype, int H, int W, int Cout_phys);

@@ -197,7 +197,7 @@ def test_conv3x3_halo_vs_torch_cpu(lib, dtype, case):
 @pytest.mark.parametrize("dtype", [CP_F32, CP_BF16])
 @pytest.mark.parametrize("case", [(2, 256, 16, 16, 64, ACT_NONE), (1, 64, 13, 21, 64, ACT_RELU), (3, 40, 32, 32, 24, ACT_LEAKY), (1, 256, 64, 64, 64, ACT_NONE)])
 def test_conv2x2_halo_vs_torch_cpu(lib, dtype, case):
-    """cp_conv2x2_halo (k = 2 / stride 1 / pad 1 on the LDS-staged halo tile: Index2Feat_module.patch_generator, pipeline.py:223-240)
+    """cp_conv2x2_halo (k = 2 / stride 1 / pad 1 on the LDS-staged halo tile: Index2Feat_module.patch_generator, pipeline.py:144-145,156)
     == F.conv2d(x, w, padding=1) * scale + shift (+ act): the (H + 1) x (W + 1) output incl. its last row / column (which see only
     zero padding below / right), ragged tiles, a channel count that is not a multiple of the chunk, pad channels zero."""
     B, Cin, H, W, Cout, act = case
