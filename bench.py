@@ -133,24 +133,29 @@ def committed_profile(kernel_prefix, tag):
     (profiles/r*_<tag>_kernel_summary.csv, made by profiles/summarize.py from a `--kernel-trace --stats` run and two separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes with the gfx950 corrections): HBM MB per launch, rocprofv3's average launch
     duration in us, and the file.  (None, None, None) when no summary for this workload / dtype / batch is committed.  These
-    figures are NOT re-measured by this run: they go stale when the kernel changes, hence the file name beside them."""
+    figures are NOT re-measured by this run: they go stale when the kernel changes, hence the file name beside them.
+    `kernel_prefix` may name a SET ("a<..> + b<..>": one entry point, several launches): the durations and the traffic of its
+    parts are SUMMED (a part missing from the summary voids the figure)."""
     import csv
-    import glob
     files = _summary_files(tag)
     if not files:
         return None, None, None
-    tot, calls, dur, dcalls = 0.0, 0, 0.0, 0
-    for r in csv.DictReader(open(files[-1])):
-        if r["kernel"] != kernel_prefix:
-            continue
-        n = int(r["calls"])
-        dur += n * float(r["avg_us"])
-        dcalls += n
-        if r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
-            tot += n * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"]))
-            calls += n
-    return ((round(tot / calls, 2) if calls else None), (round(dur / dcalls, 2) if dcalls else None),
-            os.path.relpath(files[-1], ROOT))
+    rows = list(csv.DictReader(open(files[-1])))
+    tr_sum, us_sum = 0.0, 0.0
+    for part in [p.strip() for p in kernel_prefix.split(" + ")]:
+        tot, calls, dur, dcalls = 0.0, 0, 0.0, 0
+        for r in rows:
+            if r["kernel"] != part:
+                continue
+            n = int(r["calls"])
+            dur += n * float(r["avg_us"])
+            dcalls += n
+            if r["avg_hbm_read_MB(FETCH_SIZE*2)"] and r["avg_hbm_write_MB"]:
+                tot += n * (float(r["avg_hbm_read_MB(FETCH_SIZE*2)"]) + float(r["avg_hbm_write_MB"]))
+                calls += n
+        tr_sum = (tr_sum + tot / calls) if (calls and tr_sum is not None) else None
+        us_sum = (us_sum + dur / dcalls) if (dcalls and us_sum is not None) else None
+    return ((round(tr_sum, 2) if tr_sum else None), (round(us_sum, 2) if us_sum else None), os.path.relpath(files[-1], ROOT))
 
 
 def _profile_prefix_mb_per_step(prefix, tag):
@@ -345,7 +350,8 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
 def kernel_breakdown(net, B, steps, dump=None):
     """Per-kernel device time of one step, measured live with HIP events on the launch stream (eager replay of the
     same launch program, one event pair per launch).  Returns (per family, per kernel symbol): the symbol of every
-    launch is what the library reports through cp_last_kernel(), i.e. the row name in rocprofv3's kernel stats."""
+    launch is what the library reports through cp_kernel_log(), i.e. the row name(s) in rocprofv3's kernel stats; an entry
+    point that issues several launches (cp_edgeconv_tiled: key table + gather) is ONE row named "a<..> + b<..>"."""
     from checkerpose_amd import _abi
     lib = _abi.load()
     prog = net.program_for(B)
@@ -356,11 +362,13 @@ def kernel_breakdown(net, B, steps, dump=None):
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in prog.calls]
     for it in range(steps):
         for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+            if it == 0:
+                lib.cp_kernel_log_begin()
             e0.record(stream)
             fn(sp, *args[1:])
             e1.record(stream)
-            if it == 0:
-                syms.append(lib.cp_last_kernel().decode())
+            if it == 0:          # an entry point that issues SEVERAL launches is priced as the set: "a<..> + b<..>", launch order
+                syms.append(lib.cp_kernel_log().decode() or lib.cp_last_kernel().decode())
         torch.cuda.synchronize()
         for (fn, args, name), (e0, e1), sy in zip(prog.calls, evs, syms):
             k = name.split(":")[0]
@@ -559,11 +567,13 @@ def roofline_report(out, net, B, dtype, workload, npoint, steps, dump=None):
     out["kernel_symbols"] = dict(sorted(ksym.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8])
     out["roofline"]["timing"] = ("HIP events on the launch stream around every launch of an eager replay of the same launch "
                                  "program, mean over %d steps (bench.py:kernel_breakdown)" % steps)
-    short = dom.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+    short = " + ".join(p_.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70] for p_ in dom.split(" + "))
     tr, us_prof, src = committed_profile(short, profile_tag(workload, dtype, B))
     if src is not None:      # committed rocprofv3 evidence of this exact command (same workload, dtype and batch), if any
         out["roofline"]["traffic"] = tr
-        out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch"
+        out["roofline"]["traffic_unit"] = "MB of HBM read+write per launch" + (" SET (sum over its %d kernels)" % len(dom.split(" + ")) if " + " in dom else "")
+        if tr and sv["bytes"]:                              # moved bytes / algorithmic bytes: > 1 = re-reads, partial-sector stores
+            out["roofline"]["traffic_ratio"] = round(tr * 1e6 * n / sv["bytes"], 3)
         out["roofline"]["traffic_source"] = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                              "this command; not re-measured by this run)" % src)
         if us_prof:          # the same fraction priced with rocprofv3's own average duration of that kernel

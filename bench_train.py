@@ -119,10 +119,13 @@ def run_step_bench(rk, batch=32, npoint=512, dtype="bf16", steps=40, warmup=10, 
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in prog.calls]
         syms = []
         for (fn, args, name), (e0, e1) in zip(prog.calls, evs):
+            lib.cp_kernel_log_begin()
             e0.record(stream)
             fn(sp, *args[1:])
             e1.record(stream)
-            syms.append(lib.cp_last_kernel().decode() if not name.startswith(("memset", "grad_zero", "pgrad_zero", "refresh_vec", "save_ids", "memcpy")) else name.split(":")[0])
+            # every symbol the call launched ("a + b" for a call with several launches: it is timed, and named, as the set)
+            syms.append((lib.cp_kernel_log().decode() or name.split(":")[0])
+                        if not name.startswith(("memset", "grad_zero", "pgrad_zero", "refresh_vec", "save_ids", "memcpy")) else name.split(":")[0])
         torch.cuda.synchronize()
         agg = {}
         for i, ((fn, args, name), (e0, e1), sy) in enumerate(zip(prog.calls, evs, syms)):

@@ -92,6 +92,8 @@ SIGNATURES = {
     "cp_version": (_I, []),
     "cp_strerror": (C.c_char_p, [_I]),
     "cp_last_kernel": (C.c_char_p, []),
+    "cp_kernel_log_begin": (None, []),
+    "cp_kernel_log": (C.c_char_p, []),
     "cp_chan_align": (_I, [_I]),
     "cp_packed_weight_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "cp_pack_conv_weight": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

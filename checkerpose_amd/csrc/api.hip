@@ -5,9 +5,10 @@
 
 #include "common.h"
 
-extern "C" int cp_version(void) { return 202; }   // 0.2.2: cp_graph_capture_set_deps / _tail (0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale)
+extern "C" int cp_version(void) { return 203; }   // 0.2.3: cp_kernel_log (0.2.2: cp_graph_capture_set_deps / _tail; 0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale)
 
 static thread_local char g_last_kernel[128] = "";
+static thread_local char g_kernel_log[1024] = "";   // every symbol since cp_kernel_log_begin(), " + " between them
 void cp_mark_kernel(const char* fmt, ...) {
   char tmp[128];
   va_list ap;
@@ -20,8 +21,13 @@ void cp_mark_kernel(const char* fmt, ...) {
   if (n >= 2 && tmp[0] == '(' && tmp[n - 1] == ')') { b = tmp + 1; n -= 2; }
   memcpy(g_last_kernel, b, n);
   g_last_kernel[n] = 0;
+  const size_t have = strlen(g_kernel_log);
+  if (have + n + 4 < sizeof(g_kernel_log))
+    snprintf(g_kernel_log + have, sizeof(g_kernel_log) - have, "%s%s", have ? " + " : "", g_last_kernel);
 }
 extern "C" const char* cp_last_kernel(void) { return g_last_kernel; }
+extern "C" void cp_kernel_log_begin(void) { g_kernel_log[0] = 0; }
+extern "C" const char* cp_kernel_log(void) { return g_kernel_log; }
 
 extern "C" const char* cp_strerror(int code) {
   switch (code) {

@@ -47,6 +47,11 @@ const char* cp_strerror(int code);
 /* profiling aid: symbol of the HIP kernel the calling thread's most recent entry point launched, spelled as
  * rocprofv3 --kernel-trace prints it (e.g. "conv_igemm_kernel<BF16Tag, 2, 4>"); "" before the first launch. */
 const char* cp_last_kernel(void);
+/* the same for entry points that issue SEVERAL launches (cp_edgeconv_tiled: key table + gather): cp_kernel_log_begin() clears the
+ * calling thread's log, cp_kernel_log() returns every symbol launched since, joined by " + " in launch order (the log is bounded:
+ * 1 KB, later symbols are dropped) -- bench.py prices such a call as the SET of its launches. */
+void cp_kernel_log_begin(void);
+const char* cp_kernel_log(void);
 
 /* elements per 16 bytes: 4 (f32) or 8 (bf16).  Physical channel counts are multiples of this. */
 int cp_chan_align(int dtype);

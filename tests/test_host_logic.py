@@ -120,3 +120,30 @@ def test_margin_aware_agreement_statistics():
     assert any("explained" in v for v in margin_contract_violations(clean, fr2))
     bad_tf = logit_agreement((o2[:, 0:1], o2[:, 1:7], o2[:, 7:13], ref[3], ref[4], ref[5]), ref)
     assert any("reference margin" in v for v in margin_contract_violations(bad_tf))
+
+
+def test_bench_prices_a_multi_launch_call_as_the_set(tmp_path, monkeypatch):
+    """bench.committed_profile on a "a + b" symbol (one entry point, two launches -- cp_edgeconv_tiled): durations and traffic of the
+    parts are summed; a part that the summary lacks voids the figure instead of silently pricing the rest."""
+    import bench
+    f = tmp_path / "r09_unit_kernel_summary.csv"
+    f.write_text("kernel,calls,avg_us,avg_hbm_read_MB(FETCH_SIZE*2),avg_hbm_write_MB\n"
+                 "ptable<256>,18,248.7,1155.5,766.7\n"
+                 "tiled2<256>,18,458.0,546.7,536.9\n"
+                 "other,3,10.0,,\n")
+    monkeypatch.setattr(bench, "_summary_files", lambda tag: [str(f)])
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    tr, us, src = bench.committed_profile("ptable<256> + tiled2<256>", "unit")
+    assert abs(tr - 3005.8) < 0.1 and abs(us - 706.7) < 0.05 and src.endswith("r09_unit_kernel_summary.csv")
+    tr1, us1, _ = bench.committed_profile("tiled2<256>", "unit")
+    assert abs(tr1 - 1083.6) < 0.1 and abs(us1 - 458.0) < 0.05
+    assert bench.committed_profile("ptable<256> + missing<1>", "unit")[:2] == (None, None)
+    assert bench.committed_profile("other", "unit")[:2] == (None, 10.0)
+
+
+def test_kernel_log_collects_every_symbol_since_begin():
+    """cp_kernel_log: "" after begin (no launch on the CPU box); cp_last_kernel is untouched by begin"""
+    from checkerpose_amd import _abi
+    lib = _abi.load()
+    lib.cp_kernel_log_begin()
+    assert lib.cp_kernel_log() == b""
