@@ -43,8 +43,23 @@ def ycbv_p3d(obj, n=512):
     return p3d_from(np.load(os.path.join(DATA, "fps_ycbv_21x512.npy"))[obj - 1].astype(np.float64), n)
 
 
-def build_net(npoint=512, p3d=None, seed=0, lm=False, backbone="hrnet_w18", full=True):
-    """The drop-in modules with the config of hr18GNN2_res6_gnn3Skip_mlpQuery(.txt), deterministic weights."""
+def apply_overrides(sd, overrides):
+    """Parameter values a fixture recorded beside its seed (npz keys `ov__<state-dict key>`: tests/golden/make_golden.py
+    center_and_repair) copied into a state dict in place; returns the number of tensors set."""
+    n = 0
+    if overrides is None:
+        return n
+    for k in getattr(overrides, "files", None) or overrides.keys():
+        if k.startswith("ov__"):
+            with torch.no_grad():
+                sd[k[4:]].copy_(torch.as_tensor(np.asarray(overrides[k])))
+            n += 1
+    return n
+
+
+def build_net(npoint=512, p3d=None, seed=0, lm=False, backbone="hrnet_w18", full=True, overrides=None):
+    """The drop-in modules with the config of hr18GNN2_res6_gnn3Skip_mlpQuery(.txt), deterministic weights (+ a fixture's
+    recorded parameter overrides)."""
     if lm:
         from .model.init_lm import InitNet_GNN
         from .model.pipeline_lm import PoseNet_GNNskip
@@ -62,4 +77,5 @@ def build_net(npoint=512, p3d=None, seed=0, lm=False, backbone="hrnet_w18", full
                           query_dims=None, local_k=2, leaky_slope=0.01, num_graph_module=3, graph_k=20,
                           graph_leaky_slope=0.2, query_type="mlp")
     fill_state_dict_(net.state_dict(), seed=seed)
+    apply_overrides(net.state_dict(), overrides)
     return net.eval()

@@ -58,17 +58,9 @@ def do_lm4096():
     # end to end, LM twin with per-sample graphs at N=4096 (config #5), features injected through the timm stub
     obj_ids = torch.tensor([5, 12])
     _STUB["feats"] = inject_feats(2, seed=2)
-    best = None
-    for seed in range(6):
-        net = build_ref(4096, lm_p3d, "inject", seed=seed, lm=True)
-        o = net(torch.zeros(2, 3, 256, 256), lm_p3d[obj_ids - 1], obj_ids)
-        m = decision_margin(o[0], o[1], o[2]); frac = float((o[0] > 0).float().mean())
-        print("e2e-lm4096 seed %d margin %.2e roi-frac %.2f" % (seed, m, frac), flush=True)
-        if 0.15 < frac < 0.85 and (best is None or m > best[0]):
-            best = (m, seed, o)
-    m, seed, o = best
-    save("e2e_lm4096_injected", seed=seed, margin=m, obj_ids=obj_ids.numpy(), roi=o[0], xb=o[1], yb=o[2], seg=o[3],
-         xid=o[4].numpy().astype(np.int16), yid=o[5].numpy().astype(np.int16))
+    net = build_ref(4096, lm_p3d, "inject", seed=0, lm=True)
+    MG.save_e2e("e2e_lm4096_injected", net, lambda: net(torch.zeros(2, 3, 256, 256), lm_p3d[obj_ids - 1], obj_ids), seed=0,
+                extra=lambda: {"obj_ids": obj_ids.numpy()})
 
 
 def do_n2():

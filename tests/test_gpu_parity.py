@@ -1231,7 +1231,7 @@ def test_e2e_fp32_vs_golden_hrnet_and_oracle(lib):
     """Full PoseNet_GNNskip (HRNet-W18 + decoder + 3 refine stages), fp32 path, B=1, LM-O ape N=512: against the
     golden 6-tuple (reference head on the oracle backbone) AND a live oracle run; also InitNet_GNN alone (config #1)."""
     g = golden("e2e_hrnet")
-    net = build_net(seed=int(g["seed"]))
+    net = build_net(seed=int(g["seed"]), overrides=g)
     img = det_image(1)
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **oracle_kwargs())
     net = net.to(dev())
@@ -1266,7 +1266,7 @@ def test_e2e_head_vs_reference_golden_direct(lib, name, npoint, lm, fseed, B):
     here through forward_injected_feats) -- no oracle in between: logits within 1e-4, ids bit-exact.  Covers config #2's head,
     the LM twin with per-sample graphs and config #5 (LM x 4096 keypoints)."""
     g = golden(name)
-    net = build_net(npoint=npoint, seed=int(g["seed"]), lm=lm).to(dev())
+    net = build_net(npoint=npoint, seed=int(g["seed"]), lm=lm, overrides=g).to(dev())
     feats = [f.to(dev()) for f in inject_feats(B, seed=fseed)]
     obj = torch.from_numpy(g["obj_ids"]).to(dev()) if lm else None
     img = torch.zeros(B, 3, 256, 256, device=dev())
@@ -1317,7 +1317,7 @@ def test_e2e_fp32_batch_ragged_and_stage_truncation(lib):
 
 def test_e2e_lm_per_object_graphs_vs_golden(lib):
     g = golden("e2e_lm_injected")   # head only (features injected) -> compare the full net against the live oracle instead,
-    net = build_net(seed=int(g["seed"]), lm=True)               # and the golden pins the oracle (tests/test_oracle.py)
+    net = build_net(seed=int(g["seed"]), lm=True, overrides=g)               # and the golden pins the oracle (tests/test_oracle.py)
     obj = torch.tensor([1, 9, 15, 9])
     img = det_image(4, seed=2)
     ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx[obj - 1], 512, **oracle_kwargs())

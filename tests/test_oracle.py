@@ -63,6 +63,15 @@ def test_blocks_match_reference():
 
 
 def _check_e2e(o, g, tol=1e-4):
+    """+ the fixture's own quality (round 5, tests/golden/make_golden.py center_and_repair): EVERY one of its 13 x B x N logits at
+    least 5e-4 from zero (5x the tolerance it is compared at -- the last bits count too: they are in the final ids), the final ids
+    spread over >= 24 of the 64 x and y positions (so the three Index2Feat gathers run all over the maps), a mixed RoI bit, and the
+    stored figures agree with the stored tensors."""
+    z = np.concatenate([g["roi"], g["xb"], g["yb"]], 1)
+    assert float(np.abs(z).min()) >= 5e-4 and abs(float(g["margin"]) - float(np.abs(z).min())) < 1e-9
+    div = [len(np.unique(g["xid"])), len(np.unique(g["yid"]))]
+    assert list(g["id_diversity"]) == div and min(div) >= 24, div
+    assert 0.15 < float((g["roi"] > 0).mean()) < 0.85
     roi, xb, yb, seg, xid, yid = o
     for a, k in ((roi, "roi"), (xb, "xb"), (yb, "yb"), (seg, "seg")):
         assert np.abs(a.numpy() - g[k]).max() <= tol, k
@@ -72,15 +81,14 @@ def _check_e2e(o, g, tol=1e-4):
 
 def test_e2e_injected_matches_reference():
     g = golden("e2e_injected")
-    net = build_net(seed=int(g["seed"]))
+    net = build_net(seed=int(g["seed"]), overrides=g)
     o, _ = O.posenet_forward(net.state_dict(), None, net.init_net.knn_idx, 512, img_feats=inject_feats(2), **oracle_kwargs())
     _check_e2e(o, g)
-    assert float(g["margin"]) > 1e-4
 
 
 def test_e2e_hrnet_matches_reference_head_on_oracle_backbone():
     g = golden("e2e_hrnet")
-    net = build_net(seed=int(g["seed"]))
+    net = build_net(seed=int(g["seed"]), overrides=g)
     o, inter = O.posenet_forward(net.state_dict(), det_image(1), net.init_net.knn_idx, 512, **oracle_kwargs())
     _check_e2e(o, g)
     assert [tuple(f.shape[1:]) for f in inter["img_feats"]] == [(128, 64, 64), (256, 32, 32), (512, 16, 16), (1024, 8, 8)]
@@ -91,7 +99,7 @@ def test_e2e_hrnet_matches_reference_head_on_oracle_backbone():
 
 def test_e2e_lm_matches_reference():
     g = golden("e2e_lm_injected")
-    net = build_net(seed=int(g["seed"]), lm=True)
+    net = build_net(seed=int(g["seed"]), lm=True, overrides=g)
     obj = torch.from_numpy(g["obj_ids"])
     o, _ = O.posenet_forward(net.state_dict(), None, net.init_net.knn_idx[obj - 1], 512, img_feats=inject_feats(3, seed=1),
                              **oracle_kwargs())
@@ -184,7 +192,7 @@ def test_initnet_variants_match_reference():
 def test_e2e_lm4096_matches_reference():
     """config #5 end to end: the reference's pipeline_lm.PoseNet_GNNskip at npt=4096 with per-sample graphs."""
     g = golden("e2e_lm4096_injected")
-    net = build_net(npoint=4096, seed=int(g["seed"]), lm=True)
+    net = build_net(npoint=4096, seed=int(g["seed"]), lm=True, overrides=g)
     obj = torch.from_numpy(g["obj_ids"])
     o, _ = O.posenet_forward(net.state_dict(), None, net.init_net.knn_idx[obj - 1], 4096, img_feats=inject_feats(2, seed=2),
                              **oracle_kwargs())
