@@ -238,7 +238,8 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
     from checkerpose_amd.agreement import margin_contract_violations
     keep = ("bit_agreement_min_row", "bit_agreement_all_rows", "xy_id_equal", "id_abs_err_mean_px", "seg_agreement",
             "max_abs_dlogit", "mean_abs_dlogit", "logit_rms", "tau", "flips", "flips_above_margin", "max_flip_margin",
-            "flip_rate_by_margin", "id_mismatches", "id_mismatches_explained_frac", "id_mismatches_from_subtau_self_flip")
+            "flip_rate_by_margin", "id_mismatches", "id_mismatches_explained_frac", "id_mismatches_from_subtau_self_flip",
+            "id_mismatches_self_subtau_frac", "perturbed_coverage_by_stage", "tau_cap")
     ex["bf16_agreement"] = {"vs": "fp32 HIP path (oracle-pinned <= 1e-4) on 8 crops, random-init weights",
                             "margin_contract_violations": margin_contract_violations(forced, free),
                             "free_running": {k: free[k] for k in keep if k in free}, "free_running_rows": free["bit_agreement_per_row"],

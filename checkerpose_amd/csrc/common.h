@@ -202,4 +202,7 @@ static inline int cp_num_cus() {
   return n;
 }
 static inline bool cp_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+// the branch-free epilogue activation (cp_act_apply: max(v, v * s + 0)) is LeakyReLU only for slopes in [0, 1]: anything else
+// (a slope > 1, a negative one, NaN) is refused at the entry point instead of computed wrongly
+static inline bool cp_act_ok(int act, float slope) { return act != 2 /* CP_ACT_LEAKY */ || (slope >= 0.f && slope <= 1.f); }
 static inline int cp_elem_size(int dtype) { return dtype == CP_BF16 ? 2 : 4; }

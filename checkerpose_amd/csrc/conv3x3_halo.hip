@@ -1412,7 +1412,7 @@ extern "C" int cp_pack_item_halo(int dtype, const float* w, int Cout, int Cin, i
 static int build_halo_params(const CpConvDesc* d, const void* in, const void* packed_w, const float* scale, const float* shift,
                              const void* residual, void* out, HaloParams* pp, long long* tiles) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
-  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if ((d->dtype != CP_F32 && d->dtype != CP_BF16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
     return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
@@ -1502,7 +1502,7 @@ extern "C" int cp_conv3x3_halo_up2x_supported(int dtype, int Cout) {
 extern "C" int cp_conv3x3_halo_up2x(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                                     const float* scale, const float* shift, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
-  if (!cp_conv3x3_halo_up2x_supported(d->dtype, d->Cout)) return CP_ERR_INVALID;
+  if (!cp_conv3x3_halo_up2x_supported(d->dtype, d->Cout) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
     return CP_ERR_INVALID;
   if (d->B <= 0 || d->H < 2 || d->W < 2 || (d->H & 1) || (d->W & 1)) return CP_ERR_INVALID;   // d->H, d->W: the UPSAMPLED size
@@ -1545,7 +1545,7 @@ extern "C" int cp_conv3x3_halo_seg_supported(int dtype, int Cout, int S) {
 extern "C" int cp_conv3x3_halo_seg(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
                                    const float* shift, void* out, const float* seg_w, const float* seg_b, int S, float* seg_out) {
   if (!d || !in || !packed_w || !scale || !shift || !out || !seg_w || !seg_b || !seg_out) return CP_ERR_INVALID;
-  if (!cp_conv3x3_halo_seg_supported(d->dtype, d->Cout, S)) return CP_ERR_INVALID;
+  if (!cp_conv3x3_halo_seg_supported(d->dtype, d->Cout, S) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
     return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
@@ -1600,7 +1600,7 @@ extern "C" int cp_basicblock_fused(cp_stream_t stream, const CpConvDesc* d, cons
                                    const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,
                                    const float* shift2, void* out) {
   if (!d || !in || !packed_w1 || !packed_w2 || !scale1 || !shift1 || !scale2 || !shift2 || !out) return CP_ERR_INVALID;
-  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if ((d->dtype != CP_F32 && d->dtype != CP_BF16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
     return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);

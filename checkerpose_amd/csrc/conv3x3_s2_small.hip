@@ -204,7 +204,7 @@ extern "C" int cp_pack_conv3x3_s2_small_weight(cp_stream_t stream, const float* 
 
 extern "C" int cp_conv3x3_s2_small(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w, const float* scale,
                                    const float* shift, void* out) {
-  if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
+  if (!d || !in || !packed_w || !scale || !shift || !out || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->dtype != CP_BF16 || d->out_f32 || d->o_sc != 1 || d->R != 3 || d->S != 3 || d->stride != 2 || d->pad != 1) return CP_ERR_INVALID;
   if (d->Ho != d->H / 2 || d->Wo != d->W / 2 || d->B <= 0) return CP_ERR_INVALID;
   if (!cp_conv3x3_s2_small_supported(d->H, d->W, d->Cin, d->Cout)) return CP_ERR_INVALID;

@@ -540,7 +540,7 @@ static void dispatch_nt(const ConvParams& p, int NT, hipStream_t st) {
 extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                                const float* scale, const float* shift, const void* residual, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
-  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if ((d->dtype != CP_F32 && d->dtype != CP_BF16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->R <= 0 || d->S <= 0 || d->stride <= 0)
     return CP_ERR_INVALID;

@@ -416,7 +416,7 @@ extern "C" int cp_pack_item_gemm(int dtype, const float* w, int Cout, int Cin, i
 extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                             const float* scale, const float* shift, const void* residual, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
-  if (d->dtype != CP_F32 && d->dtype != CP_BF16) return CP_ERR_INVALID;
+  if ((d->dtype != CP_F32 && d->dtype != CP_BF16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
     return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);

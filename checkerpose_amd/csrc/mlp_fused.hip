@@ -469,7 +469,10 @@ extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstr
   const long long M = (long long)B * N;
   if (M >= (1LL << 31) / MP_ROWS * MP_ROWS) return CP_ERR_RANGE;
   const int nchunk = Cin / 32;
-  const int P = (nchunk * 4 + 15) / 16 * 16;                  // 32 / 48 / 64 pieces per row image
+  // 32 / 48 / 64 pieces per row image.  Never below 32: the smallest instance is <2> (Cin <= 128 used to give P = 16, i.e. LDS sized
+  // for 16 pieces under a kernel<4> launch that addresses 64: out-of-bounds LDS, silently wrong); pieces past the row's width
+  // re-read its piece 0 under zero weights, so kernel<2> serves every Cin <= 256
+  const int P = nchunk <= 8 ? 32 : (nchunk * 4 + 15) / 16 * 16;
   const size_t lds = mlp_pair_lds(P);
   static CpDeviceOnce once;
   const int dev = cp_current_device();

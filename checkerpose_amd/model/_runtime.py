@@ -4,6 +4,7 @@ persistent I/O tensors, captures the hipGraph and replays it.  Fails loudly -- n
 import ctypes as C
 import operator
 import os
+import weakref
 
 import torch
 
@@ -13,20 +14,48 @@ from ..netbuilder import NetEmitter, emit_init_net, emit_posenet
 
 
 _VERSION_OF = operator.attrgetter("_version")
-# Any parameter / buffer / submodule (re)registration anywhere in the process moves this epoch: the cached tensor list of the eval
-# staleness check is rebuilt (and the programs dropped if the tensors are not the same objects any more) -- a reassigned
-# submodule or parameter must not leave stale tensors in the list.  One global counter: registrations are rare, a forward's check
-# is one integer compare.
-_STRUCT_EPOCH = [0]
+# A parameter / buffer / submodule (re)registration inside a drop-in model's module tree moves THAT model's epoch: its cached
+# tensor list of the eval staleness check is rebuilt on the next forward (and the programs dropped if the tensors are not the same
+# objects any more) -- a reassigned submodule or parameter must not leave stale tensors in the list.  torch offers the
+# registration hooks only process-wide, so the hook itself is global, but it is scoped: a weak map module -> root model, filled
+# when a model builds its tensor list; registrations on modules outside every tracked tree (another model, an optimizer's
+# containers, torch internals) cost one dictionary miss and touch nothing.  The hooks are installed with the first drop-in model
+# and removed again when the last tracked tree is gone.
+_TRACKED = weakref.WeakKeyDictionary()          # nn.Module (any node of a tracked tree) -> weakref to its root model
+_HOOKS = []
 
 
-def _bump_epoch(*_a):
-    _STRUCT_EPOCH[0] += 1
+def _bump_epoch(module, *_a):
+    root = _TRACKED.get(module)
+    root = root() if root is not None else None
+    if root is not None:
+        root._struct_epoch += 1
 
 
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
-torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
-torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+def _install_hooks():
+    if not _HOOKS:
+        m = torch.nn.modules.module
+        _HOOKS.extend([m.register_module_parameter_registration_hook(_bump_epoch),
+                       m.register_module_buffer_registration_hook(_bump_epoch),
+                       m.register_module_module_registration_hook(_bump_epoch)])
+
+
+def _remove_hooks_if_idle():
+    """called when a root model dies: with no live root left (children may outlive their root for a moment, or for good when the
+    caller kept one) the map is cleared and the process-wide hooks are removed"""
+    if _HOOKS and not any(r() is not None for r in list(_TRACKED.values())):
+        _TRACKED.clear()
+        for h in _HOOKS:
+            h.remove()
+        del _HOOKS[:]
+
+
+def _track_tree(root):
+    """(re)register every module of `root`'s tree; a submodule that sits in two models belongs to the one that looked last"""
+    _install_hooks()
+    ref = weakref.ref(root, lambda _r: _remove_hooks_if_idle())
+    for m in root.modules():
+        _TRACKED[m] = ref
 
 
 def _version_sum(tensors):
@@ -42,6 +71,10 @@ def _replay_half(mod, pr, which, lo, hi, device):
     kernel attribute setup happen outside a capture), then as one captured hipGraph per half (forward / backward)."""
     prog = pr["prog"]
     cur = torch.cuda.current_stream(device)
+    if getattr(prog, "wg_stream", cur.cuda_stream) != cur.cuda_stream:
+        raise RuntimeError("this training program was built for stream %#x (its weight-gradient arena is shared with the other "
+                           "programs of that stream) and is being replayed on stream %#x: build the model's training programs "
+                           "under the stream they run on, or call invalidate()" % (prog.wg_stream, cur.cuda_stream))
     lib = _abi.load()
     g = pr["graphs"].get(which)
     if not mod.use_graph or which[:3] not in TRAIN_GRAPH or not pr["warm"].get(which):
@@ -154,7 +187,7 @@ class HipForwardMixin:
         self.kernel_selection = os.environ.get("CHECKERPOSE_AMD_SELECTION", "auto")
         self.batch_buckets = os.environ.get("CHECKERPOSE_AMD_BUCKETS", "1") != "0"   # eval: pad ragged batches to a cached size
         self.check_weight_versions = os.environ.get("CHECKERPOSE_AMD_CHECK_VERSIONS", "1") != "0"   # eval: detect in-place weight edits
-        self._sig_tensors, self._sig_epoch = None, -1
+        self._sig_tensors, self._sig_epoch, self._struct_epoch = None, -1, 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
     # ---- cache control
@@ -488,12 +521,13 @@ class HipForwardMixin:
             # eval programs fold BatchNorm and pack weights at build time: an in-place edit of any parameter / buffer since then
             # (optimizer step, EMA `copy_` / `mul_` under no_grad, a child's load_state_dict) bumps its version counter -> rebuild.
             # (Edits through `p.data` do not move the counter -- torch gives `.data` a counter of its own: call invalidate().)
-            if self._sig_tensors is None or self._sig_epoch != _STRUCT_EPOCH[0]:
+            if self._sig_tensors is None or self._sig_epoch != self._struct_epoch:
+                _track_tree(self)
                 ts = list(self.parameters()) + list(self.buffers())
                 if self._sig_tensors is not None and (len(ts) != len(self._sig_tensors) or
                                                       any(a is not b for a, b in zip(ts, self._sig_tensors))):
                     self._eval_sig = None                    # other tensor objects than the programs folded: rebuild
-                self._sig_tensors, self._sig_epoch = ts, _STRUCT_EPOCH[0]
+                self._sig_tensors, self._sig_epoch = ts, self._struct_epoch
             sig = _version_sum(self._sig_tensors) + len(self._sig_tensors)      # ~2 000 tensors: the B = 1 forward is host-bound
             if self._programs and sig != getattr(self, "_eval_sig", None):
                 self._drop_eval_programs()

@@ -82,12 +82,15 @@ class InitNet_GNN(HipForwardMixin, nn.Module):
     def _keypoints(self):
         return self._p3d
 
+    def _out_rows(self, bits):
+        """the (B, 1 + 2 res_log2, N) output of init.py:120-122 out of the launch program's logit block; shared with the LM twin"""
+        r = self.res_log2          # rows of the (B,13,N) logit block: [roi | x bits at 1.. | y bits at 7..]; res_log2 > 3: packed
+        return torch.cat([bits[:, 0:4], bits[:, 7:10]], dim=1) if r == 3 else bits[:, :1 + 2 * r]
+
     def forward(self, img, return_img_feats=False, return_graph_feats=False):
         """init.py:109-128: returns out (B,7,N) | (out, img_feats) | (out, img_feats, graph_feats)."""
         res = self._run(img, None, want_feats=return_img_feats or return_graph_feats, want_graph=return_graph_feats)
-        bits = res["bits"]
-        r = self.res_log2          # rows of the (B,13,N) logit block: [roi | x bits at 1.. | y bits at 7..]; res_log2 > 3: packed
-        out = torch.cat([bits[:, 0:4], bits[:, 7:10]], dim=1) if r == 3 else bits[:, :1 + 2 * r]
+        out = self._out_rows(res["bits"])
         if return_img_feats:
             return out, res["img_feats"]
         if return_graph_feats:

@@ -11,8 +11,7 @@ class InitNet_GNN(_InitNet_GNN):
 
     def forward(self, img, obj_ids, return_img_feats=False, return_graph_feats=False):
         res = self._run(img, obj_ids, want_feats=return_img_feats or return_graph_feats, want_graph=return_graph_feats)
-        bits = res["bits"]
-        out = torch.cat([bits[:, 0:4], bits[:, 7:10]], dim=1)
+        out = self._out_rows(res["bits"])          # res_log2 != 3 too (pretrain_lm.py:141 passes it through)
         if return_img_feats:
             return out, res["img_feats"]
         if return_graph_feats:

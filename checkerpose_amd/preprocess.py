@@ -37,14 +37,27 @@ def roi_window(Bbox, resize_method, img_w, img_h):
         side = int(max(bh, bw))
         return int(x1), int(y1), int(x2), int(y2), side, side
     if resize_method == "crop_resize":
-        x1, y1, x2, y2 = int(max(x1, 0)), int(max(y1, 0)), int(min(x2, img_w)), int(min(y2, img_h))
-        return x1, y1, x2, y2, x2 - x1, y2 - y1
+        x1, y1, x2, y2 = _clamped_box(x1, y1, x2, y2, img_w, img_h)
+        # the reference cuts `img[y1:y2, x1:x2]` (:106): a NEGATIVE end (box wholly left of / above the frame) is Python's
+        # "counted from the far edge", so such a box yields the frame minus a margin, not an empty crop (n3_windows.npz pins it)
+        x2 = x2 if x2 >= 0 else max(img_w + x2, 0)
+        y2 = y2 if y2 >= 0 else max(img_h + y2, 0)
+        return x1, y1, x2, y2, max(x2 - x1, 0), max(y2 - y1, 0)
     raise NotImplementedError("unknown decoder type: %s" % resize_method)      # the reference's message (:145)
 
 
+def _clamped_box(x1, y1, x2, y2, img_w, img_h):
+    """crop_resize :94-104 / get_final_Bbox :212-220"""
+    return int(max(x1, 0)), int(max(y1, 0)), int(min(x2, img_w)), int(min(y2, img_h))
+
+
 def get_final_Bbox(Bbox, resize_method, max_x, max_y):
-    """the box the crop actually covers (bop_dataset_pytorch.py:188-222), what the post-processing maps pixel codes back with"""
-    x1, y1, x2, y2, _, _ = roi_window(Bbox, resize_method, max_x, max_y)
+    """the box the crop actually covers (bop_dataset_pytorch.py:188-222), what the post-processing maps pixel codes back with
+    (crop_resize: the clamped corners as they are, also where x2 < x1 -- the reference's own result for a box off the frame)"""
+    if resize_method == "crop_resize":
+        x1, y1, x2, y2 = _clamped_box(Bbox[0], Bbox[1], Bbox[0] + Bbox[2], Bbox[1] + Bbox[3], max_x, max_y)
+    else:
+        x1, y1, x2, y2, _, _ = roi_window(Bbox, resize_method, max_x, max_y)
     return np.array([x1, y1, x2 - x1, y2 - y1])
 
 

@@ -12,6 +12,7 @@ torch supplies memory and the autograd hook (model/_runtime.py: _TrainFn) only.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -85,18 +86,23 @@ class TrainWeightStore(WeightStore):
         return super().affine(name, scale, shift, rows)
 
 
-_WG_ARENAS = {}
+_WG_ARENAS = weakref.WeakValueDictionary()      # the TrainPrograms hold the arenas: the last program gone, its 4 GiB go back to torch
 
 
 def _shared_wgrad_arena(device):
-    """The weight-gradient partial-sum arena of `device` + the current stream (CHECKERPOSE_AMD_WGRAD_ARENA_MB, default 4096)."""
+    """The weight-gradient partial-sum arena of `device` + the current stream (CHECKERPOSE_AMD_WGRAD_ARENA_MB, default 4096), and that
+    stream's handle: partial sums of two programs that share an arena are ordered only by running on ONE stream, so a program
+    remembers the stream it was built for and `_TrainFn` refuses to replay it on another (model/_runtime.py)."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     nbytes = int(os.environ.get("CHECKERPOSE_AMD_WGRAD_ARENA_MB", "4096")) << 20
-    key = (idx, torch.cuda.current_stream(dev).cuda_stream, nbytes)
-    if key not in _WG_ARENAS:
-        _WG_ARENAS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    return _WG_ARENAS[key]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (idx, stream, nbytes)
+    arena = _WG_ARENAS.get(key)
+    if arena is None:
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _WG_ARENAS[key] = arena
+    return arena, stream
 
 
 class TrainProgram(Program):
@@ -116,7 +122,7 @@ class TrainProgram(Program):
         # (ONE arena per device and stream, shared by every TrainProgram -- the stage schedule, a ragged last batch and a second module
         # each build their own program, but the partials never outlive the backward that wrote them and backwards on one stream are
         # ordered)
-        self.wg_ws = _shared_wgrad_arena(device)
+        self.wg_ws, self.wg_stream = _shared_wgrad_arena(device)
         self._wg_off, self._wg_items, self._wg_keys, self.wg_tabs = 0, [], set(), []
         self.wg_defer = os.environ.get("CHECKERPOSE_AMD_WGRAD_DEFER", "1") != "0"        # A/B: one reduction launch per layer
         # grouped weight gradients: the partial-sum launches of up to wg_group_n layers wait for each other and go out as ONE launch

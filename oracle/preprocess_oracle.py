@@ -39,28 +39,33 @@ def window(bbox, resize_method, img_w, img_h):
         return int(x1), int(y1), int(x2), int(y2), side, side
     if resize_method == "crop_resize":
         x1, y1, x2, y2 = int(max(x1, 0)), int(max(y1, 0)), int(min(x2, img_w)), int(min(y2, img_h))
-        return x1, y1, x2, y2, x2 - x1, y2 - y1
+        # `img[y1:y2, x1:x2]` (:106) with a negative end index counts from the far edge (Python slicing): reproduced, not "fixed"
+        x2 = x2 if x2 >= 0 else max(img_w + x2, 0)
+        y2 = y2 if y2 >= 0 else max(img_h + y2, 0)
+        return x1, y1, x2, y2, max(x2 - x1, 0), max(y2 - y1, 0)
     raise NotImplementedError(resize_method)
 
 
 def final_bbox(bbox, resize_method, max_x, max_y):
     """bop_dataset_pytorch.py:188-222"""
-    x1, y1, x2, y2, _, _ = window(bbox, resize_method, max_x, max_y)
+    if resize_method == "crop_resize":
+        x1, y1 = int(max(bbox[0], 0)), int(max(bbox[1], 0))
+        x2, y2 = int(min(bbox[0] + bbox[2], max_x)), int(min(bbox[1] + bbox[3], max_y))
+    else:
+        x1, y1, x2, y2, _, _ = window(bbox, resize_method, max_x, max_y)
     return np.array([x1, y1, x2 - x1, y2 - y1])
 
 
 def roi(img, win):
+    """the pre-resize window: roi pixel (ry, rx) = image pixel (y1 + ry, x1 + rx) inside the image and inside [x1, x2) x [y1, y2),
+    zero elsewhere (crop_square_resize :78-89; pinned by tests/golden/n3_windows.npz, made by the reference's own function)"""
     x1, y1, x2, y2, rw, rh = win
     H, W = img.shape[:2]
-    out = np.zeros((rh, rw) + img.shape[2:], dtype=img.dtype)
-    for ry in range(rh):
-        iy = y1 + ry
-        if not (max(y1, 0) <= iy < min(y2, H)):
-            continue
-        for rx in range(rw):
-            ix = x1 + rx
-            if max(x1, 0) <= ix < min(x2, W):
-                out[ry, rx] = img[iy, ix]
+    out = np.zeros((max(rh, 0), max(rw, 0)) + img.shape[2:], dtype=img.dtype)
+    ya, yb = max(y1, 0), min(y2, H, y1 + rh)
+    xa, xb = max(x1, 0), min(x2, W, x1 + rw)
+    if yb > ya and xb > xa:
+        out[ya - y1:yb - y1, xa - x1:xb - x1] = img[ya:yb, xa:xb]
     return out
 
 

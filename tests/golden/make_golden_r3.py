@@ -6,8 +6,8 @@ small outputs are committed):
 
   ce             MaskedCodeLoss(loss_type="CE") (losses/code_loss.py:36-37,47-61): value and d/dlogits on seeded class logits
                  (B, C, N), class ids (B, 1, N), a mixed and an all-zero mask -> ce_loss.npz
-  init_variants  InitNet_GNN with res_log2 = 4 and with num_conv1x1 = 2 (init.py:78,83-95), backbone features injected through the
-                 timm stub -> initnet_variants.npz
+  init_variants  InitNet_GNN with res_log2 = 4 and with num_conv1x1 = 2 (init.py:78,83-95), and the LM twin with res_log2 = 4
+                 (init_lm.py:72-128), backbone features injected through the timm stub -> initnet_variants.npz
 """
 import os
 import sys
@@ -59,6 +59,19 @@ def do_init_variants():
         out[name + "_out"] = o.numpy()
         out[name + "_keys"] = np.array(sorted(net.state_dict().keys()))
         print(name, tuple(o.shape), float(o.abs().max()))
+    # round 5: the LM twin with res_log2 = 4 (init_lm.py:72-128; pretrain_lm.py:141 passes res_log2 through), per-sample graphs
+    from make_golden import R_init_lm
+    lm = np.stack([load_fps("lm", o)[:1024] for o in range(1, 16)]).astype(np.float32)
+    lm_p3d = torch.cat([p3d(lm[o].astype(np.float64), 512) for o in range(15)], 0)
+    obj_ids = torch.tensor([2, 13])
+    net = R_init_lm.InitNet_GNN(npoint=512, p3d_normed=lm_p3d, res_log2=4, backbone_name="hrnet_w18", pretrain_backbone=False,
+                                max_batch_size=8, num_graph_module=2, graph_k=20, graph_leaky_slope=0.2)
+    fill_state_dict_(net.state_dict(), seed=5)
+    net.eval()
+    o = net(torch.zeros(2, 3, 256, 256), obj_ids)
+    out["lm_res4_out"], out["lm_res4_obj_ids"] = o.numpy(), obj_ids.numpy()
+    out["lm_res4_keys"] = np.array(sorted(net.state_dict().keys()))
+    print("lm_res4", tuple(o.shape), float(o.abs().max()))
     save("initnet_variants", **out)
 
 

@@ -41,6 +41,11 @@ def test_argument_validation_returns_before_launch(lib):
     d = _abi.CpConvDesc()
     assert lib.cp_conv2d_igemm(None, C.byref(d), None, None, None, None, None, None) == -1     # null pointers
     assert lib.cp_bits_decode(None, None, 0, None, None, None, None, None, 1, 1) == -1
+    d2 = _abi.CpConvDesc()                      # a LeakyReLU slope outside [0, 1] is refused (the branch-free epilogue form needs it)
+    d2.dtype, d2.act, d2.slope = _abi.CP_BF16, 2, 1.5
+    one = C.c_void_p(16)
+    for fn in (lib.cp_conv2d_igemm, lib.cp_gemm_rows, lib.cp_conv3x3_halo):
+        assert fn(None, C.byref(d2), one, one, one, one, None, one) == -1
     assert lib.cp_graph_launch(None, None) == -1
     assert lib.cp_graph_destroy(None) == 0
     with pytest.raises(RuntimeError, match="invalid"):

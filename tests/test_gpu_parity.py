@@ -1084,6 +1084,36 @@ def test_mlp_pair_fused_vs_torch(lib, B, N, stage):
     close(got[..., 64:], ref, 2e-2)                                      # bf16 output rounding + one-ulp hidden flips
 
 
+@pytest.mark.parametrize("Cin", [64, 128, 256, 384])
+def test_mlp_pair_fused_every_instance(lib, Cin):
+    """cp_mlp_pair_fused through the C ABI at the input widths the model never uses: Cin = 64 / 128 (used to size the LDS for 16
+    pieces under a kernel<4> launch: out-of-bounds LDS, silently wrong -- now kernel<2> with zero-weight padding chunks), 256
+    (kernel<2>, full) and 384 (kernel<3>); same torch reference as above.  Unsupported widths are refused."""
+    B, N = 2, 200
+    w = [det_tensor("mpi_w1_%d" % Cin, (256, Cin), (6.0 / Cin) ** 0.5), det_tensor("mpi_w2", (256, 256), (6.0 / 256) ** 0.5)]
+    b = [det_tensor("mpi_b1", (256,), 0.1), det_tensor("mpi_b2", (256,), 0.1)]
+    x = rnd(det_tensor("mpi_x%d" % Cin, (B, N, Cin)), CP_BF16)
+    h1 = rnd(F.leaky_relu(x @ rnd(w[0], CP_BF16).t() + b[0], 0.01), CP_BF16)
+    ref = F.leaky_relu(h1 @ rnd(w[1], CP_BF16).t() + b[1], 0.01)
+    assert lib.cp_mlp_pair_fused_supported(Cin, 256, 256) == 1
+    assert lib.cp_mlp_pair_fused_supported(48, 256, 256) == 0 and lib.cp_mlp_pair_fused_supported(Cin, 128, 256) == 0
+    xin = x.to(torch.bfloat16).to(dev())
+    pk = []
+    for wi, ci in zip(w, (Cin, 256)):
+        buf = torch.empty(lib.cp_packed_gemm_weight_bytes(CP_BF16, 256, ci), dtype=torch.uint8, device=dev())
+        wd = wi.contiguous().to(dev())
+        _abi.check(lib.cp_pack_gemm_weight(st(), CP_BF16, wd.data_ptr(), 256, ci, ci, buf.data_ptr()))
+        pk.append(buf)
+    bd = [t.contiguous().to(dev()) for t in b]
+    out = torch.full((B, N, 256), 7.0, dtype=torch.bfloat16, device=dev())
+    _abi.check(lib.cp_mlp_pair_fused(st(), xin.data_ptr(), Cin, 0, Cin, B, N, pk[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                     pk[1].data_ptr(), bd[1].data_ptr(), 0.01, out.data_ptr(), 256, 0))
+    torch.cuda.synchronize()
+    close(out.float().cpu(), ref, 2e-2)
+    assert lib.cp_mlp_pair_fused(st(), xin.data_ptr(), 48, 0, 48, B, N, pk[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                 pk[1].data_ptr(), bd[1].data_ptr(), 0.01, out.data_ptr(), 256, 0) == -1
+
+
 def test_edgeconv_per_sample_graphs_lm(lib):
     """LM twin: each sample gathers along its own object's graph (pipeline_lm.py:55-57), 1-based obj_ids."""
     B, N, K, Cc = 4, 512, 20, 64
@@ -1278,20 +1308,23 @@ def test_e2e_head_vs_reference_golden_direct(lib, name, npoint, lm, fseed, B):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("name", ["res4", "conv2"])
+@pytest.mark.parametrize("name", ["res4", "conv2", "lm_res4"])
 def test_initnet_variants_vs_reference_golden(lib, name):
-    """InitNet_GNN(res_log2=4) -> (B,9,N) and InitNet_GNN(num_conv1x1=2) (init.py:78,83-95), HIP fp32 on the full backbone vs the
-    oracle, and the head alone vs the REFERENCE's output through injected features (initnet_variants.npz)."""
+    """InitNet_GNN(res_log2=4) -> (B,9,N) and InitNet_GNN(num_conv1x1=2) (init.py:78,83-95), and the LM twin with res_log2 = 4
+    (init_lm.py:72-128): HIP fp32 on the full backbone vs the oracle, and the head alone vs the REFERENCE's output through injected
+    features (initnet_variants.npz)."""
     from tests.test_oracle import build_init_variant
     g = golden("initnet_variants")
     net = build_init_variant(name)
     img = det_image(2, seed=17)
-    ref, _, _ = O.init_net_forward(net.state_dict(), "", img, net.knn_idx, 512)
+    lm = name.startswith("lm_")
+    obj = torch.from_numpy(g["lm_res4_obj_ids"]) if lm else None
+    ref, _, _ = O.init_net_forward(net.state_dict(), "", img, net.knn_idx[obj - 1] if lm else net.knn_idx, 512)
     net = net.to(dev())
-    out = net(img.to(dev()))
+    out = net(img.to(dev()), obj.to(dev())) if lm else net(img.to(dev()))
     assert tuple(out.shape) == tuple(ref.shape) == (2, net.num_out_bits, 512)
     assert float((out.cpu() - ref).abs().max()) <= 1e-4
-    res = net._run(img.to(dev()), None, inject_feats=[f.to(dev()) for f in inject_feats(2, seed=4)])
+    res = net._run(img.to(dev()), obj.to(dev()) if lm else None, inject_feats=[f.to(dev()) for f in inject_feats(2, seed=4)])
     bits = res["bits"]
     o2 = torch.cat([bits[:, 0:4], bits[:, 7:10]], 1) if net.res_log2 == 3 else bits[:, :net.num_out_bits]
     assert float((o2.cpu() - torch.from_numpy(g[name + "_out"])).abs().max()) <= 1e-4

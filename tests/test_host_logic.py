@@ -115,6 +115,18 @@ def test_margin_aware_agreement_statistics():
     xid2 = ref[4].clone(); xid2[0, 20] = 3
     fr2 = logit_agreement((o2[:, 0:1], o2[:, 1:7], o2[:, 7:13], ref[3], xid2, ref[5]), ref, tau=0.05, explain=True, knn_idx=knn)
     assert fr2["id_mismatches"] == 1 and fr2["id_mismatches_explained"] == 0
+    # (3) ... and such an unexplained flip explains NOTHING downstream: its neighbour's later mismatch stays unexplained too (round 5;
+    #     before, any earlier flip within 3 hops "explained" every later mismatch)
+    o3 = o2.clone()
+    o3[0, 4, 19] = -z[0, 4, 19]                              # keypoint 19 (20 is its neighbour 19 + 1), stage 1
+    xid3 = xid2.clone(); xid3[0, 19] = 5
+    fr3 = logit_agreement((o3[:, 0:1], o3[:, 1:7], o3[:, 7:13], ref[3], xid3, ref[5]), ref, tau=0.05, explain=True, knn_idx=knn)
+    assert fr3["id_mismatches"] == 2 and fr3["id_mismatches_explained"] == 0 and fr3["perturbed_coverage_by_stage"] == [0.0] * 4
+    assert fr["perturbed_coverage_by_stage"][0] == 0.0 and 0.0 < fr["perturbed_coverage_by_stage"][1] < 1.0
+    # tau never exceeds 10 bf16 epsilons of the logit RMS, however large the run's own error is
+    noisy = logit_agreement((o[:, 0:1] + 0.9, o[:, 1:7] - 0.7, o[:, 7:13] + 0.8, ref[3], xid, ref[5]), ref)
+    assert noisy["tau"] == noisy["tau_cap"] and abs(noisy["tau_cap"] - 10 * 2.0 ** -8 * noisy["logit_rms"]) < 1e-4
+    assert any("bf16 epsilons" in v for v in margin_contract_violations(noisy))
     clean = logit_agreement(ref, ref)
     assert margin_contract_violations(clean, clean) == []
     assert any("explained" in v for v in margin_contract_violations(clean, fr2))
@@ -147,3 +159,28 @@ def test_kernel_log_collects_every_symbol_since_begin():
     lib = _abi.load()
     lib.cp_kernel_log_begin()
     assert lib.cp_kernel_log() == b""
+
+
+def test_struct_epoch_is_scoped_to_the_model():
+    """model/_runtime.py: torch's module registration hooks are process-wide, the staleness epoch they move is per model -- a
+    registration inside a tracked model's tree bumps THAT model only, unrelated modules cost nothing, and the hooks go away with
+    the last tracked model."""
+    import gc
+    import torch
+    from checkerpose_amd.model import _runtime as RT
+    from tests.common import build_net
+    a, b = build_net(full=False), build_net(full=False, seed=2)
+    RT._track_tree(a)
+    RT._track_tree(b)
+    assert len(RT._HOOKS) == 3
+    ea, eb = a._struct_epoch, b._struct_epoch
+    torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.BatchNorm1d(3))           # somebody else's modules: nobody's epoch moves
+    assert (a._struct_epoch, b._struct_epoch) == (ea, eb)
+    a.mlp.bias = torch.nn.Parameter(torch.zeros(7))                                # a child's parameter reassigned
+    assert (a._struct_epoch, b._struct_epoch) == (ea + 1, eb)
+    b.pre_query_block[0].register_buffer("extra", torch.zeros(1))
+    a.mlp = torch.nn.Linear(64, 7)                                                 # a submodule replaced
+    assert (a._struct_epoch, b._struct_epoch) == (ea + 2, eb + 1)
+    del a, b
+    gc.collect()
+    assert not RT._HOOKS and not len(RT._TRACKED)

@@ -168,9 +168,13 @@ INIT_VARIANTS = {"res4": dict(res_log2=4), "conv2": dict(num_conv1x1=2)}
 
 def build_init_variant(name):
     from checkerpose_amd.detweights import fill_state_dict_
-    from checkerpose_amd.model.init import InitNet_GNN
-    kw = dict(dict(res_log2=3), **INIT_VARIANTS[name])
-    net = InitNet_GNN(npoint=512, p3d_normed=ape_p3d(512), backbone_name="hrnet_w18", pretrain_backbone=False, max_batch_size=8,
+    if name == "lm_res4":                                   # the LM twin (init_lm.py:72-128), per-sample graphs, res_log2 = 4
+        from checkerpose_amd.model.init_lm import InitNet_GNN
+        kw, p3 = dict(res_log2=4), lm_p3d(512)
+    else:
+        from checkerpose_amd.model.init import InitNet_GNN
+        kw, p3 = dict(dict(res_log2=3), **INIT_VARIANTS[name]), ape_p3d(512)
+    net = InitNet_GNN(npoint=512, p3d_normed=p3, backbone_name="hrnet_w18", pretrain_backbone=False, max_batch_size=8,
                       num_graph_module=2, graph_k=20, graph_leaky_slope=0.2, **kw)
     fill_state_dict_(net.state_dict(), seed=5)
     return net.eval()
@@ -187,6 +191,12 @@ def test_initnet_variants_match_reference():
         out, _, _ = O.init_net_forward(sd, "", None, net.knn_idx, 512, img_feats=inject_feats(2, seed=4))
         assert np.abs(out.numpy() - g[name + "_out"]).max() <= 1e-4
         assert net.num_out_bits == out.shape[1]
+    net = build_init_variant("lm_res4")                     # LM twin x res_log2 = 4 (the reference's init_lm.py handles any res_log2)
+    sd = net.state_dict()
+    assert sorted(k for k in sd if not k.startswith("img_backbone.")) == list(g["lm_res4_keys"])
+    obj = torch.from_numpy(g["lm_res4_obj_ids"])
+    out, _, _ = O.init_net_forward(sd, "", None, net.knn_idx[obj - 1], 512, img_feats=inject_feats(2, seed=4))
+    assert tuple(out.shape) == (2, 9, 512) and np.abs(out.numpy() - g["lm_res4_out"]).max() <= 1e-4
 
 
 def test_e2e_lm4096_matches_reference():

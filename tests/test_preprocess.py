@@ -48,6 +48,60 @@ def test_window_arithmetic_follows_the_reference_formulas():
         PP.roi_window([0, 0, 4, 4], "crop_resize_by_warp_affine", 64, 48)
 
 
+def _coded_frame(H, W):
+    """the position-coded frame of tests/golden/make_golden_n3.py: pixel (y, x) = (x % 256, y % 256, 16 (x // 256) + y // 256 + 1)"""
+    y, x = np.mgrid[0:H, 0:W]
+    return np.stack([x % 256, y % 256, 16 * (x // 256) + y // 256 + 1], -1).astype(np.uint8)
+
+
+def _n3():
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "n3_windows.npz"))
+    return g, zlib.crc32
+
+
+def test_window_arithmetic_matches_a_run_of_the_reference():
+    """n3_windows.npz = the reference's OWN padding_Bbox / get_final_Bbox / crop_square_resize / crop_resize
+    (bop_dataset_pytorch.py:55-108,147-163,188-222) run over 240 boxes (inside, across every edge, outside a 640 x 480 frame, 0- and
+    1-pixel boxes) with cv2.resize replaced by a recorder of the pre-resize window on a position-coded frame.  The product's host
+    arithmetic (preprocess.py) and the oracle's restatement must reproduce every padded box, every final box, and every window: its
+    shape, which frame pixel each window pixel came from and which are zero padding (CRC-32 of the window's bytes)."""
+    g, crc32 = _n3()
+    H, W = (int(v) for v in g["frame_hw"])
+    frame = _coded_frame(H, W)
+    n = len(g["raw"])
+    assert n >= 200
+    windows = 0
+    for i in range(n):
+        raw, padded = g["raw"][i].tolist(), g["padded"][i].tolist()
+        assert PP.padding_Bbox(raw, 1.5).tolist() == padded and PO.padding_bbox(raw, 1.5).tolist() == padded, raw
+        for k, m in (("sq", "crop_square_resize"), ("cr", "crop_resize")):
+            assert PP.get_final_Bbox(padded, m, W, H).tolist() == g[k + "_final"][i].tolist(), (raw, m)
+            assert PO.final_bbox(padded, m, W, H).tolist() == g[k + "_final"][i].tolist(), (raw, m)
+            win = PP.roi_window(padded, m, W, H)
+            assert win == PO.window(padded, m, W, H)
+            if g[k + "_raised"][i] == 1:
+                # the reference raises inside crop_square_resize (its window misses the frame; the loader then has no crop, :297-322);
+                # the kernel's contract there is a window WITHOUT any frame pixel = an all-zero crop
+                assert not PO.roi(frame, win).any(), (raw, m)
+                continue
+            if g[k + "_raised"][i] == 2:                    # empty source handed to cv2.resize (which asserts): an empty window here too
+                assert win[4] <= 0 or win[5] <= 0 or not PO.roi(frame, win).size, (raw, m)
+                continue
+            r = PO.roi(frame, win)
+            assert list(r.shape[:2]) == g[k + "_shape"][i].tolist(), (raw, m, r.shape)
+            assert int(r.any(-1).sum()) == int(g[k + "_nnz"][i]) and crc32(np.ascontiguousarray(r).tobytes()) == int(g[k + "_crc"][i]), (raw, m)
+            windows += 1
+    assert windows >= 400
+    # the loader's coordinate grid of a crop (mapping_pixel_position_to_original_position_2d :223-235 on roi_xy :266-269, float32 :380)
+    pix = np.linspace(0, 63, 64)
+    gx, gy = np.meshgrid(pix, pix)
+    for b, want in zip(g["grid_boxes"], g["grid_xy_ori"]):
+        mine = np.stack([b[2] / 64 * gx + b[0], b[3] / 64 * gy + b[1]]).astype(np.float32)
+        assert np.array_equal(mine, want)
+
+
 def test_roi_zero_padding_outside_the_image():
     img = _img(48, 64)
     win = PO.window([5, 4, 31, 45], "crop_square_resize", 64, 48)          # (-2, 4, 43, 49, 45, 45): leaves the image left and below
@@ -84,6 +138,55 @@ def test_device_crops_equal_the_oracle_bit_for_bit(method, interp):
     mask = _img(48, 64, 1, seed=3)                                             # a visibility mask: one channel, nearest (loader :310)
     got = PP.get_roi_batch(torch.from_numpy(mask).cuda(), [[5, 4, 31, 45]], 16, PP.INTER_NEAREST, method).cpu().numpy()
     assert np.array_equal(got[0], PO.get_roi(mask, [5, 4, 31, 45], 16, PO.INTER_NEAREST, method))
+
+
+@pytest.mark.gpu
+def test_device_windows_equal_the_reference_recorded_windows():
+    """cp_crop_resize_u8's pre-resize window against the windows the REFERENCE's crop_square_resize handed to cv2.resize
+    (n3_windows.npz): with crop_size = the window's side the resize is the identity (INTER_NEAREST: source index = destination
+    index; INTER_LINEAR: every coefficient pair is (2048, 0)), so the crop IS the window -- same CRC-32 as the recorded one, for every
+    box the reference produced a window for; where the reference raised (window off the frame) the crop is all zero."""
+    g, crc32 = _n3()
+    H, W = (int(v) for v in g["frame_hw"])
+    frame = torch.from_numpy(_coded_frame(H, W)).cuda()
+    by_side = {}
+    for i in range(len(g["raw"])):
+        if g["sq_raised"][i] == 2:
+            continue
+        side = int(max(g["padded"][i][2], g["padded"][i][3]))
+        by_side.setdefault(side, []).append(i)
+    checked = 0
+    for side, ids in sorted(by_side.items()):
+        for interp in (PP.INTER_NEAREST, PP.INTER_LINEAR):
+            got = PP.get_roi_batch(frame, [g["padded"][i].tolist() for i in ids], side, interp, "crop_square_resize").cpu().numpy()
+            for j, i in enumerate(ids):
+                if g["sq_raised"][i] == 1:
+                    assert not got[j].any()
+                    continue
+                assert list(got[j].shape[:2]) == g["sq_shape"][i].tolist()
+                assert crc32(np.ascontiguousarray(got[j]).tobytes()) == int(g["sq_crc"][i]), (g["raw"][i], interp)
+                checked += 1
+    assert checked >= 400
+    # crop_resize (:94-108; rectangular windows, so no identity resize): the kernel against the oracle, whose windows the fixture pins
+    # on the CPU -- incl. the boxes wholly left of / above the frame, where the reference's `img[y1:y2, x1:x2]` counts a negative end
+    # from the far edge
+    fr = _coded_frame(H, W)
+    wrap = [i for i in range(len(g["raw"])) if g["cr_raised"][i] == 0 and (g["padded"][i][0] + g["padded"][i][2] < 0 or g["padded"][i][1] + g["padded"][i][3] < 0)]
+    assert len(wrap) >= 3
+    ids = wrap[:6] + [i for i in range(8, 240, 23) if g["cr_raised"][i] == 0]
+    got = PP.get_roi_batch(frame, [g["padded"][i].tolist() for i in ids], 64, PP.INTER_LINEAR, "crop_resize").cpu().numpy()
+    for j, i in enumerate(ids):
+        assert np.array_equal(got[j], PO.get_roi(fr, g["padded"][i].tolist(), 64, PO.INTER_LINEAR, "crop_resize")), g["raw"][i]
+    # ... and the coordinate grid cp_correspondences_bbox rebuilds from a final box == the loader's own roi_xy_ori
+    from checkerpose_amd.postprocess import correspondences
+    from checkerpose_amd.synthetic import build_net, det_image
+    net = build_net(seed=1).cuda()
+    nb = len(g["grid_boxes"])
+    out = net(det_image(nb, seed=5).cuda(), None)
+    want = correspondences(out, torch.from_numpy(g["grid_xy_ori"]).cuda())
+    got = correspondences(out, Bboxes=g["grid_boxes"])
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu
