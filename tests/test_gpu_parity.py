@@ -963,6 +963,50 @@ def test_edgeconv_fused_vs_reference_form(lib, monkeypatch, Cc, pfx):
     assert out.coff == 64
 
 
+def test_edgeconv_fused_keys_saturate_at_the_f16_range(lib):
+    """The gather keys P' = s (W1 x) of cp_edgeconv_fused / cp_edgeconv_tiled are tabled as IEEE halves (v_pk_maximum3_f16):
+    |P'| beyond 65 504 is CLAMPED there, where a bf16 / fp32 table would carry the value ("Numerical range").  Pinned
+    here so that the behaviour is a documented contract, not a surprise: four channels are driven to |P'| ~ 2e5 through their folded
+    BatchNorm scale; the kernel must equal leaky(max_k clamp_f16(P'_j) + Q'_i) and must NOT equal the unclamped form there; the other
+    60 channels are untouched by the clamp."""
+    B, N, K, Cc = 2, 512, 20, 64
+    idx = O.knn(ape_p3d(512), K)                                        # (1, N, K)
+    x = rnd(det_tensor("clampx", (B, N, Cc)), CP_BF16)
+    w1 = rnd(det_tensor("clampw1", (Cc, Cc), (3.0 / Cc) ** 0.5), CP_BF16)
+    dq = rnd(det_tensor("clampdq", (Cc, Cc), (3.0 / Cc) ** 0.5), CP_BF16)        # W2 - W1
+    dq[:4] = 0.0                                                        # big channels: Q' = t (keeps the sum inside fp32 / bf16 sanity)
+    s_ = 1.0 + 0.3 * det_tensor("clamps", (Cc,))
+    s_[:4] = torch.tensor([4e5, -4e5, 2.5e5, -3e5])                     # folded scale: |P'| up to ~2e5, both signs
+    t_ = det_tensor("clampt", (Cc,), 0.5)
+    P = (x @ w1.t()) * s_                                               # (B, N, C) fp32
+    assert float(P[..., :4].abs().max()) > 1.2e5 and float(P[..., 4:].abs().max()) < 100.0
+    Q = (x @ dq.t()) * s_ + t_
+    gi = idx[0]                                                         # (N, K)
+
+    def form(tab):
+        nb = tab[:, gi]                                                 # (B, N, K, C)
+        return F.leaky_relu(nb.max(dim=2)[0] + Q, 0.2)
+    ref = form(P.clamp(-65504.0, 65504.0).to(torch.float16).float())
+    unclamped = form(P)
+    wpq = torch.cat([w1, dq], 0).contiguous().to(dev())
+    scale, shift = torch.cat([s_, s_]).to(dev()), torch.cat([torch.zeros_like(t_), t_]).to(dev())
+    pk = torch.empty(lib.cp_edgeconv_fused_weight_bytes(Cc, Cc), dtype=torch.uint8, device=dev())
+    _abi.check(lib.cp_pack_edgeconv_fused_weight(st(), wpq.data_ptr(), Cc, Cc, pk.data_ptr()))
+    xd = x.to(torch.bfloat16).to(dev())
+    idx_d = idx.to(torch.int32).contiguous().to(dev())
+    out = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=dev())
+    _abi.check(lib.cp_edgeconv_fused(st(), xd.data_ptr(), Cc, 0, pk.data_ptr(), scale.data_ptr(), shift.data_ptr(), idx_d.data_ptr(), None,
+                                     out.data_ptr(), Cc, 0, B, N, K, Cc, Cc, 1, 0.2))
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    rel = (got - ref).abs() / (ref.abs() + 1.0)
+    assert float(rel.max()) <= 2e-2, float(rel.max())                   # bf16 output rounding + f16 key rounding
+    big = got[..., :4]
+    assert float(big.max()) <= 65504.0 * 1.01 + 1.0                     # positive side saturates at the f16 maximum (+ t)
+    assert float((got - unclamped).abs()[..., :4].max()) > 3e4          # ... where the unclamped form is far away
+    assert float(((got - unclamped).abs() / (unclamped.abs() + 1.0))[..., 4:].max()) <= 2e-2   # untouched channels: no clamp in play
+
+
 @pytest.mark.parametrize("N,Cc,pfx", [(4096, 64, "init_net.pre_query_block.0"), (4096, 256, "refine_net.1.pre_query_block.2"),
                                       (1024, 256, "refine_net.0.pre_query_block.1")])
 def test_edgeconv_tiled_vs_reference_form(lib, N, Cc, pfx):
