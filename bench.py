@@ -244,6 +244,14 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
                             "margin_contract_violations": margin_contract_violations(forced, free),
                             "free_running": {k: free[k] for k in keep if k in free}, "free_running_rows": free["bit_agreement_per_row"],
                             "teacher_forced": {k: forced[k] for k in keep if k in forced}, "teacher_forced_rows": forced["bit_agreement_per_row"]}
+    # ---- the same contract on TRAINED-LIKE weights: 300 steps of the HIP training program on a synthetic task whose targets are a
+    #      function of the image (checkerpose_amd/trained_like.py), then bf16 vs fp32 eval on held-out crops (~15 s)
+    try:
+        from checkerpose_amd.trained_like import train_then_measure
+        ex["bf16_agreement"]["trained_like"] = train_then_measure(npoint, device=dev)
+    except Exception as e:          # an extra must never take the headline down
+        ex["bf16_agreement"]["trained_like"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
     # ---- post-forward rows N2 + N4 on the device: correspondences + EPnP / RANSAC pose for the whole batch (opt-in path; the
     #      reference does both per image on the host, test_network_with_test_data.py:32-115).  Random-init weights: the poses are
     #      meaningless, the launch time is what is measured.
