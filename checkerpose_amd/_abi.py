@@ -30,6 +30,11 @@ class CpChainTail(C.Structure):       # the stride-2 fuse-layer convs computed i
                 ("Cout", C.c_int32 * 3), ("out_cphys", C.c_int32 * 3), ("relu", C.c_int32 * 3)]
 
 
+class CpI2fGather(C.Structure):       # Index2Feat's gather done by cp_mlp_pair_fused_gather's loader
+    _fields_ = [("patches", C.c_void_p), ("x_id", C.c_void_p), ("y_id", C.c_void_p), ("mask", C.c_void_p), ("zeros", C.c_void_p),
+                ("p_cstride", C.c_int32), ("p_coff", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32), ("k", C.c_int32)]
+
+
 class CpFuseConv(C.Structure):
     _fields_ = [("packed_w", C.c_void_p), ("affine", C.c_void_p), ("out", C.c_void_p),
                 ("kind", C.c_int32), ("Cout", C.c_int32), ("out_cphys", C.c_int32), ("relu", C.c_int32)]
@@ -127,6 +132,8 @@ SIGNATURES = {
     "cp_mlp_query_fused": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P, _P, _L, _L, _L, _L]),
     "cp_mlp_pair_fused_supported": (_I, [_I, _I, _I]),
     "cp_mlp_pair_fused": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
+    "cp_mlp_pair_fused_gather_supported": (_I, [_I, _I, _I]),
+    "cp_mlp_pair_fused_gather": (_I, [_P, C.POINTER(CpI2fGather), _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
     "cp_hr_stem_weight_bytes": (C.c_size_t, [_I]),
     "cp_pack_hr_stem_weights": (_I, [_P, _P, _P, _P, _P]),
     "cp_hr_stem": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

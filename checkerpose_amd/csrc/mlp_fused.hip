@@ -230,12 +230,18 @@ constexpr int MP_ROWS = 32;
 constexpr int MP_HP = 32;                                    // pieces per hidden row (256 channels)
 constexpr int MP_HBUF = MP_ROWS * MP_HP * 16;                // 16 384 B
 
+typedef __attribute__((ext_vector_type(4))) int32_t i32x4;
+
 struct MlpPairParams {
   const void* in; const void* w1; const float* t1;
   const void* w2; const float* t2;
   void* out;
   int M, in_cs, in_coff, nchunk1, n_rt, out_cs, out_coff;
   float slope1, slope2;
+  // GATHER instances (cp_mlp_pair_fused_gather): the first 32 pieces of a row are Index2Feat_module's four 64-channel taps
+  // (pipeline.py:156-163), fetched by the DMA loader straight from patch_generator's output map; `in` holds only the graph part
+  const void* patches; const int32_t* x_id; const int32_t* y_id; const float* mask; const void* zeros;
+  int Nrow, Hp, Wp, p_cs, p_coff, kk;                       // Nrow: log2 of the keypoints per crop
 };
 
 // slot (in 16-byte pieces) of piece `pc` of tile row `r` in an image of P pieces per row
@@ -259,8 +265,21 @@ constexpr int L2B = MP_L2B;
 #ifndef MP_L2PRIO
 #define MP_L2PRIO 3
 #endif
-template <int NI>                                            // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
+// An opaque copy of the lane id per use site (keeps the dozen address instructions of a site inside the loop instead of hoisted,
+// spilled and reloaded -- a scratch reload is a VMEM load and costs a vmcnt(0) on the tile DMA in flight).  The gathering instance
+// has no register left even for `lane` itself (hipcc spilled IT and reloaded it in front of every site), so there the id is
+// recomputed from the hardware (v_mbcnt: two VALU instructions, nothing live across the loop).
+template <bool FRESH>
+__device__ __forceinline__ int mp_lane(int lane) {
+  int ln;
+  if constexpr (FRESH) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+  else { ln = lane; asm volatile("" : "+v"(ln)); }
+  return ln;
+}
+
+template <int NI, bool GATHER = false>                       // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
 __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
+  static_assert(!GATHER || NI == 4, "the gathering loader works on 64-piece row images (one row per DMA instruction)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int P = 16 * NI;                                  // pieces per row image: 64 (K <= 512) / 48 (K <= 384) / 32 (K <= 256)
   constexpr int XBUF = MP_ROWS * P * 16;
@@ -301,19 +320,56 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
     // layer-1 waves hold 128 weight registers) and reloaded them in front of every DMA -- and a scratch reload is a VMEM load:
     // using it needs vmcnt(0), i.e. it waited for the tile DMA'd one iteration ago (38 % of a layer-1 wave's time by the phase
     // clock, tools/mlp_stamps.py).  An opaque copy of the lane id keeps the arithmetic (a dozen VALU instructions per piece) inside.
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
+    int ln = mp_lane<GATHER>(lane);
+    if constexpr (GATHER) {
+      // One DMA instruction = one row (P = 64): the row's keypoint ids and RoI bit are wave-uniform -> scalar loads (lgkmcnt, so the
+      // counted vmcnt of the tile loop still sees DMA pieces only).  Piece pc < 32: tap pc >> 3 (sf1..sf4 of Index2Feat_module.forward,
+      // pipeline.py:158-161: (2v, 2u), (2v + k, 2u), (2v, 2u + k), (2v + k, 2u + k)), 16-byte channel group pc & 7 of the map pixel;
+      // a row whose RoI bit is 0 reads zeros (the reference multiplies the taps by the {0, 1} mask, :280); 32 <= pc < npiece: the
+      // previous graph feature from `in`; pieces past the row's width read zeros (their weights are zero too).
+      // (scalar loads by hand: hipcc cannot prove that the kernel's own stores do not alias the id arrays and used per-lane
+      //  global_load_dwords -- VMEM operations in the middle of the counted DMA stream, 24 vmcnt(0) in the loop.)  The wave's four rows
+      //  are consecutive and N % 4 == 0, so they belong to ONE crop and their ids are one s_load_dwordx4 per array.
+      long long m0 = (long long)rt * MP_ROWS + wave * NI;
+      if (m0 > p.M - NI) m0 = p.M - NI;                        // rows past the end: valid rows, never stored
+      const int b0 = (int)(m0 >> p.Nrow);                      // Nrow = log2(N) here (N is a power of two: host check)
+      i32x4 xi, yi, mk;
+      {
+        const int32_t* px = p.x_id + m0;
+        const int32_t* py = p.y_id + m0;
+        const float* pm = p.mask + m0;
+        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(xi), "=&s"(yi), "=&s"(mk) : "s"(px), "s"(py), "s"(pm) : "memory");
+      }
+      const unsigned char* const pbase = (const unsigned char*)p.patches + ((size_t)b0 * p.Hp * p.Wp * p.p_cs + p.p_coff) * 2;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int slot = (wave * NI + j) * 64 + ln;
-      const int r = slot / P, s_ = slot - r * P;
-      int pc = (s_ & ~15) + ((s_ ^ r) & 15);
-      if (pc >= npiece) pc = 0;
-      long long m = (long long)rt * MP_ROWS + r;
-      if (m >= p.M) m = p.M - 1;                              // rows past the end: a valid row, never stored
-      const unsigned char* src = (const unsigned char*)p.in + ((size_t)m * p.in_cs + p.in_coff) * 2 + (size_t)pc * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sX + buf * XBUF + (wave * NI + j) * 1024), 16, 0, 0);
+      for (int j = 0; j < NI; ++j) {
+        const int r = wave * NI + j;
+        const int pc = (ln & ~15) + ((ln ^ r) & 15);
+        const int tap = pc >> 3;
+        const int y = min(2 * yi[j] + ((tap & 1) ? p.kk : 0), p.Hp - 1), x = min(2 * xi[j] + ((tap & 2) ? p.kk : 0), p.Wp - 1);
+        const unsigned char* src = (const unsigned char*)p.zeros + (pc & 7) * 16;
+        if (pc < 32) {
+          if (mk[j] != 0) src = pbase + ((size_t)(y * p.Wp + x) * p.p_cs) * 2 + (pc & 7) * 16;      // the {0, 1} RoI bit as fp32 bits: 0 = 0.f
+        } else if (pc < npiece) {
+          src = (const unsigned char*)p.in + ((size_t)(m0 + j) * p.in_cs + p.in_coff) * 2 + (size_t)(pc - 32) * 16;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sX + buf * XBUF + (wave * NI + j) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int slot = (wave * NI + j) * 64 + ln;
+        const int r = slot / P, s_ = slot - r * P;
+        int pc = (s_ & ~15) + ((s_ ^ r) & 15);
+        if (pc >= npiece) pc = 0;
+        long long m = (long long)rt * MP_ROWS + r;
+        if (m >= p.M) m = p.M - 1;                              // rows past the end: a valid row, never stored
+        const unsigned char* src = (const unsigned char*)p.in + ((size_t)m * p.in_cs + p.in_coff) * 2 + (size_t)pc * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sX + buf * XBUF + (wave * NI + j) * 1024), 16, 0, 0);
+      }
     }
   };
   __syncthreads();                                            // weights in registers (vmcnt 0), affine table written
@@ -339,8 +395,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
       if (rt < p.n_rt) {
         // (lane geometry from an opaque copy of the lane id, per iteration: hoisted out of the loop these few values were spilled
         //  beside the 128 weight registers, and their scratch reloads -- VMEM loads -- each cost a vmcnt(0) on the tile DMA in flight)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        int ln = mp_lane<GATHER>(lane);
         const int x = ln & 15, q = ln >> 4, qx = q ^ x;
         f32x4 acc[2][2];
 #pragma unroll
@@ -392,8 +447,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
       MP_MARK(3);                                             // DMA wait
     } else {
       if (it > 0) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        int ln = mp_lane<GATHER>(lane);
         const int x = ln & 15, q = ln >> 4, qx = q ^ x;
         const int wv = wave - 8;
         const unsigned char* const hb = sH + ((it - 1) & 1) * MP_HBUF + x * (MP_HP * 16);
@@ -459,6 +513,34 @@ extern "C" int cp_mlp_pair_fused_supported(int Cin, int C1, int C2) {
   return (Cin >= 64 && Cin <= 512 && Cin % 32 == 0 && C1 == 256 && C2 == 256) ? 1 : 0;
 }
 
+static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long long M, bool gather);
+
+extern "C" int cp_mlp_pair_fused_gather_supported(int Cg, int E_ch, int k) {
+  return ((Cg == 64 || Cg == 128 || Cg == 192 || Cg == 256) && E_ch == 64 && k >= 1 && k <= 4) ? 1 : 0;      // + N a power of two >= 4 at the call
+}
+
+extern "C" int cp_mlp_pair_fused_gather(cp_stream_t stream, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff, int Cg,
+                                        int B, int N, const void* packed_w1, const float* bias1, float slope1, const void* packed_w2,
+                                        const float* bias2, float slope2, void* out, int out_cstride, int out_coff) {
+  if (!g || !g->patches || !g->x_id || !g->y_id || !g->mask || !g->zeros || !gin || !packed_w1 || !bias1 || !packed_w2 || !bias2 || !out ||
+      B <= 0 || N <= 0)
+    return CP_ERR_INVALID;
+  if (!cp_mlp_pair_fused_gather_supported(Cg, 64, g->k) || g->Hp <= 0 || g->Wp <= 0 || N < 4 || (N & (N - 1))) return CP_ERR_INVALID;   // N = 2^n
+  if (g->p_cstride % 8 || g->p_coff % 8 || g->p_coff + 64 > g->p_cstride) return CP_ERR_ALIGN;
+  if (gin_cstride % 8 || gin_coff % 8 || gin_coff + Cg > gin_cstride || out_cstride % 8 || out_coff % 8 || out_coff + 256 > out_cstride) return CP_ERR_ALIGN;
+  if (!cp_aligned16(g->patches) || !cp_aligned16(g->zeros) || !cp_aligned16(gin) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(out))
+    return CP_ERR_ALIGN;
+  const long long M = (long long)B * N;
+  if (M >= (1LL << 31) / MP_ROWS * MP_ROWS || (long long)B * g->Hp * g->Wp * g->p_cstride * 2 >= (1LL << 40)) return CP_ERR_RANGE;
+  MlpPairParams p = {};
+  p.in = gin; p.in_cs = gin_cstride; p.in_coff = gin_coff;
+  p.w1 = packed_w1; p.t1 = bias1; p.w2 = packed_w2; p.t2 = bias2; p.out = out; p.out_cs = out_cstride; p.out_coff = out_coff;
+  p.slope1 = slope1; p.slope2 = slope2;
+  p.patches = g->patches; p.x_id = g->x_id; p.y_id = g->y_id; p.mask = g->mask; p.zeros = g->zeros;
+  p.Nrow = __builtin_ctz((unsigned)N); p.Hp = g->Hp; p.Wp = g->Wp; p.p_cs = g->p_cstride; p.p_coff = g->p_coff; p.kk = g->k;
+  return mlp_pair_launch(stream, p, 256 + Cg, M, true);
+}
+
 extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
                                  const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
                                  float slope2, void* out, int out_cstride, int out_coff) {
@@ -468,26 +550,33 @@ extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstr
   if (!cp_aligned16(in) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(out)) return CP_ERR_ALIGN;
   const long long M = (long long)B * N;
   if (M >= (1LL << 31) / MP_ROWS * MP_ROWS) return CP_ERR_RANGE;
+  MlpPairParams p = {};
+  p.in = in; p.w1 = packed_w1; p.t1 = bias1; p.w2 = packed_w2; p.t2 = bias2; p.out = out;
+  p.in_cs = in_cstride; p.in_coff = in_coff;
+  p.out_cs = out_cstride; p.out_coff = out_coff; p.slope1 = slope1; p.slope2 = slope2;
+  return mlp_pair_launch(stream, p, Cin, M, false);
+}
+
+static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long long M, bool gather) {
   const int nchunk = Cin / 32;
   // 32 / 48 / 64 pieces per row image.  Never below 32: the smallest instance is <2> (Cin <= 128 used to give P = 16, i.e. LDS sized
   // for 16 pieces under a kernel<4> launch that addresses 64: out-of-bounds LDS, silently wrong); pieces past the row's width
-  // re-read its piece 0 under zero weights, so kernel<2> serves every Cin <= 256
-  const int P = nchunk <= 8 ? 32 : (nchunk * 4 + 15) / 16 * 16;
+  // re-read its piece 0 under zero weights, so kernel<2> serves every Cin <= 256.  The gathering loader always uses 64-piece images.
+  const int P = gather ? 64 : (nchunk <= 8 ? 32 : (nchunk * 4 + 15) / 16 * 16);
   const size_t lds = mlp_pair_lds(P);
   static CpDeviceOnce once;
   const int dev = cp_current_device();
   CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)mlp_pair_fused_kernel<2>, mlp_pair_lds(32)) &&
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<3>, mlp_pair_lds(48)) &&
-                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4>, mlp_pair_lds(64)));
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4>, mlp_pair_lds(64)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4, true>, mlp_pair_lds(64)));
   const int n_cu = cp_num_cus();
   if (n_cu <= 0) return CP_ERR_HIP;
-  MlpPairParams p;
-  p.in = in; p.w1 = packed_w1; p.t1 = bias1; p.w2 = packed_w2; p.t2 = bias2; p.out = out;
-  p.M = (int)M; p.in_cs = in_cstride; p.in_coff = in_coff; p.nchunk1 = nchunk; p.n_rt = (int)((M + MP_ROWS - 1) / MP_ROWS);
-  p.out_cs = out_cstride; p.out_coff = out_coff; p.slope1 = slope1; p.slope2 = slope2;
+  p.M = (int)M; p.nchunk1 = nchunk; p.n_rt = (int)((M + MP_ROWS - 1) / MP_ROWS);
   const int grid = p.n_rt < n_cu ? p.n_rt : n_cu;
   hipStream_t st = (hipStream_t)stream;
-  if (P == 32) CP_LAUNCH((mlp_pair_fused_kernel<2>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  if (gather) CP_LAUNCH((mlp_pair_fused_kernel<4, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  else if (P == 32) CP_LAUNCH((mlp_pair_fused_kernel<2>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else if (P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else CP_LAUNCH((mlp_pair_fused_kernel<4>), dim3((unsigned)grid), dim3(768), lds, st, p);
   return cp_check_launch();

@@ -37,6 +37,7 @@ USE_CONV_GROUP = os.environ.get("CHECKERPOSE_AMD_CONV_GROUP", "0") == "1"    # t
 CONV_GROUP_MAX_C = int(os.environ.get("CHECKERPOSE_AMD_CONV_GROUP_MAXC", "48"))
 USE_SPLITK = os.environ.get("CHECKERPOSE_AMD_SPLITK", "1") != "0"     # small-batch split-K routing (cp_conv2d_igemm_splitk)
 GEMM_WS_SMALL_K = os.environ.get("CHECKERPOSE_AMD_GEMM_WS_SMALL_K", "1") != "0"   # A/B: weight-stationary GEMM from K = 64
+USE_MLP_GATHER = os.environ.get("CHECKERPOSE_AMD_MLP_GATHER", "1") != "0"   # Index2Feat's 4-tap gather inside the fused MLP pair's loader (A/B switch)
 USE_PATCH_GATHER = os.environ.get("CHECKERPOSE_AMD_PATCH_GATHER", "1") != "0"   # patch conv only at the gathered taps
 USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet stem (bf16)
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
@@ -977,6 +978,50 @@ class Program:
         fl = 2 * M * (Cin * 256 + 256 * 256)
         self.flops += fl
         self.conv_log.append((keys[0], M, 512, Cin, fl, "mlp_fused", M * (Cin + 256) * self.es + (Cin * 256 + 256 * 256) * self.es))
+        return out
+
+    def can_fuse_mlp_pair_gather(self, L: Act, patches: Act, w1, w2, E_ch, k):
+        """the pair with Index2Feat's gather in its loader (cp_mlp_pair_fused_gather): L = the [local 4 x 64 | graph] concat buffer"""
+        return (USE_MLP_GATHER and self.can_fuse_mlp_pair(L, w1, w2) and patches is not None and E_ch == 64 and L.C > 256 and L.W >= 4 and (L.W & (L.W - 1)) == 0
+                and bool(self.lib.cp_mlp_pair_fused_gather_supported(int(L.C - 256), int(E_ch), int(k))))
+
+    def mlp_pair_fused_gather(self, patches: Act, xid_t, yid_t, mask_t, L: Act, keys, ws, bs, slope, N, k, out: Act = None):
+        """Index2Feat_module's 4-tap gather x RoI bit (pipeline.py:156-163,280) + pre_graph_module in one launch: the loader of the
+        fused pair fetches the taps straight from patch_generator's map, the first 256 channels of `L` are never written"""
+        Cin = L.C
+        Cg = Cin - 256
+        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(256, Cin, 1, 1), 256, Cin, Cin)
+        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(256, 256, 1, 1), 256, 256, 256)
+        ck = ("mlp_pair", keys[0])
+        if ck not in self.ws.cache:
+            self.ws.cache[ck] = (bs[0].float().contiguous(), bs[1].float().contiguous())
+        b1, b2 = self.ws.cache[ck]
+        zk = ("zeros128",)
+        if zk not in self.ws.cache:
+            self.ws.cache[zk] = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        zeros = self.ws.cache[zk]
+        self.keep += [pw1, pw2, b1, b2, zeros]
+        if out is None:
+            out = self.act(1, N, 256)
+        pt, lt, ot = patches.tbuf, L.tbuf, out.tbuf
+        a1 = (pw1.data_ptr(), b1.data_ptr(), float(slope), pw2.data_ptr(), b2.data_ptr(), float(slope))
+        descs = []
+
+        def args(P):
+            g = _abi.CpI2fGather()
+            g.patches, g.x_id, g.y_id, g.mask, g.zeros = P(pt), xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr(), zeros.data_ptr()
+            g.p_cstride, g.p_coff, g.Hp, g.Wp, g.k = patches.cstride, patches.coff, patches.H, patches.W, k
+            descs.append(g)                                   # the descriptor must outlive the (possibly deferred) call
+            return (C.byref(g), P(lt), L.cstride, L.coff + 256, Cg, self.B, N) + a1 + (P(ot), out.cstride, out.coff)
+        self.keep.append(descs)
+        self._add(self.lib.cp_mlp_pair_fused_gather, args, "mlp_fused:" + keys[0],
+                  [pt, lt, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
+        M = self.B * N
+        fl = 2 * M * (Cin * 256 + 256 * 256)
+        self.flops += fl
+        # algorithmic HBM bytes: the gathered taps overlap and repeat, so at most the patch map itself is read once
+        nby = (min(patches.B * patches.H * patches.W * 64, M * 256) + M * (Cg + 256) + Cin * 256 + 256 * 256) * self.es
+        self.conv_log.append((keys[0], M, 512, Cin, fl, "mlp_fused", nby))
         return out
 
     def permute_rows(self, x: Act, out: Act, perm_t, gids_t):

@@ -825,7 +825,10 @@ def emit_posenet(em: NetEmitter, cfg, io):
             patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(pgk + ".bias"), k, k, 1, k - 1, Ech)
         else:
             patches = p.conv(f, rp + ".patch", wpg, tp.const_vec(Ech, True), em._bias_vec(pgk, Ech), k, k, 1, k - 1, Ech)
-        if patches is not None:
+        pkeys = [rp + ".pre_graph_module.0", rp + ".pre_graph_module.2"]
+        pws = [em.W(k_ + ".weight") for k_ in pkeys]
+        gather_in_pair = tp is None and p.can_fuse_mlp_pair_gather(L, patches, pws[0], pws[1], Ech, k)
+        if patches is not None and not gather_in_pair:
             p.index2feat(patches, io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, Ech, k)
         if tp is not None:
             # the decode ops advance io["xid"/"yid"] in place: keep this stage's gather positions for the backward
@@ -834,9 +837,10 @@ def emit_posenet(em: NetEmitter, cfg, io):
                 ids_i[nm] = torch.empty_like(io[nm])
                 tp.memcpy(ids_i[nm].data_ptr(), io[nm].data_ptr(), io[nm].numel() * 4, "save_ids")
             _patch_tape(em, pgk, wpg, f, patches, L.slice(0, 4 * Ech), ids_i, N, Ech, k)
-        pkeys = [rp + ".pre_graph_module.0", rp + ".pre_graph_module.2"]
-        pws = [em.W(k_ + ".weight") for k_ in pkeys]
-        if tp is None and p.can_fuse_mlp_pair(L, pws[0], pws[1]):
+        if gather_in_pair:      # Index2Feat's gather x RoI bit inside the pair's loader: L's first 256 channels are never materialised
+            h = p.mlp_pair_fused_gather(patches, io["xid"], io["yid"], io["mask"], L, pkeys, pws, [em.W(k_ + ".bias") for k_ in pkeys],
+                                        slope, N, k)
+        elif tp is None and p.can_fuse_mlp_pair(L, pws[0], pws[1]):
             h = p.mlp_pair_fused(L, pkeys, pws, [em.W(k_ + ".bias") for k_ in pkeys], slope)     # csrc/mlp_fused.hip
         else:
             h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)

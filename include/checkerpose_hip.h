@@ -231,6 +231,25 @@ int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in
                       const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2, float slope2,
                       void* out, int out_cstride, int out_coff);
 
+/* The same with Index2Feat_module's gather (pipeline.py:156-163: four 64-channel taps of patch_generator's output map at
+ * (2v, 2u), (2v + k, 2u), (2v, 2u + k), (2v + k, 2u + k), times the {0, 1} RoI bit, :280) done by the kernel's DMA loader: the
+ * (B, N, 256) local-feature tensor is never written or read back.  Row (b, n) = [tap 0 | tap 1 | tap 2 | tap 3 | gin row], i.e. the
+ * weight packed_w1 is the (256, 256 + Cg) one of cp_mlp_pair_fused.  patches (B, Hp, Wp, p_cstride) bf16, channels
+ * [p_coff, p_coff + 64); x_id / y_id int32 (B, N), mask fp32 (B, N) as cp_bits_decode leaves them; zeros: >= 128 zero bytes (the
+ * source of rows whose RoI bit is 0); gin (B, N, gin_cstride) channels [gin_coff, gin_coff + Cg), Cg in {64, 128, 192, 256}. */
+typedef struct {
+  const void* patches;
+  const int32_t* x_id;
+  const int32_t* y_id;
+  const float* mask;
+  const void* zeros;
+  int32_t p_cstride, p_coff, Hp, Wp, k;
+} CpI2fGather;
+int cp_mlp_pair_fused_gather_supported(int Cg, int E_ch, int k);
+int cp_mlp_pair_fused_gather(cp_stream_t stream, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff, int Cg, int B, int N,
+                             const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
+                             float slope2, void* out, int out_cstride, int out_coff);
+
 /* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
  * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
 int cp_upsample2x_bilinear_ac(cp_stream_t stream, int dtype, const void* in, void* out, int B, int H, int W,

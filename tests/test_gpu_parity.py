@@ -1158,6 +1158,69 @@ def test_mlp_pair_fused_every_instance(lib, Cin):
                                  pk[1].data_ptr(), bd[1].data_ptr(), 0.01, out.data_ptr(), 256, 0) == -1
 
 
+@pytest.mark.parametrize("B,N,H,Cg", [(3, 512, 16, 64), (2, 1024, 32, 256), (1, 4096, 64, 256), (5, 64, 16, 128)])
+def test_mlp_pair_fused_gather_equals_gather_then_pair(lib, B, N, H, Cg):
+    """cp_mlp_pair_fused_gather (Index2Feat_module's 4-tap gather x RoI bit, pipeline.py:156-163,280, done by the fused pair's DMA
+    loader: the (B, N, 256) local-feature tensor never exists) == cp_index2feat_gather into the concat buffer followed by
+    cp_mlp_pair_fused, BIT FOR BIT (same rows reach the same MFMAs), and both == torch within the bf16 bounds.  Border ids (0 and
+    H/2 - 1: taps on the map's last row / column), masked rows, a channel-sliced patch map, row counts that leave the last tile
+    ragged."""
+    k, E = 2, 64
+    Hp = H + 1
+    Cin = 256 + Cg
+    pm = torch.full((B, Hp, Hp, 96), 3.0, dtype=torch.bfloat16, device=dev())         # patch map: channels [16, 80) of a wider tensor
+    pm[..., 16:80] = det_tensor("pgm%d" % H, (B, Hp, Hp, E)).to(torch.bfloat16).to(dev())
+    xid = torch.from_numpy(((np.arange(B * N).reshape(B, N) * 7 + 3) % (H // 2)).astype(np.int32))
+    yid = torch.from_numpy(((np.arange(B * N).reshape(B, N) * 5 + 1) % (H // 2)).astype(np.int32))
+    xid[:, :4] = torch.tensor([0, H // 2 - 1, 0, H // 2 - 1], dtype=torch.int32)
+    yid[:, :4] = torch.tensor([0, 0, H // 2 - 1, H // 2 - 1], dtype=torch.int32)
+    mask = (det_tensor("pgmask", (B, N)) > -0.4).float()
+    assert 0.1 < float(mask.mean()) < 0.9
+    cat = torch.zeros(B, N, Cin, dtype=torch.bfloat16, device=dev())                  # [local 256 | graph Cg]
+    cat[..., 256:] = det_tensor("pgg%d" % Cg, (B, N, Cg)).to(torch.bfloat16).to(dev())
+    w = [det_tensor("pg_w1_%d" % Cin, (256, Cin), (6.0 / Cin) ** 0.5), det_tensor("pg_w2", (256, 256), (6.0 / 256) ** 0.5)]
+    b = [det_tensor("pg_b1", (256,), 0.1), det_tensor("pg_b2", (256,), 0.1)]
+    pk = []
+    for wi, ci in zip(w, (Cin, 256)):
+        buf = torch.empty(lib.cp_packed_gemm_weight_bytes(CP_BF16, 256, ci), dtype=torch.uint8, device=dev())
+        wd = wi.contiguous().to(dev())
+        _abi.check(lib.cp_pack_gemm_weight(st(), CP_BF16, wd.data_ptr(), 256, ci, ci, buf.data_ptr()))
+        pk.append(buf)
+    bd = [t.contiguous().to(dev()) for t in b]
+    xd, yd, md = xid.to(dev()), yid.to(dev()), mask.to(dev())
+    # (a) the two-launch form: gather into the concat buffer, then the pair
+    pmc = pm[..., 16:80].contiguous()
+    _abi.check(lib.cp_index2feat_gather(st(), CP_BF16, pmc.data_ptr(), xd.data_ptr(), yd.data_ptr(), md.data_ptr(), cat.data_ptr(), B, N, Hp, Hp,
+                                        E, k, Cin, 0))
+    two = torch.full((B, N, 256), 7.0, dtype=torch.bfloat16, device=dev())
+    _abi.check(lib.cp_mlp_pair_fused(st(), cat.data_ptr(), Cin, 0, Cin, B, N, pk[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                     pk[1].data_ptr(), bd[1].data_ptr(), 0.01, two.data_ptr(), 256, 0))
+    # (b) one launch: the local part of `cat` is poisoned to prove it is never read
+    cat2 = cat.clone()
+    cat2[..., :256] = float("nan")
+    g = _abi.CpI2fGather()
+    zeros = torch.zeros(256, dtype=torch.uint8, device=dev())
+    g.patches, g.x_id, g.y_id, g.mask, g.zeros = pm.data_ptr(), xd.data_ptr(), yd.data_ptr(), md.data_ptr(), zeros.data_ptr()
+    g.p_cstride, g.p_coff, g.Hp, g.Wp, g.k = 96, 16, Hp, Hp, k
+    assert lib.cp_mlp_pair_fused_gather_supported(Cg, E, k) == 1
+    one = torch.full((B, N, 320), 7.0, dtype=torch.bfloat16, device=dev())
+    _abi.check(lib.cp_mlp_pair_fused_gather(st(), C.byref(g), cat2.data_ptr(), Cin, 256, Cg, B, N, pk[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                            pk[1].data_ptr(), bd[1].data_ptr(), 0.01, one.data_ptr(), 320, 64))
+    torch.cuda.synchronize()
+    assert float((one[..., :64].float() - 7.0).abs().max()) == 0.0
+    assert torch.equal(one[..., 64:], two)
+    # torch reference of the whole span
+    pmf = pm[..., 16:80].float().cpu()
+    bi = torch.arange(B)[:, None].expand(B, N)
+    taps = [pmf[bi, 2 * yid.long() + dy, 2 * xid.long() + dx] for dy, dx in ((0, 0), (k, 0), (0, k), (k, k))]     # sf1..sf4 (B, N, 64)
+    x = torch.cat([torch.cat(taps, -1) * mask[..., None], cat[..., 256:].float().cpu()], -1)
+    h1 = rnd(F.leaky_relu(x @ rnd(w[0], CP_BF16).t() + b[0], 0.01), CP_BF16)
+    ref = F.leaky_relu(h1 @ rnd(w[1], CP_BF16).t() + b[1], 0.01)
+    close(one[..., 64:].float().cpu(), ref, 2e-2)
+    assert lib.cp_mlp_pair_fused_gather(st(), C.byref(g), cat2.data_ptr(), Cin, 256, Cg, B, 100, pk[0].data_ptr(), bd[0].data_ptr(), 0.01,
+                                        pk[1].data_ptr(), bd[1].data_ptr(), 0.01, one.data_ptr(), 320, 64) == -1      # N not a power of two
+
+
 def test_edgeconv_per_sample_graphs_lm(lib):
     """LM twin: each sample gathers along its own object's graph (pipeline_lm.py:55-57), 1-based obj_ids."""
     B, N, K, Cc = 4, 512, 20, 64
