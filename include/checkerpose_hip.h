@@ -383,7 +383,7 @@ int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_
  *   halo int32 (G, N/512, HPAD): internal row ids of the patch's out-of-patch neighbour rows (padded with any valid row);
  *   nbr  int16 (G, N/512, 512, K): every own row's K neighbours as table SLOTS (own row j -> j, halo entry h -> 512 + h).
  * Two launches: the key table P' = s W1 x of every row (written to `key_table`, cp_edgeconv_tiled_table_bytes, plane-major
- * [crop][Cout / 8][N][16 B] order-preserving int16 keys), then per (crop, patch) the table slice in LDS by LDS-DMA, gather-max,
+ * [crop][Cout / 8][N][16 B] IEEE half-precision keys, clamped to +-65504), then per (crop, patch) the table slice in LDS by LDS-DMA, gather-max,
  * Q' on MFMA, LeakyReLU.  x / out / scale / shift as cp_edgeconv_fused; packed_w_fused = cp_pack_edgeconv_fused_weight's image,
  * packed_w_q = cp_pack_edgeconv_tiled_weight's (Q halves in 32-channel slices).
  * Supported (cp_edgeconv_tiled_supported): N a multiple of 512 above 512, K <= 20 and a multiple of 4, Cin in {64, 256},
