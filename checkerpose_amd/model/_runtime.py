@@ -63,7 +63,9 @@ def _version_sum(tensors):
         return sum(map(_VERSION_OF, tensors))
     except RuntimeError:        # inference-mode tensors (built / loaded under torch.inference_mode) track no version: they cannot be
         return sum(0 if t.is_inference() else t._version for t in tensors)   # edited in place outside inference mode either
-TRAIN_GRAPH = os.environ.get("CHECKERPOSE_AMD_TRAIN_GRAPH", "fwd,bwd").split(",")   # which halves replay as hipGraphs (A/B + debugging)
+TRAIN_GRAPH = os.environ.get("CHECKERPOSE_AMD_TRAIN_GRAPH", "fwd,bwd").split(",")
+# stream priority per graph lane of the eval programs (torch: -1 = high, 0 = default); A/B knob CHECKERPOSE_AMD_LANE_PRIO="-1,0,0"
+LANE_PRIO = [int(v) for v in os.environ.get("CHECKERPOSE_AMD_LANE_PRIO", "0").split(",") if v.strip()]   # which halves replay as hipGraphs (A/B + debugging)
 
 
 def _replay_half(mod, pr, which, lo, hi, device):
@@ -559,7 +561,10 @@ class HipForwardMixin:
                     # launched concurrently on separate streams, forked from / joined to the caller's stream
                     graphs, keep = [], []
                     for sub in prog.progs:
-                        lanes = [torch.cuda.Stream(device) for _ in range(sub.nlanes if self.use_lanes and not self.use_dag else 1)]
+                        nl_ = sub.nlanes if self.use_lanes and not self.use_dag else 1
+                        # lane priorities (they carry into the captured graph): lane 0 = the 64x64 HRNet branch, whose launch is the
+                        # longest of a module AND has the longest dependent tail (its 2nd / 3rd stride-2 fuse convs); see LANE_PRIO
+                        lanes = [torch.cuda.Stream(device, priority=(LANE_PRIO[k] if k < len(LANE_PRIO) else 0)) for k in range(nl_)]
                         if self.max_lanes and len(lanes) > self.max_lanes:      # lane k -> stream k mod max_lanes (fewer queues in the graph)
                             lanes = [lanes[k % self.max_lanes] for k in range(len(lanes))]
                         lanes[0].wait_stream(cur)
