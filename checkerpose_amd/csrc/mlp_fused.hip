@@ -279,7 +279,8 @@ __device__ __forceinline__ int mp_lane(int lane) {
 
 template <int NI, bool GATHER = false>                       // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
 __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
-  static_assert(!GATHER || NI == 4, "the gathering loader works on 64-piece row images (one row per DMA instruction)");
+  static_assert(!GATHER || NI >= 3, "the gathering loader moves one row (48 or 64 pieces) per DMA instruction");
+  constexpr int ND = GATHER ? 4 : NI;                         // DMA instructions per layer-1 wave and tile (gathering: its 4 rows, P lanes each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int P = 16 * NI;                                  // pieces per row image: 64 (K <= 512) / 48 (K <= 384) / 32 (K <= 256)
   constexpr int XBUF = MP_ROWS * P * 16;
@@ -315,6 +316,24 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
   // real width re-read its piece 0 (their weights are zero)
   const int step = gridDim.x;
   const int npiece = p.nchunk1 * 4;
+  // gathering loader: the keypoint ids / RoI bits of the wave's four rows of the tile whose DMA is issued NEXT (scalar registers)
+  i32x4 gxi = {0, 0, 0, 0}, gyi = {0, 0, 0, 0}, gmk = {0, 0, 0, 0};
+  long long gm0 = 0;
+  auto ids_issue = [&](int rt) {
+    if constexpr (GATHER) {
+      long long m0 = (long long)rt * MP_ROWS + wave * 4;
+      if (m0 > p.M - 4) m0 = p.M - 4;                          // rows past the end: valid rows, never stored
+      gm0 = m0;
+      const int32_t* px = p.x_id + m0;
+      const int32_t* py = p.y_id + m0;
+      const float* pm = p.mask + m0;
+      asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %5, 0x0"
+                   : "=&s"(gxi), "=&s"(gyi), "=&s"(gmk) : "s"(px), "s"(py), "s"(pm) : "memory");
+    }
+  };
+  auto ids_wait = [&]() {                                      // the registers are tied through the wait: no use can move above it
+    if constexpr (GATHER) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gxi), "+s"(gyi), "+s"(gmk) : : "memory");
+  };
   auto dma_tile = [&](int rt, int buf) {
     // The lane's piece offsets are loop invariants: hipcc hoisted them out of the tile loop as NI 64-bit pairs, spilled them (the
     // layer-1 waves hold 128 weight registers) and reloaded them in front of every DMA -- and a scratch reload is a VMEM load:
@@ -330,32 +349,26 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
       // (scalar loads by hand: hipcc cannot prove that the kernel's own stores do not alias the id arrays and used per-lane
       //  global_load_dwords -- VMEM operations in the middle of the counted DMA stream, 24 vmcnt(0) in the loop.)  The wave's four rows
       //  are consecutive and N % 4 == 0, so they belong to ONE crop and their ids are one s_load_dwordx4 per array.
-      long long m0 = (long long)rt * MP_ROWS + wave * NI;
-      if (m0 > p.M - NI) m0 = p.M - NI;                        // rows past the end: valid rows, never stored
+      //  The ids of THIS tile were loaded one call ahead (ids_issue / ids_wait below: issued before the tile barrier, waited for
+      //  behind it, so the barrier's skew hides the scalar-cache miss); P < 64: the upper lanes sit out (exec mask).
+      const long long m0 = gm0;
       const int b0 = (int)(m0 >> p.Nrow);                      // Nrow = log2(N) here (N is a power of two: host check)
-      i32x4 xi, yi, mk;
-      {
-        const int32_t* px = p.x_id + m0;
-        const int32_t* py = p.y_id + m0;
-        const float* pm = p.mask + m0;
-        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(xi), "=&s"(yi), "=&s"(mk) : "s"(px), "s"(py), "s"(pm) : "memory");
-      }
       const unsigned char* const pbase = (const unsigned char*)p.patches + ((size_t)b0 * p.Hp * p.Wp * p.p_cs + p.p_coff) * 2;
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int r = wave * NI + j;
+      for (int j = 0; j < 4; ++j) {
+        const int r = wave * 4 + j;
         const int pc = (ln & ~15) + ((ln ^ r) & 15);
         const int tap = pc >> 3;
-        const int y = min(2 * yi[j] + ((tap & 1) ? p.kk : 0), p.Hp - 1), x = min(2 * xi[j] + ((tap & 2) ? p.kk : 0), p.Wp - 1);
+        const int y = min(2 * gyi[j] + ((tap & 1) ? p.kk : 0), p.Hp - 1), x = min(2 * gxi[j] + ((tap & 2) ? p.kk : 0), p.Wp - 1);
         const unsigned char* src = (const unsigned char*)p.zeros + (pc & 7) * 16;
         if (pc < 32) {
-          if (mk[j] != 0) src = pbase + ((size_t)(y * p.Wp + x) * p.p_cs) * 2 + (pc & 7) * 16;      // the {0, 1} RoI bit as fp32 bits: 0 = 0.f
+          if (gmk[j] != 0) src = pbase + ((size_t)(y * p.Wp + x) * p.p_cs) * 2 + (pc & 7) * 16;     // the {0, 1} RoI bit as fp32 bits: 0 = 0.f
         } else if (pc < npiece) {
           src = (const unsigned char*)p.in + ((size_t)(m0 + j) * p.in_cs + p.in_coff) * 2 + (size_t)(pc - 32) * 16;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sX + buf * XBUF + (wave * NI + j) * 1024), 16, 0, 0);
+        if (P == 64 || ln < P)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(sX + buf * XBUF + r * (P * 16)), 16, 0, 0);
       }
     } else {
 #pragma unroll
@@ -373,14 +386,20 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
     }
   };
   __syncthreads();                                            // weights in registers (vmcnt 0), affine table written
+  auto dma_target = [&](int rt) { return rt + 2 * step < p.n_rt ? rt + 2 * step : (int)blockIdx.x; };
   if (l1) {
+    const int t1 = blockIdx.x + step < p.n_rt ? blockIdx.x + step : blockIdx.x;
+    ids_issue(blockIdx.x); ids_wait();
     dma_tile(blockIdx.x, 0);
-    if (blockIdx.x + step < p.n_rt) dma_tile(blockIdx.x + step, 1); else dma_tile(blockIdx.x, 1);
-    __builtin_amdgcn_s_waitcnt(0x0070 | NI);                  // vmcnt(NI): tile 0 has landed
+    ids_issue(t1); ids_wait();
+    dma_tile(t1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0070 | ND);                  // vmcnt(ND): tile 0 has landed
+    ids_issue(dma_target(blockIdx.x));                        // for the first iteration's DMA; waited for behind the barrier
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  if (l1) ids_wait();
 
   // iteration it: layer 1 on tile rt (sX[it % 3] -> sH[it & 1]) while tile rt + 2 step streams into sX[(it + 2) % 3]; layer 2 on
   // tile rt - step (sH[(it - 1) & 1])
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
   for (int rt = blockIdx.x; rt - step < p.n_rt; rt += step, ++it) {
     if (l1) {
       const int nb = xb >= 1 ? xb - 1 : 2;                    // (it + 2) % 3
-      dma_tile(rt + 2 * step < p.n_rt ? rt + 2 * step : blockIdx.x, nb);       // always NI pieces: the vmcnt arithmetic below counts them
+      dma_tile(dma_target(rt), nb);                           // always ND pieces: the vmcnt arithmetic below counts them
       MP_MARK(0);                                             // DMA issue
       if (rt < p.n_rt) {
         // (lane geometry from an opaque copy of the lane id, per iteration: hoisted out of the loop these few values were spilled
@@ -443,8 +462,9 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
         }
       }
       MP_MARK(2);                                             // layer-1 epilogue
-      __builtin_amdgcn_s_waitcnt(0x0070 | NI);                // vmcnt(NI), lgkmcnt(0): the tile of the NEXT iteration has landed
+      __builtin_amdgcn_s_waitcnt(0x0070 | ND);                // vmcnt(ND), lgkmcnt(0): the tile of the NEXT iteration has landed
       MP_MARK(3);                                             // DMA wait
+      ids_issue(dma_target(rt + step));                       // the next iteration's DMA target: its ids fly across the tile barrier
     } else {
       if (it > 0) {
         int ln = mp_lane<GATHER>(lane);
@@ -495,6 +515,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    if (l1) ids_wait();
     MP_MARK(4);                                               // barrier
     xb = xb == 2 ? 0 : xb + 1;
   }
@@ -561,21 +582,23 @@ static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long l
   const int nchunk = Cin / 32;
   // 32 / 48 / 64 pieces per row image.  Never below 32: the smallest instance is <2> (Cin <= 128 used to give P = 16, i.e. LDS sized
   // for 16 pieces under a kernel<4> launch that addresses 64: out-of-bounds LDS, silently wrong); pieces past the row's width
-  // re-read its piece 0 under zero weights, so kernel<2> serves every Cin <= 256.  The gathering loader always uses 64-piece images.
-  const int P = gather ? 64 : (nchunk <= 8 ? 32 : (nchunk * 4 + 15) / 16 * 16);
+  // re-read its piece 0 under zero weights, so kernel<2> serves every Cin <= 256.  The gathering loader has 48- and 64-piece instances.
+  const int P = nchunk <= 8 ? (gather ? 48 : 32) : (nchunk * 4 + 15) / 16 * 16;
   const size_t lds = mlp_pair_lds(P);
   static CpDeviceOnce once;
   const int dev = cp_current_device();
   CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)mlp_pair_fused_kernel<2>, mlp_pair_lds(32)) &&
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<3>, mlp_pair_lds(48)) &&
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<4>, mlp_pair_lds(64)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<3, true>, mlp_pair_lds(48)) &&
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<4, true>, mlp_pair_lds(64)));
   const int n_cu = cp_num_cus();
   if (n_cu <= 0) return CP_ERR_HIP;
   p.M = (int)M; p.nchunk1 = nchunk; p.n_rt = (int)((M + MP_ROWS - 1) / MP_ROWS);
   const int grid = p.n_rt < n_cu ? p.n_rt : n_cu;
   hipStream_t st = (hipStream_t)stream;
-  if (gather) CP_LAUNCH((mlp_pair_fused_kernel<4, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  if (gather && P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  else if (gather) CP_LAUNCH((mlp_pair_fused_kernel<4, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else if (P == 32) CP_LAUNCH((mlp_pair_fused_kernel<2>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else if (P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else CP_LAUNCH((mlp_pair_fused_kernel<4>), dim3((unsigned)grid), dim3(768), lds, st, p);
