@@ -30,6 +30,11 @@ class CpChainTail(C.Structure):       # the stride-2 fuse-layer convs computed i
                 ("Cout", C.c_int32 * 3), ("out_cphys", C.c_int32 * 3), ("relu", C.c_int32 * 3)]
 
 
+class CpChainTailConv(C.Structure):   # a first-level fuse conv in the tail of a 36 / 72 / 144-channel chain launch (cp_hr_branch_chain_tails)
+    _fields_ = [("packed_w", C.c_void_p), ("shift", C.c_void_p), ("out", C.c_void_p),
+                ("kind", C.c_int32), ("Cout", C.c_int32), ("out_cphys", C.c_int32), ("relu", C.c_int32)]
+
+
 class CpI2fGather(C.Structure):       # Index2Feat's gather done by cp_mlp_pair_fused_gather's loader
     _fields_ = [("patches", C.c_void_p), ("x_id", C.c_void_p), ("y_id", C.c_void_p), ("mask", C.c_void_p), ("zeros", C.c_void_p),
                 ("p_cstride", C.c_int32), ("p_coff", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32), ("k", C.c_int32)]
@@ -147,6 +152,10 @@ SIGNATURES = {
     "cp_hr_chain_tail_channels": (_I, []),
     "cp_pack_hr_chain_tail_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "cp_hr_branch_chain_tail": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P, C.POINTER(CpChainTail)]),
+    "cp_hr_chain_tailconv_supported": (_I, [_I, _I, _I, _I, _I]),
+    "cp_hr_chain_tailconv_weight_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
+    "cp_pack_hr_chain_tailconv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cp_hr_branch_chain_tails": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P, _I, C.POINTER(CpChainTailConv)]),
     "cp_upsample2x_bilinear_ac": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_fuse_sum_act": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_maxpool3x3s2": (_I, [_P, _I, _P, _P, _I, _I, _I, _I]),

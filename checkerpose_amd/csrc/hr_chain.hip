@@ -79,6 +79,14 @@ using CfgB1 = ChainCfg<36, 32, 32, 1, 1, 3, 4>;
 using CfgB2 = ChainCfg<72, 16, 16, 2, 1, 3, 0>;
 using CfgB3 = ChainCfg<144, 8, 8, 4, 2, 2, 0>;      // 4 crops per workgroup: a conv's 378 KB of weights are streamed per workgroup
 
+// a fuse-layer conv that reads this branch's finished map, run in the launch's tail off the map in LDS (cp_hr_branch_chain_tails):
+// kind 0 = the 1x1 conv towards a higher-resolution branch, kind 1 = the first 3x3 / stride-2 conv towards a lower-resolution one
+struct ChainTailConv {
+  const void* w;          // [chunk][tile][lane][16 B] (pack_chain_tail_kernel), folded-BN scale inside
+  const float* shift;     // [16 nt] folded-BN shift, zero beyond Cout
+  void* out;              // (B, H >> kind, W >> kind, out_cp) bf16
+  int kind, nt, out_cp, relu;
+};
 struct ChainParams {
   const void* src[4];
   int shift[4];
@@ -88,6 +96,8 @@ struct ChainParams {
   void* out;              // (B, H, W, CPHYS) bf16
   int B;
   int dbg;                // KNOBS builds only (CP_CHAIN_DBG): 1 = no source loads, 2 = no MFMA loop, 4 = no store, 8 = no weight stream
+  int ntail;
+  ChainTailConv tc[3];
 };
 
 #ifdef CP_DEBUG_KNOBS
@@ -146,7 +156,133 @@ __device__ __forceinline__ void stage_sources(const ChainParams& p, unsigned cha
   }
 }
 
+// One fuse-layer conv in the chain launch's tail.  The finished map is in LDS (read-only from here on: no barriers).  The eight waves
+// split the work 2-D: TG tile groups x 8 / TG fragment groups -- wave w owns channel tiles [NTW tg, NTW tg + NTW) (tg = w % TG) of the
+// OUTPUT fragments F = fg + (8 / TG) f (fg = w / TG; a fragment = 16 output pixels).  Weight fragments come straight from L2, one K
+// chunk ahead; a wave that owned every tile of a few fragments (the first version) fetched the whole conv's weight -- 60-190 KB per
+// wave for the stride-2 convs, for 1-2 MFMAs per fragment loaded: the split is chosen so that a loaded fragment feeds >= 4 MFMAs.
+// kind 1: a fragment's lanes read ring pixels two apart -- the window of output pixel (oy, ox) starts at ring (2 oy, 2 ox).
+template <typename Cfg, int KIND, int NT, int TG>
+__device__ __forceinline__ void chain_tail_conv(const ChainTailConv& t, const unsigned char* sMap, int lane, int wave, int crop0, int B) {
+  constexpr int CG = Cfg::CG, H = Cfg::H, W = Cfg::W, WP = Cfg::WP, PIX = Cfg::PIX, GRP = Cfg::GRP, MAP = Cfg::MAP, CPW = Cfg::CPW;
+  constexpr int HT = KIND ? H / 2 : H, WT = KIND ? W / 2 : W;
+  static_assert(WT >= 16 ? WT % 16 == 0 : WT == 8, "a tail fragment is 16 pixels of an output row, or two 8-pixel rows");
+  constexpr int FG = 8 / TG, NTW = (NT + TG - 1) / TG;
+  constexpr int FPC = HT * WT / 16, NF = CPW * FPC, FW = (NF + FG - 1) / FG;
+  constexpr int KC = KIND ? (9 * CG + 3) / 4 : (CG + 3) / 4;
+  constexpr uint32_t CENTER = (uint32_t)((WP + 1) * PIX);
+  const int x = lane & 15, q = lane >> 4;
+  const int tg = wave % TG, fg = wave / TG;
+  const int nt0 = tg * NTW;
+  if (nt0 >= NT) return;                                        // a tile group beyond the conv's tiles: this wave has nothing to do
+  const int ntn = nt0 + NTW <= NT ? NTW : NT - nt0;             // wave-uniform
+  uint32_t base[FW];
+  int opix[FW];                                                 // output pixel index inside the crop, -1: no fragment
+  int crop[FW];
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    const int F = fg + FG * f;
+    const int c = F / FPC, Fc = F - c * FPC;
+    int orow, ocol;
+    if (WT >= 16) { orow = Fc / (WT / 16); ocol = (Fc - orow * (WT / 16)) * 16 + x; }
+    else { orow = Fc * 2 + (x >> 3); ocol = x & 7; }
+    const bool live = F < NF;
+    crop[f] = c;
+    opix[f] = live ? orow * WT + ocol : -1;
+    base[f] = live ? (uint32_t)(c * MAP + ((KIND ? 2 * orow : orow) * WP + (KIND ? 2 * ocol : ocol)) * PIX) : 0u;
+  }
+  auto a_off = [&](int kc) -> uint32_t {
+    const int G = kc * 4 + q;
+    if (KIND) {
+      const int tap = G / CG, cg = G - tap * CG;
+      const int r = tap / 3, s_ = tap - 3 * r;
+      return G < 9 * CG ? (uint32_t)((r * WP + s_) * PIX + cg * GRP) : 0u;
+    }
+    return G < CG ? CENTER + (uint32_t)(G * GRP) : CENTER;       // K padding: zero weights, any finite data
+  };
+  const u32x4* const wt = (const u32x4*)t.w + (size_t)nt0 * 64 + lane;
+  f32x4 acc[FW][NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const f32x4 t4 = nt < ntn ? *(const f32x4*)(t.shift + q * 4 * NT + (nt0 + nt) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < FW; ++f) acc[f][nt] = t4;
+  }
+  // weight fragments PD - 1 chunks ahead in a ring of PD register sets (PD = 4 measured +-0 against 2: the tails are bound by the
+  // bytes a CU draws from L2, not by the round trips)
+  constexpr int PD = 2;
+  u32x4 wf[PD][NTW];
+#pragma unroll
+  for (int pk = 0; pk < PD - 1; ++pk)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+      if (pk < KC && nt < ntn) wf[pk][nt] = wt[(pk * NT + nt) * 64];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    if (kc + PD - 1 < KC) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+        if (nt < ntn) wf[(kc + PD - 1) % PD][nt] = wt[((kc + PD - 1) * NT + nt) * 64];
+    }
+    const uint32_t o = a_off(kc);
+    u32x4 a[FW];
+#pragma unroll
+    for (int f = 0; f < FW; ++f) a[f] = *(const u32x4*)(sMap + base[f] + o);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+      if (nt < ntn) {
+#pragma unroll
+        for (int f = 0; f < FW; ++f) mma16(wf[kc % PD][nt], a[f], acc[f][nt]);
+      }
+  }
+  // lane (x, q): channels 4 NT q + 4 nt + {0..3} of its pixel: 8-byte stores
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    const int b = crop0 + crop[f];
+    if (opix[f] < 0 || b >= B) continue;
+    unsigned char* const ob = (unsigned char*)t.out + ((size_t)b * HT * WT + opix[f]) * t.out_cp * 2;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int c0 = q * 4 * NT + (nt0 + nt) * 4;
+      if (nt < ntn && c0 < t.out_cp) {
+        u32x2 pk;
+        pk.x = pack_bf16x2(acc[f][nt][0], acc[f][nt][1]);
+        pk.y = pack_bf16x2(acc[f][nt][2], acc[f][nt][3]);
+        if (t.relu) { pk.x = relu_bf16x2(pk.x); pk.y = relu_bf16x2(pk.y); }
+        *(u32x2*)(ob + c0 * 2) = pk;
+      }
+    }
+  }
+}
+
+// the fuse-layer convs HRNet-W18 hangs on each branch (timm HighResolutionModule.fuse_layers; restated in oracle hr_module): per chain
+// configuration the (kind, tiles) pairs that exist -- anything else is refused on the host
 template <typename Cfg>
+__device__ __forceinline__ void chain_tails(const ChainParams& p, const unsigned char* sMap, int lane, int wave, int crop0) {
+#pragma unroll 1
+  for (int i = 0; i < p.ntail; ++i) {
+    const ChainTailConv t = p.tc[i];
+    if constexpr (Cfg::C == 36) {
+      // (kind, tiles, tile groups).  Measured (MI355X, eager, per launch at 256 crops): the tails add 4 / 11 / 16 us to the 36-channel
+      // chain of a stage-2 / 3 / 4 module, 5 / 22 us to the 72-channel one (stage 3 / 4: the 72 -> 144 conv fetches 2 x 189 KB of
+      // weights per workgroup at what one CU draws from L2), 5-10 us to the 144-channel one.  More tile groups (less redundant weight
+      // traffic, but 16 fragments per wave) spilled and were slower; deeper weight prefetch (PD) changed nothing.
+      if (t.kind == 0) chain_tail_conv<Cfg, 0, 2, 1>(t, sMap, lane, wave, crop0, p.B);
+      else if (t.nt == 5) chain_tail_conv<Cfg, 1, 5, 4>(t, sMap, lane, wave, crop0, p.B);
+      else chain_tail_conv<Cfg, 1, 3, 4>(t, sMap, lane, wave, crop0, p.B);
+    } else if constexpr (Cfg::C == 72) {
+      if (t.kind == 1) chain_tail_conv<Cfg, 1, 9, 4>(t, sMap, lane, wave, crop0, p.B);
+      else if (t.nt == 3) chain_tail_conv<Cfg, 0, 3, 1>(t, sMap, lane, wave, crop0, p.B);
+      else chain_tail_conv<Cfg, 0, 2, 1>(t, sMap, lane, wave, crop0, p.B);
+    } else {
+      if (t.nt == 5) chain_tail_conv<Cfg, 0, 5, 2>(t, sMap, lane, wave, crop0, p.B);
+      else if (t.nt == 3) chain_tail_conv<Cfg, 0, 3, 1>(t, sMap, lane, wave, crop0, p.B);
+      else chain_tail_conv<Cfg, 0, 2, 1>(t, sMap, lane, wave, crop0, p.B);
+    }
+  }
+}
+
+template <typename Cfg, bool TAIL = false>
 __global__ __launch_bounds__(Cfg::NTHR) void hr_chain_kernel(const ChainParams p) {
   constexpr int CG = Cfg::CG, NT_ALL = Cfg::NT_ALL, S = Cfg::S, NS = Cfg::NS, WP = Cfg::WP, HP = Cfg::HP, H = Cfg::H, W = Cfg::W;
   constexpr int MAP = Cfg::MAP, CPW = Cfg::CPW, MT = Cfg::MT, PM = Cfg::PM, NST = Cfg::NST, NTW = Cfg::NTW, SLAB = Cfg::SLAB, WITER = Cfg::WITER;
@@ -355,6 +491,31 @@ __global__ __launch_bounds__(Cfg::NTHR) void hr_chain_kernel(const ChainParams p
         ((u32x4*)p.out)[(((size_t)b * H + y) * W + xx) * CG + g] = *(const u32x4*)(sMap + c * MAP + ((y + 1) * WP + xx + 1) * PIX + g * GRP);
     }
   }
+  // ---- tail: the module's first-level fuse convs fed by this branch, off the map that is still in LDS (the stores above are in flight)
+  if constexpr (TAIL) chain_tails<Cfg>(p, sMap, lane, wave, crop0);
+}
+
+// tail-conv packing: [chunk kc][tile nt][lane][8 bf16]; K group G = 4 kc + q: kind 1 -> tap G / CG, input channel 8 (G % CG) + e;
+// kind 0 -> input channel 8 G + e (G < CG); tile row `row` of tile nt = output channel (row >> 2) * 4 NT + 4 nt + (row & 3)
+__global__ void pack_chain_tail_kernel(const float* __restrict__ w, const float* __restrict__ scale, uint16_t* __restrict__ out, int Cin,
+                                       int CG, int Cout, int NT, int kind, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % 8);
+  const int lane = (int)((i / 8) % 64);
+  size_t blk = i / 512;
+  const int nt = (int)(blk % NT);
+  const int kc = (int)(blk / NT);
+  const int row = lane & 15, q = lane >> 4;
+  const int G = kc * 4 + q;
+  int tap = -1, cin = 0;
+  if (kind) { tap = G / CG; cin = (G % CG) * 8 + e; if (tap >= 9) tap = -1; }
+  else if (G < CG) { tap = 0; cin = G * 8 + e; }
+  const int n = (row >> 2) * 4 * NT + nt * 4 + (row & 3);
+  const int KK = kind ? 9 : 1;
+  float v = 0.f;
+  if (tap >= 0 && cin < Cin && n < Cout) v = w[((size_t)n * Cin + cin) * KK + tap] * (scale ? scale[n] : 1.f);
+  out[i] = (uint16_t)f32_to_bf16_bits(v);
 }
 
 // packing: [chunk kc][tile nt][lane][16 B]; lane (row = lane & 15, q = lane >> 4), element e: K group G = 4 kc + q ->
@@ -382,10 +543,23 @@ template <typename Cfg>
 int launch_chain(hipStream_t st, const ChainParams& p) {
   static CpDeviceOnce once;                  // per template instance, per device
   const int dev = cp_current_device();
-  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)hr_chain_kernel<Cfg>, Cfg::LDS));
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)hr_chain_kernel<Cfg, false>, Cfg::LDS) &&
+                                  cp_set_max_lds((const void*)hr_chain_kernel<Cfg, true>, Cfg::LDS));
   const unsigned grid = (unsigned)((p.B + Cfg::CPW - 1) / Cfg::CPW);
-  CP_LAUNCH((hr_chain_kernel<Cfg>), dim3(grid), dim3(Cfg::NTHR), Cfg::LDS, st, p);
+  if (p.ntail > 0) CP_LAUNCH((hr_chain_kernel<Cfg, true>), dim3(grid), dim3(Cfg::NTHR), Cfg::LDS, st, p);
+  else CP_LAUNCH((hr_chain_kernel<Cfg, false>), dim3(grid), dim3(Cfg::NTHR), Cfg::LDS, st, p);
   return cp_check_launch();
+}
+
+// (kind, tiles) pairs chain_tails() is instantiated for, per chain configuration; -> K chunks of the packed weight, 0 = unsupported
+int tail_conv_chunks(int C, int kind, int nt) {
+  const int CG = (C + 7) / 8;
+  bool ok = false;
+  if (C == 36) ok = (kind == 0 && nt == 2) || (kind == 1 && (nt == 5 || nt == 3));
+  else if (C == 72) ok = (kind == 0 && (nt == 2 || nt == 3)) || (kind == 1 && nt == 9);
+  else if (C == 144) ok = kind == 0 && (nt == 2 || nt == 3 || nt == 5);
+  if (!ok) return 0;
+  return kind ? (9 * CG + 3) / 4 : (CG + 3) / 4;
 }
 
 struct ChainInfo { int C, H, W, KCP, NT_ALL, CG, AFF; size_t conv_w; };
@@ -435,7 +609,35 @@ extern "C" int cp_pack_hr_chain_tail_weight(cp_stream_t stream, const float* w, 
 }
 
 static int branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
-                        const void* packed_w, const float* affine, void* out, const CpChainTail* tail);
+                        const void* packed_w, const float* affine, void* out, const CpChainTail* tail, int ntail = 0,
+                        const CpChainTailConv* tconvs = nullptr);
+
+// ---- tails of the 36 / 72 / 144-channel chains (cp_hr_branch_chain_tails): any of the first-level fuse convs that read the branch
+extern "C" int cp_hr_chain_tailconv_supported(int C, int H, int W, int kind, int Cout) {
+  ChainInfo ci;
+  if (C == 18 || !chain_info(C, H, W, &ci) || Cout <= 0 || (kind != 0 && kind != 1)) return 0;
+  return tail_conv_chunks(C, kind, (Cout + 15) / 16) > 0 ? 1 : 0;
+}
+extern "C" size_t cp_hr_chain_tailconv_weight_bytes(int C, int H, int W, int kind, int Cout) {
+  if (!cp_hr_chain_tailconv_supported(C, H, W, kind, Cout)) return 0;
+  const int nt = (Cout + 15) / 16;
+  return (size_t)tail_conv_chunks(C, kind, nt) * nt * 1024;
+}
+extern "C" int cp_pack_hr_chain_tailconv_weight(cp_stream_t stream, const float* w, const float* scale, int C, int H, int W, int kind, int Cout,
+                                                void* packed) {
+  if (!w || !packed || !cp_hr_chain_tailconv_supported(C, H, W, kind, Cout)) return CP_ERR_INVALID;
+  if (!cp_aligned16(packed)) return CP_ERR_ALIGN;
+  const int nt = (Cout + 15) / 16;
+  const size_t total = cp_hr_chain_tailconv_weight_bytes(C, H, W, kind, Cout) / 2;
+  CP_LAUNCH(pack_chain_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale, (uint16_t*)packed, C,
+            (C + 7) / 8, Cout, nt, kind, total);
+  return cp_check_launch();
+}
+extern "C" int cp_hr_branch_chain_tails(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs, const int32_t* shifts,
+                                        int relu_in, const void* packed_w, const float* affine, void* out, int ntail, const CpChainTailConv* convs) {
+  if (ntail < 1 || ntail > 3 || !convs || C == 18) return CP_ERR_INVALID;
+  return branch_chain(stream, B, C, H, W, nsrc, srcs, shifts, relu_in, packed_w, affine, out, nullptr, ntail, convs);
+}
 
 extern "C" int cp_hr_branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs,
                                   const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out) {
@@ -450,7 +652,7 @@ extern "C" int cp_hr_branch_chain_tail(cp_stream_t stream, int B, int C, int H, 
 }
 
 static int branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs, const int32_t* shifts, int relu_in,
-                        const void* packed_w, const float* affine, void* out, const CpChainTail* tail) {
+                        const void* packed_w, const float* affine, void* out, const CpChainTail* tail, int ntail, const CpChainTailConv* tconvs) {
   ChainInfo ci;
   if (B <= 0 || !srcs || !shifts || nsrc < 1 || nsrc > 4 || !packed_w || !affine || !out) return CP_ERR_INVALID;
   if (!chain_info(C, H, W, &ci)) return CP_ERR_INVALID;
@@ -467,6 +669,17 @@ static int branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc
   p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0;
   p.w = packed_w; p.aff = affine; p.out = out; p.B = B;
   p.dbg = cp_knob("CP_CHAIN_DBG") ? atoi(cp_knob("CP_CHAIN_DBG")) : 0;
+  p.ntail = 0;
+  for (int i = 0; i < ntail; ++i) {
+    const CpChainTailConv& c = tconvs[i];
+    const int nt = (c.Cout + 15) / 16;
+    if (!c.packed_w || !c.shift || !c.out || c.out == out || !cp_hr_chain_tailconv_supported(C, H, W, c.kind, c.Cout)) return CP_ERR_INVALID;
+    if (c.out_cphys % 8 || c.Cout > c.out_cphys || c.out_cphys > nt * 16) return CP_ERR_INVALID;
+    if (!cp_aligned16(c.packed_w) || !cp_aligned16(c.shift) || !cp_aligned16(c.out)) return CP_ERR_ALIGN;
+    p.tc[i].w = c.packed_w; p.tc[i].shift = c.shift; p.tc[i].out = c.out;
+    p.tc[i].kind = c.kind; p.tc[i].nt = nt; p.tc[i].out_cp = c.out_cphys; p.tc[i].relu = c.relu ? 1 : 0;
+  }
+  p.ntail = ntail;
   hipStream_t st = (hipStream_t)stream;
   if (C == CfgB1::C) return launch_chain<CfgB1>(st, p);
   if (C == CfgB2::C) return launch_chain<CfgB2>(st, p);

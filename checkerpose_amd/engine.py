@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpChainTail, CpConvDesc, CpConvGroupItem, CpFuseConv
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpChainTail, CpChainTailConv, CpConvDesc, CpConvGroupItem, CpFuseConv
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
@@ -25,6 +25,7 @@ USE_FUSE_OUT = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT", "1") != "0"   # HRNet 
 USE_S2_SMALL = os.environ.get("CHECKERPOSE_AMD_S2_SMALL", "1") != "0"   # LDS-staged 3x3 / stride-2 conv for wide inputs (transition1[1])
 USE_SEG_FUSED = os.environ.get("CHECKERPOSE_AMD_SEG_FUSED", "1") != "0"   # seg_block inside the last decoder conv's epilogue
 USE_HALO2 = os.environ.get("CHECKERPOSE_AMD_HALO2", "1") != "0"     # k = 2 / pad 1 convs on the LDS-staged halo kernel (A/B: the generic kernel)
+USE_CHAIN_TAILS = os.environ.get("CHECKERPOSE_AMD_CHAIN_TAILS", "1") != "0"   # the 36 / 72 / 144-channel chain launches also run the first-level fuse convs fed by their branch (A/B switch)
 USE_CHAIN_TAIL = os.environ.get("CHECKERPOSE_AMD_CHAIN_TAIL", "1") != "0"   # the 64x64 chain launch also runs the stride-2 fuse convs that read its output
 FUSE_OUT_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_MIN_BATCH", "1"))   # grouped first-level fuse-layer launches: at every batch
 #   (after per-conv branches too; 350 -> 317 graph nodes below 40 crops: B = 1 1.60 -> 1.58 ms, B = 8 1.88 -> 1.68, B = 32 3.10 -> 2.99; -1: with the chains)
@@ -659,6 +660,67 @@ class Program:
         nb = self.B * H * W * C_ * self.es
         self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es))
         return out
+
+    def can_chain_tails(self, C_, H, W, convs):
+        """every first-level fuse conv fed by this (36 / 72 / 144-channel) branch fits its chain launch's tail (cp_hr_branch_chain_tails);
+        convs: [(wkey, w, scale, shift, k in (1, 3), relu)] as for hr_fuse_out"""
+        return (USE_CHAIN_TAILS and self.can_chain(C_, H, W) and 1 <= len(convs) <= 3 and
+                all(bool(self.lib.cp_hr_chain_tailconv_supported(C_, H, W, 1 if c[4] == 3 else 0, int(c[1].shape[0]))) for c in convs))
+
+    def hr_chain_tails(self, name, srcs, shifts, relu_in, ws, affs, C_, H, W, convs):
+        """hr_chain + the module's first-level fuse convs that read this branch, in the launch's tail off the map in LDS; returns
+        (out, [conv outputs]) -- the outputs hr_fuse_out would have produced (same shapes, bf16 rounding of a different K order)"""
+        lib = self.lib
+        blob, aff = self.ws.pack_chain(name, ws, affs, C_, H, W)
+        out = self.act(H, W, C_)
+        arr = (CpChainTailConv * len(convs))()
+        touts, keep, fl_t, nb_t = [], [], 0, 0
+        for i, (wkey, w, scale, shift, k, relu) in enumerate(convs):
+            kind = 1 if k == 3 else 0
+            Cout = int(w.shape[0])
+            ck = ("chain_tailconv", wkey)
+            if ck not in self.ws.cache:
+                buf = torch.empty(lib.cp_hr_chain_tailconv_weight_bytes(C_, H, W, kind, Cout), dtype=torch.uint8, device=self.device)
+                wc = w.contiguous()
+                sc = scale.to(device=self.device, dtype=torch.float32).contiguous()
+                self.ws.keep += [wc, sc]
+                st = torch.cuda.current_stream(self.device).cuda_stream
+                _abi.check(lib.cp_pack_hr_chain_tailconv_weight(st, wc.data_ptr(), sc.data_ptr(), C_, H, W, kind, Cout, buf.data_ptr()),
+                           "cp_pack_hr_chain_tailconv_weight(%s)" % wkey)
+                sh = torch.zeros(_rup(Cout, 16), dtype=torch.float32, device=self.device)
+                sh[:Cout] = shift
+                self.ws.cache[ck] = (buf, sh)
+            buf, sh = self.ws.cache[ck]
+            o = self.act(H >> kind, W >> kind, Cout)
+            assert o.coff == 0 and o.cstride == o.Cphys
+            arr[i].packed_w, arr[i].shift = buf.data_ptr(), sh.data_ptr()
+            arr[i].kind, arr[i].Cout, arr[i].out_cphys, arr[i].relu = kind, Cout, o.Cphys, 1 if relu else 0
+            touts.append(o)
+            keep += [buf, sh]
+            fl_t += 2 * self.B * o.H * o.W * k * k * C_ * Cout
+            nb_t += self.B * o.H * o.W * Cout * self.es + k * k * C_ * Cout * self.es
+        n = len(srcs)
+        arr_p = (C.c_void_p * 4)()
+        arr_s = (C.c_int32 * 4)(*([int(v) for v in shifts] + [0] * (4 - n)))
+        self.keep += [arr_p, arr_s, blob, aff, arr] + keep
+        for s_, sh_ in zip(srcs, shifts):
+            assert s_.coff == 0 and s_.cstride == s_.Cphys == out.Cphys and (s_.H << sh_, s_.W << sh_) == (H, W)
+        tbs, ot, tts = [s_.tbuf for s_ in srcs], out.tbuf, [o.tbuf for o in touts]
+        bp, ap = blob.data_ptr(), aff.data_ptr()
+
+        def argb(P):
+            for i, t in enumerate(tbs):
+                arr_p[i] = P(t)
+            for i, t in enumerate(tts):
+                arr[i].out = P(t)
+            return (self.B, C_, H, W, n, arr_p, arr_s, 1 if relu_in else 0, bp, ap, P(ot), len(convs), arr)
+
+        self._add(lib.cp_hr_branch_chain_tails, argb, "hr_chain:" + name, tbs, [ot] + tts)
+        fl = 8 * 2 * self.B * H * W * 9 * C_ * C_ + fl_t
+        self.flops += fl
+        nb = self.B * H * W * C_ * self.es
+        self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es + nb_t))
+        return out, touts
 
     def _hr_chain_tail(self, name, srcs, shifts, relu_in, blob, aff, out, C_, H, W, tail):
         lib = self.lib

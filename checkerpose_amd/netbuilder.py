@@ -341,6 +341,21 @@ class NetEmitter:
                     for i, o in zip(range(j + 1, nb), touts):
                         first[(i, j)] = o
                     continue
+                # (round 5) the other chains likewise: every first-level fuse conv that reads branch j -- the 1x1 convs towards the
+                # higher-resolution branches and the first stride-2 conv towards each lower-resolution one -- in the chain launch's tail
+                lst_t = []
+                for i in range(nb):
+                    q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+                    if j > i:
+                        lst_t.append((i, q + ".0", q + ".1", 1, False))
+                    elif j < i:
+                        lst_t.append((i, q + ".0.0", q + ".0.1", 3, i - j > 1))
+                tcv = [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (k, relu) for (_, ck, bk, k, relu) in lst_t]
+                if nb > 1 and p.can_chain_tails(C_, H, W, tcv):
+                    xs[j], touts = p.hr_chain_tails(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W, tcv)
+                    for (i, _, _, _, _), o in zip(lst_t, touts):
+                        first[(i, j)] = o
+                    continue
                 xs[j] = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W)
             else:
                 xs[j] = self._materialize(xs[j])

@@ -340,6 +340,26 @@ int cp_hr_branch_chain_tail(cp_stream_t stream, int B, int C, int H, int W, int 
                             const int32_t* shifts, int relu_in, const void* packed_w, const float* affine, void* out,
                             const CpChainTail* tail);
 
+/* The same for the 36 / 72 / 144-channel chains (round 5): ANY first-level fuse-layer conv that reads the branch -- kind 0: the 1x1
+ * conv + BN towards a higher-resolution branch (output at the branch's resolution), kind 1: the first 3x3 / stride-2 conv + BN
+ * (+ ReLU when the chain goes on) towards a lower-resolution one (output at half resolution) -- runs in the chain launch's tail off
+ * the map in LDS: the grouped cp_hr_fuse_out launch behind the chain and its re-read of the map go away.  Up to 3 convs per launch;
+ * weights packed by cp_pack_hr_chain_tailconv_weight (folded-BN scale inside), shift: fp32 [16 ceil(Cout / 16)] (zero beyond Cout);
+ * out (B, H >> kind, W >> kind, out_cphys) bf16, out_cphys a multiple of 8 in [Cout, 16 ceil(Cout / 16)].  Supported (kind, Cout)
+ * pairs are HRNet-W18's: C = 36: 1x1 -> 18, s2 -> 72 / 36; C = 72: 1x1 -> 18 / 36, s2 -> 144; C = 144: 1x1 -> 18 / 36 / 72. */
+typedef struct {
+  const void* packed_w;
+  const float* shift;
+  void* out;
+  int32_t kind, Cout, out_cphys, relu;
+} CpChainTailConv;
+int cp_hr_chain_tailconv_supported(int C, int H, int W, int kind, int Cout);
+size_t cp_hr_chain_tailconv_weight_bytes(int C, int H, int W, int kind, int Cout);
+int cp_pack_hr_chain_tailconv_weight(cp_stream_t stream, const float* w, const float* scale, int C, int H, int W, int kind, int Cout,
+                                     void* packed);
+int cp_hr_branch_chain_tails(cp_stream_t stream, int B, int C, int H, int W, int nsrc, const void* const* srcs, const int32_t* shifts,
+                             int relu_in, const void* packed_w, const float* affine, void* out, int ntail, const CpChainTailConv* convs);
+
 /* The first-level fuse-layer convs of a timm HighResolutionModule that read ONE branch's output `src` (B, H, W, cin_phys) bf16
  * (timm HighResolutionModule.fuse_layers inside backbone.py:35): up to 4 convs per launch, each
  *   kind 0: 1x1 conv + folded BN at the source resolution (the term towards a higher-resolution branch, before its nearest

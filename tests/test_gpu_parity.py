@@ -704,6 +704,82 @@ def test_hr_branch_chain_tail_vs_fuse_out_and_torch(lib, tconvs):
     assert lib.cp_pack_hr_chain_tail_weight(st(), keep[0].data_ptr(), keep[1].data_ptr(), 36, 9, 40, tb.data_ptr()) == -1     # past 96 channels
 
 
+@pytest.mark.parametrize("Cc,H,W,B,tconvs", [
+    (36, 32, 32, 3, [(0, 18, False), (1, 72, False), (1, 36, True)]),      # stage 4, branch 1: 1x1 -> 0, s2 -> 2, s2 (+ReLU) towards 3
+    (36, 32, 32, 2, [(0, 18, False)]),                                     # stage 2
+    (72, 16, 16, 5, [(0, 18, False), (0, 36, False), (1, 144, False)]),    # stage 4, branch 2 (two crops per workgroup, ragged batch)
+    (144, 8, 8, 6, [(0, 18, False), (0, 36, False), (0, 72, False)]),      # stage 4, branch 3 (four crops per workgroup, ragged batch)
+])
+def test_hr_branch_chain_tails_vs_torch(lib, Cc, H, W, B, tconvs):
+    """cp_hr_branch_chain_tails (round 5): the 36 / 72 / 144-channel chain launches also produce the first-level fuse-layer convs that read
+    their branch (timm HighResolutionModule.fuse_layers[i][j]: the 1x1 conv + BN towards higher-resolution branches, the first 3x3 /
+    stride-2 conv + BN (+ ReLU) towards lower-resolution ones) off the map in LDS.  The chain output is bit-identical to
+    cp_hr_branch_chain's; every tail output matches torch's conv over that (bf16) output with the BN scale folded into bf16 weights --
+    the reference cp_hr_fuse_out is held to; padded channels exactly zero; unsupported (kind, Cout) pairs are refused."""
+    from checkerpose_amd._abi import CpChainTailConv
+    dtype = CP_BF16
+    terms = [det_tensor("ct0_%d" % Cc, (B, Cc, H, W)), det_tensor("ct1_%d" % Cc, (B, Cc, H // 2, W // 2))]
+    shifts = [0, 1]
+    ws = [det_tensor("ctw%d_%d" % (i, Cc), (Cc, Cc, 3, 3), (2.0 / (Cc * 9)) ** 0.5 * 1.5) for i in range(8)]
+    affs = [(1.0 + 0.3 * det_tensor("cts%d" % i, (Cc,)), 0.2 * det_tensor("ctb%d" % i, (Cc,))) for i in range(8)]
+    for i in range(1, 8, 2):
+        affs[i] = (affs[i][0] * 0.4, affs[i][1])
+    blob = torch.empty(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev())
+    for i, w in enumerate(ws):
+        wd, sd_ = w.contiguous().to(dev()), affs[i][0].contiguous().to(dev())
+        _abi.check(lib.cp_pack_hr_chain_weight(st(), wd.data_ptr(), sd_.data_ptr(), Cc, H, W, i, blob.data_ptr()))
+        torch.cuda.synchronize()
+    n = lib.cp_hr_chain_affine_floats(Cc, H, W)
+    aff = torch.zeros(8, 2, n)
+    for i, (s_, t_) in enumerate(affs):
+        aff[i, 0, :Cc], aff[i, 1, :Cc] = s_, t_
+    aff = aff.to(dev())
+    srcs = [to_cl(t, dtype) for t in terms]
+    cp = srcs[0].shape[-1]
+    arr_p = (C.c_void_p * 4)(*([s_.data_ptr() for s_ in srcs] + [None] * 2))
+    arr_s = (C.c_int32 * 4)(*(shifts + [0, 0]))
+    plain = torch.full((B, H, W, cp), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_hr_branch_chain(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), plain.data_ptr()), "hr chain")
+    arr = (CpChainTailConv * len(tconvs))()
+    keep, touts, tw = [], [], []
+    for i, (kind, Cout, relu) in enumerate(tconvs):
+        k = 3 if kind else 1
+        assert lib.cp_hr_chain_tailconv_supported(Cc, H, W, kind, Cout) == 1
+        w = det_tensor("ctt%d_%d" % (i, Cc), (Cout, Cc, k, k), (2.0 / (Cc * k * k)) ** 0.5 * 1.7)
+        scale, shift = 1.0 + 0.3 * det_tensor("ctts%d" % i, (Cout,)), 0.2 * det_tensor("cttt%d" % i, (Cout,))
+        ocp = rup(Cout, 8)
+        wd, sd_ = w.contiguous().to(dev()), scale.contiguous().to(dev())
+        buf = torch.empty(lib.cp_hr_chain_tailconv_weight_bytes(Cc, H, W, kind, Cout), dtype=torch.uint8, device=dev())
+        _abi.check(lib.cp_pack_hr_chain_tailconv_weight(st(), wd.data_ptr(), sd_.data_ptr(), Cc, H, W, kind, Cout, buf.data_ptr()), "tail pack")
+        sh = torch.zeros(rup(Cout, 16), dtype=torch.float32, device=dev())
+        sh[:Cout] = shift.to(dev())
+        o = torch.full((B, H >> kind, W >> kind, ocp), float("nan"), dtype=DT[dtype], device=dev())
+        arr[i].packed_w, arr[i].shift, arr[i].out = buf.data_ptr(), sh.data_ptr(), o.data_ptr()
+        arr[i].kind, arr[i].Cout, arr[i].out_cphys, arr[i].relu = kind, Cout, ocp, 1 if relu else 0
+        touts.append(o)
+        tw.append((kind, w, scale, shift, relu))
+        keep += [wd, sd_, buf, sh]
+    out = torch.full((B, H, W, cp), float("nan"), dtype=DT[dtype], device=dev())
+    _abi.check(lib.cp_hr_branch_chain_tails(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), len(tconvs), arr),
+               "hr chain tails")
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16)), "the chain's own output must not change"
+    x = from_cl(out, Cc)                                       # exactly the (bf16) map the tails read from LDS
+    for (kind, w, scale, shift, relu), o in zip(tw, touts):
+        Cout = w.shape[0]
+        wq = rnd(w * scale.view(-1, 1, 1, 1), dtype)           # the scale lives in the bf16 weights
+        r = (F.conv2d(x, wq, None, 2, 1) if kind else F.conv2d(x, wq)) + shift.view(1, -1, 1, 1)
+        r = F.relu(r) if relu else r
+        assert bool(torch.isfinite(o.float()).all()), "every output element must be written"
+        if o.shape[-1] > Cout:
+            assert float(o[..., Cout:].float().abs().max()) == 0.0, "padded channels must be exactly zero"
+        close(from_cl(o, Cout), r, TOL[dtype])
+    assert lib.cp_hr_chain_tailconv_supported(Cc, H, W, 1, 18) == 0 and lib.cp_hr_chain_tailconv_supported(18, 64, 64, 0, 18) == 0
+    assert lib.cp_hr_branch_chain_tails(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), 4, arr) == -1
+    arr[0].out = out.data_ptr()                                # a tail output aliasing the chain output: refused
+    assert lib.cp_hr_branch_chain_tails(st(), B, Cc, H, W, 2, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), 1, arr) == -1
+
+
 @pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 13, 21), (9, 8, 16), (3, 64, 64)])
 def test_bottleneck_fused_vs_torch_cpu(lib, shape, ds):
