@@ -12,8 +12,8 @@ torch.cuda._sleep(1000000)
 torch.cuda.synchronize()
 e0.record(); torch.cuda._sleep(10000000); e1.record(); torch.cuda.synchronize()
 cyc_per_ms = 10000000 / e0.elapsed_time(e1)
-for B in (1, 8):
-    for ml in (1, 2, 3, 4, 0):
+for B in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 8)):
+    for ml in ([int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 2, 3, 4, 0)):
         net = build_net(npoint=512, seed=1).to(dev).eval()
         net.set_compute_dtype("bf16")
         net.max_lanes = ml
