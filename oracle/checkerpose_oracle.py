@@ -23,8 +23,14 @@ Pinning status
   the reference; backbone.py:5,35,48-49), which is absent from /root/reference and
   not installable offline.  `hrnet_features` / `resnet34_features` below restate timm's
   published HighResolutionNetFeatures(hrnet_w18, feature_location='incre') and
-  ResNet-34 layouts; they are anchored only on the reference's
-  channel/stride contract (pipeline.py:6-15, init.py:15-24,111).
+  ResNet-34 layouts; they are anchored on the reference's
+  channel/stride contract (pipeline.py:6-15, init.py:15-24,111) and CROSS-CHECKED (not pinned:
+  it is not the reference's dependency) against the one independent implementation this image
+  holds, HF transformers' ResNet: `resnet34_features` == `ResNetModel` configured as ResNet-34
+  with the same weights, `_bottleneck` / `_basic_block` == `ResNetBottleNeckLayer` /
+  `ResNetBasicLayer` on HRNet's own blocks (tests/test_oracle.py, 1e-5).  The HRNet ASSEMBLY
+  (`_hr_module`, `hrnet_features`: transitions, branches, fuse layers) has no second
+  implementation offline.
 
 Every function cites the reference file:line (relative to /root/reference/checkerpose)
 it follows.
