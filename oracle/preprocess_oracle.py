@@ -10,7 +10,9 @@ published 8-bit algorithm (modules/imgproc/src/resize.cpp, 4.x): INTER_LINEAR in
 saturate_cast<short>(c * 2048) with round-half-even, source column clamped with fx reset at both borders, source rows clamped with
 the coefficients kept, horizontal pass in int32, vertical pass `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2` --
 and INTER_NEAREST (`min(floor(dx * scale), w - 1)`).  The window arithmetic (int() truncation towards zero, zero padding outside the
-image) follows the reference's own lines and is exact.  Pure numpy, meant for small cases."""
+image) follows the reference's own lines and is pinned by a run of the reference's own crop functions (tests/golden/n3_windows.npz).
+Cross-check of the resize (not a pin): torch's `interpolate` samples with the same half-pixel geometry in floating point;
+tests/test_preprocess.py holds INTER_LINEAR to one grey level of it and INTER_NEAREST to equality.  Pure numpy, meant for small cases."""
 import numpy as np
 
 INTER_NEAREST, INTER_LINEAR = 0, 1          # cv2's values

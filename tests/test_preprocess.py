@@ -27,6 +27,24 @@ def test_resize_oracle_known_values_and_invariants():
     assert PO.resize_u8(np.array([[255, 0]], np.uint8), 4, 1, PO.INTER_LINEAR).tolist() == [[255, 191, 64, 0]]
 
 
+def test_resize_oracle_against_torch_interpolate():
+    """Independent cross-check of the UNPINNED resize restatement (cv2 is absent): torch's `interpolate` implements the same sampling
+    geometry -- half-pixel centres, source index clamped at the borders, no antialiasing; legacy `nearest` = floor(dst * scale) -- in
+    floating point.  cv2's 8-bit INTER_LINEAR differs from it only by its 11-bit coefficients and the final rounding: at most one
+    grey level.  INTER_NEAREST must agree exactly.  Up- and down-scaling, non-integer ratios, the loader's 256 x 256 target."""
+    import torch.nn.functional as F
+    for (h, w, oh, ow, seed) in ((48, 64, 256, 256, 1), (300, 217, 256, 256, 2), (97, 131, 64, 80, 3), (31, 17, 256, 256, 4), (640, 480, 256, 256, 5)):
+        img = _img(h, w, seed=seed)
+        x = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+        lin = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        got = PO.resize_u8(img, ow, oh, PO.INTER_LINEAR).astype(np.float64)
+        d = np.abs(got - lin)
+        assert d.max() <= 1.0 + 1e-3, (h, w, oh, ow, float(d.max()))
+        assert d.mean() <= 0.3, float(d.mean())
+        near = F.interpolate(x, size=(oh, ow), mode="nearest")[0].permute(1, 2, 0).numpy().astype(np.uint8)
+        assert np.array_equal(PO.resize_u8(img, ow, oh, PO.INTER_NEAREST), near), (h, w, oh, ow)
+
+
 def test_window_arithmetic_follows_the_reference_formulas():
     """padding_Bbox :147-163 and the square window of crop_square_resize :55-77 / get_final_Bbox :188-207, worked by hand"""
     # box (10, 12, 21, 30), ratio 1.5: padded w = int(31.5) = 31, h = 45; centre (20.5, 27) -> (int(5.0), int(4.5), 31, 45)
