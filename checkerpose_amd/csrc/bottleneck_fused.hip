@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
   // per-iteration lane constants for the compiler to hoist and spill); the two right-hand columns take 2 more loads.
   const int scol = tid >> 5, spc = tid & 31;
   const int erow = tid >> 6, ecol = BTW + ((tid >> 5) & 1);     // extras: rows 0..7 (it 10), rows 8..9 (it 11, tid < 128)
-  auto issue_loads = [&](int li, u32x4* xv) {
+  auto issue_loads = [&](int li, u32x4* xv, int lo = 0, int hi = 1 << 20) {
     const int b = (li / tpi) * 8 + xcd;
     const int trem = li % tpi;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
         const int base = ((b * p.H + y0) * p.W + gx) * p.in_cs + p.in_coff + spc * 8;
 #pragma unroll
         for (int it = 0; it < BPH; ++it) {
+          if (it < lo || it >= hi) continue;
           const bool ok = cok & ((unsigned)(y0 + it) < (unsigned)p.H);
           const uint32_t off = ok ? (uint32_t)(base + it * p.W * p.in_cs) * 2u : 0x80000000u;
           xv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
+        if (BPH + e < lo || BPH + e >= hi) continue;
         const int gy = y0 + erow + 8 * e, gx = x0 + ecol;
         const bool ok = tok & (e == 0 || tid < 128) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
         const uint32_t off = ok ? (uint32_t)(((b * p.H + gy) * p.W + gx) * p.in_cs + p.in_coff + spc * 8) * 2u : 0x80000000u;
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     } else {                                                     // narrow input: piece i = tid + 512 it -> (pixel, piece)
 #pragma unroll
       for (int it = 0; it < XITER; ++it) {
+        if (it < lo || it >= hi) continue;
         const int i = tid + 512 * it;
         const int hp = i / XPLANES, pc = i % XPLANES;
         const int py = hp / BPW, px = hp - py * BPW;
@@ -148,6 +151,15 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     // from LDS feeds two MFMAs (one tile per wave and six fragments read each fragment four times: LDS-port bound)
     const int nt1 = 2 * (wave & 1), fr1 = 3 * (wave >> 1);
     u32x4 W1[2][XCH];
+    // conv1's weight fragments come from L2 per tile (16 KB per wave: resident next to conv2's 18 and conv3's 4 fragments they do not
+    // fit 256 VGPRs).  The first W1_EARLY K chunks take off BEFORE the halo leaves its registers, so their L2 latency runs under the
+    // staging writes (vmcnt is in-order: the halo loads are older and return first); all 8 early spill (measured: 4 early -1.6 %)
+    constexpr int W1_EARLY = XCH < 4 ? XCH : 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kc = 0; kc < W1_EARLY; ++kc) W1[t][kc] = ((const u32x4*)p.w1)[((nt1 + t) * XCH + kc) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage: registers -> LDS planes
     if constexpr (XCH == 8) {
       unsigned char* dst = sX + spc * PITCH_X + scol * 16;
@@ -163,12 +175,16 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
         *(u32x4*)(sX + (i % XPLANES) * PITCH_X + (i / XPLANES) * 16) = xv[it];
       }
     }
-    // (16 KB per wave from L2, issued once the staged registers are free: resident next to conv2's 18 and conv3's 4
-    // fragments they do not fit 256 VGPRs)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int kc = 0; kc < XCH; ++kc) W1[t][kc] = ((const u32x4*)p.w1)[((nt1 + t) * XCH + kc) * 64 + lane];
+      for (int kc = W1_EARLY; kc < XCH; ++kc) W1[t][kc] = ((const u32x4*)p.w1)[((nt1 + t) * XCH + kc) * 64 + lane];
+    // the first HALO_EARLY of the next tile's halo loads take off right behind conv1's weights (vmcnt is in-order: conv1 waits for
+    // its weights with these still in flight): as many as fit beside conv1's operands without spilling (3: -1.5 %; 4 spill)
+    constexpr int HALO_EARLY = 3;
+    __builtin_amdgcn_sched_barrier(0);
+    issue_loads(li + nbx, xv, 0, HALO_EARLY);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 
     // ---- conv1 (1x1, K = 256): channel tiles nt1, nt1 + 1, fragments fr1 .. fr1 + 2 of the halo
@@ -205,9 +221,9 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
       }
     }
     __syncthreads();
-    // next tile's halo loads take off now (conv1's weight fragments are dead) and stay in registers until this tile's
-    // output has left the x planes: they are in flight under conv2, conv3 and the store phase
-    issue_loads(li + nbx, xv);
+    // the rest of the next tile's halo loads take off now (conv1's weight fragments are dead) and stay in registers until this
+    // tile's output has left the x planes: they are in flight under conv2, conv3 and the store phase
+    issue_loads(li + nbx, xv, HALO_EARLY);
 
     // ---- conv2 (3x3 on t1): channel tile nt, rows 4*half .. 4*half+3
     {
