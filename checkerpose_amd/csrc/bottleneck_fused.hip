@@ -45,6 +45,26 @@ __device__ __forceinline__ void mma_bf16(const u32x4& w, const u32x4& a, f32x4& 
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
 }
 
+// epilogue arithmetic on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32, one v_cvt_pk_bf16_f32, ReLU as max(int16, 0) on the packed pair):
+// the phase clock (tools/bottleneck_stamps.py) put conv3 + residual at 25 % of a tile with 288 scalar VALU instructions per wave
+// beside its 32 MFMAs.  Same fma / add / rounding per value as the scalar form; a result of -0.0 is stored as +0.0.
+__device__ __forceinline__ cp_f32x2 bn_pair(const f32x4& v, int h) { return h ? cp_f32x2{v[2], v[3]} : cp_f32x2{v[0], v[1]}; }
+__device__ __forceinline__ cp_f32x2 bn_bf16_pair(uint32_t r) { return cp_f32x2{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)}; }
+__device__ __forceinline__ uint32_t bn_pack_relu(cp_f32x2 v) {
+  return relu_bf16x2(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, cp_bf16x2)));
+}
+
+#ifdef CP_DEBUG_KNOBS          // phase clock of workgroup 0 (tools/bottleneck_stamps.py): s_memtime sums per wave, -DCP_DEBUG_KNOBS builds only
+__device__ unsigned long long b_stamps[8][10];
+#define B_T0() unsigned long long b_t = __builtin_amdgcn_s_memtime(), b_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define B_MARK(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); b_acc[k] += n_ - b_t; b_t = n_; } while (0)
+#define B_DUMP() do { if (blockIdx.x == 0 && lane == 0) for (int k_ = 0; k_ < 10; ++k_) b_stamps[wave][k_] = b_acc[k_]; } while (0)
+#else
+#define B_T0() do {} while (0)
+#define B_MARK(k) do {} while (0)
+#define B_DUMP() do {} while (0)
+#endif
+
 template <int XCH, bool HAS_DS>
 __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckParams p) {
   constexpr int XPLANES = XCH * 4;
@@ -141,6 +161,7 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
   u32x4 xv[XITER];
   int li = j0;
   issue_loads(li, xv);
+  B_T0();
   for (; (li / tpi) * 8 + xcd < p.B; li += nbx) {
     const int b = (li / tpi) * 8 + xcd;
     const int trem = li % tpi;
@@ -185,7 +206,9 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
     __builtin_amdgcn_sched_barrier(0);
     issue_loads(li + nbx, xv, 0, HALO_EARLY);
     __builtin_amdgcn_sched_barrier(0);
+    B_MARK(0);
     __syncthreads();
+    B_MARK(1);
 
     // ---- conv1 (1x1, K = 256): channel tiles nt1, nt1 + 1, fragments fr1 .. fr1 + 2 of the halo
     {
@@ -212,15 +235,17 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
           const int py = p1 / BPW, px = p1 - py * BPW;
           const int gy = y0 - 1 + py, gx = x0 - 1 + px;
           const bool inimg = (p1 < BNPIX) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[f][t][e] * sc[e] + sh[e], 0.f) : 0.f;
-          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          u32x2 pk;
+          pk.x = bn_pack_relu(bn_pair(acc[f][t], 0) * bn_pair(sc, 0) + bn_pair(sh, 0));
+          pk.y = bn_pack_relu(bn_pair(acc[f][t], 1) * bn_pair(sc, 1) + bn_pair(sh, 1));
+          if (!inimg) pk = u32x2{0u, 0u};
           *(u32x2*)(sT1 + (c0 >> 3) * PITCH_X + p1 * 16 + (c0 & 7) * 2) = pk;
         }
       }
     }
+    B_MARK(2);
     __syncthreads();
+    B_MARK(3);
     // the rest of the next tile's halo loads take off now (conv1's weight fragments are dead) and stay in registers until this
     // tile's output has left the x planes: they are in flight under conv2, conv3 and the store phase
     issue_loads(li + nbx, xv, HALO_EARLY);
@@ -251,14 +276,15 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
       const f32x4 sc = *(const f32x4*)(a_s2 + c0), sh = *(const f32x4*)(a_t2 + c0);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[f][e] * sc[e] + sh[e], 0.f);
-        u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        u32x2 pk;
+        pk.x = bn_pack_relu(bn_pair(acc[f], 0) * bn_pair(sc, 0) + bn_pair(sh, 0));
+        pk.y = bn_pack_relu(bn_pair(acc[f], 1) * bn_pair(sc, 1) + bn_pair(sh, 1));
         *(u32x2*)(sT2 + (c0 >> 3) * PITCH_T + ((half * 4 + f) * 16 + x) * 16 + (c0 & 7) * 2) = pk;
       }
     }
+    B_MARK(4);
     __syncthreads();
+    B_MARK(5);
     // ---- conv3 (1x1, K = 64): channel tiles 2*wave, 2*wave+1, all 8 rows (two passes of 4: bounds the live
     // accumulators + operands); + residual (x tile in LDS), written back in place
     constexpr int RP = HAS_DS ? 2 : 4;                           // rows per pass (two accumulator sets with the shortcut)
@@ -305,10 +331,9 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
           unsigned char* col = sO + (c0 >> 3) * PITCH_T + (fh * RP * 16 + x) * 16 + (c0 & 7) * 2;
 #pragma unroll
           for (int f = 0; f < RP; ++f) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[f][t][e] * sc[e] + sh[e] + (accd[f][t][e] * scd[e] + shd[e]), 0.f);
-            u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            u32x2 pk;
+            pk.x = bn_pack_relu(bn_pair(acc[f][t], 0) * bn_pair(sc, 0) + bn_pair(sh, 0) + (bn_pair(accd[f][t], 0) * bn_pair(scd, 0) + bn_pair(shd, 0)));
+            pk.y = bn_pack_relu(bn_pair(acc[f][t], 1) * bn_pair(sc, 1) + bn_pair(sh, 1) + (bn_pair(accd[f][t], 1) * bn_pair(scd, 1) + bn_pair(shd, 1)));
             *(u32x2*)(col + f * 256) = pk;
           }
         } else {
@@ -317,18 +342,17 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
           for (int f = 0; f < RP; ++f) {
             u32x2* rp = (u32x2*)(col + f * BPW * 16);
             const u32x2 r2 = *rp;
-            float v[4];
-            v[0] = fmaxf(acc[f][t][0] * sc[0] + sh[0] + __uint_as_float(r2.x << 16), 0.f);
-            v[1] = fmaxf(acc[f][t][1] * sc[1] + sh[1] + __uint_as_float(r2.x & 0xffff0000u), 0.f);
-            v[2] = fmaxf(acc[f][t][2] * sc[2] + sh[2] + __uint_as_float(r2.y << 16), 0.f);
-            v[3] = fmaxf(acc[f][t][3] * sc[3] + sh[3] + __uint_as_float(r2.y & 0xffff0000u), 0.f);
-            u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            u32x2 pk;
+            pk.x = bn_pack_relu(bn_pair(acc[f][t], 0) * bn_pair(sc, 0) + bn_pair(sh, 0) + bn_bf16_pair(r2.x));
+            pk.y = bn_pack_relu(bn_pair(acc[f][t], 1) * bn_pair(sc, 1) + bn_pair(sh, 1) + bn_bf16_pair(r2.y));
             *rp = pk;
           }
         }
       }
     }
+    B_MARK(6);
     __syncthreads();
+    B_MARK(7);
 
     // ---- this tile's output leaves LDS (the next tile's halo loads have been in flight since conv1)
     {
@@ -342,11 +366,20 @@ __global__ __launch_bounds__(512) void bottleneck_fused_kernel(const BottleneckP
         if (ox < p.W && y0 + row < p.H) *(u32x4*)(gp + (long long)row * p.o_sy) = v;
       }
     }
+    B_MARK(8);
     __syncthreads();
+    B_MARK(9);
   }
+  B_DUMP();
 }
 
 }  // namespace
+
+#ifdef CP_DEBUG_KNOBS
+extern "C" int cp_debug_bottleneck_stamps(unsigned long long* out80) {
+  return hipMemcpyFromSymbol(out80, HIP_SYMBOL(b_stamps), sizeof(unsigned long long) * 80) == hipSuccess ? CP_OK : CP_ERR_HIP;
+}
+#endif
 
 extern "C" int cp_bottleneck_fused(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w1,
                                    const float* scale1, const float* shift1, const void* packed_w2, const float* scale2,

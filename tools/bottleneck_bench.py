@@ -19,7 +19,7 @@ def pack(co, ci, r):
     return pw
 
 
-for cin in (256, 64):
+for cin in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (256, 64)):
     ds = cin == 64
     x = torch.randn(B, H, H, cin, device=dev).to(torch.bfloat16)
     out = torch.empty(B, H, H, 256, device=dev, dtype=torch.bfloat16)
