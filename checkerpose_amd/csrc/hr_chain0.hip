@@ -353,6 +353,361 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
   Z_DUMP();
 }
 
+// ------------------------------------------------------------------------------------------------ pipelined form
+// (built only with -DCP_C0_PIPE: an alternative to hr_chain0_kernel, bit-identical and 2-6 % faster per launch, which the step does not
+// show -- HISTORY.md "Round 5"; tools/chain0_pipe_check.py holds the two builds against each other)
+#ifdef CP_C0_PIPE
+// The same eight convs as a PIPELINE of waves: wave s runs conv s row by row, conv s + 1 follows two rows behind; four more waves
+// (one per SIMD) stage x0 (the fuse sum) a quarter row each and, when the launch has a tail, run its stride-2 fuse convs (one
+// 32-channel slab per wave) behind conv 7.  Between two stages sits a ring of rows in LDS (8 deep; x0's 6, the tail's feed 4: 66 rows x 2.4 KB
+// instead of the whole 157 KB map), handed over through row counters in LDS -- no workgroup barrier after the prologue: the waves drift
+// apart, so one wave's epilogue and LDS traffic run beside another's MFMAs instead of all eight doing the same thing between the
+// same two barriers.  The BasicBlock residual is read from the ring two stages back (it never leaves the chip: the band form moves
+// 550 MB of HBM traffic per launch for 96 MB of results), and a conv's weight fragments are loaded once per crop.
+// Same K order and the same arithmetic per value as the band form: bit-identical outputs (tools/chain0_pipe_check.py).
+// Ring row: [plane ch 0-7][66 px][16 B] | [plane ch 8-15][66 px][16 B] | [plane ch 16-17][66 px][4 B]; pixel 0 / 65 = the zero padding.
+constexpr int PD0 = 6, PDM = 8, PD8 = 4;                             // ring depths: ring 0 (x0), rings 1 .. 7, ring 8 (conv 7's output, read by the tail)
+constexpr int PP1 = ZWP * 16, PP2 = 2 * ZWP * 16;                 // plane offsets inside a ring row
+constexpr int PROW = (2 * ZWP * 16 + ZWP * 4 + 15) / 16 * 16;     // 2384
+constexpr int PRING = PDM * PROW;
+constexpr int PROWS = PD0 + 7 * PDM + PD8;                           // 66 ring rows
+constexpr int PZERO = PROWS * PROW;                                   // a row of zeros: image rows -1 and 64
+constexpr int PCNT = PZERO + PROW;                                 // 32 uint32 counters: [r] rows written to ring r (1 .. 8), [PC_CONS + s] output rows conv s has
+constexpr int PC_CONS = 10, PC_PART = 20, PC_TAIL = 24;             // finished, [PC_PART + k] ring-0 rows staging part k has written, [PC_TAIL + k] tail rows slab k has finished
+constexpr int PSHF = PCNT + 128;                                   // float shift[8][32]: the folded-BN shifts (read per row: 8 registers fewer per wave)
+constexpr int PLDS = PSHF + 8 * ZAFF * 4;
+#ifndef CP_C0_PFD
+#define CP_C0_PFD 1
+#endif
+constexpr int PFD = CP_C0_PFD;                                      // fragment prefetch distance of the conv waves, in K chunks
+constexpr int PSW = 4;                                              // staging / tail waves (one per SIMD: a single one made its SIMD the pipeline's slowest)
+constexpr int PNW = 8 + PSW, PNT = 64 * PNW;
+constexpr uint32_t POOR = 0x100000u;                               // a DS write this far out is discarded (tools/lds_probe/oor.py): predication by address
+static_assert(PLDS <= 160 * 1024, "LDS budget");
+
+typedef __attribute__((address_space(3))) volatile uint32_t p_cnt_t;     // the counters are read / written with DS instructions (a generic
+                                                                          // volatile pointer compiles to FLAT loads: slow, and every LDS wait becomes lgkmcnt(0))
+__device__ __forceinline__ int p_peek(const p_cnt_t* c) { return (int)__builtin_amdgcn_readfirstlane(*c); }
+__device__ __forceinline__ void p_wait(const p_cnt_t* c, int need) {     // bounded: a lost hand-over ends in wrong numbers, not in a hung box
+  for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+    if (p_peek(c) >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void p_post(p_cnt_t* c0, p_cnt_t* c1, uint32_t v, int lane) {
+  // behind the row's LDS writes in program order: the LDS executes one wave's DS instructions in order, so whoever reads the new count
+  // reads the row too -- no wait in between (a full lgkmcnt(0) here was 300 of a row's ~3 900 cycles)
+  asm volatile("" ::: "memory");
+  if (lane == 0) { if (c0) *c0 = v; if (c1) *c1 = v; }
+}
+__device__ __forceinline__ int p_depth(int r) { return r == 0 ? PD0 : (r == 8 ? PD8 : PDM); }
+__device__ __forceinline__ uint32_t p_ring(int r) { return (uint32_t)((r == 0 ? 0 : PD0 + (r - 1) * PDM) * PROW); }          // byte offset of ring r
+__device__ __forceinline__ uint32_t p_slot(int r, int y) { return (uint32_t)((r == 0 ? y % PD0 : (r == 8 ? (y & (PD8 - 1)) : (y & (PDM - 1)))) * PROW); }
+
+// per-lane K-group geometry of one wave (hr_chain0_kernel's, with the tap ROW taken out -- it selects the ring row -- and the pixel
+// step as a parameter: 1 for the chain convs, 2 for the stride-2 tail).  Tap rows: chunk 0 -> 0; chunk 1 -> 0 (q < 2) / 1; chunk 2 -> 1;
+// chunk 3 -> 2; chunk 4: lanes q < 2 read the four dwords of their 16-byte group of tap 8 (row 2), lanes q = 2 / 3 four taps' 2-channel
+// pairs (rows 0 0 0 1 / 1 1 2 2); chunk 5 -> tap 8 (row 2).
+struct PGeo { uint32_t c16[4], c4[4], c4l, fs16, fs4, fs4l; };
+__device__ __forceinline__ PGeo p_geo(int x, int q, int step) {
+  PGeo g;
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    const int G = 4 * kc + q;
+    const int tap = G >> 1, cg = G & 1;
+    const int sft = tap - 3 * ((tap * 11) >> 5);
+    g.c16[kc] = (uint32_t)(cg * PP1 + (sft + step * x) * 16);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int tap = (q == 3 ? 4 : 0) + e;
+    const int sft = tap - 3 * ((tap * 11) >> 5);
+    g.c4[e] = q < 2 ? (uint32_t)(q * PP1 + (2 + step * x) * 16 + 4 * e) : (uint32_t)(PP2 + (sft + step * x) * 4);
+  }
+  g.c4l = (uint32_t)(PP2 + (2 + step * x) * 4);
+  g.fs16 = (uint32_t)(step * 256);                                   // bytes from one fragment (16 output pixels) to the next: 16-byte planes
+  g.fs4l = (uint32_t)(step * 64);                                    // ... the 4-byte plane
+  g.fs4 = q < 2 ? g.fs16 : g.fs4l;                                   // ... the plane this lane reads in chunk 4
+  return g;
+}
+// the six fragment-set loads of one output row (NF fragments), ring rows rb[0..2] = the three tap rows
+template <int NF>
+__device__ __forceinline__ void p_load(u32x4* a, int kc, const unsigned char* smem, const PGeo& g, const uint32_t* rb, bool qlo, bool q3) {
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (kc == 0) a[f] = *(const u32x4*)(smem + rb[0] + g.c16[0] + f * g.fs16);
+    else if (kc == 1) a[f] = *(const u32x4*)(smem + (qlo ? rb[0] : rb[1]) + g.c16[1] + f * g.fs16);
+    else if (kc == 2) a[f] = *(const u32x4*)(smem + rb[1] + g.c16[2] + f * g.fs16);
+    else if (kc == 3) a[f] = *(const u32x4*)(smem + rb[2] + g.c16[3] + f * g.fs16);
+    else if (kc == 4) {
+      const uint32_t d0 = (qlo ? rb[2] : q3 ? rb[1] : rb[0]) + g.c4[0], d1 = (qlo ? rb[2] : q3 ? rb[1] : rb[0]) + g.c4[1];
+      const uint32_t d2 = (qlo || q3 ? rb[2] : rb[0]) + g.c4[2], d3 = (qlo || q3 ? rb[2] : rb[1]) + g.c4[3];
+      a[f] = u32x4{*(const uint32_t*)(smem + d0 + f * g.fs4), *(const uint32_t*)(smem + d1 + f * g.fs4),
+                   *(const uint32_t*)(smem + d2 + f * g.fs4), *(const uint32_t*)(smem + d3 + f * g.fs4)};
+    } else a[f].x = *(const uint32_t*)(smem + rb[2] + g.c4l + f * g.fs4l);     // tap 8's pair (q = 0; the other K slots meet zero weights)
+  }
+}
+
+// staging wave `part`: pixels [16 part, 16 part + 16) of every x0 row (48 (pixel, 16-byte piece) items on lanes 0 .. 47), and -- parts
+// 0 .. nslab - 1 of a launch with a tail -- slab `part` of the stride-2 fuse convs, one output row per two rows conv 7 delivers
+template <int NSRC>
+__device__ __forceinline__ void p_stage_and_tail(const Chain0Params& p, unsigned char* smem, int lane, int b, int part) {
+  p_cnt_t* const cnt = (p_cnt_t*)(smem + PCNT);
+  const int x = lane & 15, q = lane >> 4;
+  const bool qlo = q < 2, q3 = q == 3;
+  const int g = lane % 3, px = (64 / PSW) * part + lane / 3;
+  const bool live = lane < 3 * (64 / PSW);
+  const int nslab = (p.tnp + 3) >> 2;
+  const bool tail = part < nslab;
+  // tail: this slab's weights (two tiles) and epilogue constants
+  u32x4 Wt[ZKC][2];
+  const PGeo tg = p_geo(x, q, 2);
+  const int piece = part * 4 + q;
+  const int cvi = piece >= p.tps[2] ? 2 : (piece >= p.tps[1] ? 1 : 0);
+  const bool tlive = tail && piece < p.tnp;
+  f32x4 tt0 = f32x4{0.f, 0.f, 0.f, 0.f}, tt1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned char* ob = nullptr;
+  int cph = 8;
+  bool trelu = false;
+  if (tail) {
+    const u32x4* const wt = (const u32x4*)p.tw + (size_t)part * ZKC * 2 * 64;
+#pragma unroll
+    for (int kc = 0; kc < ZKC; ++kc) { Wt[kc][0] = wt[(kc * 2 + 0) * 64 + lane]; Wt[kc][1] = wt[(kc * 2 + 1) * 64 + lane]; }
+    if (tlive) { tt0 = *(const f32x4*)(p.tshift + piece * 8); tt1 = *(const f32x4*)(p.tshift + piece * 8 + 4); }
+    cph = p.tcph[cvi];
+    trelu = p.trelu[cvi] != 0;
+    ob = (unsigned char*)p.tout[cvi] + ((size_t)b * 1024 * cph + (size_t)(piece - p.tps[cvi]) * 8) * 2;
+  } else {
+#pragma unroll
+    for (int kc = 0; kc < ZKC; ++kc) { Wt[kc][0] = u32x4{0u, 0u, 0u, 0u}; Wt[kc][1] = u32x4{0u, 0u, 0u, 0u}; }
+  }
+  int ys = 0, oy = tail ? 0 : ZH / 2;
+  for (uint32_t spin = 0; spin < (1u << 22) && (ys < ZH || oy < ZH / 2); ++spin) {
+    bool did = false;
+    if (ys < ZH && (ys < PD0 || p_peek(cnt + PC_CONS + 1) >= ys - (PD0 - 1))) {          // ring 0's slot is free: conv 1 (its residual reader, the later one) is through with row ys - PD
+      u32x4 v[NSRC];
+#pragma unroll
+      for (int k = 0; k < NSRC; ++k) {
+        const int sh = p.shift[k];
+        const size_t o = (((size_t)b * (ZH >> sh) + (ys >> sh)) * (ZW >> sh) + (px >> sh)) * 3 + g;
+        v[k] = live ? ((const u32x4*)p.src[k])[o] : u32x4{0u, 0u, 0u, 0u};
+      }
+      const uint32_t ro = p_slot(0, ys);
+      float acc[8], f[8];
+#pragma unroll
+      for (int k = 0; k < NSRC; ++k) {
+        Vec16<BF16Tag>::unpack(v[k], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (k == 0) ? f[j] : acc[j] + f[j];
+      }
+      if (p.relu_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      }
+      const u32x4 pk = Vec16<BF16Tag>::pack(acc);
+      const uint32_t a16 = live && g < 2 ? ro + (uint32_t)(g * PP1 + (px + 1) * 16) : POOR;
+      const uint32_t a4 = live && g == 2 ? ro + (uint32_t)(PP2 + (px + 1) * 4) : POOR;
+      *(u32x4*)(smem + a16) = pk;
+      *(uint32_t*)(smem + a4) = pk.x;
+      p_post(cnt + PC_PART + part, (p_cnt_t*)nullptr, (uint32_t)(ys + 1), lane);
+      ++ys;
+      did = true;
+    }
+    if (oy < ZH / 2 && p_peek(cnt + 8) >= (2 * oy + 2 < ZH ? 2 * oy + 2 : ZH)) {      // conv 7's rows 2 oy - 1 .. 2 oy + 1 are in ring 8
+      asm volatile("" ::: "memory");
+      uint32_t rb[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int yy = 2 * oy - 1 + r;
+        rb[r] = yy < 0 ? (uint32_t)PZERO : p_ring(8) + p_slot(8, yy);
+      }
+      f32x4 acc[2][2];
+      u32x4 af[2][2];
+      p_load<2>(af[0], 0, smem, tg, rb, qlo, q3);
+#pragma unroll
+      for (int kc = 0; kc < ZKC; ++kc) {
+        if (kc + 1 < ZKC) p_load<2>(af[(kc + 1) & 1], kc + 1, smem, tg, rb, qlo, q3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (kc == 0) {
+            acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wt[0][0]), __builtin_bit_cast(bf16x8, af[0][f]), tt0, 0, 0, 0);
+            acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wt[0][1]), __builtin_bit_cast(bf16x8, af[0][f]), tt1, 0, 0, 0);
+          } else {
+            mma16z(Wt[kc][0], af[kc & 1][f], acc[f][0]);
+            mma16z(Wt[kc][1], af[kc & 1][f], acc[f][1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tlive) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          float e[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j]; e[4 + j] = acc[f][1][j]; }
+          u32x4 pk = Vec16<BF16Tag>::pack(e);
+          if (trelu) { pk.x = relu_bf16x2(pk.x); pk.y = relu_bf16x2(pk.y); pk.z = relu_bf16x2(pk.z); pk.w = relu_bf16x2(pk.w); }
+          *(u32x4*)(ob + (size_t)(oy * 32 + 16 * f + x) * cph * 2) = pk;
+        }
+      }
+      p_post(cnt + PC_TAIL + part, (p_cnt_t*)nullptr, (uint32_t)(oy + 1), lane);
+      ++oy;
+      did = true;
+    }
+    if (!did) __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+__global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+  p_cnt_t* const cnt = (p_cnt_t*)(smem + PCNT);
+
+  // ---- prologue: zero padding pixels of every ring row, the zero row, the counters, the shifts
+  for (int i = tid; i < PROWS * 2; i += PNT) {                     // (ring row, left / right)
+    const int rr = i >> 1, px = (i & 1) ? ZWP - 1 : 0;
+    unsigned char* const row = smem + rr * PROW;
+    *(u32x4*)(row + px * 16) = u32x4{0u, 0u, 0u, 0u};
+    *(u32x4*)(row + PP1 + px * 16) = u32x4{0u, 0u, 0u, 0u};
+    *(uint32_t*)(row + PP2 + px * 4) = 0u;
+  }
+  for (int i = tid; i < PROW / 16; i += PNT) *(u32x4*)(smem + PZERO + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 32) cnt[tid] = 0u;
+  if (tid < 8 * ZAFF) ((float*)(smem + PSHF))[tid] = p.aff[(tid / ZAFF) * 2 * ZAFF + ZAFF + (tid % ZAFF)];
+  __syncthreads();
+
+  if (wave >= 8) {                                                  // staging (+ tail) waves
+    switch (p.nsrc) {
+      case 1: p_stage_and_tail<1>(p, smem, lane, b, wave - 8); break;
+      case 2: p_stage_and_tail<2>(p, smem, lane, b, wave - 8); break;
+      case 3: p_stage_and_tail<3>(p, smem, lane, b, wave - 8); break;
+      default: p_stage_and_tail<4>(p, smem, lane, b, wave - 8); break;
+    }
+    return;
+  }
+
+  // ---- conv wave s: weights in registers for the whole crop
+  const int s = wave;
+  const bool second = s & 1;
+  const int nslab = (p.tnp + 3) >> 2;
+  const u32x4* const wg = (const u32x4*)p.w + (size_t)s * ZKC * 2 * 64;
+  u32x4 Wf[ZKC][2];
+#pragma unroll
+  for (int kc = 0; kc < ZKC; ++kc)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) Wf[kc][nt] = wg[(kc * 2 + nt) * 64 + lane];
+  const float* const sh = (const float*)(smem + PSHF) + s * ZAFF + q * 8;
+  const PGeo cg = p_geo(x, q, 1);
+  const bool q3 = q == 3, qlo = q < 2;
+  uint32_t wb16 = q < 2 ? (uint32_t)(q * PP1 + (1 + x) * 16) : POOR, wb4 = q == 2 ? (uint32_t)(PP2 + (1 + x) * 4) : POOR;
+  asm volatile("" : "+v"(wb16), "+v"(wb4));
+  const uint32_t rin = p_ring(s), rout = p_ring(s + 1), rrs = p_ring(second ? s - 1 : 0);
+  const int dout = p_depth(s + 1);
+  const size_t gpix0 = (size_t)b * ZH * ZW;
+
+  Z_T0();
+#pragma unroll 1
+  for (int y = 0; y < ZH; ++y) {
+    const int need = y + 2 < ZH ? y + 2 : ZH;                       // input rows y - 1 .. y + 1 are in ring s
+    Z_MARK(0);                         // (loop overhead)
+    if (s == 0) {                                                   // ring 0 arrives in PSW parts
+#pragma unroll
+      for (int k = 0; k < PSW; ++k) p_wait(cnt + PC_PART + k, need);
+    } else p_wait(cnt + s, need);
+    Z_MARK(1);                         // waiting for the input rows
+    uint32_t rb[3];                                                 // ring rows of the three tap rows (uniform)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y - 1 + r;
+      rb[r] = (yy < 0 || yy >= ZH) ? (uint32_t)PZERO : rin + p_slot(s, yy);
+    }
+    // residual (second conv of a block): the block's input row y from the ring two stages back
+    u32x4 rbig[4];
+    uint32_t rsm[4];
+    if (second) {
+      const uint32_t rr = rrs + p_slot(s - 1, y);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        rbig[f] = *(const u32x4*)(smem + rr + (q & 1) * PP1 + (1 + x) * 16 + f * 256);
+        rsm[f] = *(const uint32_t*)(smem + rr + PP2 + (1 + x) * 4 + f * 64);
+      }
+    }
+    f32x4 acc[4][2];
+    u32x4 af[PFD + 1][4];              // fragment sets PFD chunks ahead of the MFMAs (the phase clock put an LDS round trip per chunk on the row's path)
+    const f32x4 t0 = *(const f32x4*)(sh), t1 = *(const f32x4*)(sh + 4);
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) p_load<4>(af[k], k, smem, cg, rb, qlo, q3);
+#pragma unroll
+    for (int kc = 0; kc < ZKC; ++kc) {
+      if (kc + PFD < ZKC) p_load<4>(af[(kc + PFD) % (PFD + 1)], kc + PFD, smem, cg, rb, qlo, q3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        if (kc == 0) {
+          acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][0]), __builtin_bit_cast(bf16x8, af[0][f]), t0, 0, 0, 0);
+          acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][1]), __builtin_bit_cast(bf16x8, af[0][f]), t1, 0, 0, 0);
+        } else {
+          mma16z(Wf[kc][0], af[kc % (PFD + 1)][f], acc[f][0]);
+          mma16z(Wf[kc][1], af[kc % (PFD + 1)][f], acc[f][1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    Z_MARK(2);                         // fragment reads + MFMAs
+    // ---- epilogue: lane (x, q) holds channels 8q .. 8q+7 of pixel (y, 16 f + x)
+    u32x4 v[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j]; e[4 + j] = acc[f][1][j]; }
+      if (second) {
+        const u32x4 raw = u32x4{qlo ? rbig[f].x : rsm[f], rbig[f].y, rbig[f].z, rbig[f].w};      // q = 2: channels 18 .. 23 are never stored
+        float r8[8];
+        Vec16<BF16Tag>::unpack(raw, r8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] += r8[j];
+      }
+      u32x4 pk = Vec16<BF16Tag>::pack(e);
+      pk.x = relu_bf16x2(pk.x); pk.y = relu_bf16x2(pk.y); pk.z = relu_bf16x2(pk.z); pk.w = relu_bf16x2(pk.w);
+      v[f] = pk;
+    }
+    Z_MARK(3);                         // epilogue
+    if (s == 7 && q < 3) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) ((u32x4*)p.out)[(gpix0 + y * ZW + f * 16 + x) * 3 + q] = v[f];
+    }
+    if (s < 7 || nslab > 0) {
+      // the slot of ring s + 1 still holds row y - (the ring's depth).  Its readers: conv s + 1 (input rows) and, for an even ring, conv s + 2's residual --
+      // which trails conv s + 1, so waiting for the later one covers both; ring 8's readers are the tail waves (row j is last used by
+      // tail row (j + 1) / 2)
+      if (y >= dout) {
+        if (s == 7) {
+          for (int k = 0; k < nslab; ++k) p_wait(cnt + PC_TAIL + k, (y - dout + 1) / 2 + 1);
+        } else if (second) p_wait(cnt + PC_CONS + s + 2, y - (dout - 1));
+        else p_wait(cnt + PC_CONS + s + 1, y - (dout - 2));
+      }
+      Z_MARK(4);                       // waiting for the output slot
+      const uint32_t ro = rout + p_slot(s + 1, y);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        *(u32x4*)(smem + ro + wb16 + f * 256) = v[f];
+        *(uint32_t*)(smem + ro + wb4 + f * 64) = v[f].x;
+      }
+      p_post(cnt + s + 1, cnt + PC_CONS + s, (uint32_t)(y + 1), lane);
+    } else p_post(cnt + PC_CONS + s, (p_cnt_t*)nullptr, (uint32_t)(y + 1), lane);
+    Z_MARK(5);                         // write + post
+  }
+  Z_DUMP();
+}
+#endif  // CP_C0_PIPE
+
 // [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
 //   G < 18: tap G >> 1, input channel 8 (G & 1) + e;   18 <= G < 21: tap 4 (G - 18) + e / 2 (< 9), input channel 16 + (e & 1);   else zero.
 // tile row `row` of tile nt is output channel (row >> 2) * 8 + 4 nt + (row & 3).
@@ -440,6 +795,14 @@ int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, c
     if (ps * 8 > ZTAIL_CH) return CP_ERR_INVALID;
     p.tnp = ps; p.tw = tail->packed_w; p.tshift = tail->shift;
   }
+#ifdef CP_C0_PIPE
+  {
+    static CpDeviceOnce once_p;
+    CP_LDS_ATTR_ONCE(once_p, dev, cp_set_max_lds((const void*)hr_chain0p_kernel, PLDS));
+    CP_LAUNCH(hr_chain0p_kernel, dim3((unsigned)B), dim3(PNT), PLDS, st, p);
+    return cp_check_launch();
+  }
+#endif
   CP_LAUNCH(hr_chain0_kernel, dim3((unsigned)B), dim3(512), ZLDS, st, p);
   return cp_check_launch();
 }
