@@ -1,4 +1,8 @@
-// The 64x64x18 branch of an HRNet module (branch 0: 4 BasicBlocks = 8 convs) as ONE launch per crop with the map in LDS.
+// The 64x64x18 branch of an HRNet module (branch 0: 4 BasicBlocks = 8 convs) as ONE launch per crop.  Two forms, bit-identical:
+//   * the PIPELINED form (hr_chain0p_kernel, further down; the one launched): rows stream through the eight convs, a wave per conv, over rings of
+//     rows in LDS; the residual never leaves the chip (117-165 MB of HBM traffic per 256-crop launch);
+//   * the BAND form (hr_chain0_kernel, rounds 2-4, launched by -DCP_C0_BAND builds): the whole map in LDS, updated in place band by band; the
+//     residual goes through HBM (486-570 MB per launch).  Described first, because the pipelined form reuses its K order and fragment geometry:
 //
 // The other branches (hr_chain.hip) keep a conv's whole output in registers and write it back over the input map.  Here the
 // map alone fills the LDS (66 x 66 ring pixels x 36 B = 157 KB) and a conv's output does not fit in registers (4096 px x 32
@@ -353,10 +357,9 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
   Z_DUMP();
 }
 
-// ------------------------------------------------------------------------------------------------ pipelined form
-// (built only with -DCP_C0_PIPE: an alternative to hr_chain0_kernel, bit-identical and 2-6 % faster per launch, which the step does not
-// show -- HISTORY.md "Round 5"; tools/chain0_pipe_check.py holds the two builds against each other)
-#ifdef CP_C0_PIPE
+// ------------------------------------------------------------------------------------------------ pipelined form (the one launched)
+// (-DCP_C0_BAND builds launch hr_chain0_kernel above instead: tools/chain0_pipe_check.py holds the two forms against each other bit for bit;
+// measurements in HISTORY.md "Round 5" and profiles/r05_chain0_band_vs_pipelined_pmc.txt)
 // The same eight convs as a PIPELINE of waves: wave s runs conv s row by row, conv s + 1 follows two rows behind; four more waves
 // (one per SIMD) stage x0 (the fuse sum) a quarter row each and, when the launch has a tail, run its stride-2 fuse convs (one
 // 32-channel slab per wave) behind conv 7.  Between two stages sits a ring of rows in LDS (8 deep; x0's 6, the tail's feed 4: 66 rows x 2.4 KB
@@ -369,7 +372,6 @@ __global__ __launch_bounds__(512) void hr_chain0_kernel(const Chain0Params p) {
 constexpr int PD0 = 6, PDM = 8, PD8 = 4;                             // ring depths: ring 0 (x0), rings 1 .. 7, ring 8 (conv 7's output, read by the tail)
 constexpr int PP1 = ZWP * 16, PP2 = 2 * ZWP * 16;                 // plane offsets inside a ring row
 constexpr int PROW = (2 * ZWP * 16 + ZWP * 4 + 15) / 16 * 16;     // 2384
-constexpr int PRING = PDM * PROW;
 constexpr int PROWS = PD0 + 7 * PDM + PD8;                           // 66 ring rows
 constexpr int PZERO = PROWS * PROW;                                   // a row of zeros: image rows -1 and 64
 constexpr int PCNT = PZERO + PROW;                                 // 32 uint32 counters: [r] rows written to ring r (1 .. 8), [PC_CONS + s] output rows conv s has
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j]; e[4 + j] = acc[f][1][j]; }
       if (second) {
-        const u32x4 raw = u32x4{qlo ? rbig[f].x : rsm[f], rbig[f].y, rbig[f].z, rbig[f].w};      // q = 2: channels 18 .. 23 are never stored
+        const u32x4 raw = u32x4{qlo ? rbig[f].x : rsm[f], qlo ? rbig[f].y : 0u, qlo ? rbig[f].z : 0u, qlo ? rbig[f].w : 0u};   // q = 2: channels 18 .. 23 stay exactly zero (conv 7 stores them)
         float r8[8];
         Vec16<BF16Tag>::unpack(raw, r8);
 #pragma unroll
@@ -706,8 +708,6 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
   }
   Z_DUMP();
 }
-#endif  // CP_C0_PIPE
-
 // [conv][chunk][tile][lane][8 bf16]: lane (row = lane & 15, q = lane >> 4), element e, K group G = 4 kc + q:
 //   G < 18: tap G >> 1, input channel 8 (G & 1) + e;   18 <= G < 21: tap 4 (G - 18) + e / 2 (< 9), input channel 16 + (e & 1);   else zero.
 // tile row `row` of tile nt is output channel (row >> 2) * 8 + 4 nt + (row & 3).
@@ -795,7 +795,7 @@ int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, c
     if (ps * 8 > ZTAIL_CH) return CP_ERR_INVALID;
     p.tnp = ps; p.tw = tail->packed_w; p.tshift = tail->shift;
   }
-#ifdef CP_C0_PIPE
+#ifndef CP_C0_BAND
   {
     static CpDeviceOnce once_p;
     CP_LDS_ATTR_ONCE(once_p, dev, cp_set_max_lds((const void*)hr_chain0p_kernel, PLDS));
