@@ -594,8 +594,14 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
     return;
   }
 
-  // ---- conv wave s: weights in registers for the whole crop
+  // ---- conv wave s: weights in registers for the whole crop.  Waves w and w + 4 share a SIMD: they get convs 2k and 2k + 1, which run a stage
+  // latency (most of a row period) apart, so their MFMA phases mostly miss each other -- convs s and s + 4 run four stage latencies = almost
+  // exactly a whole number of periods apart and would meet in the matrix pipe every row
+#ifdef CP_C0_PLAIN_MAP
   const int s = wave;
+#else
+  const int s = 2 * (wave & 3) + (wave >> 2);
+#endif
   const bool second = s & 1;
   const int nslab = (p.tnp + 3) >> 2;
   const u32x4* const wg = (const u32x4*)p.w + (size_t)s * ZKC * 2 * 64;
