@@ -668,6 +668,11 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     Z_MARK(2);                         // fragment reads + MFMAs
+#ifndef CP_C0_LATE_CONS
+    // this row's input rows and its residual row have been READ (the LDS returns a wave's reads in order, the last chunk's were waited for):
+    // the stages upstream may have their slots back now, an epilogue earlier than at the end of the row
+    p_post(cnt + PC_CONS + s, (p_cnt_t*)nullptr, (uint32_t)(y + 1), lane);
+#endif
     // ---- epilogue: lane (x, q) holds channels 8q .. 8q+7 of pixel (y, 16 f + x)
     u32x4 v[4];
 #pragma unroll
@@ -708,8 +713,13 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
         *(u32x4*)(smem + ro + wb16 + f * 256) = v[f];
         *(uint32_t*)(smem + ro + wb4 + f * 64) = v[f].x;
       }
+#ifdef CP_C0_LATE_CONS
       p_post(cnt + s + 1, cnt + PC_CONS + s, (uint32_t)(y + 1), lane);
     } else p_post(cnt + PC_CONS + s, (p_cnt_t*)nullptr, (uint32_t)(y + 1), lane);
+#else
+      p_post(cnt + s + 1, (p_cnt_t*)nullptr, (uint32_t)(y + 1), lane);
+    }
+#endif
     Z_MARK(5);                         // write + post
   }
   Z_DUMP();
