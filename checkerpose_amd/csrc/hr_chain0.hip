@@ -611,6 +611,16 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) Wf[kc][nt] = wg[(kc * 2 + nt) * 64 + lane];
   const float* const sh = (const float*)(smem + PSHF) + s * ZAFF + q * 8;
+#ifndef CP_C0_PRIO_ODD
+#define CP_C0_PRIO_ODD 2
+#endif
+#ifndef CP_C0_PRIO_EVEN
+#define CP_C0_PRIO_EVEN 1
+#endif
+  // the second conv of a block carries the residual epilogue: the slower stage of its SIMD pair, and the pipeline runs at its slowest stage;
+  // both above the staging / tail waves (priorities 2 / 1 / 0: -4 % against none, measured in steps of 2 %)
+  if (second) __builtin_amdgcn_s_setprio(CP_C0_PRIO_ODD);
+  else if (CP_C0_PRIO_EVEN) __builtin_amdgcn_s_setprio(CP_C0_PRIO_EVEN);
   const PGeo cg = p_geo(x, q, 1);
   const bool q3 = q == 3, qlo = q < 2;
   uint32_t wb16 = q < 2 ? (uint32_t)(q * PP1 + (1 + x) * 16) : POOR, wb4 = q == 2 ? (uint32_t)(PP2 + (1 + x) * 4) : POOR;
@@ -640,9 +650,10 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
     uint32_t rsm[4];
     if (second) {
       const uint32_t rr = rrs + p_slot(s - 1, y);
+      const uint32_t rbg = (qlo ? rr : (uint32_t)PZERO) + (uint32_t)((q & 1) * PP1 + (1 + x) * 16);     // lanes q >= 2: the zero row (channels 18 .. 23 stay zero)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        rbig[f] = *(const u32x4*)(smem + rr + (q & 1) * PP1 + (1 + x) * 16 + f * 256);
+        rbig[f] = *(const u32x4*)(smem + rbg + f * 256);
         rsm[f] = *(const uint32_t*)(smem + rr + PP2 + (1 + x) * 4 + f * 64);
       }
     }
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { e[j] = acc[f][0][j]; e[4 + j] = acc[f][1][j]; }
       if (second) {
-        const u32x4 raw = u32x4{qlo ? rbig[f].x : rsm[f], qlo ? rbig[f].y : 0u, qlo ? rbig[f].z : 0u, qlo ? rbig[f].w : 0u};   // q = 2: channels 18 .. 23 stay exactly zero (conv 7 stores them)
+        const u32x4 raw = u32x4{qlo ? rbig[f].x : rsm[f], rbig[f].y, rbig[f].z, rbig[f].w};      // (q >= 2: .yzw read from the zero row; q = 3's .x is never stored)
         float r8[8];
         Vec16<BF16Tag>::unpack(raw, r8);
 #pragma unroll
