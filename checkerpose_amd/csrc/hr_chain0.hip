@@ -393,7 +393,11 @@ __device__ __forceinline__ int p_peek(const p_cnt_t* c) { return (int)__builtin_
 __device__ __forceinline__ void p_wait(const p_cnt_t* c, int need) {     // bounded: a lost hand-over ends in wrong numbers, not in a hung box
   for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
     if (p_peek(c) >= need) break;
+#ifdef CP_C0_SPIN
+    __builtin_amdgcn_s_sleep(CP_C0_SPIN);
+#else
     __builtin_amdgcn_s_sleep(1);
+#endif
   }
   asm volatile("" ::: "memory");
 }
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
 #define CP_C0_PRIO_EVEN 1
 #endif
   // the second conv of a block carries the residual epilogue: the slower stage of its SIMD pair, and the pipeline runs at its slowest stage;
-  // both above the staging / tail waves (priorities 2 / 1 / 0: -4 % against none, measured in steps of 2 %)
+  // both above the staging / tail waves (priorities 2 / 1 / 0)
   if (second) __builtin_amdgcn_s_setprio(CP_C0_PRIO_ODD);
   else if (CP_C0_PRIO_EVEN) __builtin_amdgcn_s_setprio(CP_C0_PRIO_EVEN);
   const PGeo cg = p_geo(x, q, 1);

@@ -15,6 +15,23 @@ def bind(path):
     return lib
 
 
+def timed_pair(runs, rounds=5, reps=20):
+    """the two builds alternate inside one process (whichever runs second in a process measures 2-3 % faster): median of `rounds` per build"""
+    t = [[], []]
+    for r in range(rounds):
+        for k in ((0, 1) if r % 2 == 0 else (1, 0)):
+            for _ in range(3):
+                runs[k]()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                runs[k]()
+            e1.record(); torch.cuda.synchronize()
+            t[k].append(e0.elapsed_time(e1) / reps * 1e3)
+    med = [sorted(v)[len(v) // 2] for v in t]
+    return "lib 0: median %.1f us (min %.1f)   lib 1: median %.1f us (min %.1f)   ratio %.3f" % (med[0], min(t[0]), med[1], min(t[1]), med[1] / med[0])
+
 libs = [bind(sys.argv[1]), bind(sys.argv[2])]
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
@@ -49,18 +66,13 @@ for (B, nsrc, relu_in, seed) in ((3, 1, 0, 1), (5, 3, 1, 2), (2, 4, 1, 3), (256,
                                                                                                 float(outs[0].abs().max())), flush=True)
     ok &= same
     if B == 256:
-        for k, lib in enumerate(libs):
-            def run():
-                lib.cp_hr_branch_chain(st, B, Cc, H, W, nsrc, arr_p, arr_s, relu_in, blob.data_ptr(), aff.data_ptr(), out.data_ptr())
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                run()
-            e1.record(); torch.cuda.synchronize()
-            print("   lib %d: %.1f us" % (k, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
+        runs = []
+        for lib in libs:
+            blob_ = torch.zeros(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev)
+            for i in range(8):
+                lib.cp_pack_hr_chain_weight(st, ws[i].data_ptr(), scs[i].data_ptr(), Cc, H, W, i, blob_.data_ptr())
+            runs.append((lambda lib=lib, blob_=blob_: lib.cp_hr_branch_chain(st, B, Cc, H, W, nsrc, arr_p, arr_s, relu_in, blob_.data_ptr(), aff.data_ptr(), out.data_ptr())))
+        print("   " + timed_pair(runs), flush=True)
 # ---- with a tail (cp_hr_branch_chain_tail): the chain output AND every tail output, bit for bit; timing at B = 256
 from checkerpose_amd._abi import CpChainTail
 for (B, nsrc, tconvs, seed) in ((3, 2, [(36, False)], 11), (5, 3, [(18, True), (72, False)], 12), (4, 4, [(18, True), (18, True), (36, False)], 13),
@@ -107,15 +119,5 @@ for (B, nsrc, tconvs, seed) in ((3, 2, [(36, False)], 11), (5, 3, [(18, True), (
     print("tail B=%3d nsrc=%d convs %s: equal %s  max|d| %.4g" % (B, nsrc, [c for c, _ in tconvs], same, worst), flush=True)
     ok &= same
     if B == 256:
-        for k in range(2):
-            run = res[k][1]
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                run()
-            e1.record(); torch.cuda.synchronize()
-            print("   lib %d: %.1f us" % (k, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
+        print("   " + timed_pair([res[0][1], res[1][1]]), flush=True)
 print("ALL EQUAL" if ok else "MISMATCH")
