@@ -1,4 +1,5 @@
-"""In-kernel phase clock of hr_chain0 (workgroup 0, no tail): needs a -DCP_DEBUG_KNOBS build of hr_chain0.hip, e.g.
+"""In-kernel phase clock of the 64 x 64 chain (workgroup 0, no tail; the pipelined form, or the band form when the library's file name contains
+"band" = a -DCP_C0_BAND build): needs a -DCP_DEBUG_KNOBS build of hr_chain0.hip, e.g.
 CHECKERPOSE_AMD_LIB=build/lib_knobs.so python tools/chain0_stamps.py [B]"""
 import ctypes as C
 import sys
@@ -12,7 +13,7 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 Cc, H, W, cp = 18, 64, 64, 24
-names = (["loop", "wait input", "reads + MFMAs", "epilogue", "wait slot", "write + post", "-", "-"] if "pipe" in _abi.LIB_PATH else ["prologue", "band MFMA+reads", "band epilogue", "band barrier", "write-back", "conv barrier", "tail", "-"])
+names = (["loop", "wait input", "reads + MFMAs", "epilogue", "wait slot", "write + post", "-", "-"] if "band" not in _abi.LIB_PATH else ["prologue", "band MFMA+reads", "band epilogue", "band barrier", "write-back", "conv barrier", "tail", "-"])
 for nsrc in (1, 3):
     srcs = [torch.randn(B, H, W, cp, device=dev).to(torch.bfloat16) for _ in range(nsrc)]
     blob = torch.zeros(lib.cp_hr_chain_weight_bytes(Cc, H, W), dtype=torch.uint8, device=dev)
