@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CHECKERPOSE_AMD_LIB") or os.path.join(_HERE, "libcheckerpose_hip.so")   # override: kernel A/B builds
 
-CP_F32, CP_BF16 = 0, 1
+CP_F32, CP_BF16, CP_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 LOSS_BCE, LOSS_L1 = 0, 1
 
@@ -100,6 +100,8 @@ class CpWgradDesc(C.Structure):
 # name -> (restype, argtypes); exactly the symbols declared in include/checkerpose_hip.h
 SIGNATURES = {
     "cp_version": (_I, []),
+    "cp_set_deterministic": (None, [_I]),
+    "cp_get_deterministic": (_I, []),
     "cp_strerror": (C.c_char_p, [_I]),
     "cp_last_kernel": (C.c_char_p, []),
     "cp_kernel_log_begin": (None, []),
@@ -135,10 +137,13 @@ SIGNATURES = {
     "cp_gemm_rows": (_I, [_P, C.POINTER(CpConvDesc), _P, _P, _P, _P, _P, _P]),
     "cp_mlp_query_fused_supported": (_I, [_I, _I, _I, _I]),
     "cp_mlp_query_fused": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P, _P, _L, _L, _L, _L]),
+    "cp_mlp_query_fused_t": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P, _P, _L, _L, _L, _L]),
     "cp_mlp_pair_fused_supported": (_I, [_I, _I, _I]),
     "cp_mlp_pair_fused": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
+    "cp_mlp_pair_fused_t": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
     "cp_mlp_pair_fused_gather_supported": (_I, [_I, _I, _I]),
     "cp_mlp_pair_fused_gather": (_I, [_P, C.POINTER(CpI2fGather), _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
+    "cp_mlp_pair_fused_gather_t": (_I, [_P, _I, C.POINTER(CpI2fGather), _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _I]),
     "cp_hr_stem_weight_bytes": (C.c_size_t, [_I]),
     "cp_pack_hr_stem_weights": (_I, [_P, _P, _P, _P, _P]),
     "cp_hr_stem": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -169,6 +174,8 @@ SIGNATURES = {
     "cp_edgeconv_fused_weight_bytes": (C.c_size_t, [_I, _I]),
     "cp_pack_edgeconv_fused_weight": (_I, [_P, _P, _I, _I, _P]),
     "cp_edgeconv_fused": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_pack_edgeconv_fused_weight_t": (_I, [_P, _I, _P, _I, _I, _P]),
+    "cp_edgeconv_fused_t": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
     "cp_edgeconv_tiled_supported": (_I, [_I, _I, _I, _I, _I]),
     "cp_edgeconv_tiled_weight_bytes": (C.c_size_t, [_I, _I]),
     "cp_edgeconv_tiled_table_bytes": (C.c_size_t, [_I, _I, _I]),
@@ -180,6 +187,7 @@ SIGNATURES = {
     "cp_index2feat_conv_weight_bytes": (C.c_size_t, []),
     "cp_pack_index2feat_conv_weight": (_I, [_P, _P, _P]),
     "cp_index2feat_conv": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "cp_index2feat_conv_t": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "cp_index2feat_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cp_bits_decode": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
     "cp_correspondences": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
@@ -279,6 +287,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the .so is stale: also loud
             fn.restype, fn.argtypes = res, args
+        if os.environ.get("CHECKERPOSE_AMD_DETERMINISTIC", "0") == "1":     # deterministic training mode (include/checkerpose_hip.h)
+            lib.cp_set_deterministic(1)
         _lib = lib
     return _lib
 

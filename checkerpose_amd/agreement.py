@@ -184,3 +184,73 @@ def margin_contract_violations(forced, free=None):
         bad.append("free-running: only %.1f %% of %d id mismatches start at the keypoint's own near-tie (the neighbourhood rule alone "
                    "explains the rest)" % (100 * free["id_mismatches_self_subtau_frac"], free["id_mismatches"]))
     return bad
+
+
+# ---- attribution of the bf16 error to the three block groups (round 6)
+GROUPS = ("backbone", "decoder", "gnn")
+
+
+def _tail_stats(out, ref, init_bits=3):
+    """compact error statistics of one teacher-forced run against the fp32 run: mean / max |dlogit|, the tail (max and the 99.9th
+    percentile over the mean), flips by reference margin, and the same mean / max per refinement stage's rows"""
+    zo = torch.cat([t.detach().float().cpu() for t in out[:3]], 1)
+    zr = torch.cat([t.detach().float().cpu() for t in ref[:3]], 1)
+    d = (zo - zr).abs()
+    mean = float(d.mean())
+    st = torch.tensor(row_stages(out[1].shape[1], out[2].shape[1], init_bits))
+    ms = _margin_stats(zo, zr, 4.0 * mean)
+    res = {"mean_abs_dlogit": round(mean, 6), "max_abs_dlogit": round(float(d.max()), 5),
+           "max_over_mean": round(float(d.max()) / max(mean, 1e-30), 2),
+           "p999_over_mean": round(float(torch.quantile(d.flatten()[:: max(1, d.numel() // 4_000_000)], 0.999)) / max(mean, 1e-30), 2),
+           "rms_dlogit": round(float(d.pow(2).mean().sqrt()), 6),
+           "flips": ms["flips"], "max_flip_margin": ms["max_flip_margin"],
+           "max_flip_margin_over_mean": round(ms["max_flip_margin"] / max(mean, 1e-30), 2),
+           "flips_by_margin": {k: v["flips"] for k, v in ms["flip_rate_by_margin"].items()},
+           "by_stage": {}}
+    for s_ in range(int(st.max()) + 1):
+        ds = d[:, st == s_]
+        res["by_stage"]["stage%d" % s_] = {"mean": round(float(ds.mean()), 6), "max": round(float(ds.max()), 5)}
+    return res
+
+
+def attribute_groups(net, img, obj_ids=None, log=None):
+    """Where the bf16 path's logit error comes from: the network is split into `backbone` (image -> the four pyramid features),
+    `decoder` (features -> the three maps the refinement stages gather from) and `gnn` (InitNet's head + the three refinement
+    stages: everything per keypoint), and each group runs in bf16 ALONE -- the other two in fp32 -- by exchanging the group
+    boundaries (NCHW fp32 tensors) between the fp32 and the bf16 programs of the same weights (`forward_hooks`).  Every run is
+    teacher-forced with the fp32 logits, so a row's error is arithmetic only.  Returns {group or "all" or "head": _tail_stats}.
+    `rss_check` = sqrt(sum of the three groups' rms^2) / rms of the all-bf16 run: ~1 when the groups' errors add independently."""
+    say = log or (lambda s: None)
+    was = net.compute_dtype
+    B, N = img.shape[0], net.npoint
+    with torch.no_grad():
+        net.set_compute_dtype("fp32")
+        ref, side32 = net.forward_hooks(img, want_feats=True, want_dec=True, obj_ids=obj_ids)
+        ref = [t.clone() for t in ref]
+        feats32 = [t.clone() for t in side32["img_feats"]]
+        dec32 = [t.clone() for t in side32["dec_feats"]]
+        t = torch.zeros(B, 13, N, device=img.device)
+        t[:, 0:1], t[:, 1:1 + ref[1].shape[1]], t[:, 7:7 + ref[2].shape[1]] = ref[0], ref[1], ref[2]
+        say("attribution: fp32 reference done")
+        net.set_compute_dtype("bf16")
+        out_all, side16 = net.forward_hooks(img, teacher_bits=t, want_feats=True, obj_ids=obj_ids)
+        out_all = [x.clone() for x in out_all]
+        feats16 = [x.clone() for x in side16["img_feats"]]
+        out_head, sd = net.forward_hooks(img, teacher_bits=t, feats=feats32, want_dec=True, obj_ids=obj_ids)
+        out_head = [x.clone() for x in out_head]
+        dec16 = [x.clone() for x in sd["dec_feats"]]
+        out_gnn, _ = net.forward_hooks(img, teacher_bits=t, feats=feats32, dec=dec32, obj_ids=obj_ids)
+        out_gnn = [x.clone() for x in out_gnn]
+        say("attribution: bf16 runs done")
+        net.set_compute_dtype("fp32")
+        out_bb, _ = net.forward_hooks(img, teacher_bits=t, feats=feats16, obj_ids=obj_ids)
+        out_bb = [x.clone() for x in out_bb]
+        out_dec, _ = net.forward_hooks(img, teacher_bits=t, feats=feats32, dec=dec16, obj_ids=obj_ids)
+        out_dec = [x.clone() for x in out_dec]
+        net.set_compute_dtype(was)
+    res = {"all": _tail_stats(out_all, ref), "backbone": _tail_stats(out_bb, ref), "decoder": _tail_stats(out_dec, ref),
+           "gnn": _tail_stats(out_gnn, ref), "head(decoder+gnn)": _tail_stats(out_head, ref)}
+    rss = sum(res[g]["rms_dlogit"] ** 2 for g in GROUPS) ** 0.5
+    res["rss_check"] = round(rss / max(res["all"]["rms_dlogit"], 1e-30), 3)
+    res["logit_rms"] = round(float(torch.cat(ref[:3], 1).float().pow(2).mean().sqrt()), 4)
+    return res

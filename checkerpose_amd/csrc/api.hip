@@ -5,7 +5,12 @@
 
 #include "common.h"
 
-extern "C" int cp_version(void) { return 203; }   // 0.2.3: cp_kernel_log (0.2.2: cp_graph_capture_set_deps / _tail; 0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale)
+extern "C" int cp_version(void) { return 204; }   // 0.2.4: cp_set_deterministic, cp_status_*; 0.2.3: cp_kernel_log (0.2.2: cp_graph_capture_set_deps / _tail; 0.2.1: cp_pack_hr_chain_weight takes the folded-BN scale)
+
+// process-wide mode switch of the TRAINING entry points (include/checkerpose_hip.h): every accumulation in a fixed order
+std::atomic<int> g_cp_deterministic{0};
+extern "C" void cp_set_deterministic(int on) { g_cp_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int cp_get_deterministic(void) { return g_cp_deterministic.load(std::memory_order_relaxed); }
 
 static thread_local char g_last_kernel[128] = "";
 static thread_local char g_kernel_log[1024] = "";   // every symbol since cp_kernel_log_begin(), " + " between them

@@ -86,9 +86,48 @@ __device__ __forceinline__ float f16_lo(uint32_t w) { return (float)__builtin_bi
 __device__ __forceinline__ float f16_hi(uint32_t w) { return (float)__builtin_bit_cast(cp_h2, w).y; }
 constexpr uint32_t CP_F16X2_NEG_INF = 0xFC00FC00u;
 
+// ---- keypoint-side (GNN) kernels in IEEE half (CP_F16, round 6): same bytes and the same MFMA rate as bf16 with 3 more mantissa
+// bits.  EdgeConv differences x_j - x_i of neighbouring keypoints cancel most of |x|, so the storage rounding of x is amplified
+// there; on trained-like weights the keypoint side produced 73 % of the bf16 path's logit-error variance.
+// H = false: bf16 (v_mfma_f32_16x16x32_bf16, v_cvt_pk_bf16_f32); H = true: f16 (v_mfma_f32_16x16x32_f16, saturating v_cvt_pk_f16_f32).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool H>
+__device__ __forceinline__ f32x4 cp_mma16(const u32x4& w, const u32x4& a, const f32x4& acc) {
+  if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+// two floats -> one packed f16 pair, saturating, with the clamp on the PACKED result (v_cvt_pk_f16_f32 rounds an overflow to +-inf;
+// v_pk_min_f16 / v_pk_max_f16 bring it back to +-65504 in place: no temporaries -- the fmed3 form of pack_f16x2_sat cost the fused MLP
+// pair, which has no register to spare, 8 spilled VGPRs)
+__device__ __forceinline__ uint32_t pack_f16x2_sat_pk(float a, float b) {
+  cp_h2 r;
+  r.x = (_Float16)a;
+  r.y = (_Float16)b;
+  const cp_h2 hi = {(_Float16)65504.f, (_Float16)65504.f}, lo = {(_Float16)-65504.f, (_Float16)-65504.f};
+  r = __builtin_elementwise_max(__builtin_elementwise_min(r, hi), lo);
+  return __builtin_bit_cast(uint32_t, r);
+}
+template <bool H>
+__device__ __forceinline__ uint32_t cp_pack2(float lo, float hi) {
+  if constexpr (H) return pack_f16x2_sat_pk(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+template <bool H>
+__device__ __forceinline__ u32x4 cp_pack8(const float* f) {
+  u32x4 v; v.x = cp_pack2<H>(f[0], f[1]); v.y = cp_pack2<H>(f[2], f[3]); v.z = cp_pack2<H>(f[4], f[5]); v.w = cp_pack2<H>(f[6], f[7]);
+  return v;
+}
+__device__ __forceinline__ uint32_t f32_to_f16_bits_sat(float f) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+// storage bits of one element: dtype CP_BF16 or CP_F16 (weight packers, scalar epilogues)
+__device__ __forceinline__ uint32_t f32_to_half_bits(float f, int dtype) { return dtype == CP_F16 ? f32_to_f16_bits_sat(f) : f32_to_bf16_bits(f); }
+
 // element type tags
 struct F32Tag { using elem = float; static constexpr int E = 4; static constexpr int dtype = CP_F32; };
 struct BF16Tag { using elem = uint16_t; static constexpr int E = 8; static constexpr int dtype = CP_BF16; };
+struct F16Tag { using elem = uint16_t; static constexpr int E = 8; static constexpr int dtype = CP_F16; };      // IEEE half (keypoint side)
 
 // 16-byte vector <-> E floats
 template <typename Tag> struct Vec16;
@@ -143,7 +182,9 @@ template <> __device__ __forceinline__ float load_elem<F32Tag>(const void* p, si
 template <> __device__ __forceinline__ float load_elem<BF16Tag>(const void* p, size_t i) {
   return bf16_bits_to_f32(((const uint16_t*)p)[i]);
 }
+template <> __device__ __forceinline__ float load_elem<F16Tag>(const void* p, size_t i) { return f16_bits_to_f32(((const uint16_t*)p)[i]); }
 template <typename Tag> __device__ __forceinline__ void store_elem(void* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_elem<F16Tag>(void* p, size_t i, float v) { ((uint16_t*)p)[i] = (uint16_t)f32_to_f16_bits_sat(v); }
 template <> __device__ __forceinline__ void store_elem<F32Tag>(void* p, size_t i, float v) { ((float*)p)[i] = v; }
 template <> __device__ __forceinline__ void store_elem<BF16Tag>(void* p, size_t i, float v) {
   ((uint16_t*)p)[i] = (uint16_t)f32_to_bf16_bits(v);
@@ -158,6 +199,9 @@ static inline const char* cp_knob(const char* name) { return getenv(name); }
 #else
 static inline const char* cp_knob(const char*) { return nullptr; }
 #endif
+// cp_set_deterministic(): the training entry points then accumulate in a fixed order (no floating-point atomics)
+extern std::atomic<int> g_cp_deterministic;
+static inline bool cp_deterministic() { return g_cp_deterministic.load(std::memory_order_relaxed) != 0; }
 // profiling aid (cp_last_kernel): every launch site records the symbol it launches, spelled as rocprofv3 prints it
 void cp_mark_kernel(const char* fmt, ...);
 #define CP_LAUNCH(kernel, ...) do { cp_mark_kernel("%s", #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
@@ -205,4 +249,4 @@ static inline bool cp_aligned16(const void* p) { return (((uintptr_t)p) & 15u) =
 // the branch-free epilogue activation (cp_act_apply: max(v, v * s + 0)) is LeakyReLU only for slopes in [0, 1]: anything else
 // (a slope > 1, a negative one, NaN) is refused at the entry point instead of computed wrongly
 static inline bool cp_act_ok(int act, float slope) { return act != 2 /* CP_ACT_LEAKY */ || (slope >= 0.f && slope <= 1.f); }
-static inline int cp_elem_size(int dtype) { return dtype == CP_BF16 ? 2 : 4; }
+static inline int cp_elem_size(int dtype) { return (dtype == CP_BF16 || dtype == CP_F16) ? 2 : 4; }

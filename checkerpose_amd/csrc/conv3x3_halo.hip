@@ -766,6 +766,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p)
         v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
       }
       if (E == 4) *(f32x4*)((float*)p.out + obase[mt] + nt * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      else if (KS == 2 && p.seg_S == CP_F16) {       // k = 2 instance only (cp_conv2x2_halo, CpConvDesc.out_f32 = 2): IEEE-half output rows
+        u32x2 pk; pk.x = cp_pack2<true>(v[0], v[1]); pk.y = cp_pack2<true>(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + obase[mt] + nt * 4) = pk;
+      }
       else { u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); *(u32x2*)((uint16_t*)p.out + obase[mt] + nt * 4) = pk; }
     }
   }
@@ -1680,10 +1683,14 @@ extern "C" int cp_conv2x2_halo(cp_stream_t stream, const CpConvDesc* d, const vo
   if (!cp_conv2x2_halo_supported(d->dtype, d->H, d->W, d->Cout)) return CP_ERR_INVALID;
   CpConvDesc d3 = *d;                      // the shared checks are the 3x3 kernel's; extents and weight size are set here
   d3.R = d3.S = 3; d3.Ho = d->H; d3.Wo = d->W;
+  const bool half_out = d->out_f32 == 2;   // bf16 conv, rows written as IEEE half (the keypoint side's storage type, CP_F16)
+  if (half_out && (d->dtype != CP_BF16 || residual)) return CP_ERR_INVALID;
+  if (half_out) d3.out_f32 = 0;
   HaloParams p;
   long long tt;
   const int rcb = build_halo_params(&d3, in, packed_w, scale, shift, residual, out, &p, &tt);
   if (rcb) return rcb;
+  p.seg_S = half_out ? CP_F16 : 0;         // (this kernel family has no seg head: the field carries the output format)
   p.tiles_x = (d->Wo + HTW - 1) / HTW; p.tiles_y = (d->Ho + HTH - 1) / HTH;
   tt = (long long)d->B * p.tiles_x * p.tiles_y;
   if (tt >= (1LL << 28)) return CP_ERR_RANGE;

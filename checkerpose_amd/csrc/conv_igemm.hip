@@ -49,6 +49,10 @@ template <> struct Mma<BF16Tag> {
   }
 };
 
+template <> struct Mma<F16Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) { acc = cp_mma16<true>(w, a, acc); }
+};
+
 template <typename Tag, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int E = Tag::E;
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // Residuals are ALL loaded before the first store: `res` may alias `out` (no __restrict__), so a load issued
   // after a store would be ordered behind it and the epilogue would degrade into MT*NT serial memory round trips.
   const bool vec = (p.o_sc == 1);
-  const bool f32io = p.out_f32 || E == 4;
+  const bool f32io = p.out_f32 == 1 || E == 4;
+  const bool h16out = p.out_f32 == 2 || (Tag::dtype == CP_F16 && p.out_f32 == 0);      // IEEE-half output rows (no residual: host check)
   long long pix[MT];
   bool pok[MT];
 #pragma unroll
@@ -311,6 +316,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
         if (f32io) {
           *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+        } else if (h16out) {
+          u32x2 pk; pk.x = cp_pack2<true>(v[0], v[1]); pk.y = cp_pack2<true>(v[2], v[3]);
+          *(u32x2*)((uint16_t*)p.out + o) = pk;
         } else {
           u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
           *(u32x2*)((uint16_t*)p.out + o) = pk;
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
           if (p.res) y += f32io ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
           y = cp_act_apply(y, cp_act_slope(p.act, p.slope));
           if (f32io) ((float*)p.out)[o] = y;
+          else if (h16out) ((uint16_t*)p.out)[o] = (uint16_t)f32_to_f16_bits_sat(y);
           else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
         }
       }
@@ -417,7 +426,8 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
   __syncthreads();
 
   // ---- one (pixel, 4 channels) item per thread: sum the KS partials in wave order, then the tiled kernel's epilogue
-  const bool f32io = p.out_f32 || E == 4;
+  const bool f32io = p.out_f32 == 1 || E == 4;
+  const bool h16out = p.out_f32 == 2 || (Tag::dtype == CP_F16 && p.out_f32 == 0);      // IEEE-half output rows (no residual: host check)
   for (int it = threadIdx.x; it < T * 64; it += KS * 64) {
     const int t = it >> 6, l = it & 63;
     const int mt = t / NT, nt = t - mt * NT;
@@ -473,6 +483,7 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
         if (p.res) y += f32io ? ((const float*)p.res)[o] : bf16_bits_to_f32(((const uint16_t*)p.res)[o]);
         y = cp_act_apply(y, cp_act_slope(p.act, p.slope));
         if (f32io) ((float*)p.out)[o] = y;
+        else if (h16out) ((uint16_t*)p.out)[o] = (uint16_t)f32_to_f16_bits_sat(y);
         else ((uint16_t*)p.out)[o] = (uint16_t)f32_to_bf16_bits(y);
       }
     }
@@ -522,7 +533,7 @@ static void launch(ConvParams p, hipStream_t st) {
   p.old_map = cp_knob("CP_OLD_MAP") ? 1 : 0;
   dim3 grid((unsigned)((p.m_blocks + 7) / 8 * 8) * p.n_blocks);
   const size_t lds = p.epi_lds ? (size_t)4 * MT * 16 * (NT * 16 + 4) * sizeof(float) : 0;
-  cp_mark_kernel("conv_igemm_kernel<%s, %d, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : "F32Tag", MT, NT);
+  cp_mark_kernel("conv_igemm_kernel<%s, %d, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : (Tag::dtype == CP_F16 ? "F16Tag" : "F32Tag"), MT, NT);
   hipLaunchKernelGGL((conv_igemm_kernel<Tag, MT, NT>), grid, dim3(256), lds, st, p);
 }
 
@@ -540,7 +551,11 @@ static void dispatch_nt(const ConvParams& p, int NT, hipStream_t st) {
 extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                                const float* scale, const float* shift, const void* residual, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
-  if ((d->dtype != CP_F32 && d->dtype != CP_BF16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
+  if ((d->dtype != CP_F32 && d->dtype != CP_BF16 && d->dtype != CP_F16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
+  // IEEE half at the keypoint side's edges: dtype CP_F16 = half input rows + half weights (cp_pack_conv_weight(CP_F16)); out_f32 = 2 =
+  // half OUTPUT rows of a bf16 conv.  Neither takes a residual (the epilogue's residual decode is bf16 / fp32).
+  const bool halfish = d->dtype == CP_F16 || d->out_f32 == 2;
+  if (d->out_f32 < 0 || d->out_f32 > 2 || (d->out_f32 == 2 && d->dtype != CP_BF16) || (halfish && residual)) return CP_ERR_INVALID;
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->R <= 0 || d->S <= 0 || d->stride <= 0)
     return CP_ERR_INVALID;
@@ -554,7 +569,7 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   const long long M = (long long)d->B * d->Ho * d->Wo;
   if (M >= (1LL << 31)) return CP_ERR_RANGE;
   if (d->o_sc == 1) {  // vector epilogue: 4 consecutive channels per store
-    const int oes = d->out_f32 ? 4 : es;
+    const int oes = d->out_f32 == 1 ? 4 : es;
     if ((d->o_base % 4) || (d->o_sb % 4) || (d->o_sy % 4) || (d->o_sx % 4)) return CP_ERR_ALIGN;
     if (((uintptr_t)out % (4 * oes)) || (residual && ((uintptr_t)residual % (4 * oes)))) return CP_ERR_ALIGN;
   }
@@ -572,7 +587,7 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx; p.o_sc = d->o_sc;
 
   int nts = 1;
-  if (const int ks = d->ksplit == -1 ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles, &nts)) {
+  if (const int ks = (d->ksplit == -1 || halfish) ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles, &nts)) {
     hipStream_t st_ = (hipStream_t)stream;
     if (ks == 8) { if (nts == 3) launch_splitk<3, 8>(p, st_); else if (nts == 2) launch_splitk<2, 8>(p, st_); else launch_splitk<1, 8>(p, st_); }
     else         { if (nts == 3) launch_splitk<3, 4>(p, st_); else if (nts == 2) launch_splitk<2, 4>(p, st_); else launch_splitk<1, 4>(p, st_); }
@@ -591,13 +606,14 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   int MT = (blocks4 >= 512 && p.KC > 4) ? 4 : 2;
   if (const char* e = cp_knob("CP_CONV_MT")) MT = atoi(e) == 2 ? 2 : 4;   // kernel-work A/B switch
   // coalesced LDS epilogue: channels-last vector output, NT in {1,2,4}, 16-byte alignment of every row piece
-  const int oes_ = d->out_f32 ? 4 : es;
+  const int oes_ = d->out_f32 == 1 ? 4 : es;
   const int cpl = 16 / oes_;
-  p.epi_lds = (MT == 2 && d->o_sc == 1 && !d->out_f32 && (NT == 1 || NT == 2 || NT == 4) && d->Cout % cpl == 0 && d->o_base % cpl == 0 &&
+  p.epi_lds = (MT == 2 && d->o_sc == 1 && !d->out_f32 && !halfish && (NT == 1 || NT == 2 || NT == 4) && d->Cout % cpl == 0 && d->o_base % cpl == 0 &&
                d->o_sb % cpl == 0 && d->o_sy % cpl == 0 && d->o_sx % cpl == 0 && ((uintptr_t)out % 16) == 0 &&
                (!residual || ((uintptr_t)residual % 16) == 0) && !cp_knob("CP_NO_EPI_LDS")) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_F32) { if (MT == 4) dispatch_nt<F32Tag, 4>(p, NT, st); else dispatch_nt<F32Tag, 2>(p, NT, st); }
+  else if (d->dtype == CP_F16) dispatch_nt<F16Tag, 2>(p, NT, st);      // (small per-keypoint Linears: the light tile only)
   else                    { if (MT == 4) dispatch_nt<BF16Tag, 4>(p, NT, st); else dispatch_nt<BF16Tag, 2>(p, NT, st); }
   return cp_check_launch();
 }

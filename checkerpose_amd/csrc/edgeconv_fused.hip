@@ -37,7 +37,7 @@ struct EdgeFusedParams {
 };
 
 
-template <int CIN>
+template <int CIN, bool H = false>                            // H: x rows, weights and output rows in IEEE half (CP_F16; common.h cp_mma16)
 __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedParams p) {
   constexpr int KC = CIN / 32;                              // 32-deep K chunks
   constexpr int HALF = KC * 4 * 1024;                       // bytes of one (slice, half) weight image
@@ -108,8 +108,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
-                                                               acc[f][nt], 0, 0, 0);
+          acc[f][nt] = cp_mma16<H>(wf[kc & 1][nt], xa[f][kc], acc[f][nt]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -208,8 +207,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
           for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-              aq[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[fp + h][kc]),
-                                                                  aq[h][nt], 0, 0, 0);
+              aq[h][nt] = cp_mma16<H>(wf[kc & 1][nt], xa[fp + h][kc], aq[h][nt]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -228,8 +226,8 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
             v[2 * j + 1] = y1 > 0.f ? y1 : y1 * p.slope;
           }
           uint16_t* dst = (uint16_t*)p.out + ((size_t)b * EF_N + n) * p.out_cs + p.out_coff + s * 64 + q * 16;
-          *(u32x4*)dst = Vec16<BF16Tag>::pack(v);
-          *(u32x4*)(dst + 8) = Vec16<BF16Tag>::pack(v + 8);
+          *(u32x4*)dst = cp_pack8<H>(v);
+          *(u32x4*)(dst + 8) = cp_pack8<H>(v + 8);
         }
       }
     }
@@ -239,7 +237,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
 
 // [slice][half P/Q][chunk][tile][lane][8 bf16]; tile row r of tile nt = output channel 64 slice + (r >> 2) * 16 + 4 nt + (r & 3)
 // of wpq rows [0, Cout) (P half) / [Cout, 2 Cout) (Q half); element e of lane (r, q): input channel 32 chunk + 8 q + e.
-__global__ void pack_edgeconv_fused_kernel(const float* __restrict__ wpq, uint16_t* __restrict__ out, int Cin, int Cout, size_t total) {
+__global__ void pack_edgeconv_fused_kernel(const float* __restrict__ wpq, uint16_t* __restrict__ out, int Cin, int Cout, size_t total, int dtype) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int KC = Cin / 32;
@@ -253,7 +251,7 @@ __global__ void pack_edgeconv_fused_kernel(const float* __restrict__ wpq, uint16
   const int r = lane & 15, q = lane >> 4;
   const int c = s * 64 + (r >> 2) * 16 + nt * 4 + (r & 3);
   const int cin = kc * 32 + q * 8 + e;
-  out[i] = (uint16_t)f32_to_bf16_bits(wpq[((size_t)(half * Cout + c)) * Cin + cin]);
+  out[i] = (uint16_t)f32_to_half_bits(wpq[((size_t)(half * Cout + c)) * Cin + cin], dtype);
 }
 
 }  // namespace
@@ -264,30 +262,46 @@ extern "C" int cp_edgeconv_fused_supported(int N, int K, int Cin, int Cout) {
 
 extern "C" size_t cp_edgeconv_fused_weight_bytes(int Cin, int Cout) { return (size_t)2 * Cout * Cin * 2; }
 
-extern "C" int cp_pack_edgeconv_fused_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed) {
-  if (!wpq || !packed || !cp_edgeconv_fused_supported(EF_N, 4, Cin, Cout)) return CP_ERR_INVALID;
+extern "C" int cp_pack_edgeconv_fused_weight_t(cp_stream_t stream, int dtype, const float* wpq, int Cin, int Cout, void* packed) {
+  if (!wpq || !packed || !cp_edgeconv_fused_supported(EF_N, 4, Cin, Cout) || (dtype != CP_BF16 && dtype != CP_F16)) return CP_ERR_INVALID;
   if (!cp_aligned16(packed)) return CP_ERR_ALIGN;
   const size_t total = (size_t)2 * Cout * Cin;
-  CP_LAUNCH(pack_edgeconv_fused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpq, (uint16_t*)packed, Cin, Cout, total);
+  CP_LAUNCH(pack_edgeconv_fused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpq, (uint16_t*)packed, Cin, Cout, total, dtype);
   return cp_check_launch();
 }
 
-extern "C" int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w,
-                                 const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
-                                 int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope) {
-  if (!x || !packed_w || !scale || !shift || !idx || !out || B <= 0 || G <= 0) return CP_ERR_INVALID;
+extern "C" int cp_pack_edgeconv_fused_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed) {
+  return cp_pack_edgeconv_fused_weight_t(stream, CP_BF16, wpq, Cin, Cout, packed);
+}
+
+extern "C" int cp_edgeconv_fused_t(cp_stream_t stream, int dtype, const void* x, int in_cstride, int in_coff, const void* packed_w,
+                                   const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
+                                   int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope) {
+  if (!x || !packed_w || !scale || !shift || !idx || !out || B <= 0 || G <= 0 || (dtype != CP_BF16 && dtype != CP_F16)) return CP_ERR_INVALID;
   if (!cp_edgeconv_fused_supported(N, K, Cin, Cout)) return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + Cout > out_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(x) || !cp_aligned16(packed_w) || !cp_aligned16(scale) || !cp_aligned16(shift) || !cp_aligned16(out)) return CP_ERR_ALIGN;
   static CpDeviceOnce once;
   const int dev = cp_current_device();
   CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)edgeconv_fused_kernel<64>, EF_LDS) &&
-                                  cp_set_max_lds((const void*)edgeconv_fused_kernel<256>, EF_LDS));
+                                  cp_set_max_lds((const void*)edgeconv_fused_kernel<256>, EF_LDS) &&
+                                  cp_set_max_lds((const void*)edgeconv_fused_kernel<64, true>, EF_LDS) &&
+                                  cp_set_max_lds((const void*)edgeconv_fused_kernel<256, true>, EF_LDS));
   EdgeFusedParams p;
   p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.idx = idx; p.gids = graph_ids; p.out = out;
   p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.K = K; p.Cout = Cout; p.slope = slope;
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 64) CP_LAUNCH((edgeconv_fused_kernel<64>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
+  if (dtype == CP_F16) {
+    if (Cin == 64) CP_LAUNCH((edgeconv_fused_kernel<64, true>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
+    else CP_LAUNCH((edgeconv_fused_kernel<256, true>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
+  } else if (Cin == 64) CP_LAUNCH((edgeconv_fused_kernel<64>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
   else CP_LAUNCH((edgeconv_fused_kernel<256>), dim3((unsigned)B), dim3(512), EF_LDS, st, p);
   return cp_check_launch();
+}
+
+extern "C" int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w,
+                                 const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
+                                 int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope) {
+  return cp_edgeconv_fused_t(stream, CP_BF16, x, in_cstride, in_coff, packed_w, scale, shift, idx, graph_ids, out, out_cstride, out_coff, B, N,
+                             K, Cin, Cout, G, slope);
 }

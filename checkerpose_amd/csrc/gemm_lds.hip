@@ -388,7 +388,7 @@ extern "C" size_t cp_packed_gemm_weight_bytes(int dtype, int Cout, int cin_phys)
 
 extern "C" int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w, int Cout, int Cin, int cin_phys, void* packed) {
   if (!w || !packed || Cout <= 0 || Cin <= 0 || cin_phys < Cin) return CP_ERR_INVALID;
-  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;      // CP_F16: the fused MLP kernels' half images
   const int E = cp_chan_align(dtype);
   if (cin_phys % E || !cp_aligned16(packed)) return CP_ERR_ALIGN;
   const int nchunk = (cin_phys + 4 * E - 1) / (4 * E);
@@ -396,6 +396,8 @@ extern "C" int cp_pack_gemm_weight(cp_stream_t stream, int dtype, const float* w
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
     CP_LAUNCH(pack_gemm_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
+  else if (dtype == CP_F16)
+    CP_LAUNCH(pack_gemm_weight_kernel<F16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
   else
     CP_LAUNCH(pack_gemm_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, nchunk, nullptr, total);
   return cp_check_launch();

@@ -35,6 +35,7 @@ struct MlpQueryParams {
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+template <bool H>                                              // H: rows, weights and hidden rows in IEEE half (CP_F16; common.h cp_mma16)
 __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sX = smem;                             // 2 x MQ_BUF
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
               const u32x4 a = *(const u32x4*)(ab + kc * 4 * MQ_PITCH + mt * 256);
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc][t]), __builtin_bit_cast(bf16x8, a), acc[mt][t], 0, 0, 0);
+                acc[mt][t] = cp_mma16<H>(W[kc][t], a, acc[mt][t]);
             }
           // lane (x, q): rows 32 mh + 16 mt + x, hidden channels (2 wave + h) * 32 + 8 q + {0..7} = piece (2 wave + h) * 4 + q
 #pragma unroll
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
                 v[j] = leaky(acc[mt][2 * h][j] * s0[j] + t0[j], p.slope1);
                 v[4 + j] = leaky(acc[mt][2 * h + 1][j] * s1[j] + t1[j], p.slope1);
               }
-              *(u32x4*)(sH + (it & 1) * MQ_BUF + ((2 * wave + h) * 4 + q) * MQ_PITCH + (mh * 32 + mt * 16 + x) * 16) = Vec16<BF16Tag>::pack(v);
+              *(u32x4*)(sH + (it & 1) * MQ_BUF + ((2 * wave + h) * 4 + q) * MQ_PITCH + (mh * 32 + mt * 16 + x) * 16) = cp_pack8<H>(v);
             }
           }
         }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
         const u32x4 a = *(const u32x4*)(ab + kc * 4 * MQ_PITCH);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc][t]), __builtin_bit_cast(bf16x8, a), acc[t], 0, 0, 0);
+          acc[t] = cp_mma16<H>(W[kc][t], a, acc[t]);
       }
       // lane (x, q): row 16 v4 + x, hidden-2 channels 32 h + 8 q + {0..7}; layer 3 on the fp32 values
       float d0 = 0.f, d1 = 0.f;
@@ -184,12 +185,13 @@ __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryPara
 
 extern "C" int cp_mlp_query_fused_supported(int C0, int C1, int C2, int C3) { return (C0 == 256 && C1 == 256 && C2 == 64 && C3 == 2) ? 1 : 0; }
 
-extern "C" int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int B, int N,
+extern "C" int cp_mlp_query_fused_t(cp_stream_t stream, int dtype, const void* in, int in_cstride, int in_coff, int B, int N,
                                   const void* packed_w1, const float* scale1, const float* shift1, float slope1,
                                   const void* packed_w2, const float* scale2, const float* shift2, float slope2,
                                   const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn,
                                   long long o_sc) {
-  if (!in || !packed_w1 || !scale1 || !shift1 || !packed_w2 || !scale2 || !shift2 || !w3 || !b3 || !out || B <= 0 || N <= 0)
+  if (!in || !packed_w1 || !scale1 || !shift1 || !packed_w2 || !scale2 || !shift2 || !w3 || !b3 || !out || B <= 0 || N <= 0 ||
+      (dtype != CP_BF16 && dtype != CP_F16))
     return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + 256 > in_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(in) || !cp_aligned16(packed_w1) || !cp_aligned16(packed_w2) || !cp_aligned16(scale1) || !cp_aligned16(shift1) ||
@@ -200,7 +202,8 @@ extern "C" int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cst
   if (in_bytes >= (1LL << 32) || M >= (1LL << 31)) return CP_ERR_RANGE;
   static CpDeviceOnce once;
   const int dev = cp_current_device();
-  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)mlp_query_fused_kernel, MQ_LDS));
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)mlp_query_fused_kernel<false>, MQ_LDS) &&
+                                  cp_set_max_lds((const void*)mlp_query_fused_kernel<true>, MQ_LDS));
   const int n_cu = cp_num_cus();
   if (n_cu <= 0) return CP_ERR_HIP;
   MlpQueryParams p;
@@ -209,8 +212,18 @@ extern "C" int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cst
   p.in_bytes = (uint32_t)in_bytes; p.slope1 = slope1; p.slope2 = slope2;
   p.o_base = o_base; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sc = o_sc;
   const int grid = p.n_rt < n_cu ? p.n_rt : n_cu;
-  CP_LAUNCH(mlp_query_fused_kernel, dim3((unsigned)grid), dim3(512), MQ_LDS, (hipStream_t)stream, p);
+  if (dtype == CP_F16) CP_LAUNCH((mlp_query_fused_kernel<true>), dim3((unsigned)grid), dim3(512), MQ_LDS, (hipStream_t)stream, p);
+  else CP_LAUNCH((mlp_query_fused_kernel<false>), dim3((unsigned)grid), dim3(512), MQ_LDS, (hipStream_t)stream, p);
   return cp_check_launch();
+}
+
+extern "C" int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int B, int N,
+                                  const void* packed_w1, const float* scale1, const float* shift1, float slope1,
+                                  const void* packed_w2, const float* scale2, const float* shift2, float slope2,
+                                  const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn,
+                                  long long o_sc) {
+  return cp_mlp_query_fused_t(stream, CP_BF16, in, in_cstride, in_coff, B, N, packed_w1, scale1, shift1, slope1, packed_w2, scale2, shift2,
+                              slope2, w3, b3, out, o_base, o_sb, o_sn, o_sc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -277,7 +290,7 @@ __device__ __forceinline__ int mp_lane(int lane) {
   return ln;
 }
 
-template <int NI, bool GATHER = false>                       // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2
+template <int NI, bool GATHER = false, bool H = false>       // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2; H: IEEE half (CP_F16)
 __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
   static_assert(!GATHER || NI >= 3, "the gathering loader moves one row (48 or 64 pieces) per DMA instruction");
   constexpr int ND = GATHER ? 4 : NI;                         // DMA instructions per layer-1 wave and tile (gathering: its 4 rows, P lanes each)
@@ -441,8 +454,8 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
               const int kc = 2 * k2 + h;
-              acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2]), __builtin_bit_cast(bf16x8, a[h][f]), acc[f][0], 0, 0, 0);
-              acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[kc * 2 + 1]), __builtin_bit_cast(bf16x8, a[h][f]), acc[f][1], 0, 0, 0);
+              acc[f][0] = cp_mma16<H>(W[kc * 2], a[h][f], acc[f][0]);
+              acc[f][1] = cp_mma16<H>(W[kc * 2 + 1], a[h][f], acc[f][1]);
             }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
             v[j] = leaky(acc[f][0][j] + t0[j], p.slope1);
             v[4 + j] = leaky(acc[f][1][j] + t1[j], p.slope1);
           }
-          *(u32x4*)(sH + (it & 1) * MP_HBUF + (f * 16 + x) * (MP_HP * 16) + (wave >> 2) * 256 + (((4 * (wave & 3)) ^ qx) << 4)) = Vec16<BF16Tag>::pack(v);
+          *(u32x4*)(sH + (it & 1) * MP_HBUF + (f * 16 + x) * (MP_HP * 16) + (wave >> 2) * 256 + (((4 * (wave & 3)) ^ qx) << 4)) = cp_pack8<H>(v);
         }
       }
       MP_MARK(2);                                             // layer-1 epilogue
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
             for (int h = 0; h < L2B; ++h)
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[(L2B * k4 + h) * 4 + t]), __builtin_bit_cast(bf16x8, a[h]), acc[t], 0, 0, 0);
+                acc[t] = cp_mma16<H>(W[(L2B * k4 + h) * 4 + t], a[h], acc[t]);
             __builtin_amdgcn_sched_barrier(0);
           }
           const long long m = (long long)(rt - step) * MP_ROWS + f * 16 + x;
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
               v[j] = leaky(acc[2 * h][j] + t0[j], p.slope2);
               v[4 + j] = leaky(acc[2 * h + 1][j] + t1[j], p.slope2);
             }
-            if (m < p.M) *(u32x4*)((uint16_t*)p.out + (size_t)m * p.out_cs + p.out_coff + c) = Vec16<BF16Tag>::pack(v);
+            if (m < p.M) *(u32x4*)((uint16_t*)p.out + (size_t)m * p.out_cs + p.out_coff + c) = cp_pack8<H>(v);
           }
         }
       }
@@ -534,15 +547,16 @@ extern "C" int cp_mlp_pair_fused_supported(int Cin, int C1, int C2) {
   return (Cin >= 64 && Cin <= 512 && Cin % 32 == 0 && C1 == 256 && C2 == 256) ? 1 : 0;
 }
 
-static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long long M, bool gather);
+static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long long M, bool gather, int dtype);
 
 extern "C" int cp_mlp_pair_fused_gather_supported(int Cg, int E_ch, int k) {
   return ((Cg == 64 || Cg == 128 || Cg == 192 || Cg == 256) && E_ch == 64 && k >= 1 && k <= 4) ? 1 : 0;      // + N a power of two >= 4 at the call
 }
 
-extern "C" int cp_mlp_pair_fused_gather(cp_stream_t stream, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff, int Cg,
-                                        int B, int N, const void* packed_w1, const float* bias1, float slope1, const void* packed_w2,
-                                        const float* bias2, float slope2, void* out, int out_cstride, int out_coff) {
+extern "C" int cp_mlp_pair_fused_gather_t(cp_stream_t stream, int dtype, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff,
+                                          int Cg, int B, int N, const void* packed_w1, const float* bias1, float slope1,
+                                          const void* packed_w2, const float* bias2, float slope2, void* out, int out_cstride, int out_coff) {
+  if (dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;
   if (!g || !g->patches || !g->x_id || !g->y_id || !g->mask || !g->zeros || !gin || !packed_w1 || !bias1 || !packed_w2 || !bias2 || !out ||
       B <= 0 || N <= 0)
     return CP_ERR_INVALID;
@@ -559,12 +573,20 @@ extern "C" int cp_mlp_pair_fused_gather(cp_stream_t stream, const CpI2fGather* g
   p.slope1 = slope1; p.slope2 = slope2;
   p.patches = g->patches; p.x_id = g->x_id; p.y_id = g->y_id; p.mask = g->mask; p.zeros = g->zeros;
   p.Nrow = __builtin_ctz((unsigned)N); p.Hp = g->Hp; p.Wp = g->Wp; p.p_cs = g->p_cstride; p.p_coff = g->p_coff; p.kk = g->k;
-  return mlp_pair_launch(stream, p, 256 + Cg, M, true);
+  return mlp_pair_launch(stream, p, 256 + Cg, M, true, dtype);
 }
 
-extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
-                                 const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
-                                 float slope2, void* out, int out_cstride, int out_coff) {
+extern "C" int cp_mlp_pair_fused_gather(cp_stream_t stream, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff, int Cg,
+                                        int B, int N, const void* packed_w1, const float* bias1, float slope1, const void* packed_w2,
+                                        const float* bias2, float slope2, void* out, int out_cstride, int out_coff) {
+  return cp_mlp_pair_fused_gather_t(stream, CP_BF16, g, gin, gin_cstride, gin_coff, Cg, B, N, packed_w1, bias1, slope1, packed_w2, bias2, slope2,
+                                    out, out_cstride, out_coff);
+}
+
+extern "C" int cp_mlp_pair_fused_t(cp_stream_t stream, int dtype, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
+                                   const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
+                                   float slope2, void* out, int out_cstride, int out_coff) {
+  if (dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;
   if (!in || !packed_w1 || !bias1 || !packed_w2 || !bias2 || !out || B <= 0 || N <= 0) return CP_ERR_INVALID;
   if (!cp_mlp_pair_fused_supported(Cin, 256, 256)) return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + 256 > out_cstride) return CP_ERR_ALIGN;
@@ -575,10 +597,17 @@ extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstr
   p.in = in; p.w1 = packed_w1; p.t1 = bias1; p.w2 = packed_w2; p.t2 = bias2; p.out = out;
   p.in_cs = in_cstride; p.in_coff = in_coff;
   p.out_cs = out_cstride; p.out_coff = out_coff; p.slope1 = slope1; p.slope2 = slope2;
-  return mlp_pair_launch(stream, p, Cin, M, false);
+  return mlp_pair_launch(stream, p, Cin, M, false, dtype);
 }
 
-static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long long M, bool gather) {
+extern "C" int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
+                                 const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
+                                 float slope2, void* out, int out_cstride, int out_coff) {
+  return cp_mlp_pair_fused_t(stream, CP_BF16, in, in_cstride, in_coff, Cin, B, N, packed_w1, bias1, slope1, packed_w2, bias2, slope2, out,
+                             out_cstride, out_coff);
+}
+
+static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long long M, bool gather, int dtype) {
   const int nchunk = Cin / 32;
   // 32 / 48 / 64 pieces per row image.  Never below 32: the smallest instance is <2> (Cin <= 128 used to give P = 16, i.e. LDS sized
   // for 16 pieces under a kernel<4> launch that addresses 64: out-of-bounds LDS, silently wrong); pieces past the row's width
@@ -591,13 +620,24 @@ static int mlp_pair_launch(cp_stream_t stream, MlpPairParams& p, int Cin, long l
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<3>, mlp_pair_lds(48)) &&
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<4>, mlp_pair_lds(64)) &&
                                   cp_set_max_lds((const void*)mlp_pair_fused_kernel<3, true>, mlp_pair_lds(48)) &&
-                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4, true>, mlp_pair_lds(64)));
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4, true>, mlp_pair_lds(64)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<2, false, true>, mlp_pair_lds(32)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<3, false, true>, mlp_pair_lds(48)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4, false, true>, mlp_pair_lds(64)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<3, true, true>, mlp_pair_lds(48)) &&
+                                  cp_set_max_lds((const void*)mlp_pair_fused_kernel<4, true, true>, mlp_pair_lds(64)));
   const int n_cu = cp_num_cus();
   if (n_cu <= 0) return CP_ERR_HIP;
   p.M = (int)M; p.nchunk1 = nchunk; p.n_rt = (int)((M + MP_ROWS - 1) / MP_ROWS);
   const int grid = p.n_rt < n_cu ? p.n_rt : n_cu;
   hipStream_t st = (hipStream_t)stream;
-  if (gather && P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  if (dtype == CP_F16) {
+    if (gather && P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3, true, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+    else if (gather) CP_LAUNCH((mlp_pair_fused_kernel<4, true, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+    else if (P == 32) CP_LAUNCH((mlp_pair_fused_kernel<2, false, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+    else if (P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3, false, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+    else CP_LAUNCH((mlp_pair_fused_kernel<4, false, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
+  } else if (gather && P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else if (gather) CP_LAUNCH((mlp_pair_fused_kernel<4, true>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else if (P == 32) CP_LAUNCH((mlp_pair_fused_kernel<2>), dim3((unsigned)grid), dim3(768), lds, st, p);
   else if (P == 48) CP_LAUNCH((mlp_pair_fused_kernel<3>), dim3((unsigned)grid), dim3(768), lds, st, p);

@@ -2,7 +2,7 @@
 // plumbing, not the hot loop -- written for clarity, coalesced on the write side.
 #include "common.h"
 
-extern "C" int cp_chan_align(int dtype) { return dtype == CP_BF16 ? 8 : 4; }
+extern "C" int cp_chan_align(int dtype) { return (dtype == CP_BF16 || dtype == CP_F16) ? 8 : 4; }
 
 extern "C" size_t cp_packed_weight_bytes(int dtype, int cout_rows, int cin_phys, int R, int S) {
   const int E = cp_chan_align(dtype), KCH = 4 * E;
@@ -48,7 +48,7 @@ extern "C" int cp_pack_conv_weight(cp_stream_t stream, int dtype, const float* w
                                    int cin_phys, int transposed, int phase, const int32_t* row_map, int cout_rows,
                                    void* packed) {
   if (!w || !packed || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || cout_rows <= 0) return CP_ERR_INVALID;
-  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype);
   if (cin_phys < Cin || cin_phys % E) return CP_ERR_ALIGN;
   if (transposed && (phase < 0 || phase > 3 || R != 1 + (phase >> 1) || S != 1 + (phase & 1))) return CP_ERR_INVALID;
@@ -59,6 +59,9 @@ extern "C" int cp_pack_conv_weight(cp_stream_t stream, int dtype, const float* w
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
     CP_LAUNCH(pack_weight_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
+                       R, S, cin_phys, transposed, phase, row_map, cout_rows, KC, total);
+  else if (dtype == CP_F16)
+    CP_LAUNCH(pack_weight_kernel<F16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
                        R, S, cin_phys, transposed, phase, row_map, cout_rows, KC, total);
   else
     CP_LAUNCH(pack_weight_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,

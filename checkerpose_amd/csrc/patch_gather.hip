@@ -25,6 +25,7 @@ struct PatchParams {
   uint32_t in_bytes;
 };
 
+template <bool HOUT>                                           // HOUT: the output rows leave as IEEE half (CP_F16: the keypoint side's storage type)
 __global__ __launch_bounds__(512) void patch_gather_kernel(const PatchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(512) void patch_gather_kernel(const PatchParams p) 
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * nt + j] = (acc[t][nt][j] + bs[4 * nt + j]) * mk;
-    *(u32x4*)(ob + t * PG_COUT) = Vec16<BF16Tag>::pack(v);
-    *(u32x4*)(ob + t * PG_COUT + 8) = Vec16<BF16Tag>::pack(v + 8);
+    *(u32x4*)(ob + t * PG_COUT) = cp_pack8<HOUT>(v);
+    *(u32x4*)(ob + t * PG_COUT + 8) = cp_pack8<HOUT>(v + 8);
   }
 }
 
@@ -157,9 +158,10 @@ extern "C" int cp_pack_index2feat_conv_weight(cp_stream_t stream, const float* w
   return cp_check_launch();
 }
 
-extern "C" int cp_index2feat_conv(cp_stream_t stream, const void* f, int in_cstride, int in_coff, const void* packed_w, const float* bias,
-                                  const int32_t* x_id, const int32_t* y_id, const float* mask, void* out, int B, int N, int H, int W,
-                                  int k, int out_cstride, int out_coff) {
+extern "C" int cp_index2feat_conv_t(cp_stream_t stream, int out_dtype, const void* f, int in_cstride, int in_coff, const void* packed_w,
+                                    const float* bias, const int32_t* x_id, const int32_t* y_id, const float* mask, void* out, int B, int N,
+                                    int H, int W, int k, int out_cstride, int out_coff) {
+  if (out_dtype != CP_BF16 && out_dtype != CP_F16) return CP_ERR_INVALID;
   if (!f || !packed_w || !bias || !x_id || !y_id || !mask || !out || B <= 0 || N <= 0 || H <= 0 || W <= 0 || k != 2) return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + PG_CIN > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + 4 * PG_COUT > out_cstride)
     return CP_ERR_ALIGN;
@@ -168,12 +170,21 @@ extern "C" int cp_index2feat_conv(cp_stream_t stream, const void* f, int in_cstr
   if (in_bytes >= (1LL << 31)) return CP_ERR_RANGE;
   static CpDeviceOnce once;
   const int dev = cp_current_device();
-  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)patch_gather_kernel, PG_LDS));
+  CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)patch_gather_kernel<false>, PG_LDS) &&
+                                  cp_set_max_lds((const void*)patch_gather_kernel<true>, PG_LDS));
   PatchParams p;
   p.f = f; p.w = packed_w; p.bias = bias; p.xid = x_id; p.yid = y_id; p.mask = mask; p.out = out;
   p.B = B; p.N = N; p.H = H; p.W = W; p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.k = k;
   p.in_bytes = (uint32_t)in_bytes;
   const unsigned grid = (unsigned)(B * ((N + 127) / 128));
-  CP_LAUNCH(patch_gather_kernel, dim3(grid), dim3(512), PG_LDS, (hipStream_t)stream, p);
+  if (out_dtype == CP_F16) CP_LAUNCH((patch_gather_kernel<true>), dim3(grid), dim3(512), PG_LDS, (hipStream_t)stream, p);
+  else CP_LAUNCH((patch_gather_kernel<false>), dim3(grid), dim3(512), PG_LDS, (hipStream_t)stream, p);
   return cp_check_launch();
+}
+
+extern "C" int cp_index2feat_conv(cp_stream_t stream, const void* f, int in_cstride, int in_coff, const void* packed_w, const float* bias,
+                                  const int32_t* x_id, const int32_t* y_id, const float* mask, void* out, int B, int N, int H, int W,
+                                  int k, int out_cstride, int out_coff) {
+  return cp_index2feat_conv_t(stream, CP_BF16, f, in_cstride, in_coff, packed_w, bias, x_id, y_id, mask, out, B, N, H, W, k, out_cstride,
+                              out_coff);
 }

@@ -189,7 +189,11 @@ __device__ __forceinline__ void fin_bwd_channel(const double* partial, const Fin
 
 // the fp64 accumulators of the two-launch forms are replicated CP_BN_ACC_SETS times (block b adds into set b % SETS, the
 // consumer sums the sets): 512 blocks hitting the same 48 addresses serialised in the L2 atomic unit
+// Deterministic mode (cp_set_deterministic): CP_BN_DET_SETS sets and at most as many blocks per launch -- every block then owns
+// its set (one add into a zeroed slot is exact), and the consumers add the sets in index order.
 constexpr int CP_BN_ACC_SETS = 8;
+constexpr int CP_BN_DET_SETS = 64;
+static inline int bn_acc_sets() { return cp_deterministic() ? CP_BN_DET_SETS : CP_BN_ACC_SETS; }
 
 struct ColsumParams {
   const void* a; int a_cs, a_coff;      // mode 0: x ; mode 1: dy
@@ -200,6 +204,7 @@ struct ColsumParams {
   int M, G, RL, rpb;
   double* partial;                      // [nblk][2][G*E]
   double* acc; int acc_stride;          // non-NULL: fp64 atomics into acc[which*acc_stride + c] instead of block partials
+  int sets;                             // ... replicated `sets` times (a power of two): block b adds into set b % sets
 };
 
 template <typename Tag, int MODE>
@@ -264,7 +269,7 @@ __device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red,
     if (tid < 2 * CP) {
       double s = 0.0;
       for (int k = 0; k < T; ++k) s += red2[k * 2 * CP + tid];
-      if (p.acc) unsafeAtomicAdd(p.acc + ((bid & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
+      if (p.acc) unsafeAtomicAdd(p.acc + ((bid & (p.sets - 1)) * 2 + which) * p.acc_stride + c, s);
       else p.partial[((size_t)bid * 2 + which) * CP + c] = s;
     }
     return;
@@ -274,7 +279,7 @@ __device__ __forceinline__ void colsum2_body(const ColsumParams& p, double* red,
     const int pc = c / E, j = c - pc * E;
     double s = 0.0;
     for (int r = 0; r < p.RL; ++r) s += red[(r * p.G + pc) * 2 * E + which * E + j];
-    if (p.acc) unsafeAtomicAdd(p.acc + ((bid & (CP_BN_ACC_SETS - 1)) * 2 + which) * p.acc_stride + c, s);
+    if (p.acc) unsafeAtomicAdd(p.acc + ((bid & (p.sets - 1)) * 2 + which) * p.acc_stride + c, s);
     else p.partial[((size_t)bid * 2 + which) * CP + c] = s;
   }
 }
@@ -787,12 +792,13 @@ static int colsum_plan_acc(int M, int Cphys, int E, int* G, int* RL, int* nblk, 
   cap = cap < 32 ? 32 : (cap > max_blocks ? max_blocks : cap);
   if (by_size > cap) cap = (int)(by_size > big_blocks ? big_blocks : by_size);
   nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  if (cp_deterministic() && nb > CP_BN_DET_SETS) nb = CP_BN_DET_SETS;      // one block per accumulator set
   *rpb = (M + nb - 1) / nb;
   *nblk = (M + *rpb - 1) / *rpb;
   return CP_OK;
 }
 
-extern "C" size_t cp_bn_acc_doubles(int C) { return (size_t)CP_BN_ACC_SETS * 2 * ((size_t)(C + 15) / 16 * 16); }
+extern "C" size_t cp_bn_acc_doubles(int C) { return (size_t)bn_acc_sets() * 2 * ((size_t)(C + 15) / 16 * 16); }
 
 static int build_bn_stats(int dtype, const void* x, int M, int C, int x_cstride, int x_coff, double* acc, ColsumParams* out, int* nblk) {
   if (!acc || M <= 0 || C <= 0) return CP_ERR_INVALID;
@@ -802,7 +808,7 @@ static int build_bn_stats(int dtype, const void* x, int M, int C, int x_cstride,
   if (rc) return rc;
   ColsumParams p = {};
   if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, nblk, &p.rpb))) return rc;
-  p.a = x; p.a_cs = x_cstride; p.a_coff = x_coff; p.M = M; p.acc = acc; p.acc_stride = Cvec;
+  p.a = x; p.a_cs = x_cstride; p.a_coff = x_coff; p.M = M; p.acc = acc; p.acc_stride = Cvec; p.sets = bn_acc_sets();
   *out = p;
   return CP_OK;
 }
@@ -828,7 +834,7 @@ struct BnApplyParams {
   const void* x; int x_cs, x_coff;
   const void* res; int r_cs, r_coff;
   void* y; int y_cs, y_coff;
-  const double* acc; int Cvec, C;
+  const double* acc; int Cvec, C, sets;
   double count;
   const float* gamma; const float* beta;
   float eps, momentum;
@@ -845,8 +851,8 @@ __device__ __forceinline__ void bn_apply_coef(const BnApplyParams& p, float* s_c
     float sc = 0.f, sh = 0.f;
     if (c < p.C) {
       double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-      for (int k = 0; k < CP_BN_ACC_SETS; ++k) { a1 += p.acc[(2 * k) * p.Cvec + c]; a2 += p.acc[(2 * k + 1) * p.Cvec + c]; }
+#pragma unroll 8
+      for (int k = 0; k < p.sets; ++k) { a1 += p.acc[(2 * k) * p.Cvec + c]; a2 += p.acc[(2 * k + 1) * p.Cvec + c]; }
       const double mu = a1 * inv;
       double var = a2 * inv - mu * mu;
       var = var > 0.0 ? var : 0.0;
@@ -977,7 +983,7 @@ static int build_bn_apply(int dtype, const void* x, int x_cstride, int x_coff, c
   if (res && (rc = check_cl(dtype, res, res_cstride, res_coff, Cphys))) return rc;
   BnApplyParams p;
   p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.res = res; p.r_cs = res_cstride; p.r_coff = res_coff;
-  p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = (C + 15) / 16 * 16; p.C = C; p.count = (double)M;
+  p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = (C + 15) / 16 * 16; p.C = C; p.count = (double)M; p.sets = bn_acc_sets();
   p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum; p.rmean = running_mean; p.rvar = running_var;
   p.mean = mean; p.rstd = rstd; p.G = Cphys / E; p.act = act; p.slope = slope; p.total = (size_t)M * p.G;
   *out = p;
@@ -1017,7 +1023,7 @@ static int build_bn_bwd_sums(int dtype, const void* dy, int dy_cstride, int dy_c
   if ((rc = colsum_plan_acc(M, Cphys, E, &p.G, &p.RL, nblk, &p.rpb))) return rc;
   p.a = dy; p.a_cs = dy_cstride; p.a_coff = dy_coff; p.y = yy; p.y_cs = y_cstride; p.y_coff = y_coff;
   p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.mean = mean; p.rstd = rstd; p.slope = act == CP_ACT_RELU ? 0.f : slope; p.act = act;
-  p.M = M; p.acc = acc; p.acc_stride = Cvec;
+  p.M = M; p.acc = acc; p.acc_stride = Cvec; p.sets = bn_acc_sets();
   *out = p;
   return CP_OK;
 }
@@ -1037,7 +1043,7 @@ extern "C" int cp_bn_bwd_accumulate(cp_stream_t stream, int dtype, const void* d
 
 struct BnBwdApplyParams {
   BnBwdParams q;
-  const double* acc; int C; double count;
+  const double* acc; int C, sets; double count;
   const float* gamma; const float* mean; const float* rstd;
   float* dgamma; float* dbeta;
 };
@@ -1052,8 +1058,8 @@ __device__ __forceinline__ void bn_bwd_coef(const BnBwdApplyParams& pp, float* s
     float ca = 0.f, cb = 0.f, cr = 0.f, mu = 0.f;
     if (c < pp.C) {
       double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int k = 0; k < CP_BN_ACC_SETS; ++k) { s1 += pp.acc[(2 * k) * p.Cvec + c]; s2 += pp.acc[(2 * k + 1) * p.Cvec + c]; }
+#pragma unroll 8
+      for (int k = 0; k < pp.sets; ++k) { s1 += pp.acc[(2 * k) * p.Cvec + c]; s2 += pp.acc[(2 * k + 1) * p.Cvec + c]; }
       if (p.x) {
         const float rs = pp.rstd[c];
         ca = (pp.gamma ? pp.gamma[c] : 1.f) * rs;
@@ -1185,7 +1191,7 @@ static int build_bn_bwd_apply(int dtype, const void* dy, int dy_cstride, int dy_
   q.x = x; q.x_cs = x_cstride; q.x_coff = x_coff; q.dx = dx; q.dx_cs = dx_cstride; q.dx_coff = dx_coff;
   q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
   q.coef = nullptr; q.Cvec = (C + 15) / 16 * 16; q.G = Cphys / E; q.slope = act == CP_ACT_RELU ? 0.f : slope; q.total = (size_t)M * q.G;
-  pp.acc = acc; pp.C = C; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
+  pp.acc = acc; pp.C = C; pp.sets = bn_acc_sets(); pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
   *out = pp;
   *blocks = (unsigned)((q.total + 255) / 256);
   *Cphys_out = Cphys;
@@ -1350,6 +1356,7 @@ extern "C" int cp_bn_train_fused(cp_stream_t stream, int dtype, const void* x, i
                                  int C, int act, float slope, float* mean, float* rstd) {
   if (!acc || !counter || !mean || !rstd || M <= 0 || C <= 0) return CP_ERR_INVALID;
   if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (cp_deterministic()) return CP_ERR_INVALID;      // the one-launch forms add many blocks per set: use cp_bn_stats_accumulate + cp_bn_apply
   const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
   int rc;
   if ((rc = check_cl(dtype, x, x_cstride, x_coff, Cphys)) || (rc = check_cl(dtype, y, y_cstride, y_coff, Cphys))) return rc;
@@ -1357,8 +1364,9 @@ extern "C" int cp_bn_train_fused(cp_stream_t stream, int dtype, const void* x, i
   ColsumParams cs = {};
   int nblk;
   if ((rc = colsum_plan_fused(M, Cphys, E, &cs.G, &cs.RL, &nblk, &cs.rpb))) return rc;
-  cs.a = x; cs.a_cs = x_cstride; cs.a_coff = x_coff; cs.M = M; cs.acc = acc; cs.acc_stride = Cvec;
+  cs.a = x; cs.a_cs = x_cstride; cs.a_coff = x_coff; cs.M = M; cs.acc = acc; cs.acc_stride = Cvec; cs.sets = CP_BN_ACC_SETS;
   BnApplyParams p;
+  p.sets = CP_BN_ACC_SETS;
   p.x = x; p.x_cs = x_cstride; p.x_coff = x_coff; p.res = res; p.r_cs = res_cstride; p.r_coff = res_coff;
   p.y = y; p.y_cs = y_cstride; p.y_coff = y_coff; p.acc = acc; p.Cvec = Cvec; p.C = C; p.count = (double)M;
   p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum; p.rmean = running_mean; p.rvar = running_var;
@@ -1375,7 +1383,7 @@ extern "C" int cp_bn_bwd_fused(cp_stream_t stream, int dtype, const void* dy, in
                                int dx_cstride, int dx_coff, void* dres, int dres_cstride, int dres_coff, int dres_accumulate,
                                float* dgamma, float* dbeta) {
   if (!acc || !counter || M <= 0 || C <= 0 || (x && (!mean || !rstd))) return CP_ERR_INVALID;
-  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if ((dtype != CP_F32 && dtype != CP_BF16) || cp_deterministic()) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype), Cphys = (C + E - 1) / E * E, Cvec = (C + 15) / 16 * 16;
   int rc;
   if ((rc = check_cl(dtype, dy, dy_cstride, dy_coff, Cphys)) || (rc = check_cl(dtype, dx, dx_cstride, dx_coff, Cphys))) return rc;
@@ -1388,14 +1396,14 @@ extern "C" int cp_bn_bwd_fused(cp_stream_t stream, int dtype, const void* dy, in
   if ((rc = colsum_plan_fused(M, Cphys, E, &cs.G, &cs.RL, &nblk, &cs.rpb))) return rc;
   cs.a = dy; cs.a_cs = dy_cstride; cs.a_coff = dy_coff; cs.y = yy; cs.y_cs = y_cstride; cs.y_coff = y_coff;
   cs.x = x; cs.x_cs = x_cstride; cs.x_coff = x_coff; cs.mean = mean; cs.rstd = rstd; cs.slope = act == CP_ACT_RELU ? 0.f : slope; cs.act = act;
-  cs.M = M; cs.acc = acc; cs.acc_stride = Cvec;
+  cs.M = M; cs.acc = acc; cs.acc_stride = Cvec; cs.sets = CP_BN_ACC_SETS;
   BnBwdApplyParams pp;
   BnBwdParams& q = pp.q;
   q.dy = dy; q.dy_cs = dy_cstride; q.dy_coff = dy_coff; q.y = yy; q.y_cs = y_cstride; q.y_coff = y_coff;
   q.x = x; q.x_cs = x_cstride; q.x_coff = x_coff; q.dx = dx; q.dx_cs = dx_cstride; q.dx_coff = dx_coff;
   q.dres = dres; q.dr_cs = dres_cstride; q.dr_coff = dres_coff; q.dr_acc = dres_accumulate;
   q.coef = nullptr; q.Cvec = Cvec; q.G = Cphys / E; q.slope = act == CP_ACT_RELU ? 0.f : slope; q.total = (size_t)M * q.G;
-  pp.acc = acc; pp.C = C; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
+  pp.acc = acc; pp.C = C; pp.sets = CP_BN_ACC_SETS; pp.count = (double)M; pp.gamma = gamma; pp.mean = mean; pp.rstd = rstd; pp.dgamma = dgamma; pp.dbeta = dbeta;
   const size_t lds = 4 * coef_floats(dtype, Cphys) * sizeof(float);
   if (dtype == CP_F32) CP_LAUNCH(bn_fused_bwd_kernel<F32Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, pp, counter);
   else CP_LAUNCH(bn_fused_bwd_kernel<BF16Tag>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, cs, pp, counter);

@@ -678,6 +678,7 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
       const int tb = q.co_blocks * q.ci_blocks;
       const size_t per_slice = (size_t)tb * 9 * 4096 * sizeof(float);
       const bool use_ws = workspace && cp_aligned16(workspace) && workspace_bytes >= per_slice;
+      if (!use_ws && cp_deterministic()) return CP_ERR_INVALID;       // no atomics in deterministic mode: partial tiles need a workspace
       int S = (target_blocks > 0 ? target_blocks : (use_ws ? 256 : 1024)) / tb;              // one block per CU (400 VGPRs): one round of blocks
       if (S > q.n_tiles / 2) S = q.n_tiles / 2;
       if (use_ws && (size_t)S * per_slice > workspace_bytes) S = (int)(workspace_bytes / per_slice);
@@ -733,7 +734,8 @@ static int wgrad_impl(cp_stream_t stream, const CpWgradDesc* d, const void* dy, 
   // small layers: with few valid elements the atomics are cheaper than a second (reduction) launch -- the ~30 G atomics/s
   // limit only bites from ~1e5 atomics per launch on
   static const long long atomics_max = cp_knob("CP_WGRAD_ATOMICS_MAX") ? atoll(cp_knob("CP_WGRAD_ATOMICS_MAX")) : 32768;
-  if (use_ws && (long long)d->Cout * d->Cin * d->R * d->S * nslice <= atomics_max) use_ws = false;
+  if (use_ws && !cp_deterministic() && (long long)d->Cout * d->Cin * d->R * d->S * nslice <= atomics_max) use_ws = false;
+  if (!use_ws && cp_deterministic()) return CP_ERR_INVALID;           // (see cp_set_deterministic)
   if (tiles > 65535) return CP_ERR_RANGE;
   p.ws = use_ws ? (float*)workspace : nullptr;
   dim3 grid(nslice, (unsigned)tiles);

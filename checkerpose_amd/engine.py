@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _abi
-from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F32, CpChainTail, CpChainTailConv, CpConvDesc, CpConvGroupItem, CpFuseConv
+from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU, CP_BF16, CP_F16, CP_F32, CpChainTail, CpChainTailConv, CpConvDesc, CpConvGroupItem, CpFuseConv
 
 _TORCH_DT = {CP_F32: torch.float32, CP_BF16: torch.bfloat16}
 USE_HALO = os.environ.get("CHECKERPOSE_AMD_HALO", "1") != "0"   # LDS-halo 3x3 kernel (A/B switch for kernel work)
@@ -44,6 +44,10 @@ USE_STEM = os.environ.get("CHECKERPOSE_AMD_STEM", "1") != "0"   # fused HRNet st
 STEM_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_STEM_MIN_BATCH", "96"))   # one persistent workgroup per crop: measured
 #   crossover against the tiled launches (tools/batch_sweep.py, MI355X): chains win from 64 crops, stem + EdgeConv from 96
 USE_EDGE_FUSED = os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED", "1") != "0"   # EdgeConv layer (node GEMM + gather-max) in one launch
+# bf16 programs run the per-keypoint (GNN) block group -- conv1x1's output rows, the EdgeConv layers, Index2Feat's rows, both MLP stacks --
+# in IEEE half (CP_F16: same bytes, same MFMA rate, 3 more mantissa bits) when every op of the group takes its fused per-crop kernel;
+# on trained-like weights that group produced 73 % of the bf16 path's logit-error variance.  A/B switch.
+USE_GNN_F16 = os.environ.get("CHECKERPOSE_AMD_GNN_F16", "1") != "0"
 USE_EDGE_TILED = os.environ.get("CHECKERPOSE_AMD_EDGE_TILED", "1") != "0"   # N > 512: patches of 512 keypoints, table slices in LDS (cp_edgeconv_tiled)
 EDGE_FUSED_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_EDGE_FUSED_MIN_BATCH", "96"))   # one workgroup per crop: needs crops to fill the chip
 CHAIN_MIN_BATCH = int(os.environ.get("CHECKERPOSE_AMD_CHAIN_MIN_BATCH", "40"))   # below: per-conv launches (a crop's chain runs on ONE CU)
@@ -102,11 +106,12 @@ class WeightStore:
             raise RuntimeError("parameter %s must be an fp32 tensor on %s" % (key, self.device))
         return t.detach().contiguous()
 
-    def pack(self, name, w, Cout, Cin, R, S, cin_phys, cout_rows, transposed=0, phase=0, row_map=None):
-        ck = (name, cin_phys, cout_rows, transposed, phase)
+    def pack(self, name, w, Cout, Cin, R, S, cin_phys, cout_rows, transposed=0, phase=0, row_map=None, dtype=None):
+        dtype = self.dtype if dtype is None else dtype
+        ck = (name, cin_phys, cout_rows, transposed, phase) + (() if dtype == self.dtype else (dtype,))
         if ck in self.cache:
             return self.cache[ck]
-        nbytes = self.lib.cp_packed_weight_bytes(self.dtype, cout_rows, cin_phys, R, S)
+        nbytes = self.lib.cp_packed_weight_bytes(dtype, cout_rows, cin_phys, R, S)
         out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         rm = None
         if row_map is not None:
@@ -115,7 +120,7 @@ class WeightStore:
         w = w.contiguous()
         self.keep.append(w)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        _abi.check(self.lib.cp_pack_conv_weight(st, self.dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
+        _abi.check(self.lib.cp_pack_conv_weight(st, dtype, w.data_ptr(), Cout, Cin, R, S, cin_phys, transposed, phase,
                                                 rm.data_ptr() if rm is not None else None, cout_rows, out.data_ptr()),
                    "cp_pack_conv_weight(%s)" % name)
         self.cache[ck] = out
@@ -149,16 +154,17 @@ class WeightStore:
         self.cache[ck] = out
         return out
 
-    def pack_gemm(self, name, w, Cout, Cin, cin_phys):
+    def pack_gemm(self, name, w, Cout, Cin, cin_phys, dtype=None):
         """1x1 / Linear weights in the LDS-GEMM kernel's image (cp_pack_gemm_weight)."""
-        ck = ("gemm", name, cin_phys)
+        dtype = self.dtype if dtype is None else dtype
+        ck = ("gemm", name, cin_phys) + (() if dtype == self.dtype else (dtype,))
         if ck in self.cache:
             return self.cache[ck]
-        out = torch.empty(self.lib.cp_packed_gemm_weight_bytes(self.dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
+        out = torch.empty(self.lib.cp_packed_gemm_weight_bytes(dtype, Cout, cin_phys), dtype=torch.uint8, device=self.device)
         w = w.contiguous()
         self.keep.append(w)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        _abi.check(self.lib.cp_pack_gemm_weight(st, self.dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
+        _abi.check(self.lib.cp_pack_gemm_weight(st, dtype, w.data_ptr(), Cout, Cin, cin_phys, out.data_ptr()),
                    "cp_pack_gemm_weight(%s)" % name)
         self.cache[ck] = out
         return out
@@ -228,6 +234,20 @@ class Program:
         self.mlp_min_rows = MLP_FUSED_MIN_ROWS
         self.fuse_out_min = FUSE_OUT_MIN_BATCH if FUSE_OUT_MIN_BATCH >= 0 else CHAIN_MIN_BATCH
         self._raw = {}         # (ptr, nbytes) -> TBuf of a raw-pointer operand (see raw())
+        self.gnn_half = False  # the keypoint-side tensors of this (bf16) program are IEEE half (set by the runtime, see USE_GNN_F16)
+
+    @property
+    def gdt(self):
+        """storage / MFMA type of the keypoint-side (GNN) block group"""
+        return CP_F16 if self.gnn_half else self.dtype
+
+    def wants_gnn_half(self, N, K, tiled_hpad=None):
+        """every op of the keypoint side would take its fused per-crop kernel at this batch: the group can run in half"""
+        if not (USE_GNN_F16 and self.dtype == CP_BF16 and USE_MLP_FUSED and self.mlp_min_rows <= self.B * N):
+            return False
+        if N == 512:
+            return self.can_fuse_edgeconv(N, K, 64, 64) and self.can_fuse_edgeconv(N, K, 256, 256)
+        return False
 
     # ---- tensors
     def tensor(self, nelem, es=None):
@@ -309,15 +329,19 @@ class Program:
     # ---- ops
     def conv(self, x: Act, wkey, w, scale, shift, R, S, stride, pad, Cout, act=ACT_NONE, slope=0.0, residual: Act = None,
              out: Act = None, transposed=0, phase=0, row_map=None, cout_rows=None, out_f32=False, ostr=None,
-             out_tbuf=None, out_hw=None, w_shape=None):
-        """Generic conv / linear.  `w` is the fp32 source weight in PyTorch layout; returns the output Act."""
+             out_tbuf=None, out_hw=None, w_shape=None, out_half=False, in_half=False):
+        """Generic conv / linear.  `w` is the fp32 source weight in PyTorch layout; returns the output Act.
+        out_half: a bf16 conv whose output rows are IEEE half (the producer of a keypoint-side tensor, CpConvDesc.out_f32 = 2);
+        in_half: input rows and weights are IEEE half (a keypoint-side Linear on the generic kernel, CpConvDesc.dtype = CP_F16)."""
+        if out_half or in_half:
+            assert self.dtype == CP_BF16 and residual is None and not (out_half and out_f32)
         E = self.E
         wCout, wCin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
         rows = cout_rows if cout_rows is not None else wCout
         if wCin != x.C:
             raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
         halo = (USE_HALO and R == 3 and S == 3 and stride == 1 and pad == 1 and ostr is None and not out_f32
-                and not transposed and row_map is None and x.W >= 16 and x.H >= 8)
+                and not transposed and row_map is None and x.W >= 16 and x.H >= 8 and not (out_half or in_half))
         if halo and wCout <= 80 and self.dtype == CP_F32:
             # small-Cout variant pads Cin to 64-byte chunks PER TAP: in fp32 (MFMA-bound) that only pays when the
             # padding waste is small (measured: 18/36-channel convs are faster on the generic kernel in fp32)
@@ -326,16 +350,16 @@ class Program:
         # also pays at K = 64 .. 127 (incre conv3 + shortcut of the 32^2 branch: 98 -> 72 us)
         kmin = 16 * self.E if not (self.dtype == CP_BF16 and residual is None and x.B * x.H * x.W >= 16384 and GEMM_WS_SMALL_K) else 64
         gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
-                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= kmin)
+                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= kmin and not (out_half or in_half))
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
                    and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= self.chain_min
-                   and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
+                   and not (out_half or in_half) and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
         # k = 2 / pad 1 (Index2Feat's patch_generator over the whole map): the small-Cout halo kernel with four taps
         halo2 = (USE_HALO2 and self.dtype == CP_BF16 and R == 2 and S == 2 and stride == 1 and pad == 1 and ostr is None and not out_f32
-                 and not transposed and row_map is None and not self.ws.repacks_every_step   # (eval programs:
+                 and not transposed and row_map is None and not in_half and not self.ws.repacks_every_step   # (eval programs:
                  # the training program repacks its weights every step through the pack-item tables, which have no entry for this image)
                  and bool(self.lib.cp_conv2x2_halo_supported(self.dtype, x.H, x.W, _rup(wCout, self.E))))
-        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small or halo2)
+        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small or halo2) and not (out_half or in_half)
                 and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
                                                     R * S * x.Cphys, _rup(wCout, self.E))):
             halo = gemm = s2small = halo2 = False      # small batch: the generic kernel's split-K variant beats the tiled specialists
@@ -367,16 +391,16 @@ class Program:
         elif gemm:
             packed = self.ws.pack_gemm(wkey, w, wCout, wCin, x.Cphys)
         else:
-            packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map)
+            packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map, **({"dtype": CP_F16} if in_half else {}))
         sc, sh = self.ws.affine(wkey + "#" + str(phase), scale, shift, rows)
         Ho, Wo = out_hw if out_hw is not None else ((x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1)
         d = CpConvDesc()
-        d.dtype, d.out_f32 = self.dtype, 1 if out_f32 else 0
+        d.dtype, d.out_f32 = (CP_F16 if in_half else self.dtype), (1 if out_f32 else (2 if out_half else 0))
         d.B, d.H, d.W = x.B, x.H, x.W
         d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
         d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = R, S, stride, pad, Ho, Wo
         d.act, d.slope = act, slope
-        d.ksplit = 0 if self.splitk else -1
+        d.ksplit = 0 if (self.splitk and not (out_half or in_half)) else -1
         if ostr is None:
             if out is None:
                 out = self.act(Ho, Wo, Cout)
@@ -898,6 +922,7 @@ class Program:
         return out
 
     def edge_gather(self, pq: Act, idx_t, gids_t, out: Act, K, C_, G, slope):
+        assert not self.gnn_half, "keypoint side in half: every EdgeConv layer must take a fused kernel"
         fn = self.lib.cp_edgeconv_gather_max
         pt, ot = pq.tbuf, out.tbuf
         ip = idx_t.data_ptr()
@@ -914,17 +939,18 @@ class Program:
     def edge_fused(self, x: Act, wkey, wpq, scale, shift, idx_t, gids_t, out: Act, K, G, slope):
         """whole EdgeConv layer in one launch (cp_edgeconv_fused): wpq fp32 (2 C', C) = [W1 ; W2 - W1]"""
         Co2, Cin = wpq.shape[0], wpq.shape[1]
-        ck = ("edge_fused", wkey)
+        gdt = self.gdt
+        ck = ("edge_fused", wkey, gdt)
         if ck not in self.ws.cache:
             buf = torch.empty(self.lib.cp_edgeconv_fused_weight_bytes(Cin, Co2 // 2), dtype=torch.uint8, device=self.device)
             w2 = wpq.reshape(Co2, Cin).contiguous()
             self.ws.keep.append(w2)
             st = torch.cuda.current_stream(self.device).cuda_stream
-            _abi.check(self.lib.cp_pack_edgeconv_fused_weight(st, w2.data_ptr(), Cin, Co2 // 2, buf.data_ptr()), "cp_pack_edgeconv_fused_weight")
+            _abi.check(self.lib.cp_pack_edgeconv_fused_weight_t(st, gdt, w2.data_ptr(), Cin, Co2 // 2, buf.data_ptr()), "cp_pack_edgeconv_fused_weight")
             self.ws.cache[ck] = (buf, scale.contiguous(), shift.contiguous())
         buf, sc, sh = self.ws.cache[ck]
         self.keep += [buf, sc, sh]
-        fn = self.lib.cp_edgeconv_fused
+        fn = self.lib.cp_edgeconv_fused_t
         xt, ot = x.tbuf, out.tbuf
         sk = ("edge_sched", idx_t.data_ptr(), tuple(idx_t.shape))
         if EDGE_SCHED and sk not in self.ws.cache:      # the same graph, every keypoint's list reordered against LDS bank conflicts
@@ -938,7 +964,7 @@ class Program:
         gp = gids_t.data_ptr() if gids_t is not None else None
         N = x.W
         a = (buf.data_ptr(), sc.data_ptr(), sh.data_ptr(), ip, gp)
-        self._add(fn, lambda P: (P(xt), x.cstride, x.coff) + a + (P(ot), out.cstride, out.coff, self.B, N, K, Cin, Co2 // 2, G, slope),
+        self._add(fn, lambda P: (gdt, P(xt), x.cstride, x.coff) + a + (P(ot), out.cstride, out.coff, self.B, N, K, Cin, Co2 // 2, G, slope),
                   "edge_fused:" + wkey, [xt], [ot])
         fl = 2 * self.B * N * Cin * Co2
         self.flops += fl
@@ -994,8 +1020,9 @@ class Program:
         """MLP_QueryNet (pipeline.py:168-180) in one launch: ws = the three nn.Linear weights, bs their biases; the two logits of
         row (b, n) go to out_tbuf[ostr[0] + b * ostr[1] + n * ostr[3] + c * ostr[4]] (fp32)"""
         N = x.W
-        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(ws[0].shape[0], ws[0].shape[1], 1, 1), 256, 256, 256)
-        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(ws[1].shape[0], ws[1].shape[1], 1, 1), 64, 256, 256)
+        gdt = self.gdt
+        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(ws[0].shape[0], ws[0].shape[1], 1, 1), 256, 256, 256, dtype=gdt)
+        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(ws[1].shape[0], ws[1].shape[1], 1, 1), 64, 256, 256, dtype=gdt)
         ck = ("mlp_query", keys[0])
         if ck not in self.ws.cache:
             dev = self.device
@@ -1008,7 +1035,7 @@ class Program:
         a1 = (pw1.data_ptr(), s1.data_ptr(), t1.data_ptr(), float(slope), pw2.data_ptr(), s2.data_ptr(), t2.data_ptr(), float(slope),
               w3.data_ptr(), b3.data_ptr())
         o = (int(ostr[0]), int(ostr[1]), int(ostr[3]), int(ostr[4]))
-        self._add(self.lib.cp_mlp_query_fused, lambda P: (P(xt), x.cstride, x.coff, self.B, N) + a1 + (P(out_tbuf),) + o,
+        self._add(self.lib.cp_mlp_query_fused_t, lambda P: (gdt, P(xt), x.cstride, x.coff, self.B, N) + a1 + (P(out_tbuf),) + o,
                   "mlp_fused:" + keys[0], [xt], [out_tbuf])
         M = self.B * N
         fl = 2 * M * (256 * 256 + 256 * 64 + 64 * 2)
@@ -1023,8 +1050,9 @@ class Program:
     def mlp_pair_fused(self, x: Act, keys, ws, bs, slope, out: Act = None):
         """pre_graph_module (two nn.Linear + LeakyReLU) in one launch: the 256-channel hidden rows stay on chip"""
         N, Cin = x.W, x.C
-        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(256, Cin, 1, 1), 256, Cin, Cin)
-        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(256, 256, 1, 1), 256, 256, 256)
+        gdt = self.gdt
+        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(256, Cin, 1, 1), 256, Cin, Cin, dtype=gdt)
+        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(256, 256, 1, 1), 256, 256, 256, dtype=gdt)
         ck = ("mlp_pair", keys[0])
         if ck not in self.ws.cache:
             self.ws.cache[ck] = (bs[0].float().contiguous(), bs[1].float().contiguous())
@@ -1034,7 +1062,7 @@ class Program:
             out = self.act(1, N, 256)
         xt, ot = x.tbuf, out.tbuf
         a1 = (pw1.data_ptr(), b1.data_ptr(), float(slope), pw2.data_ptr(), b2.data_ptr(), float(slope))
-        self._add(self.lib.cp_mlp_pair_fused, lambda P: (P(xt), x.cstride, x.coff, Cin, self.B, N) + a1 + (P(ot), out.cstride, out.coff),
+        self._add(self.lib.cp_mlp_pair_fused_t, lambda P: (gdt, P(xt), x.cstride, x.coff, Cin, self.B, N) + a1 + (P(ot), out.cstride, out.coff),
                   "mlp_fused:" + keys[0], [xt], [ot])
         M = self.B * N
         fl = 2 * M * (Cin * 256 + 256 * 256)
@@ -1052,8 +1080,9 @@ class Program:
         fused pair fetches the taps straight from patch_generator's map, the first 256 channels of `L` are never written"""
         Cin = L.C
         Cg = Cin - 256
-        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(256, Cin, 1, 1), 256, Cin, Cin)
-        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(256, 256, 1, 1), 256, 256, 256)
+        gdt = self.gdt
+        pw1 = self.ws.pack_gemm(keys[0], ws[0].reshape(256, Cin, 1, 1), 256, Cin, Cin, dtype=gdt)
+        pw2 = self.ws.pack_gemm(keys[1], ws[1].reshape(256, 256, 1, 1), 256, 256, 256, dtype=gdt)
         ck = ("mlp_pair", keys[0])
         if ck not in self.ws.cache:
             self.ws.cache[ck] = (bs[0].float().contiguous(), bs[1].float().contiguous())
@@ -1074,9 +1103,9 @@ class Program:
             g.patches, g.x_id, g.y_id, g.mask, g.zeros = P(pt), xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr(), zeros.data_ptr()
             g.p_cstride, g.p_coff, g.Hp, g.Wp, g.k = patches.cstride, patches.coff, patches.H, patches.W, k
             descs.append(g)                                   # the descriptor must outlive the (possibly deferred) call
-            return (C.byref(g), P(lt), L.cstride, L.coff + 256, Cg, self.B, N) + a1 + (P(ot), out.cstride, out.coff)
+            return (gdt, C.byref(g), P(lt), L.cstride, L.coff + 256, Cg, self.B, N) + a1 + (P(ot), out.cstride, out.coff)
         self.keep.append(descs)
-        self._add(self.lib.cp_mlp_pair_fused_gather, args, "mlp_fused:" + keys[0],
+        self._add(self.lib.cp_mlp_pair_fused_gather_t, args, "mlp_fused:" + keys[0],
                   [pt, lt, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
         M = self.B * N
         fl = 2 * M * (Cin * 256 + 256 * 256)
@@ -1120,10 +1149,11 @@ class Program:
             self.ws.cache[ck] = (buf, bias.contiguous())
         buf, bs = self.ws.cache[ck]
         self.keep += [buf, bs]
-        fn = self.lib.cp_index2feat_conv
+        fn = self.lib.cp_index2feat_conv_t
+        gdt = self.gdt
         ft, ot = f.tbuf, out.tbuf
         a = (buf.data_ptr(), bs.data_ptr(), xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())
-        self._add(fn, lambda P: (P(ft), f.cstride, f.coff) + a + (P(ot), f.B, N, f.H, f.W, k, out.cstride, out.coff),
+        self._add(fn, lambda P: (gdt, P(ft), f.cstride, f.coff) + a + (P(ot), f.B, N, f.H, f.W, k, out.cstride, out.coff),
                   "patch_gather:" + wkey, [ft, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
         fl = 2 * f.B * 4 * N * 64 * 4 * f.C
         self.flops += fl
@@ -1134,6 +1164,7 @@ class Program:
         return out
 
     def index2feat(self, patches: Act, xid_t, yid_t, mask_t, out: Act, N, E_ch, k):
+        assert not self.gnn_half, "keypoint side in half: Index2Feat's gather must ride in a fused kernel"
         fn = self.lib.cp_index2feat_gather
         pt, ot = patches.tbuf, out.tbuf
         args = (xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())

@@ -235,6 +235,18 @@ class HipForwardMixin:
         self.invalidate()
         return self
 
+    @property
+    def deterministic(self):
+        """deterministic training mode (checkerpose_amd.set_deterministic): process-wide, readable / settable on any drop-in model"""
+        return bool(_abi.load().cp_get_deterministic())
+
+    @deterministic.setter
+    def deterministic(self, on):
+        lib = _abi.load()
+        if bool(lib.cp_get_deterministic()) != bool(on):
+            lib.cp_set_deterministic(1 if on else 0)
+            self.invalidate()              # launch plans (block counts, accumulator sets, reduction paths) depend on the mode
+
     def set_compute_dtype(self, name):
         if name not in DTYPES:
             raise ValueError("compute dtype must be one of %s" % sorted(DTYPES))
@@ -243,13 +255,15 @@ class HipForwardMixin:
         return self
 
     # ---- program construction
-    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False, u8=False, inject=False):
+    def _build(self, lib, B, size, stage, want_feats, want_graph, device, teacher=False, u8=False, inject=False, inject_dec=False,
+               want_dec=False):
         dtype = DTYPES[self.compute_dtype]
         cfg = self._net_cfg()
         cfg["img_size"] = size
         cfg["stage"] = stage
         cfg["uint8_input"] = u8
         cfg["inject_feats"] = inject
+        cfg["inject_dec"], cfg["export_dec"] = inject_dec, want_dec
         N = cfg["npoint"]
         sd = self.state_dict()
         if dtype not in self._stores:
@@ -278,6 +292,14 @@ class HipForwardMixin:
             from ..netbuilder import IMG_FEATS_DIMS as _FD
             io["inject"] = [torch.zeros(B, c, size >> (2 + i), size >> (2 + i), dtype=torch.float32, device=device)
                             for i, c in enumerate(_FD[cfg["backbone"]])]
+        if inject_dec or want_dec:      # attribution hook (agreement.attribute_groups): the decoder stages' output maps, NCHW fp32
+            nst = stage if stage is not None else cfg["res_log2"] - 3
+            mk = lambda: [torch.zeros(B, cfg["num_filters"], size >> (4 - i), size >> (4 - i), dtype=torch.float32, device=device)   # noqa: E731
+                          for i in range(nst)]
+            if inject_dec:
+                io["inject_dec"] = mk()
+            if want_dec:
+                io["dec_feats"] = mk()
         # batch slices: independent sub-programs that the captured graph runs concurrently (see ProgramGroup)
         nsplit = self.batch_splits if (B >= 8 * self.batch_splits and B % self.batch_splits == 0) else 1
         # the kernels address every tensor through 32-bit buffer descriptors (< 2 GiB): the widest one is the last decoder
@@ -309,6 +331,8 @@ class HipForwardMixin:
                 prog.chain_min = prog.stem_min = prog.edge_min = prog.mlp_min_rows = prog.fuse_out_min = 1 << 30
                 prog.splitk = False
             sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
+            # the per-keypoint block group in IEEE half when each of its ops takes the fused per-crop kernel at this batch (engine.USE_GNN_F16)
+            prog.gnn_half = (not want_graph) and prog.wants_gnn_half(N, idx.shape[2])
             ext = None
             if tiled is not None and prog.can_tile_edgeconv(N, idx.shape[2], 64, 64, tiled["HPAD"]):
                 # large graphs: the program works in the patch-ordered INTERNAL keypoint numbering (graph_sched.tile_schedule): its
@@ -438,7 +462,7 @@ class HipForwardMixin:
         lib = _abi.load()
         device = img.device
         B, size = img.shape[0], img.shape[2]
-        key = (B, size, stage, self.compute_dtype, u8)
+        key = (B, size, stage, self.compute_dtype, u8, bool(lib.cp_get_deterministic()))
         pr = self._train_programs.get(key)
         if pr is not None and pr["ptrs"] != self._storage_signature():
             for g in pr["graphs"].values():
@@ -498,9 +522,10 @@ class HipForwardMixin:
         self._stale_eval = False
 
     # ---- one forward
-    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False, teacher_bits=None, inject_feats=None):
+    def _run(self, img, obj_ids, stage=None, want_feats=False, want_graph=False, teacher_bits=None, inject_feats=None,
+             inject_dec=None, want_dec=False):
         if self.training:
-            if want_feats or want_graph or teacher_bits is not None or inject_feats is not None:
+            if want_feats or want_graph or teacher_bits is not None or inject_feats is not None or inject_dec is not None or want_dec:
                 raise RuntimeError("checkerpose_amd: return_img_feats / return_graph_feats / teacher forcing are eval-mode only")
             return self._run_train(img, obj_ids, stage=stage)
         if not (torch.is_tensor(img) and img.is_cuda):
@@ -534,12 +559,13 @@ class HipForwardMixin:
             if self._programs and sig != getattr(self, "_eval_sig", None):
                 self._drop_eval_programs()
             self._eval_sig = sig
-        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None, u8, inject_feats is not None)
+        key = (B, size, stage, self.compute_dtype, want_feats, want_graph, teacher_bits is not None, u8, inject_feats is not None,
+               inject_dec is not None, want_dec)
         pr = self._programs.get(key)
         if pr is None:
             with torch.cuda.device(device):
                 pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None, u8,
-                                 inject_feats is not None)
+                                 inject_feats is not None, inject_dec is not None, want_dec)
             self._programs[key] = pr
         io, prog = pr["io"], pr["prog"]
         with torch.cuda.device(device):
@@ -549,6 +575,9 @@ class HipForwardMixin:
                 io["decode_bits"][:Bu].copy_(teacher_bits)
             if inject_feats is not None:
                 for dst, src in zip(io["inject"], inject_feats):
+                    dst[:Bu].copy_(src)
+            if inject_dec is not None:
+                for dst, src in zip(io["inject_dec"], inject_dec):
                     dst[:Bu].copy_(src)
             if self.LM:
                 if obj_ids is None:
@@ -598,7 +627,7 @@ class HipForwardMixin:
             else:
                 prog.run(cur.cuda_stream)
                 pr["warm"] = True
-        out = {k: io[k] for k in ("bits", "seg", "x64", "y64", "img_feats", "graph_feats") if k in io}
+        out = {k: io[k] for k in ("bits", "seg", "x64", "y64", "img_feats", "graph_feats", "dec_feats") if k in io}
         if Bu != B:
             out = {k: ([t[:Bu] for t in v] if isinstance(v, list) else v[:Bu]) for k, v in out.items()}
         if self.clone_outputs:

@@ -157,6 +157,17 @@ class PoseNet_GNNskip(HipForwardMixin, nn.Module):
         active = stage if stage is not None else self.num_refine_steps
         return self._outputs(self._run(img, obj_ids, stage=stage, teacher_bits=teacher_bits, inject_feats=feats), active)
 
+    def forward_hooks(self, img, teacher_bits=None, feats=None, dec=None, want_feats=False, want_dec=False, stage=None, obj_ids=None):
+        """Attribution hook (agreement.attribute_groups): one forward with any of the three block groups' inputs GIVEN -- `feats`
+        (the backbone's four features, NCHW fp32) replaces the backbone, `dec` (the decoder stages' output maps, NCHW fp32) replaces
+        what the refinement stages gather from -- and / or their outputs returned (`want_feats`, `want_dec`).  Two models of the
+        same weights at different compute dtypes exchange these tensors to run ONE group in bf16 and the rest in fp32.
+        Returns (6-tuple, {"img_feats": [...], "dec_feats": [...]})."""
+        active = stage if stage is not None else self.num_refine_steps
+        res = self._run(img, obj_ids, stage=stage, teacher_bits=teacher_bits, inject_feats=feats, inject_dec=dec,
+                        want_feats=want_feats, want_dec=want_dec)
+        return self._outputs(res, active), {k: res[k] for k in ("img_feats", "dec_feats") if k in res}
+
     def forward(self, img, p3d_normed, stage=None):
         """pipeline.py:351-384.  `p3d_normed` is accepted for signature parity; it has no numeric effect in the
         reference either (only forwarded to MLP_QueryNet, which ignores it: pipeline.py:174-180,295)."""

@@ -612,9 +612,9 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
     w = em.W(c1key + ".weight")
     g0 = p.act(1, N, 64)
     npix = f.H * f.W
-    if tp is None:
+    if tp is None:      # (p.gnn_half: from here to the logits the rows are IEEE half -- engine.USE_GNN_F16)
         p.conv(f, c1key, w, em._unit(N), em.W(c1key + ".bias"), 1, 1, 1, 0, N,
-               ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+               ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf, out_half=p.gnn_half)
     else:
         p.conv(f, c1key, w, tp.const_vec(N, True), em._bias_vec(c1key, N), 1, 1, 1, 0, N,
                ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
@@ -659,7 +659,7 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
         shv = tp.live_vec(10, [(0, bl, 0, 4), (7, bl, 4, 3)]) if r3 else tp.live_vec(rows, [(0, bl, 0, rows)])
     p.conv(g, pfx + "mlp", wl.view(nbits, 64, 1, 1), scv, shv,
            1, 1, 1, 0, rows, row_map=rmap, cout_rows=rows, out_f32=True,
-           ostr=(0, 13 * N, 0, 1, N), out_tbuf=io["bits_tb"])
+           ostr=(0, 13 * N, 0, 1, N), out_tbuf=io["bits_tb"], in_half=(tp is None and p.gnn_half))
     if tp is not None:       # incoming gradient: rows [roi, x.., y..] gathered by the autograd hook into (B, 1 + 2r, N)
         em._out_layer_bwd(pfx + "mlp", wl.view(nbits, 64, 1, 1), g, nbits, io["dinit"], 0, nbits * N, 1, N)
     return g
@@ -829,6 +829,12 @@ def emit_posenet(em: NetEmitter, cfg, io):
         # ---- Refine_moduleGNN.forward pipeline.py:262-298
         p.sync(0, 1)
         p.set_lane(1)
+        fdec = f                                                # the decoder's own map: what the next decoder stage continues from
+        if tp is None and cfg.get("export_dec"):                # attribution hooks (HipForwardMixin._run(want_dec / inject_dec)): the map
+            p.to_nchw_f32(f, io["dec_feats"][i])                # the refinement stage gathers from, exported / replaced by a GIVEN one
+        if tp is None and cfg.get("inject_dec"):
+            t_ = io["inject_dec"][i]
+            f = p.nchw_to_nhwc(t_, t_.shape[1], t_.shape[2], t_.shape[3])
         rp = "refine_net.%d" % i
         wpg = em.W(rp + ".local_feat_ext_block.patch_generator.weight")     # (E, nf, k, k)
         Ech = wpg.shape[0]
@@ -837,7 +843,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
             p.index2feat_conv(f, rp + ".patch", wpg, em.W(pgk + ".bias"), io["xid"], io["yid"], io["mask"], L.slice(0, 4 * Ech), N, k)
             patches = None
         elif tp is None:
-            patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(pgk + ".bias"), k, k, 1, k - 1, Ech)
+            patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(pgk + ".bias"), k, k, 1, k - 1, Ech, out_half=p.gnn_half)
         else:
             patches = p.conv(f, rp + ".patch", wpg, tp.const_vec(Ech, True), em._bias_vec(pgk, Ech), k, k, 1, k - 1, Ech)
         pkeys = [rp + ".pre_graph_module.0", rp + ".pre_graph_module.2"]
@@ -858,6 +864,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
         elif tp is None and p.can_fuse_mlp_pair(L, pws[0], pws[1]):
             h = p.mlp_pair_fused(L, pkeys, pws, [em.W(k_ + ".bias") for k_ in pkeys], slope)     # csrc/mlp_fused.hip
         else:
+            assert not p.gnn_half, "keypoint side in half: pre_graph_module must take the fused pair kernel"
             h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)
             h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope)
         Lnext = local_buf(i + 1) if i + 1 < active else None
@@ -877,6 +884,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
                               ((4 + i) * N, 13 * N, 0, 1, 6 * N))
             q = None
         else:
+            assert not p.gnn_half, "keypoint side in half: MLP_QueryNet must take the fused kernel"
             q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope)
             q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope)
         if q is None:
@@ -891,6 +899,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
             em._out_layer_bwd(qk, wq4, q, 2, io["dbits"], (4 + i) * N, 13 * N, 1, 6 * N)
         p.decode(dbits, i, io["mask"], io["xid"], io["yid"], io["x64"], io["y64"], N)
         L = Lnext
+        f = fdec
     # seg_block Conv2d(nf -> seg_dim, 1x1) on the last feature map, NCHW fp32 out (pipeline.py:349,383)
     if active > 0:
         p.set_lane(0)

@@ -54,8 +54,9 @@ def make_batch(B, pos, gen, device):
     return img, roi_gt, x_gt, y_gt, m_vis, m_full
 
 
-def train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, held_out=8, device=None, log=None):
-    from .agreement import logit_agreement, margin_contract_violations
+def train_net(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, device=None, log=None):
+    """`steps` steps of the repository's training program (bf16) on the synthetic translation task.  Returns (net in train mode's
+    final state, canonical positions, the generator the held-out crops continue from, losses every 25 steps)."""
     from .losses.code_loss import MaskedCodeLoss, UnmaskedCodeLoss
     from .losses.mask_loss import MaskLoss_interpolate
     from .optim import Adam
@@ -88,8 +89,19 @@ def train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, held_ou
                     log("trained_like step %d loss %.4f" % (it, losses[-1]))
     finally:
         torch.set_grad_enabled(was_grad)
+    return net, pos, gen, losses
+
+
+def train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, held_out=8, device=None, log=None, attribution=False,
+                       selection="per_crop"):
+    from .agreement import attribute_groups, logit_agreement, margin_contract_violations
+    dev = torch.device(device if device is not None else "cuda")
+    N = npoint
+    net, pos, gen, losses = train_net(npoint, steps, batch, lr, seed, dev, log)
     with torch.no_grad():
         net.eval()
+        if selection is not None:      # "per_crop": the launches the bench's 256-crop step is made of (the held-out batch is small, and
+            net.set_kernel_selection(selection)    # "auto" would pick the small-batch kernels, whose keypoint side stays bf16)
         img, roi_gt, x_gt, y_gt, m_vis, m_full = make_batch(held_out, pos, gen, dev)
         net.set_compute_dtype("fp32")
         net.clone_outputs = True
@@ -115,7 +127,8 @@ def train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, held_ou
             "held_out": {"crops": held_out, "roi_bit_accuracy_vs_gt": round(acc_roi, 4), "code_bit_accuracy_vs_gt_inside_roi": round(acc_bits, 4),
                          "logit_abs_median": round(float(absz.median()), 4),
                          "logits_below_0.05": round(float((absz < 0.05).float().mean()), 5)},
-            "vs": "fp32 HIP eval path of the same trained weights, %d held-out crops" % held_out,
+            "vs": "fp32 HIP eval path of the same trained weights, %d held-out crops, kernel selection %r" % (held_out, selection),
             "margin_contract_violations": margin_contract_violations(forced, free),
             "teacher_forced": {k: forced[k] for k in keep if k in forced},
-            "free_running": {k: free[k] for k in keep if k in free}}
+            "free_running": {k: free[k] for k in keep if k in free},
+            **({"attribution": attribute_groups(net, img, log=log)} if attribution else {})}

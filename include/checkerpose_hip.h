@@ -31,7 +31,11 @@ extern "C" {
 
 typedef void* cp_stream_t;
 
-enum { CP_F32 = 0, CP_BF16 = 1 };
+/* CP_F16 (IEEE half storage, f16 MFMA, fp32 accumulate; values saturate at +-65504): accepted ONLY by the keypoint-side entry
+ * points that say so (cp_edgeconv_fused_t, cp_edgeconv_tiled_t, cp_mlp_pair_fused*_t, cp_mlp_query_fused_t, cp_index2feat_conv_t,
+ * cp_pack_gemm_weight, cp_conv2d_igemm with CpConvDesc.dtype = CP_F16 / out_f32 = 2) -- the bf16 program runs its per-keypoint
+ * (GNN) block group in f16: same bytes and MFMA rate, 3 more mantissa bits where EdgeConv's neighbour differences cancel. */
+enum { CP_F32 = 0, CP_BF16 = 1, CP_F16 = 2 };
 enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_LEAKY = 2 };
 enum { CP_LOSS_BCE = 0, CP_LOSS_L1 = 1 };   /* loss_type of losses/code_loss.py ("CE": cp_masked_ce_loss) */
 enum {
@@ -52,6 +56,17 @@ const char* cp_last_kernel(void);
  * 1 KB, later symbols are dropped) -- bench.py prices such a call as the SET of its launches. */
 void cp_kernel_log_begin(void);
 const char* cp_kernel_log(void);
+
+/* Deterministic training mode (process-wide switch; default off).  The reference's step (train.py:303-320) is deterministic on
+ * CPU; the default training entry points here accumulate BatchNorm sums, small weight gradients and Index2Feat's scatter with
+ * floating-point atomics, whose order varies from run to run.  With the switch on: cp_bn_* accumulate one block per accumulator
+ * set (cp_bn_acc_doubles() grows to 64 sets; consumers add the sets in index order), cp_conv2d_wgrad_* always go through partial
+ * tiles + the fixed-order reduction (a call without a workspace is refused: CP_ERR_INVALID), cp_index2feat_gather_bwd* sums each
+ * patch pixel's contributions in keypoint order.  Same inputs + same launch plan => bit-identical gradients.  The switch is
+ * read when an entry point is CALLED (and when a size query is answered): set it before building launch programs / graphs and
+ * rebuild them after changing it.  The eval path has no atomics and ignores it. */
+void cp_set_deterministic(int on);
+int cp_get_deterministic(void);
 
 /* elements per 16 bytes: 4 (f32) or 8 (bf16).  Physical channel counts are multiples of this. */
 int cp_chan_align(int dtype);
@@ -87,7 +102,8 @@ int cp_pack_conv_weight(cp_stream_t stream, int dtype, const float* w, int Cout,
  * ------------------------------------------------------------------------------------------- */
 typedef struct CpConvDesc {
   int32_t dtype;          /* CP_F32 | CP_BF16: type of in / packed weights / residual / out */
-  int32_t out_f32;        /* 1: out (and residual) are fp32 regardless of dtype (final logits, seg) */
+  int32_t out_f32;        /* 1: out (and residual) are fp32 regardless of dtype (final logits, seg); 2 (cp_conv2d_igemm, cp_conv2x2_halo,
+                             dtype CP_BF16, no residual): out rows are IEEE half (CP_F16: the producer of a keypoint-side tensor) */
   int32_t B, H, W;        /* input spatial size */
   int32_t Cin;            /* channels contracted (physical, multiple of cp_chan_align) */
   int32_t in_cstride;     /* elements between consecutive input pixels (>= in_coff + Cin) */
@@ -221,6 +237,11 @@ int cp_mlp_query_fused(cp_stream_t stream, const void* in, int in_cstride, int i
                        const void* packed_w1, const float* scale1, const float* shift1, float slope1,
                        const void* packed_w2, const float* scale2, const float* shift2, float slope2,
                        const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn, long long o_sc);
+/* the same with the rows, both packed weight images (cp_pack_gemm_weight(dtype, ...)) and the on-chip hidden rows in `dtype` = CP_BF16 or CP_F16 */
+int cp_mlp_query_fused_t(cp_stream_t stream, int dtype, const void* in, int in_cstride, int in_coff, int B, int N,
+                         const void* packed_w1, const float* scale1, const float* shift1, float slope1,
+                         const void* packed_w2, const float* scale2, const float* shift2, float slope2,
+                         const float* w3, const float* b3, float* out, long long o_base, long long o_sb, long long o_sn, long long o_sc);
 
 /* Refine_moduleGNN.pre_graph_module (pipeline.py:237-240, applied at :283-286: Linear(Cin -> 256) + LeakyReLU, Linear(256 -> 256) +
  * LeakyReLU over the concatenated [local | previous graph] feature rows) as ONE launch, bf16: the hidden rows stay in LDS.
@@ -230,6 +251,10 @@ int cp_mlp_pair_fused_supported(int Cin, int C1, int C2);
 int cp_mlp_pair_fused(cp_stream_t stream, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
                       const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2, float slope2,
                       void* out, int out_cstride, int out_coff);
+/* ... in `dtype` = CP_BF16 or CP_F16 (input rows, weights, hidden rows, output rows) */
+int cp_mlp_pair_fused_t(cp_stream_t stream, int dtype, const void* in, int in_cstride, int in_coff, int Cin, int B, int N,
+                        const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
+                        float slope2, void* out, int out_cstride, int out_coff);
 
 /* The same with Index2Feat_module's gather (pipeline.py:156-163: four 64-channel taps of patch_generator's output map at
  * (2v, 2u), (2v + k, 2u), (2v, 2u + k), (2v + k, 2u + k), times the {0, 1} RoI bit, :280) done by the kernel's DMA loader: the
@@ -249,6 +274,10 @@ int cp_mlp_pair_fused_gather_supported(int Cg, int E_ch, int k);
 int cp_mlp_pair_fused_gather(cp_stream_t stream, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff, int Cg, int B, int N,
                              const void* packed_w1, const float* bias1, float slope1, const void* packed_w2, const float* bias2,
                              float slope2, void* out, int out_cstride, int out_coff);
+/* ... in `dtype` = CP_BF16 or CP_F16 (patch map, graph rows, weights, hidden rows, output rows: ONE type) */
+int cp_mlp_pair_fused_gather_t(cp_stream_t stream, int dtype, const CpI2fGather* g, const void* gin, int gin_cstride, int gin_coff, int Cg,
+                               int B, int N, const void* packed_w1, const float* bias1, float slope1, const void* packed_w2,
+                               const float* bias2, float slope2, void* out, int out_cstride, int out_coff);
 
 /* nn.UpsamplingBilinear2d(scale_factor=2) == interpolate(align_corners=True), pipeline.py:199.
  * Reads channels [in_coff, in_coff+C) of (B,H,W,in_cstride), writes [out_coff, ..) of (B,2H,2W,out_cstride). */
@@ -395,6 +424,11 @@ int cp_pack_edgeconv_fused_weight(cp_stream_t stream, const float* wpq, int Cin,
 int cp_edgeconv_fused(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w,
                       const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
                       int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope);
+/* ... in `dtype` = CP_BF16 or CP_F16 (x rows, packed weights, output rows; the gather keys are IEEE halves either way) */
+int cp_pack_edgeconv_fused_weight_t(cp_stream_t stream, int dtype, const float* wpq, int Cin, int Cout, void* packed);
+int cp_edgeconv_fused_t(cp_stream_t stream, int dtype, const void* x, int in_cstride, int in_coff, const void* packed_w,
+                        const float* scale, const float* shift, const int32_t* idx, const int32_t* graph_ids, void* out,
+                        int out_cstride, int out_coff, int B, int N, int K, int Cin, int Cout, int G, float slope);
 
 /* EdgeConv layer for LARGE graphs (N = 1024 .. 32768 keypoints in patches of 512, bf16; BASELINE config #5: npt = 4096), the
  * LDS-staged gather of cp_edgeconv_fused, tiled (edgeconv_tiled.hip; same reference lines as above).  The caller works in an
@@ -438,6 +472,10 @@ int cp_pack_index2feat_conv_weight(cp_stream_t stream, const float* w, void* pac
 int cp_index2feat_conv(cp_stream_t stream, const void* f, int in_cstride, int in_coff, const void* packed_w, const float* bias,
                        const int32_t* x_id, const int32_t* y_id, const float* mask, void* out, int B, int N, int H, int W, int k,
                        int out_cstride, int out_coff);
+/* ... the (bf16) conv's output rows written as `out_dtype` = CP_BF16 or CP_F16 */
+int cp_index2feat_conv_t(cp_stream_t stream, int out_dtype, const void* f, int in_cstride, int in_coff, const void* packed_w,
+                         const float* bias, const int32_t* x_id, const int32_t* y_id, const float* mask, void* out, int B, int N,
+                         int H, int W, int k, int out_cstride, int out_coff);
 
 /* Bit decode (pipeline.py:72-127, 367-369, 380-381) on the fp32 logit block `bits` (B, 13, N):
  * row 0 = roi, rows 1..6 = x bits (MSB first), rows 7..12 = y bits.

@@ -317,3 +317,40 @@ def test_bf16_contract_on_trained_like_weights():
     assert tf["bit_agreement_min_row"] >= 0.97 and tf["seg_agreement"] >= 0.99 and tf["mean_abs_dlogit_over_rms"] <= 0.02, tf
     assert fr["bit_agreement_min_row"] >= 0.90 and fr["xy_id_equal"] >= 0.80 and fr["id_abs_err_mean_px"] <= 1.0, fr
     assert fr["id_mismatches_explained_frac"] >= 0.90, fr
+
+
+def _train_steps(steps, deterministic, seed=1, batch=8):
+    """`steps` steps of the trained-like task (checkerpose_amd/trained_like.py) -> every parameter and buffer, on the CPU"""
+    import checkerpose_amd
+    from checkerpose_amd.trained_like import train_net
+    checkerpose_amd.set_deterministic(deterministic)
+    try:
+        net, _, _, losses = train_net(npoint=512, steps=steps, batch=batch, lr=5e-4, seed=seed)
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, losses
+    finally:
+        checkerpose_amd.set_deterministic(False)
+
+
+def test_deterministic_training_mode_is_bit_reproducible():
+    """`checkerpose_amd.set_deterministic(True)` (CHECKERPOSE_AMD_DETERMINISTIC=1, `net.deterministic = True`): two runs of the same 50
+    training steps (train.py:303-320's sequence through the HIP training program: train-mode forward, five losses, backward, Adam)
+    end in BIT-IDENTICAL parameters and BatchNorm buffers -- what the reference's CPU step gives for free.  BatchNorm sums go one
+    block per accumulator set, every weight gradient through the fixed-order partial-tile reduction, Index2Feat's scatter as an
+    ordered gather (include/checkerpose_hip.h: cp_set_deterministic)."""
+    a, la = _train_steps(50, True)
+    b, lb = _train_steps(50, True)
+    assert la == lb, (la, lb)
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, "%d of %d tensors differ between two deterministic runs, e.g. %s" % (len(bad), len(a), bad[:5])
+    assert la[-1] < la[0]
+
+
+def test_deterministic_mode_matches_default_mode_numerically():
+    """the deterministic mode changes the ORDER of the accumulations only: after 3 steps its parameters agree with the default
+    mode's to rounding (the default mode's own run-to-run spread is of the same size)"""
+    a, _ = _train_steps(3, True)
+    b, _ = _train_steps(3, False)
+    worst = max(float((a[k].float() - b[k].float()).abs().max()) / (1e-6 + float(b[k].float().abs().max())) for k in a
+                if a[k].dtype.is_floating_point)
+    assert worst <= 2e-2, worst
