@@ -181,6 +181,8 @@ SIGNATURES = {
     "cp_edgeconv_tiled_table_bytes": (C.c_size_t, [_I, _I, _I]),
     "cp_pack_edgeconv_tiled_weight": (_I, [_P, _P, _I, _I, _P]),
     "cp_edgeconv_tiled": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "cp_pack_edgeconv_tiled_weight_t": (_I, [_P, _I, _P, _I, _I, _P]),
+    "cp_edgeconv_tiled_t": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
     "cp_permute_rows": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "cp_permute_cols": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "cp_index2feat_conv_supported": (_I, [_I, _I, _I]),

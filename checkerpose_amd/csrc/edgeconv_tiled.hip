@@ -45,7 +45,7 @@ __device__ __forceinline__ void crop_patch(int NB, int B, int& b, int& t) {
 
 // ------------------------------------------------------------------------------------------------ launch 1: the key table
 // weights: the P halves of cp_pack_edgeconv_fused_weight's image ([64-channel slice][half][32-deep chunk][tile][lane][8 bf16])
-template <int CIN>
+template <int CIN, bool H = false>                            // H: x rows and weights in IEEE half (CP_F16; common.h cp_mma16); the keys are halves either way
 __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledParams p) {
   constexpr int KC = CIN / 32;
   constexpr int HALF = KC * 4 * 1024;
@@ -103,8 +103,7 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
-                                                               acc[f][nt], 0, 0, 0);
+          acc[f][nt] = cp_mma16<H>(wf[kc & 1][nt], xa[f][kc], acc[f][nt]);
       __builtin_amdgcn_sched_barrier(0);
     }
     // lane (x, q): keypoint row0 + 16 f + x, channels 64 s + 16 q + 4 nt + reg = planes 8 s + 2 q, 8 s + 2 q + 1
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 // weights: Q halves in 32-channel slices, [slice][32-deep chunk][tile 0..1][lane][8 bf16]; tile row r of tile nt of slice s
 // = output channel 32 s + (r >> 2) * 8 + 4 nt + (r & 3) of wpq rows [Cout, 2 Cout)  ->  lane (x, q) ends with channels
 // 32 s + 8 q + 4 nt + reg
-template <int CIN, bool DB>
+template <int CIN, bool DB, bool H = false>
 __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledParams p) {
   constexpr int KC = CIN / 32;
   constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
@@ -323,8 +322,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kc & 1][nt]), __builtin_bit_cast(bf16x8, xa[f][kc]),
-                                                               acc[f][nt], 0, 0, 0);
+          acc[f][nt] = cp_mma16<H>(wf[kc & 1][nt], xa[f][kc], acc[f][nt]);
       __builtin_amdgcn_sched_barrier(0);
     }
     const int c0 = s * 32 + q * 8;                                   // slice s = channels 32 s .. 32 s + 31, lane group q its 8 q .. 8 q + 7
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledPara
         v[2 * j] = fmaxf(y0, y0 * p.slope);                            // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
         v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
       }
-      *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = Vec16<BF16Tag>::pack(v);
+      *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = cp_pack8<H>(v);
     }
     __syncthreads();                                                // DB: table(s + 1) landed, weights(s) / table(s) free.  !DB: both landed
     if (DB && s + 1 < nslice) w_issue(s + 1);                       // awaited at the next mid-slice barrier, a whole gather away
@@ -380,7 +378,7 @@ __device__ __forceinline__ void lds_only_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int CIN>
+template <int CIN, bool H = false>
 __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledParams p) {
   constexpr int KC = CIN / 32;
   constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
@@ -540,8 +538,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
           for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-              acc[h2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[st & 1][nt]),
-                                                                    __builtin_bit_cast(bf16x8, xa[2 * fp + h2][st]), acc[h2][nt], 0, 0, 0);
+              acc[h2][nt] = cp_mma16<H>(wf[st & 1][nt], xa[2 * fp + h2][st], acc[h2][nt]);
         }
         __builtin_amdgcn_sched_barrier(0);
         pkmax5x4_f16(m[h], r[h][0], r[h][1], r[h][2], r[h][3]);
@@ -574,7 +571,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
           v[2 * j] = fmaxf(y0, y0 * p.slope);                          // LeakyReLU, 0 <= slope <= 1 (checked by the entry point)
           v[2 * j + 1] = fmaxf(y1, y1 * p.slope);
         }
-        *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = Vec16<BF16Tag>::pack(v);
+        *(u32x4*)((uint16_t*)p.out + (row0 + f * 16 + x) * p.out_cs + p.out_coff + c0) = cp_pack8<H>(v);
       }
       if (fp == 0) ET_MARK(4); else ET_MARK(8);                       // epilogues
     }
@@ -585,7 +582,7 @@ __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledPar
 }
 
 // Q halves, 32-channel slices (see the kernel's header comment)
-__global__ void pack_edgeconv_tiled_q_kernel(const float* __restrict__ wpq, uint16_t* __restrict__ out, int Cin, int Cout, size_t total) {
+__global__ void pack_edgeconv_tiled_q_kernel(const float* __restrict__ wpq, uint16_t* __restrict__ out, int Cin, int Cout, size_t total, int dtype) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int KC = Cin / 32;
@@ -598,7 +595,7 @@ __global__ void pack_edgeconv_tiled_q_kernel(const float* __restrict__ wpq, uint
   const int r = lane & 15, q = lane >> 4;
   const int c = s * 32 + (r >> 2) * 8 + nt * 4 + (r & 3);
   const int cin = kc * 32 + q * 8 + e;
-  out[i] = (uint16_t)f32_to_bf16_bits(wpq[((size_t)(Cout + c)) * Cin + cin]);
+  out[i] = (uint16_t)f32_to_half_bits(wpq[((size_t)(Cout + c)) * Cin + cin], dtype);
 }
 
 // keypoint renumbering at the program's boundary.  rows: out[b, i, :] = in[b, perm[g, i], :] (row_bytes a multiple of 16)
@@ -650,19 +647,24 @@ extern "C" int cp_edgeconv_tiled_supported(int N, int K, int Cin, int Cout, int 
 extern "C" size_t cp_edgeconv_tiled_weight_bytes(int Cin, int Cout) { return (size_t)Cout * Cin * 2; }
 extern "C" size_t cp_edgeconv_tiled_table_bytes(int B, int N, int Cout) { return (size_t)B * N * Cout * 2; }
 
-extern "C" int cp_pack_edgeconv_tiled_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed) {
-  if (!wpq || !packed || !cp_edgeconv_tiled_supported(2 * ET_BLK, 4, Cin, Cout, 64)) return CP_ERR_INVALID;
+extern "C" int cp_pack_edgeconv_tiled_weight_t(cp_stream_t stream, int dtype, const float* wpq, int Cin, int Cout, void* packed) {
+  if (!wpq || !packed || !cp_edgeconv_tiled_supported(2 * ET_BLK, 4, Cin, Cout, 64) || (dtype != CP_BF16 && dtype != CP_F16)) return CP_ERR_INVALID;
   if (!cp_aligned16(packed)) return CP_ERR_ALIGN;
   const size_t total = (size_t)Cout * Cin;
-  CP_LAUNCH(pack_edgeconv_tiled_q_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpq, (uint16_t*)packed, Cin, Cout, total);
+  CP_LAUNCH(pack_edgeconv_tiled_q_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpq, (uint16_t*)packed, Cin, Cout, total, dtype);
   return cp_check_launch();
 }
 
-extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w_fused,
-                                 const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo,
-                                 const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
-                                 int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope) {
+extern "C" int cp_pack_edgeconv_tiled_weight(cp_stream_t stream, const float* wpq, int Cin, int Cout, void* packed) {
+  return cp_pack_edgeconv_tiled_weight_t(stream, CP_BF16, wpq, Cin, Cout, packed);
+}
+
+extern "C" int cp_edgeconv_tiled_t(cp_stream_t stream, int dtype, const void* x, int in_cstride, int in_coff, const void* packed_w_fused,
+                                   const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo,
+                                   const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
+                                   int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope) {
   if (!x || !packed_w_fused || !packed_w_q || !scale || !shift || !halo || !nbr || !key_table || !out || B <= 0 || G <= 0) return CP_ERR_INVALID;
+  if (dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;
   if (!cp_edgeconv_tiled_supported(N, K, Cin, Cout, HPAD) || !(slope >= 0.f && slope <= 1.f)) return CP_ERR_INVALID;
   if (in_cstride % 8 || in_coff % 8 || in_coff + Cin > in_cstride || out_cstride % 8 || out_coff % 8 || out_coff + Cout > out_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(x) || !cp_aligned16(packed_w_fused) || !cp_aligned16(packed_w_q) || !cp_aligned16(scale) || !cp_aligned16(shift) ||
@@ -682,24 +684,43 @@ extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstri
                                   cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, true>, want) &&
                                   cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, true>, want) &&
                                   cp_set_max_lds((const void*)edgeconv_tiled2_kernel<64>, want) &&
-                                  cp_set_max_lds((const void*)edgeconv_tiled2_kernel<256>, want));
+                                  cp_set_max_lds((const void*)edgeconv_tiled2_kernel<256>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_ptable_kernel<64, true>, lds1[0]) &&
+                                  cp_set_max_lds((const void*)edgeconv_ptable_kernel<256, true>, lds1[1]) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, false, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, false, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<64, true, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled_kernel<256, true, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled2_kernel<64, true>, want) &&
+                                  cp_set_max_lds((const void*)edgeconv_tiled2_kernel<256, true>, want));
   EdgeTiledParams p;
   p.x = x; p.scale = scale; p.shift = shift; p.halo = halo; p.nbr = nbr; p.gids = graph_ids; p.ptab = key_table; p.out = out;
   p.in_cs = in_cstride; p.in_coff = in_coff; p.out_cs = out_cstride; p.out_coff = out_coff; p.B = B; p.N = N; p.NB = N / ET_BLK; p.K = K;
   p.Cout = Cout; p.HPAD = HPAD; p.slope = slope;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(((B + 7) / 8) * p.NB * 8);
+  const bool h = dtype == CP_F16;
   p.w = packed_w_fused;
-  if (Cin == 64) CP_LAUNCH((edgeconv_ptable_kernel<64>), dim3(grid), dim3(512), lds1[0], st, p);
-  else CP_LAUNCH((edgeconv_ptable_kernel<256>), dim3(grid), dim3(512), lds1[1], st, p);
+#define CP_ET(KERNEL, LDS) CP_LAUNCH((KERNEL), dim3(grid), dim3(512), LDS, st, p)
+  if (Cin == 64) { if (h) CP_ET((edgeconv_ptable_kernel<64, true>), lds1[0]); else CP_ET((edgeconv_ptable_kernel<64>), lds1[0]); }
+  else { if (h) CP_ET((edgeconv_ptable_kernel<256, true>), lds1[1]); else CP_ET((edgeconv_ptable_kernel<256>), lds1[1]); }
   p.w = packed_w_q;
-  if (il && Cin == 64) CP_LAUNCH((edgeconv_tiled2_kernel<64>), dim3(grid), dim3(512), lds2, st, p);
-  else if (il) CP_LAUNCH((edgeconv_tiled2_kernel<256>), dim3(grid), dim3(512), lds2, st, p);
-  else if (Cin == 64 && db) CP_LAUNCH((edgeconv_tiled_kernel<64, true>), dim3(grid), dim3(512), lds2, st, p);
-  else if (Cin == 64) CP_LAUNCH((edgeconv_tiled_kernel<64, false>), dim3(grid), dim3(512), lds2, st, p);
-  else if (db) CP_LAUNCH((edgeconv_tiled_kernel<256, true>), dim3(grid), dim3(512), lds2, st, p);
-  else CP_LAUNCH((edgeconv_tiled_kernel<256, false>), dim3(grid), dim3(512), lds2, st, p);
+  if (il && Cin == 64) { if (h) CP_ET((edgeconv_tiled2_kernel<64, true>), lds2); else CP_ET((edgeconv_tiled2_kernel<64>), lds2); }
+  else if (il) { if (h) CP_ET((edgeconv_tiled2_kernel<256, true>), lds2); else CP_ET((edgeconv_tiled2_kernel<256>), lds2); }
+  else if (Cin == 64 && db) { if (h) CP_ET((edgeconv_tiled_kernel<64, true, true>), lds2); else CP_ET((edgeconv_tiled_kernel<64, true>), lds2); }
+  else if (Cin == 64) { if (h) CP_ET((edgeconv_tiled_kernel<64, false, true>), lds2); else CP_ET((edgeconv_tiled_kernel<64, false>), lds2); }
+  else if (db) { if (h) CP_ET((edgeconv_tiled_kernel<256, true, true>), lds2); else CP_ET((edgeconv_tiled_kernel<256, true>), lds2); }
+  else { if (h) CP_ET((edgeconv_tiled_kernel<256, false, true>), lds2); else CP_ET((edgeconv_tiled_kernel<256, false>), lds2); }
+#undef CP_ET
   return cp_check_launch();
+}
+
+extern "C" int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstride, int in_coff, const void* packed_w_fused,
+                                 const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo,
+                                 const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
+                                 int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope) {
+  return cp_edgeconv_tiled_t(stream, CP_BF16, x, in_cstride, in_coff, packed_w_fused, packed_w_q, scale, shift, halo, nbr, graph_ids, key_table,
+                             out, out_cstride, out_coff, B, N, K, Cin, Cout, G, HPAD, slope);
 }
 
 extern "C" int cp_permute_rows(cp_stream_t stream, const void* in, void* out, const int32_t* perm, const int32_t* graph_ids,

@@ -247,7 +247,8 @@ class Program:
             return False
         if N == 512:
             return self.can_fuse_edgeconv(N, K, 64, 64) and self.can_fuse_edgeconv(N, K, 256, 256)
-        return False
+        return (tiled_hpad is not None and self.can_tile_edgeconv(N, K, 64, 64, tiled_hpad)
+                and self.can_tile_edgeconv(N, K, 256, 256, tiled_hpad))
 
     # ---- tensors
     def tensor(self, nelem, es=None):
@@ -982,30 +983,31 @@ class Program:
         Co2, Cin = wpq.shape[0], wpq.shape[1]
         Co, N = Co2 // 2, x.W
         st = torch.cuda.current_stream(self.device).cuda_stream
-        ck = ("edge_fused", wkey)
+        gdt = self.gdt
+        ck = ("edge_fused", wkey, gdt)
         if ck not in self.ws.cache:
             buf = torch.empty(self.lib.cp_edgeconv_fused_weight_bytes(Cin, Co), dtype=torch.uint8, device=self.device)
             w2 = wpq.reshape(Co2, Cin).contiguous()
             self.ws.keep.append(w2)
-            _abi.check(self.lib.cp_pack_edgeconv_fused_weight(st, w2.data_ptr(), Cin, Co, buf.data_ptr()), "cp_pack_edgeconv_fused_weight")
+            _abi.check(self.lib.cp_pack_edgeconv_fused_weight_t(st, gdt, w2.data_ptr(), Cin, Co, buf.data_ptr()), "cp_pack_edgeconv_fused_weight")
             self.ws.cache[ck] = (buf, scale.contiguous(), shift.contiguous())
         buf, sc, sh = self.ws.cache[ck]
-        cq = ("edge_tiled_q", wkey)
+        cq = ("edge_tiled_q", wkey, gdt)
         if cq not in self.ws.cache:
             bq = torch.empty(self.lib.cp_edgeconv_tiled_weight_bytes(Cin, Co), dtype=torch.uint8, device=self.device)
             w2 = wpq.reshape(Co2, Cin).contiguous()
             self.ws.keep.append(w2)
-            _abi.check(self.lib.cp_pack_edgeconv_tiled_weight(st, w2.data_ptr(), Cin, Co, bq.data_ptr()), "cp_pack_edgeconv_tiled_weight")
+            _abi.check(self.lib.cp_pack_edgeconv_tiled_weight_t(st, gdt, w2.data_ptr(), Cin, Co, bq.data_ptr()), "cp_pack_edgeconv_tiled_weight")
             self.ws.cache[cq] = bq
         bq = self.ws.cache[cq]
         ktab = self.tensor(self.lib.cp_edgeconv_tiled_table_bytes(self.B, N, Co), es=1)
         self.keep += [buf, sc, sh, bq, tiled["halo"], tiled["nbr"]]
-        fn = self.lib.cp_edgeconv_tiled
+        fn = self.lib.cp_edgeconv_tiled_t
         xt, ot = x.tbuf, out.tbuf
         gp = gids_t.data_ptr() if gids_t is not None else None
         a = (buf.data_ptr(), bq.data_ptr(), sc.data_ptr(), sh.data_ptr(), tiled["halo"].data_ptr(), tiled["nbr"].data_ptr(), gp)
         HPAD = tiled["HPAD"]
-        self._add(fn, lambda P: (P(xt), x.cstride, x.coff) + a + (P(ktab), P(ot), out.cstride, out.coff, self.B, N, K, Cin, Co, G, HPAD, slope),
+        self._add(fn, lambda P: (gdt, P(xt), x.cstride, x.coff) + a + (P(ktab), P(ot), out.cstride, out.coff, self.B, N, K, Cin, Co, G, HPAD, slope),
                   "edge_tiled:" + wkey, [xt], [ot, ktab])
         fl = 2 * self.B * N * Cin * Co2
         self.flops += fl

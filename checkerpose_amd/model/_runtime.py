@@ -21,14 +21,13 @@ _VERSION_OF = operator.attrgetter("_version")
 # when a model builds its tensor list; registrations on modules outside every tracked tree (another model, an optimizer's
 # containers, torch internals) cost one dictionary miss and touch nothing.  The hooks are installed with the first drop-in model
 # and removed again when the last tracked tree is gone.
-_TRACKED = weakref.WeakKeyDictionary()          # nn.Module (any node of a tracked tree) -> weakref to its root model
+_TRACKED = weakref.WeakKeyDictionary()          # nn.Module (any node of a tracked tree) -> WeakSet of the root models it sits in
 _HOOKS = []
 
 
 def _bump_epoch(module, *_a):
-    root = _TRACKED.get(module)
-    root = root() if root is not None else None
-    if root is not None:
+    roots = _TRACKED.get(module)
+    for root in (list(roots) if roots is not None else ()):       # a submodule shared by several drop-in models moves ALL of them
         root._struct_epoch += 1
 
 
@@ -43,7 +42,7 @@ def _install_hooks():
 def _remove_hooks_if_idle():
     """called when a root model dies: with no live root left (children may outlive their root for a moment, or for good when the
     caller kept one) the map is cleared and the process-wide hooks are removed"""
-    if _HOOKS and not any(r() is not None for r in list(_TRACKED.values())):
+    if _HOOKS and not any(len(r) for r in list(_TRACKED.values())):
         _TRACKED.clear()
         for h in _HOOKS:
             h.remove()
@@ -51,11 +50,16 @@ def _remove_hooks_if_idle():
 
 
 def _track_tree(root):
-    """(re)register every module of `root`'s tree; a submodule that sits in two models belongs to the one that looked last"""
+    """(re)register every module of `root`'s tree; a submodule that sits in two models (a shared backbone, an init net reachable from
+    two PoseNets) is tracked for both"""
     _install_hooks()
-    ref = weakref.ref(root, lambda _r: _remove_hooks_if_idle())
+    if getattr(root, "_track_fin", None) is None:
+        object.__setattr__(root, "_track_fin", weakref.finalize(root, _remove_hooks_if_idle))
     for m in root.modules():
-        _TRACKED[m] = ref
+        s_ = _TRACKED.get(m)
+        if s_ is None:
+            s_ = _TRACKED[m] = weakref.WeakSet()
+        s_.add(root)
 
 
 def _version_sum(tensors):
@@ -332,7 +336,7 @@ class HipForwardMixin:
                 prog.splitk = False
             sio["graph"] = dict(idx=idx, gids=sio["gids"], K=idx.shape[2], G=G)
             # the per-keypoint block group in IEEE half when each of its ops takes the fused per-crop kernel at this batch (engine.USE_GNN_F16)
-            prog.gnn_half = (not want_graph) and prog.wants_gnn_half(N, idx.shape[2])
+            prog.gnn_half = (not want_graph) and prog.wants_gnn_half(N, idx.shape[2], tiled["HPAD"] if tiled is not None else None)
             ext = None
             if tiled is not None and prog.can_tile_edgeconv(N, idx.shape[2], 64, 64, tiled["HPAD"]):
                 # large graphs: the program works in the patch-ordered INTERNAL keypoint numbering (graph_sched.tile_schedule): its
@@ -563,6 +567,8 @@ class HipForwardMixin:
                inject_dec is not None, want_dec)
         pr = self._programs.get(key)
         if pr is None:
+            if self.check_weight_versions:
+                _track_tree(self)               # (also covers a model that was deep-copied together with its epoch)
             with torch.cuda.device(device):
                 pr = self._build(lib, B, size, stage, want_feats, want_graph, device, teacher_bits is not None, u8,
                                  inject_feats is not None, inject_dec is not None, want_dec)

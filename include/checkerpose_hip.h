@@ -450,6 +450,12 @@ int cp_edgeconv_tiled(cp_stream_t stream, const void* x, int in_cstride, int in_
                       const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo,
                       const int16_t* nbr, const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff,
                       int B, int N, int K, int Cin, int Cout, int G, int HPAD, float slope);
+/* ... in `dtype` = CP_BF16 or CP_F16 (x rows, both packed weight images, output rows; the key table holds IEEE halves either way) */
+int cp_pack_edgeconv_tiled_weight_t(cp_stream_t stream, int dtype, const float* wpq, int Cin, int Cout, void* packed);
+int cp_edgeconv_tiled_t(cp_stream_t stream, int dtype, const void* x, int in_cstride, int in_coff, const void* packed_w_fused,
+                        const void* packed_w_q, const float* scale, const float* shift, const int32_t* halo, const int16_t* nbr,
+                        const int32_t* graph_ids, void* key_table, void* out, int out_cstride, int out_coff, int B, int N, int K,
+                        int Cin, int Cout, int G, int HPAD, float slope);
 /* The renumbering at the launch program's boundary (perm int32 (G, N): internal row i = original keypoint perm[g][i];
  * graph_ids (B) or NULL).  Rows of `row_bytes` (a multiple of 16): out[b][i] = in[b][perm[g_b][i]].  Columns of (B, R, N)
  * arrays of 4- / 8-byte elements (logit block, ids): scatter = 1: out[b][r][perm[g_b][i]] = in[b][r][i] (internal -> original),

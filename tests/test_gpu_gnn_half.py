@@ -310,3 +310,51 @@ def test_bf16_program_with_the_keypoint_side_in_half_is_closer_to_fp32(monkeypat
         assert pr.gnn_half is half
     print("teacher-forced mean |dlogit| vs fp32: keypoint side half %.5f, bf16 %.5f" % (err[True], err[False]))
     assert err[True] < 0.9 * err[False], err
+
+
+@pytest.mark.parametrize("N,Cc", [(1024, 256), (4096, 64)])
+def test_edgeconv_tiled_half_vs_torch(lib, N, Cc):
+    """cp_edgeconv_tiled_t(CP_F16) (N > 512: key-table launch + per-patch gather launch) with x / W in half == the factored form in
+    torch with the same roundings, on real LM graphs in the patch order of graph_sched.tile_schedule"""
+    import numpy as np
+    from checkerpose_amd.graph_sched import tile_schedule
+    from tests.common import lm_p3d
+    objs = [0, 4]
+    P3 = lm_p3d(N)[objs]
+    idx = O.knn(P3, 20)                                                  # (2, N, K) original numbering
+    sc = tile_schedule(idx.numpy(), P3.numpy())
+    assert sc is not None and lib.cp_edgeconv_tiled_supported(N, 20, Cc, Cc, sc["HPAD"])
+    gsel = torch.tensor([1, 0, 1])
+    B, K = 3, 20
+    x = rnd(det_tensor("htx%d_%d" % (Cc, N), (B, N, Cc)), CP_F16)
+    w1 = rnd(det_tensor("htw1%d" % Cc, (Cc, Cc), (3.0 / Cc) ** 0.5), CP_F16)
+    dq = rnd(det_tensor("htdq%d" % Cc, (Cc, Cc), (3.0 / Cc) ** 0.5), CP_F16)
+    s_ = 1.0 + 0.3 * det_tensor("hts%d" % Cc, (Cc,))
+    s_[::7] *= -1.0
+    t_ = det_tensor("htt%d" % Cc, (Cc,), 0.5)
+    Pk = ((x @ w1.t()) * s_).to(torch.float16).float()
+    Q = (x @ dq.t()) * s_ + t_
+    ref = torch.stack([F.leaky_relu(Pk[i][idx[gsel[i]]].max(dim=1)[0] + Q[i], 0.2) for i in range(B)])      # (B, N, C) original order
+    wpq = torch.cat([w1, dq], 0).contiguous().to(dev())
+    scale, shift = torch.cat([s_, s_]).to(dev()), torch.cat([torch.zeros_like(t_), t_]).to(dev())
+    pf = torch.empty(lib.cp_edgeconv_fused_weight_bytes(Cc, Cc), dtype=torch.uint8, device=dev())
+    pq = torch.empty(lib.cp_edgeconv_tiled_weight_bytes(Cc, Cc), dtype=torch.uint8, device=dev())
+    _abi.check(lib.cp_pack_edgeconv_fused_weight_t(st(), CP_F16, wpq.data_ptr(), Cc, Cc, pf.data_ptr()))
+    _abi.check(lib.cp_pack_edgeconv_tiled_weight_t(st(), CP_F16, wpq.data_ptr(), Cc, Cc, pq.data_ptr()))
+    perm = torch.from_numpy(sc["perm"]).to(dev())
+    halo, nbr = torch.from_numpy(sc["halo"]).contiguous().to(dev()), torch.from_numpy(sc["nbr"]).contiguous().to(dev())
+    gids = gsel.to(torch.int32).to(dev())
+    x_orig = x.to(torch.float16).contiguous().to(dev())
+    x_int = torch.empty_like(x_orig)
+    _abi.check(lib.cp_permute_rows(st(), x_orig.data_ptr(), x_int.data_ptr(), perm.data_ptr(), gids.data_ptr(), B, N, Cc * 2))
+    ktab = torch.empty(lib.cp_edgeconv_tiled_table_bytes(B, N, Cc), dtype=torch.uint8, device=dev())
+    out = torch.full((B, N, Cc), 7.0, dtype=torch.float16, device=dev())
+    _abi.check(lib.cp_edgeconv_tiled_t(st(), CP_F16, x_int.data_ptr(), Cc, 0, pf.data_ptr(), pq.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                       halo.data_ptr(), nbr.data_ptr(), gids.data_ptr(), ktab.data_ptr(), out.data_ptr(), Cc, 0,
+                                       B, N, K, Cc, Cc, 2, int(sc["HPAD"]), 0.2))
+    torch.cuda.synchronize()
+    got_int = out.float().cpu()
+    got = torch.empty_like(got_int)
+    for i in range(B):
+        got[i][sc["perm"][gsel[i]].astype(np.int64)] = got_int[i]        # internal row r holds original keypoint perm[r]
+    close(got, ref, TOL_H)

@@ -184,3 +184,26 @@ def test_struct_epoch_is_scoped_to_the_model():
     del a, b
     gc.collect()
     assert not RT._HOOKS and not len(RT._TRACKED)
+
+
+def test_struct_epoch_reaches_every_model_that_shares_a_submodule():
+    """a submodule that sits in TWO drop-in models (a shared head, an init net reachable from two PoseNets): a registration inside it
+    moves both models' epochs (round 5 kept one root per module: the model that looked last), and both forget it when they die"""
+    import gc
+    import torch
+    from checkerpose_amd.model import _runtime as RT
+    from tests.common import build_net
+    a, b = build_net(full=False), build_net(full=False, seed=2)
+    b.mlp = a.mlp                                                                  # shared
+    RT._track_tree(a)
+    RT._track_tree(b)
+    ea, eb = a._struct_epoch, b._struct_epoch
+    a.mlp.bias = torch.nn.Parameter(torch.zeros(7))
+    assert (a._struct_epoch, b._struct_epoch) == (ea + 1, eb + 1)
+    del a
+    gc.collect()
+    b.mlp.weight = torch.nn.Parameter(torch.zeros(7, 64))
+    assert b._struct_epoch == eb + 2 and len(RT._HOOKS) == 3
+    del b
+    gc.collect()
+    assert not RT._HOOKS and not len(RT._TRACKED)

@@ -110,7 +110,9 @@ for (B, nsrc, tconvs, seed) in ((3, 2, [(36, False)], 11), (5, 3, [(18, True), (
         out = torch.full((B, H, W, cp), 7.0, device=dev).to(torch.bfloat16)
         arr_p = (C.c_void_p * 4)(*([s_.data_ptr() for s_ in srcs] + [None] * (4 - nsrc)))
         arr_s = (C.c_int32 * 4)(*(shifts + [0] * (4 - nsrc)))
-        call = lambda: lib.cp_hr_branch_chain_tail(st, B, Cc, H, W, nsrc, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), C.byref(tl))
+        # every name the loop rebinds is bound PER ITERATION (round 5 timed libs[1] against itself here: the lambda closed over the globals)
+        call = lambda lib=lib, blob=blob, out=out, tl=tl, arr_p=arr_p, arr_s=arr_s: lib.cp_hr_branch_chain_tail(
+            st, B, Cc, H, W, nsrc, arr_p, arr_s, 1, blob.data_ptr(), aff.data_ptr(), out.data_ptr(), C.byref(tl))
         assert call() == 0
         torch.cuda.synchronize()
         res.append(([out.float().clone()] + [o.float().clone() for o in touts], call, (blob, tb, tsh, tl, touts, out)))
