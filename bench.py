@@ -229,26 +229,41 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
     net32.clone_outputs = True
     img8 = det_image(8, seed=3).to(dev)
     ref = net32(img8, None)
-    net_bf16.clone_outputs = True
+    # measured on the launches the TIMED step is made of: the per-crop kernel selection (what "auto" picks at 256 crops: LDS-resident
+    # chains / EdgeConv / MLP stacks, keypoint side in IEEE half) pinned for this 8-crop batch -- "auto" would pick the small-batch kernels
+    net_pc = build(npoint).to(dev).set_compute_dtype("bf16")
+    net_pc.load_state_dict(net_bf16.state_dict())
+    net_pc.set_kernel_selection("per_crop")
+    net_pc.clone_outputs = True
     t = torch.zeros(8, 13, npoint, device=dev)
     t[:, 0:1], t[:, 1:7], t[:, 7:13] = ref[0], ref[1], ref[2]
-    forced = logit_agreement(net_bf16.forward_teacher_forced(img8, t), ref)
-    free = logit_agreement(net_bf16(img8, None), ref, tau=forced["tau"], explain=True, knn_idx=net_bf16.init_net.knn_idx)
-    net_bf16.clone_outputs = False
+    forced = logit_agreement(net_pc.forward_teacher_forced(img8, t), ref)
+    free = logit_agreement(net_pc(img8, None), ref, tau=forced["tau"], explain=True, knn_idx=net_pc.init_net.knn_idx)
+    half_on = bool(net_pc.program_for(8).progs[0].gnn_half)
+    del net_pc
     from checkerpose_amd.agreement import margin_contract_violations
     keep = ("bit_agreement_min_row", "bit_agreement_all_rows", "xy_id_equal", "id_abs_err_mean_px", "seg_agreement",
             "max_abs_dlogit", "mean_abs_dlogit", "logit_rms", "tau", "flips", "flips_above_margin", "max_flip_margin",
             "flip_rate_by_margin", "id_mismatches", "id_mismatches_explained_frac", "id_mismatches_from_subtau_self_flip",
             "id_mismatches_self_subtau_frac", "perturbed_coverage_by_stage", "tau_cap")
     ex["bf16_agreement"] = {"vs": "fp32 HIP path (oracle-pinned <= 1e-4) on 8 crops, random-init weights",
+                            "kernel_selection": "per_crop (the launches of the timed step)", "keypoint_side_half": half_on,
                             "margin_contract_violations": margin_contract_violations(forced, free),
                             "free_running": {k: free[k] for k in keep if k in free}, "free_running_rows": free["bit_agreement_per_row"],
                             "teacher_forced": {k: forced[k] for k in keep if k in forced}, "teacher_forced_rows": forced["bit_agreement_per_row"]}
     # ---- the same contract on TRAINED-LIKE weights: 300 steps of the HIP training program on a synthetic task whose targets are a
     #      function of the image (checkerpose_amd/trained_like.py), then bf16 vs fp32 eval on held-out crops (~15 s)
+    #      Deterministic training mode: the trained network is the same in every run.  `attribution`: each block group (backbone |
+    #      decoder | gnn) in bf16 ALONE against the fp32 path.  The contract itself is ASSERTED in tests/test_gpu_train_step.py and
+    #      checked by `tools/trained_like_stats.py` (non-zero exit on a violation); here it is reported.
     try:
+        import checkerpose_amd
         from checkerpose_amd.trained_like import train_then_measure
-        ex["bf16_agreement"]["trained_like"] = train_then_measure(npoint, device=dev)
+        checkerpose_amd.set_deterministic(True)
+        try:
+            ex["bf16_agreement"]["trained_like"] = train_then_measure(npoint, device=dev, attribution=(npoint == 512))
+        finally:
+            checkerpose_amd.set_deterministic(False)
     except Exception as e:          # an extra must never take the headline down
         ex["bf16_agreement"]["trained_like"] = {"error": repr(e)[:300]}
     torch.cuda.empty_cache()

@@ -96,20 +96,21 @@ __device__ __forceinline__ f32x4 cp_mma16(const u32x4& w, const u32x4& a, const 
   if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
 }
-// two floats -> one packed f16 pair, saturating, with the clamp on the PACKED result (v_cvt_pk_f16_f32 rounds an overflow to +-inf;
-// v_pk_min_f16 / v_pk_max_f16 bring it back to +-65504 in place: no temporaries -- the fmed3 form of pack_f16x2_sat cost the fused MLP
-// pair, which has no register to spare, 8 spilled VGPRs)
-__device__ __forceinline__ uint32_t pack_f16x2_sat_pk(float a, float b) {
+// Saturating f32 -> f16 conversions for free: MODE.FP16_OVFL (hwreg(HW_REG_MODE) bit 23) makes an f16 RESULT that overflows come out as
+// +-65504 instead of +-inf (true infinities stay infinite).  Verified on gfx950 for v_cvt_pk_f16_f32 and v_cvt_f16_f32
+// (tools/f16_probe/ovfl.hip: 1e6 -> 0x7bff, -1e6 -> 0xfbff, 65520 -> 0x7bff, inf -> 0x7c00).  The explicit clamps cost the fused EdgeConv
+// launch 3 of 69 us (v_pk_min_f16 + v_pk_max_f16 per pair in the barrier-bound epilogue; the fmed3 form also 8 spilled VGPRs in the
+// fused MLP pair).  MODE is per-wave state initialised at wave launch: a kernel that packs halves calls cp_f16_saturate_on() FIRST.
+__device__ __forceinline__ void cp_f16_saturate_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory"); }
+__device__ __forceinline__ uint32_t pack_f16x2_ovfl(float a, float b) {      // one v_cvt_pk_f16_f32; saturates under cp_f16_saturate_on()
   cp_h2 r;
   r.x = (_Float16)a;
   r.y = (_Float16)b;
-  const cp_h2 hi = {(_Float16)65504.f, (_Float16)65504.f}, lo = {(_Float16)-65504.f, (_Float16)-65504.f};
-  r = __builtin_elementwise_max(__builtin_elementwise_min(r, hi), lo);
   return __builtin_bit_cast(uint32_t, r);
 }
 template <bool H>
 __device__ __forceinline__ uint32_t cp_pack2(float lo, float hi) {
-  if constexpr (H) return pack_f16x2_sat_pk(lo, hi);
+  if constexpr (H) return pack_f16x2_ovfl(lo, hi);         // the kernel has called cp_f16_saturate_on()
   else return pack_bf16x2(lo, hi);
 }
 template <bool H>
@@ -117,7 +118,7 @@ __device__ __forceinline__ u32x4 cp_pack8(const float* f) {
   u32x4 v; v.x = cp_pack2<H>(f[0], f[1]); v.y = cp_pack2<H>(f[2], f[3]); v.z = cp_pack2<H>(f[4], f[5]); v.w = cp_pack2<H>(f[6], f[7]);
   return v;
 }
-__device__ __forceinline__ uint32_t f32_to_f16_bits_sat(float f) {
+__device__ __forceinline__ uint32_t f32_to_f16_bits_sat(float f) {      // explicit clamp: weight packers, scalar epilogues (no mode bit needed)
   return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }

@@ -627,6 +627,7 @@ static inline bool halo_wide(int Cout) { return Cout >= 256 && Cout % 256 == 0 &
 // zero padding); the generic kernel read every pixel row four times through the texture path (10 % of any roof at N = 4096).
 template <typename Tag, int NT, int KS = 3>
 __global__ __launch_bounds__(256) void conv3x3_halo_s_kernel(const HaloParams p) {
+  if (KS == 2 && p.seg_S == CP_F16) cp_f16_saturate_on();      // half output rows saturate at +-65504 (common.h)
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
   constexpr int ES = 16 / E;

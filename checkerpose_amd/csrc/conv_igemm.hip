@@ -55,6 +55,7 @@ template <> struct Mma<F16Tag> {
 
 template <typename Tag, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+  if (p.out_f32 == 2 || Tag::dtype == CP_F16) cp_f16_saturate_on();      // half output rows saturate at +-65504 (common.h)
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
   constexpr int ES = 16 / E;  // sizeof(elem)

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
   float* const sScale = (float*)(smem + EF_TABLE + 2 * EF_WBUF + EF_IDX);      // [2 Cout] then shift [2 Cout] at + 512
   float* const sShift = sScale + 512;
 
+  cp_f16_saturate_on();                                       // the f16 key pack (and the half output rows) saturate at +-65504: common.h
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,14 +130,14 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const EdgeFusedPara
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         u32x4 lo, hi;
-        lo.x = (pack_f16x2_sat(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
-        lo.y = (pack_f16x2_sat(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
-        lo.z = (pack_f16x2_sat(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
-        lo.w = (pack_f16x2_sat(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
-        hi.x = (pack_f16x2_sat(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
-        hi.y = (pack_f16x2_sat(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
-        hi.z = (pack_f16x2_sat(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
-        hi.w = (pack_f16x2_sat(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+        lo.x = (pack_f16x2_ovfl(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+        lo.y = (pack_f16x2_ovfl(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+        lo.z = (pack_f16x2_ovfl(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+        lo.w = (pack_f16x2_ovfl(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+        hi.x = (pack_f16x2_ovfl(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+        hi.y = (pack_f16x2_ovfl(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+        hi.z = (pack_f16x2_ovfl(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+        hi.w = (pack_f16x2_ovfl(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
         unsigned char* dst = sP + (2 * q) * EF_PLANE + (wave * 64 + f * 16 + x) * 16;       // 16 consecutive rows: 16 slots
         *(u32x4*)dst = lo;
         *(u32x4*)(dst + EF_PLANE) = hi;

@@ -47,6 +47,7 @@ __device__ __forceinline__ void crop_patch(int NB, int B, int& b, int& t) {
 // weights: the P halves of cp_pack_edgeconv_fused_weight's image ([64-channel slice][half][32-deep chunk][tile][lane][8 bf16])
 template <int CIN, bool H = false>                            // H: x rows and weights in IEEE half (CP_F16; common.h cp_mma16); the keys are halves either way
 __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledParams p) {
+  cp_f16_saturate_on();                                       // the f16 key pack saturates at +-65504 (common.h)
   constexpr int KC = CIN / 32;
   constexpr int HALF = KC * 4 * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       u32x4 lo, hi;
-      lo.x = (pack_f16x2_sat(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
-      lo.y = (pack_f16x2_sat(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
-      lo.z = (pack_f16x2_sat(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
-      lo.w = (pack_f16x2_sat(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
-      hi.x = (pack_f16x2_sat(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
-      hi.y = (pack_f16x2_sat(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
-      hi.z = (pack_f16x2_sat(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
-      hi.w = (pack_f16x2_sat(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
+      lo.x = (pack_f16x2_ovfl(acc[f][0][0] * sc[0], acc[f][0][1] * sc[1]));
+      lo.y = (pack_f16x2_ovfl(acc[f][0][2] * sc[2], acc[f][0][3] * sc[3]));
+      lo.z = (pack_f16x2_ovfl(acc[f][1][0] * sc[4], acc[f][1][1] * sc[5]));
+      lo.w = (pack_f16x2_ovfl(acc[f][1][2] * sc[6], acc[f][1][3] * sc[7]));
+      hi.x = (pack_f16x2_ovfl(acc[f][2][0] * sc[8], acc[f][2][1] * sc[9]));
+      hi.y = (pack_f16x2_ovfl(acc[f][2][2] * sc[10], acc[f][2][3] * sc[11]));
+      hi.z = (pack_f16x2_ovfl(acc[f][3][0] * sc[12], acc[f][3][1] * sc[13]));
+      hi.w = (pack_f16x2_ovfl(acc[f][3][2] * sc[14], acc[f][3][3] * sc[15]));
       const size_t r = (size_t)t * ET_BLK + wave * 64 + f * 16 + x;
       unsigned char* dst = tab + ((size_t)(8 * s + 2 * q) * p.N + r) * 16;
       *(u32x4*)dst = lo;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(512) void edgeconv_ptable_kernel(const EdgeTiledPar
 // 32 s + 8 q + 4 nt + reg
 template <int CIN, bool DB, bool H = false>
 __global__ __launch_bounds__(512) void edgeconv_tiled_kernel(const EdgeTiledParams p) {
+  if constexpr (H) cp_f16_saturate_on();
   constexpr int KC = CIN / 32;
   constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
   constexpr int NTAB = DB ? 2 : 1;
@@ -380,6 +382,7 @@ __device__ __forceinline__ void lds_only_barrier() {
 
 template <int CIN, bool H = false>
 __global__ __launch_bounds__(512) void edgeconv_tiled2_kernel(const EdgeTiledParams p) {
+  if constexpr (H) cp_f16_saturate_on();
   constexpr int KC = CIN / 32;
   constexpr int WQ = KC * 2 * 1024;                                 // bytes of one slice of Q weights
   constexpr int WH = WQ / 2, KH = KC / 2;                           // one K half: bytes, chunks

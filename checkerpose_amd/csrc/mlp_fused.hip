@@ -37,6 +37,7 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 
 template <bool H>                                              // H: rows, weights and hidden rows in IEEE half (CP_F16; common.h cp_mma16)
 __global__ __launch_bounds__(512) void mlp_query_fused_kernel(const MlpQueryParams p) {
+  if constexpr (H) cp_f16_saturate_on();                     // half packs saturate at +-65504 (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sX = smem;                             // 2 x MQ_BUF
   unsigned char* const sH = smem + 2 * MQ_BUF;                // 2 x MQ_BUF
@@ -292,6 +293,7 @@ __device__ __forceinline__ int mp_lane(int lane) {
 
 template <int NI, bool GATHER = false, bool H = false>       // DMA instructions per layer-1 wave and tile = P / 16: 4 / 3 / 2; H: IEEE half (CP_F16)
 __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams p) {
+  if constexpr (H) cp_f16_saturate_on();                     // half packs saturate at +-65504 (common.h)
   static_assert(!GATHER || NI >= 3, "the gathering loader moves one row (48 or 64 pieces) per DMA instruction");
   constexpr int ND = GATHER ? 4 : NI;                         // DMA instructions per layer-1 wave and tile (gathering: its 4 rows, P lanes each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -27,6 +27,7 @@ struct PatchParams {
 
 template <bool HOUT>                                           // HOUT: the output rows leave as IEEE half (CP_F16: the keypoint side's storage type)
 __global__ __launch_bounds__(512) void patch_gather_kernel(const PatchParams p) {
+  if constexpr (HOUT) cp_f16_saturate_on();                  // half output rows saturate at +-65504 (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -296,27 +296,34 @@ def test_train_mode_accepts_uint8_crops():
         assert float((a - b).abs().max()) <= 1e-5 * (1 + float(b.abs().max()))
 
 
-def test_bf16_contract_on_trained_like_weights():
+@pytest.mark.parametrize("seed", [1, 4])
+def test_bf16_contract_on_trained_like_weights(seed):
     """checkerpose_amd/trained_like.py: 300 steps of the HIP training program (train.py:300-320's step sequence, bf16, B = 32) on the
-    synthetic translation task -- the loss must fall, the network must generalise to held-out crops -- then the bf16 eval path against
-    the fp32 eval path of the SAME trained weights.  The training step accumulates with atomics, so the trained weights -- and every
-    statistic below -- differ from run to run (the recorded runs: profiles/r05_trained_like_*.json; a 120-step network has 14 % of its
-    logits within 0.05 of zero and its free-running id agreement moved between 0.88 and 0.95).  Asserted here with room for that: the
-    hard clause of the margin contract with 50 % slack (the contract itself, 0.2 or 4 % of the logit RMS, is evaluated by
-    `margin_contract_violations` and reported in bench.py's line), no teacher-forced flip at a margin of 1 or more, the row / id
-    agreement floors, and the free-running id mismatches traced to upstream near-ties."""
+    synthetic translation task -- the loss must fall, the network must generalise to held-out crops -- then the bf16 eval path (the
+    bench's kernel selection: keypoint side in IEEE half) against the fp32 eval path of the SAME trained weights.  Training runs in
+    the deterministic mode (cp_set_deterministic), so the trained network -- and every statistic below -- is the same in every run.
+    Asserted with the contract's OWN clauses (agreement.margin_contract_violations == [], no slack) and its floors: teacher-forced
+    rows >= 98 %, seg >= 99 %, mean |dlogit| <= 2 % of the logit RMS; free-running rows >= 95 %, final id pairs >= 90 %.  Recorded:
+    profiles/r06_trained_like_*.json (seeds 1-5 at 300 steps and seed 1 at 3 000 steps: no violation in any; seed 4 is the run
+    with the lowest free-running agreement)."""
+    import checkerpose_amd
     from checkerpose_amd.trained_like import train_then_measure
-    r = train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, held_out=4)
+    checkerpose_amd.set_deterministic(True)
+    try:
+        r = train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=seed, held_out=8)
+    finally:
+        checkerpose_amd.set_deterministic(False)
     ls = r["loss_every_25_steps"]
     assert ls[-1] < 0.5 * ls[0], ls
     assert r["held_out"]["roi_bit_accuracy_vs_gt"] >= 0.9, r["held_out"]
     tf, fr = r["teacher_forced"], r["free_running"]
-    print("trained-like:", r["held_out"], "violations:", r["margin_contract_violations"],
-          "tf max flip margin %.3f (rms %.2f)" % (tf["max_flip_margin"], tf["logit_rms"]), "fr id equal %.4f" % fr["xy_id_equal"])
-    assert tf["max_flip_margin"] < 1.5 * max(0.2, 0.04 * tf["logit_rms"]) and tf["flip_rate_by_margin"]["1-inf"]["flips"] == 0, tf
-    assert tf["bit_agreement_min_row"] >= 0.97 and tf["seg_agreement"] >= 0.99 and tf["mean_abs_dlogit_over_rms"] <= 0.02, tf
-    assert fr["bit_agreement_min_row"] >= 0.90 and fr["xy_id_equal"] >= 0.80 and fr["id_abs_err_mean_px"] <= 1.0, fr
-    assert fr["id_mismatches_explained_frac"] >= 0.90, fr
+    print("trained-like seed %d:" % seed, r["held_out"], "violations:", r["margin_contract_violations"],
+          "tf max flip margin %.3f = %.2f x mean (rms %.2f)" % (tf["max_flip_margin"], tf["max_flip_margin"] / tf["mean_abs_dlogit"], tf["logit_rms"]),
+          "fr id equal %.4f" % fr["xy_id_equal"])
+    assert r["margin_contract_violations"] == [], r["margin_contract_violations"]
+    assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99 and tf["mean_abs_dlogit_over_rms"] <= 0.02, tf
+    assert tf["max_abs_dlogit"] <= 0.5 and tf["flip_rate_by_margin"]["0.2-1"]["flips"] == 0 and tf["flip_rate_by_margin"]["1-inf"]["flips"] == 0, tf
+    assert fr["bit_agreement_min_row"] >= 0.95 and fr["xy_id_equal"] >= 0.90 and fr["id_abs_err_mean_px"] <= 0.5, fr
 
 
 def _train_steps(steps, deterministic, seed=1, batch=8):

@@ -35,3 +35,4 @@ if __name__ == "__main__":
                   fr.get("id_mismatches_self_subtau_frac", 1.0), r["margin_contract_violations"]), flush=True)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(res, open(a.out, "w"))
+    sys.exit(1 if any(r["margin_contract_violations"] for r in res) else 0)          # the dedicated check: a violation fails the call
