@@ -100,6 +100,7 @@ class CpWgradDesc(C.Structure):
 # name -> (restype, argtypes); exactly the symbols declared in include/checkerpose_hip.h
 SIGNATURES = {
     "cp_version": (_I, []),
+    "cp_device_status": (_I, [_P, _I]),
     "cp_set_deterministic": (None, [_I]),
     "cp_get_deterministic": (_I, []),
     "cp_strerror": (C.c_char_p, [_I]),
@@ -293,6 +294,26 @@ def load():
             lib.cp_set_deterministic(1)
         _lib = lib
     return _lib
+
+
+STATUS_BITS = {1: "CP_STATUS_CHAIN0_HANDOVER: the pipelined 64 x 64 HRNet chain (hr_chain0p_kernel) gave up a bounded wait for a row "
+                  "hand-over between its waves -- the outputs of that forward are wrong",
+               2: "CP_STATUS_CHAIN0_STAGING: hr_chain0p_kernel's staging / tail loop ran out of its bound before finishing its rows"}
+
+
+def device_status(clear=True):
+    """the current device's sticky status word (include/checkerpose_hip.h: cp_device_status); synchronises the device"""
+    w = C.c_uint32(0)
+    check(load().cp_device_status(C.byref(w), 1 if clear else 0), "cp_device_status")
+    return int(w.value)
+
+
+def raise_on_device_status(where=""):
+    """RuntimeError if a kernel reported a failure of its own since the last look (the word is cleared: the error is raised once)"""
+    w = device_status(clear=True)
+    if w:
+        msgs = [m for b, m in STATUS_BITS.items() if w & b] or ["unknown bits"]
+        raise RuntimeError("checkerpose_hip: device status %#x%s -- %s" % (w, (" (" + where + ")") if where else "", "; ".join(msgs)))
 
 
 def check(code, what=""):

@@ -12,6 +12,32 @@ std::atomic<int> g_cp_deterministic{0};
 extern "C" void cp_set_deterministic(int on) { g_cp_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int cp_get_deterministic(void) { return g_cp_deterministic.load(std::memory_order_relaxed); }
 
+// ---- device-side error channel: ONE sticky uint32 per device (allocated on the first call of that device, outside any capture),
+// OR-ed into by kernels that can detect a failure of their own (bit list: include/checkerpose_hip.h), read back by cp_device_status()
+static std::atomic<uint32_t*> g_status_word[256];
+uint32_t* cp_status_word(bool create) {
+  const int dev = cp_current_device();
+  if (dev < 0 || dev > 255) return nullptr;
+  uint32_t* p = g_status_word[dev].load(std::memory_order_acquire);
+  if (p || !create) return p;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(nullptr, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+  uint32_t* q = nullptr;
+  if (hipMalloc((void**)&q, 256) != hipSuccess) return nullptr;
+  if (hipMemset(q, 0, 256) != hipSuccess) { (void)hipFree(q); return nullptr; }
+  uint32_t* expect = nullptr;
+  if (!g_status_word[dev].compare_exchange_strong(expect, q, std::memory_order_acq_rel)) { (void)hipFree(q); return expect; }
+  return q;
+}
+extern "C" int cp_device_status(uint32_t* status_out, int clear) {
+  if (!status_out) return CP_ERR_INVALID;
+  uint32_t* p = cp_status_word(true);
+  if (!p) return CP_ERR_HIP;
+  if (hipMemcpy(status_out, p, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CP_ERR_HIP;      // synchronises with the device
+  if (clear && *status_out && hipMemset(p, 0, sizeof(uint32_t)) != hipSuccess) return CP_ERR_HIP;
+  return CP_OK;
+}
+
 static thread_local char g_last_kernel[128] = "";
 static thread_local char g_kernel_log[1024] = "";   // every symbol since cp_kernel_log_begin(), " + " between them
 void cp_mark_kernel(const char* fmt, ...) {

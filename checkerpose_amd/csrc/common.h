@@ -203,6 +203,9 @@ static inline const char* cp_knob(const char*) { return nullptr; }
 // cp_set_deterministic(): the training entry points then accumulate in a fixed order (no floating-point atomics)
 extern std::atomic<int> g_cp_deterministic;
 static inline bool cp_deterministic() { return g_cp_deterministic.load(std::memory_order_relaxed) != 0; }
+// device-side error channel (api.hip): the current device's sticky status word, or nullptr (not created yet and `create` false / a capture
+// is under way); kernels that get a non-null pointer atomicOr their failure bit into it
+uint32_t* cp_status_word(bool create);
 // profiling aid (cp_last_kernel): every launch site records the symbol it launches, spelled as rocprofv3 prints it
 void cp_mark_kernel(const char* fmt, ...);
 #define CP_LAUNCH(kernel, ...) do { cp_mark_kernel("%s", #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)

@@ -48,6 +48,8 @@ struct Chain0Params {
   const void* tw;         // [slab][7][2][64][16 B], BN scale folded in, zero rows beyond a conv's channels
   const float* tshift;    // [ZTAIL_CH] folded-BN shift per combined channel
   void* tout[3];          // (B, 32, 32, tcph[i]) bf16
+  uint32_t* status;       // the device's sticky status word (api.hip) or nullptr: a bounded wait that runs out ORs its bit in
+  int dbg_spin_limit;     // 0 = the shipped bounds; KNOBS builds: CP_C0_FORCE_TIMEOUT=n bounds every hand-over wait to n polls (test hook)
 };
 constexpr int ZTAIL_CH = 96;
 
@@ -390,14 +392,21 @@ static_assert(PLDS <= 160 * 1024, "LDS budget");
 typedef __attribute__((address_space(3))) volatile uint32_t p_cnt_t;     // the counters are read / written with DS instructions (a generic
                                                                           // volatile pointer compiles to FLAT loads: slow, and every LDS wait becomes lgkmcnt(0))
 __device__ __forceinline__ int p_peek(const p_cnt_t* c) { return (int)__builtin_amdgcn_readfirstlane(*c); }
-__device__ __forceinline__ void p_wait(const p_cnt_t* c, int need) {     // bounded: a lost hand-over ends in wrong numbers, not in a hung box
-  for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+// bounded: a lost hand-over must not hang the box -- and must not pass silently either: the wave that gives up ORs
+// CP_STATUS_CHAIN0_HANDOVER into the device's status word (the launch's numbers are wrong from here on; the host raises when it looks)
+__device__ __forceinline__ void p_wait(const p_cnt_t* c, int need, const Chain0Params& p) {
+  const uint32_t limit = p.dbg_spin_limit > 0 ? (uint32_t)p.dbg_spin_limit : (1u << 20);
+  uint32_t spin = 0;
+  for (; spin < limit; ++spin) {
     if (p_peek(c) >= need) break;
 #ifdef CP_C0_SPIN
     __builtin_amdgcn_s_sleep(CP_C0_SPIN);
 #else
     __builtin_amdgcn_s_sleep(1);
 #endif
+  }
+  if (spin == limit && p.status && p_peek(c) < need) {
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicOr(p.status, (uint32_t)CP_STATUS_CHAIN0_HANDOVER);
   }
   asm volatile("" ::: "memory");
 }
@@ -564,6 +573,7 @@ __device__ __forceinline__ void p_stage_and_tail(const Chain0Params& p, unsigned
     }
     if (!did) __builtin_amdgcn_s_sleep(1);
   }
+  if ((ys < ZH || oy < ZH / 2) && p.status && lane == 0) atomicOr(p.status, (uint32_t)CP_STATUS_CHAIN0_STAGING);      // ran out of its bound
 }
 
 __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
@@ -640,8 +650,8 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
     Z_MARK(0);                         // (loop overhead)
     if (s == 0) {                                                   // ring 0 arrives in PSW parts
 #pragma unroll
-      for (int k = 0; k < PSW; ++k) p_wait(cnt + PC_PART + k, need);
-    } else p_wait(cnt + s, need);
+      for (int k = 0; k < PSW; ++k) p_wait(cnt + PC_PART + k, need, p);
+    } else p_wait(cnt + s, need, p);
     Z_MARK(1);                         // waiting for the input rows
     uint32_t rb[3];                                                 // ring rows of the three tap rows (uniform)
 #pragma unroll
@@ -717,9 +727,9 @@ __global__ __launch_bounds__(PNT) void hr_chain0p_kernel(const Chain0Params p) {
       // tail row (j + 1) / 2)
       if (y >= dout) {
         if (s == 7) {
-          for (int k = 0; k < nslab; ++k) p_wait(cnt + PC_TAIL + k, (y - dout + 1) / 2 + 1);
-        } else if (second) p_wait(cnt + PC_CONS + s + 2, y - (dout - 1));
-        else p_wait(cnt + PC_CONS + s + 1, y - (dout - 2));
+          for (int k = 0; k < nslab; ++k) p_wait(cnt + PC_TAIL + k, (y - dout + 1) / 2 + 1, p);
+        } else if (second) p_wait(cnt + PC_CONS + s + 2, y - (dout - 1), p);
+        else p_wait(cnt + PC_CONS + s + 1, y - (dout - 2), p);
       }
       Z_MARK(4);                       // waiting for the output slot
       const uint32_t ro = rout + p_slot(s + 1, y);
@@ -811,6 +821,8 @@ int cp_chain0_launch(hipStream_t st, int B, int nsrc, const void* const* srcs, c
   Chain0Params p = {};
   for (int k = 0; k < 4; ++k) { p.src[k] = k < nsrc ? srcs[k] : nullptr; p.shift[k] = k < nsrc ? shifts[k] : 0; }
   p.nsrc = nsrc; p.relu_in = relu_in ? 1 : 0; p.w = packed_w; p.aff = affine; p.out = out; p.B = B;
+  p.status = cp_status_word(true);      // (nullptr while a capture is under way and the word does not exist yet: the models create it first)
+  p.dbg_spin_limit = cp_knob("CP_C0_FORCE_TIMEOUT") ? atoi(cp_knob("CP_C0_FORCE_TIMEOUT")) : 0;
   if (tail) {
     if (tail->nconv < 1 || tail->nconv > 3 || !tail->packed_w || !tail->shift) return CP_ERR_INVALID;
     if (!cp_aligned16(tail->packed_w) || !cp_aligned16(tail->shift)) return CP_ERR_ALIGN;

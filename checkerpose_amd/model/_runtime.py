@@ -197,9 +197,17 @@ class HipForwardMixin:
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
     # ---- cache control
+    def check_device_status(self):
+        """Raise if a kernel reported a failure of its own (include/checkerpose_hip.h: cp_device_status) since the last look.
+        Synchronises the device.  Called by the model wherever it synchronises anyway (program build, invalidate()); call it
+        yourself behind a batch of forwards whose results matter."""
+        with torch.cuda.device(next(self.parameters()).device):
+            _abi.raise_on_device_status(type(self).__name__)
+
     def invalidate(self):
         """Drop packed weights / programs (called on load_state_dict, .to()/.cuda(), dtype change)."""
         lib = _abi._lib
+        had_programs = bool(getattr(self, "_programs", None) or getattr(self, "_train_programs", None))
         for pr in getattr(self, "_programs", {}).values():
             if pr.get("graph") and lib is not None:
                 for g in pr["graph"]:
@@ -212,6 +220,10 @@ class HipForwardMixin:
         self._train_programs = {}
         self._sig_tensors = None
         self._tiled = None
+        p0 = next(self.parameters(), None)
+        if had_programs and lib is not None and p0 is not None and p0.is_cuda:     # the programs that ran: did one of their kernels report a failure?
+            with torch.cuda.device(p0.device):
+                _abi.raise_on_device_status("%s.invalidate()" % type(self).__name__)
         # the owning PoseNet folded this init net's weights into ITS programs, and vice versa: drop those too
         for other in (getattr(self, "_owner", None), getattr(self, "init_net", None)):
             other = other() if callable(other) and not isinstance(other, torch.nn.Module) else other
@@ -375,6 +387,7 @@ class HipForwardMixin:
         prog = ProgramGroup(progs)
         torch.cuda.current_stream(device).synchronize()      # weight packing done before temporaries die
         ws.keep.clear()
+        _abi.raise_on_device_status("building a program")   # also creates the device's status word BEFORE any launch / capture
         return dict(prog=prog, io=io, graph=None, warm=False, side=None)
 
     def _tile_tables(self, lib, B, N, idx_dev, device):

@@ -68,6 +68,17 @@ const char* cp_kernel_log(void);
 void cp_set_deterministic(int on);
 int cp_get_deterministic(void);
 
+/* Device-side error channel: one sticky status word per device, OR-ed into by kernels that can detect a failure of their own, read by
+ * the host wherever it synchronises anyway (the drop-in models: program build, invalidate(), check_device_status()).  The call
+ * synchronises the device (a plain hipMemcpy), creates the word on first use (call it once OUTSIDE a stream capture before launching
+ * -- the models do) and, with clear != 0, resets a non-zero word.  Bits:
+ *   CP_STATUS_CHAIN0_HANDOVER  the pipelined 64 x 64 chain (cp_hr_branch_chain*, hr_chain0p_kernel) gave up a bounded wait for a row
+ *                              hand-over between its waves: that launch's output is WRONG (the bound keeps the box alive, this bit
+ *                              keeps the result honest)
+ *   CP_STATUS_CHAIN0_STAGING   the same kernel's staging / tail loop ran out of its bound before finishing its rows */
+enum { CP_STATUS_CHAIN0_HANDOVER = 1, CP_STATUS_CHAIN0_STAGING = 2 };
+int cp_device_status(uint32_t* status_out, int clear);
+
 /* elements per 16 bytes: 4 (f32) or 8 (bf16).  Physical channel counts are multiples of this. */
 int cp_chan_align(int dtype);
 
