@@ -445,6 +445,50 @@ def self_launch(script, n):
     return subprocess.call(cmd, env=env)
 
 
+def gpu_local_cpus(index, sysfs="/sys/class/drm"):
+    """the host cores next to the `index`-th AMD GPU of this node: `local_cpulist` of its PCI device (sysfs; display-class AMD
+    devices in PCI bus order, the order ROCm enumerates them in) -> sorted core list, or None when sysfs does not say.
+    Pure file reads: no GPU call."""
+    import glob
+    devs = {}
+    for card in glob.glob(os.path.join(sysfs, "card[0-9]*")):
+        d = os.path.join(card, "device")
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                continue
+            if not open(os.path.join(d, "class")).read().strip().startswith(("0x03", "0x12")):      # display / processing accelerator
+                continue
+            devs[os.path.basename(os.path.realpath(d))] = open(os.path.join(d, "local_cpulist")).read().strip()
+        except OSError:
+            continue
+    if index >= len(devs):
+        return None
+    cpus = set()
+    for part in devs[sorted(devs)[index]].split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus) or None
+
+
+def pin_rank_to_gpu_numa_node(local_rank, world):
+    """N > 1: bind this rank's host threads to the cores of its GPU's NUMA node BEFORE the first GPU call (the PCIe-inclusive legs --
+    `host_u8`, the data-parallel step's host side -- then feed each GPU from local memory).  Returns what was done, for the line."""
+    if world <= 1 or os.environ.get("CHECKERPOSE_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = gpu_local_cpus(local_rank)
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(set(cpus or ()) & allowed)
+        if not cpus or len(cpus) == len(allowed):
+            return None
+        os.sched_setaffinity(0, cpus)
+        return "%d cores: %d-%d" % (len(cpus), cpus[0], cpus[-1])
+    except (OSError, ValueError):
+        return None
+
+
 class Ranks:
     """This process's place in the job: torchrun's environment, the process group, the device."""
 
@@ -454,6 +498,7 @@ class Ranks:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = os.environ.get("CHECKERPOSE_BENCH_BACKEND", "nccl")    # "gloo": exercise the N>1 path on a 1-GPU box / on CPU
         self.dist, self.dev = None, None
+        self.cpu_affinity = pin_rank_to_gpu_numa_node(self.local, self.world) if self.backend == "nccl" else None   # before any GPU call
         if not dry_run:
             ndev = torch.cuda.device_count()
             if self.world > 1 and self.backend == "nccl" and ndev < self.world:
@@ -774,7 +819,8 @@ def main():
            "config": {"workload": wl["name"] + ", PoseNet_GNNskip forward, deterministic random-init weights",
                       "crops_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d (no forward collective)" % world,
                       "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls)},
-           "ranks_seen": seen, "per_rank_ms": per_rank, "backend": rk.backend if world > 1 else None}
+           "ranks_seen": seen, "per_rank_ms": per_rank, "backend": rk.backend if world > 1 else None,
+           "cpu_affinity": rk.cpu_affinity}
     if a.workload == "ycbv_rr21":
         out["config"]["streams"] = max(a.streams, 1)
     if rank == 0:

@@ -41,5 +41,35 @@ def main(stats_dir, fetch_dir, write_dir, out_prefix):
     print(open(out_prefix + "_kernel_summary.csv").read())
 
 
+def sq_missing(bench_json, sq_csv):
+    """kernel symbols of a bench line (`kernel_symbols`: the launches the timed step spends its time in) that have NO row in an SQ
+    counter file (tools/pmc_sq.sh) -- round 5 committed counters of a build that was no longer the launched one.  The bench line
+    collapses the chain instances to `hr_chain_kernel<Cfg, true>`: any `hr_chain_kernel<ChainCfg<...>, true>` row covers it."""
+    import json
+    txt = open(bench_json).read()
+    line = [ln for ln in txt.splitlines() if ln.startswith("{")][-1]
+    syms = list(json.loads(line).get("kernel_symbols", {}))
+    have = [r["kernel"] for r in csv.DictReader(open(sq_csv))]
+
+    def covered(sym):
+        for part in sym.split(" + "):                                  # a call that issues several launches
+            base = part.split("<")[0]
+            if "<Cfg" in part:
+                tail = part.split("<Cfg", 1)[1]                          # e.g. ", true>"
+                ok = any(h.startswith(base + "<ChainCfg<") and h.endswith(tail) for h in have)
+            else:
+                ok = any(h == part or h.startswith(part) or part.startswith(h) for h in have)   # (the SQ file cuts names at 64 characters)
+            if not ok:
+                return False
+        return True
+    return [s_ for s_ in syms if not covered(s_)]
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    if len(sys.argv) > 1 and sys.argv[1] == "check":                     # python profiles/summarize.py check <bench line .json> <sq counters .csv>
+        miss = sq_missing(sys.argv[2], sys.argv[3])
+        if miss:
+            sys.exit("SQ counter file %s has no row for: %s" % (sys.argv[3], "; ".join(miss)))
+        print("every kernel symbol of %s has SQ counters in %s" % (sys.argv[2], sys.argv[3]))
+    else:
+        main(*sys.argv[1:5])

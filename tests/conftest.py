@@ -18,6 +18,13 @@ def lib():
     return _abi.load()
 
 
+def dp_child_plan(ndev):
+    """(backend, ranks) of the data-parallel child job: a node with several GPUs runs one rank per GPU over RCCL ("nccl" IS RCCL on
+    ROCm: the gradient all-reduce over xGMI that BASELINE config #3 names), up to 8; a 1-GPU box rehearses the same code with two
+    ranks sharing the GPU over gloo"""
+    return ("nccl", min(int(ndev), 8)) if int(ndev) >= 2 else ("gloo", 2)
+
+
 def pytest_sessionstart(session):
     """`-m gpu` sessions on a GPU box: start the 2-rank data-parallel child job of tests/test_gpu_zz_dp.py NOW, before anything in
     this process touches the GPU (torch.cuda.device_count() does not initialise it on this image)."""
@@ -33,20 +40,23 @@ def pytest_sessionstart(session):
         return
     try:
         import torch
-        if torch.cuda.device_count() < 1:
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
             return
     except Exception:
         return
+    backend, nproc = dp_child_plan(ndev)
+    cfg._dp_plan = (backend, nproc)
     import socket
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     log = tempfile.NamedTemporaryFile(prefix="dp_child_", suffix=".log", delete=False)
-    env = dict(os.environ, CHECKERPOSE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CHECKERPOSE_BENCH_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     # one child shell, two jobs one after the other (never more than two extra processes on the GPU): the 2-rank training step, then
     # `python bench.py --gpus 2` launching its OWN two ranks (no torchrun environment: bench.self_launch), a tiny batch
     env_clean = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = ("%s -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port %d %s; rc=$?; "
-           "%s %s --gpus 2 --batch 8 --steps 3 --warmup 2 --no-extras --no-cpu-baseline --no-breakdown; echo BENCH_SELF_LAUNCH_RC=$?; exit $rc"
-           % (sys.executable, port, os.path.join(ROOT, "tests", "dp_step_child.py"), sys.executable, os.path.join(ROOT, "bench.py")))
+    cmd = ("%s -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port %d %s; rc=$?; "
+           "%s %s --gpus %d --batch 8 --steps 3 --warmup 2 --no-extras --no-cpu-baseline --no-breakdown; echo BENCH_SELF_LAUNCH_RC=$?; exit $rc"
+           % (sys.executable, nproc, port, os.path.join(ROOT, "tests", "dp_step_child.py"), sys.executable, os.path.join(ROOT, "bench.py"), nproc))
     proc = subprocess.Popen(["bash", "-c", cmd], stdout=log, stderr=subprocess.STDOUT, env=env_clean, cwd=ROOT)
     cfg._dp_child = (proc, log.name)
 

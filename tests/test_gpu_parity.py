@@ -1555,8 +1555,8 @@ _ORACLE_CACHE = {}
 
 
 def _lm4096_case():
-    """config #5's test case (LM twin, 4096 keypoints, seed 2, objects LM_OBJ_IDS[3] / [11]) and its CPU-oracle forward, computed
-    once per session: three tests share it (fp32 e2e, bf16 contract on both EdgeConv paths) and the oracle takes ~10 s"""
+    """config #5's full-network case (LM twin, 4096 keypoints, seed 2, objects LM_OBJ_IDS[3] / [11]) and its CPU-oracle forward,
+    computed once per session (the oracle takes ~10 s)"""
     if "lm4096" not in _ORACLE_CACHE:
         from tests.common import LM_OBJ_IDS
         obj = torch.tensor([LM_OBJ_IDS[3], LM_OBJ_IDS[11]])
@@ -1567,6 +1567,20 @@ def _lm4096_case():
     obj, sd, img, ref = _ORACLE_CACHE["lm4096"]
     net = build_net(npoint=4096, seed=2, lm=True)
     return obj, net, img, ref
+
+
+def _lm4096_golden_case():
+    """config #5's REFERENCE-made case: the head (everything the reference's own code pins) on injected backbone features with the
+    repaired weights of `e2e_lm4096_injected` (every one of its 13 x B x 4096 logits >= 1e-3 from zero, tests/golden/make_golden.py:
+    center_and_repair) -- the 6-tuple the reference's PoseNet_GNNskip_LM produced is the comparison target, no oracle in between.
+    -> (obj_ids, net, feats, ref 6-tuple of CPU tensors)"""
+    g = golden("e2e_lm4096_injected")
+    net = build_net(npoint=4096, seed=int(g["seed"]), lm=True, overrides=g)
+    feats = inject_feats(2, seed=2)
+    obj = torch.from_numpy(g["obj_ids"])
+    ref = tuple(torch.from_numpy(g[k]) for k in ("roi", "xb", "yb", "seg", "xid", "yid"))
+    assert float(g["margin"]) >= 5e-4
+    return obj, net, feats, ref
 
 
 def _teacher_bits(ref):
@@ -1587,9 +1601,16 @@ def test_e2e_lm13_n4096_config5(lib):
     net = net.to(dev())
     out_t = net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()), obj_ids=obj.to(dev()))
     _cmp_e2e(out_t, ref)
+    # free-running: this seed's smallest decision margin (5.6e-5) is BELOW the 1e-4 tolerance, so a legitimate fp32 difference may
+    # flip that decision and everything downstream of it.  Compared where the comparison is meaningful: ids must be equal on every
+    # keypoint whose own decision logits all clear 2e-4 in a crop whose EVERY decision clears it; the logits of such crops at 1e-4.
+    # (The reference-pinned free-running check of config #5 at a 1e-3 margin is test_e2e_head_vs_reference_golden_direct.)
     out = net(img.to(dev()), None, obj.to(dev()))
-    if margin > 4e-5:
-        _cmp_e2e(out, ref)
+    clear = z.abs().amin(dim=(1, 2)) > 2e-4                           # per crop
+    print("config #5 full net: decision margin %.2e, crops with every decision beyond 2e-4: %s" % (margin, clear.tolist()))
+    for b in range(z.shape[0]):
+        if bool(clear[b]):
+            _cmp_e2e([t[b:b + 1] for t in out], [t[b:b + 1] for t in ref])
     assert tuple(out[1].shape) == (2, 6, 4096) and out[4].dtype == torch.int64
 
 
@@ -1634,7 +1655,8 @@ def test_e2e_bf16_accuracy_contract(lib, monkeypatch, chain):
 @pytest.mark.parametrize("tiled", [False, True])
 def test_e2e_bf16_accuracy_contract_n4096_lm(lib, monkeypatch, tiled):
     """The same written contract on BASELINE config #5 in the dtype `bench.py --workload lm13_n4096` times: LM shared estimator,
-    per-sample graphs, npt=4096, bf16, against the CPU oracle (pinned for this config by knn_lm4096 + e2e_lm4096_injected);
+    per-sample graphs, npt=4096, bf16, against the REFERENCE's own 6-tuple of `e2e_lm4096_injected` (injected backbone features,
+    repaired weights: every logit >= 1e-3 from zero -- the decision margin no longer sits below the tolerance);
     both EdgeConv paths: node GEMM + L2 gather (small batches) and the patch-tiled LDS-staged launches (cp_edgeconv_tiled: the
     program then runs in the internal patch order, so this also covers the row renumbering and the un-permuted outputs)."""
     from checkerpose_amd import engine
@@ -1642,15 +1664,17 @@ def test_e2e_bf16_accuracy_contract_n4096_lm(lib, monkeypatch, tiled):
     from tests.common import LM_OBJ_IDS
     monkeypatch.setattr(engine, "EDGE_FUSED_MIN_BATCH", 1 if tiled else 1 << 30)
     monkeypatch.setattr(engine, "MLP_FUSED_MIN_ROWS", 1 if tiled else 1 << 30)
-    obj, net, img, ref = _lm4096_case()
+    obj, net, feats, ref = _lm4096_golden_case()                      # reference-made 6-tuple, every logit >= 1e-3 from zero
     net = net.to(dev()).set_compute_dtype("bf16")
-    tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), _teacher_bits(ref).to(dev()), obj_ids=obj.to(dev())), ref)
-    fr = logit_agreement(net(img.to(dev()), None, obj.to(dev())), ref, tau=tf["tau"], explain=True, knn_idx=net.init_net.knn_idx,
-                         graph_ids=obj - 1)
+    img = torch.zeros(2, 3, 256, 256, device=dev())
+    fd = [f.to(dev()) for f in feats]
+    tf = logit_agreement(net.forward_injected_feats(img, fd, obj_ids=obj.to(dev()), teacher_bits=_teacher_bits(ref).to(dev())), ref)
+    fr = logit_agreement(net.forward_injected_feats(img, fd, obj_ids=obj.to(dev())), ref, tau=tf["tau"], explain=True,
+                         knn_idx=net.init_net.knn_idx, graph_ids=obj - 1)
     print("bf16 N=4096 LM teacher-forced:", tf)
     print("bf16 N=4096 LM free-running  :", fr)
     assert margin_contract_violations(tf, fr) == [], (margin_contract_violations(tf, fr), tf, fr)
-    names = [c[2].split(":")[0] for c in net.program_for(2).calls]
+    names = [c[2].split(":")[0] for pr in net._programs.values() for c in pr["prog"].calls]
     assert ("edge_tiled" in names) == tiled and ("edge_gather" in names) != tiled
     assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99, tf
     assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, tf

@@ -19,8 +19,10 @@ def test_two_rank_dp_training_step_on_one_gpu(request):
         proc.kill()
         raise
     out = open(log).read()
+    backend, nproc = request.config._dp_plan
     assert rc == 0, out[-4000:]
-    assert "DP_STEP_OK world=2" in out, out[-4000:]
+    assert "DP_STEP_OK world=%d" % nproc in out, out[-4000:]
+    print("data-parallel step: %d ranks over %s" % (nproc, backend))
 
 
 def test_bench_gpus_2_launches_its_own_ranks_on_the_gpu(request):
@@ -38,5 +40,6 @@ def test_bench_gpus_2_launches_its_own_ranks_on_the_gpu(request):
     lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"ranks_seen"' in ln]
     assert len(lines) == 1, out[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and len(d["per_rank_ms"]) == 2 and d["backend"] == "gloo"
-    assert d["config"]["global_batch"] == 16 and d["value"] > 0
+    backend, nproc = request.config._dp_plan
+    assert d["n_gpus"] == nproc and d["ranks_seen"] == list(range(nproc)) and len(d["per_rank_ms"]) == nproc and d["backend"] == backend
+    assert d["config"]["global_batch"] == 8 * nproc and d["value"] > 0

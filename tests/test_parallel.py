@@ -148,3 +148,39 @@ def test_bench_rejects_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"], env=env, capture_output=True, text=True,
                        timeout=120, cwd=root)
     assert p.returncode != 0 and "launcher started 2 ranks" in (p.stderr + p.stdout)
+
+
+def test_dp_child_plan_picks_rccl_when_the_node_has_several_gpus():
+    """tests/conftest.py: the GPU-side data-parallel job (tests/dp_step_child.py + `bench.py --gpus N`) runs one rank per GPU over
+    RCCL as soon as the box shows two or more (config #3's gradient all-reduce over xGMI: never exercised on the 1-GPU boxes), up to 8;
+    a 1-GPU box keeps the two-rank gloo rehearsal"""
+    from tests.conftest import dp_child_plan
+    assert dp_child_plan(1) == ("gloo", 2)
+    assert dp_child_plan(2) == ("nccl", 2) and dp_child_plan(4) == ("nccl", 4) and dp_child_plan(8) == ("nccl", 8)
+    assert dp_child_plan(16) == ("nccl", 8)
+
+
+def test_gpu_local_cpus_reads_the_pci_devices_numa_cores(tmp_path):
+    """bench.gpu_local_cpus: AMD display / accelerator devices of a (fake) sysfs tree in PCI bus order -> the core list of the i-th one;
+    other vendors and other device classes are skipped; a missing index gives None (no pinning)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    pci = tmp_path / "pci"
+    drm = tmp_path / "drm"
+    drm.mkdir()
+    spec = [("card0", "0000:05:00.0", "0x1a03", "0x030000", "0-7"),            # the board's VGA chip
+            ("card2", "0000:c3:00.0", "0x1002", "0x120000", "48-63,112-127"),
+            ("card1", "0000:43:00.0", "0x1002", "0x038000", "0-15,64-79"),
+            ("card3", "0000:e3:00.0", "0x1002", "0x040300", "0-3")]            # an audio function
+    for card, addr, vendor, cls, cpus in spec:
+        d = pci / addr
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n"); (d / "class").write_text(cls + "\n"); (d / "local_cpulist").write_text(cpus + "\n")
+        (drm / card).mkdir()
+        os.symlink(str(d), str(drm / card / "device"))
+    assert bench.gpu_local_cpus(0, str(drm)) == list(range(0, 16)) + list(range(64, 80))
+    assert bench.gpu_local_cpus(1, str(drm)) == list(range(48, 64)) + list(range(112, 128))
+    assert bench.gpu_local_cpus(2, str(drm)) is None
+    assert bench.pin_rank_to_gpu_numa_node(0, 1) is None                       # a single-GPU run is never pinned
