@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--npoint", type=int, default=512)
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true", help="time the deterministic training mode (cp_set_deterministic) as the main line")
+    ap.add_argument("--no-deterministic-cost", action="store_true", help="skip the second, deterministic-mode measurement of the default run")
     a = ap.parse_args()
     from bench import Ranks, self_launch
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # not under torchrun: launch the N ranks ourselves (no GPU call here)
@@ -186,7 +188,21 @@ def main():
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
         raise SystemExit("bench_train: --gpus %d but the launcher started %s ranks" % (a.gpus, os.environ["WORLD_SIZE"]))
     rk = Ranks()
+    import checkerpose_amd
+    checkerpose_amd.set_deterministic(a.deterministic)
     out = run_step_bench(rk, a.batch, a.npoint, a.dtype, a.steps, a.warmup, not a.no_breakdown)
+    out["deterministic"] = bool(a.deterministic)
+    if rk.world == 1 and not a.deterministic and not a.no_deterministic_cost:
+        # what bit-reproducible training costs: the same step with every accumulation in a fixed order (include/checkerpose_hip.h)
+        checkerpose_amd.set_deterministic(True)
+        try:
+            d = run_step_bench(rk, a.batch, a.npoint, a.dtype, max(a.steps // 2, 5), 5, False)
+            out["deterministic_mode"] = {"crops_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                                         "slowdown": round(d["ms_per_step"] / out["ms_per_step"], 3),
+                                         "note": "CHECKERPOSE_AMD_DETERMINISTIC=1 / checkerpose_amd.set_deterministic(True): BatchNorm sums one block per "
+                                                 "accumulator set, weight gradients through the fixed-order reduction, Index2Feat scatter as an ordered gather"}
+        finally:
+            checkerpose_amd.set_deterministic(False)
     if rk.rank == 0 and rk.world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.npoint)
     if rk.rank == 0:
