@@ -155,6 +155,14 @@ template <> struct Vec16<BF16Tag> {
   }
 };
 
+template <> struct Vec16<F16Tag> {            // pack() saturates under cp_f16_saturate_on() (the kernel sets the mode bit first)
+  static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+    f[0] = f16_lo(v.x); f[1] = f16_hi(v.x); f[2] = f16_lo(v.y); f[3] = f16_hi(v.y);
+    f[4] = f16_lo(v.z); f[5] = f16_hi(v.z); f[6] = f16_lo(v.w); f[7] = f16_hi(v.w);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) { return cp_pack8<true>(f); }
+};
+
 // align_corners source coordinate of output index o (scale s = (n - 1) / (2 n - 1)): left neighbour, step to the right one, the
 // right one's weight.  `contract(off)`: hipcc's default -ffp-contract=fast may fuse s * o - i0 into one fma in one kernel and
 // not in another (__fmul_rn / __fsub_rn are plain * and - in HIP); with the pragma every kernel derives the same weights.

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // fp32 rounding of the accumulator, not bit for bit.
 template <typename Tag, int NT, int KS>
 __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvParams p) {
+  if (p.out_f32 == 2 || Tag::dtype == CP_F16) cp_f16_saturate_on();      // half output rows saturate at +-65504 (common.h)
   constexpr int E = Tag::E, KCH = 4 * E, ES = 16 / E, MT = 2, T = MT * NT;
   constexpr int U = NT == 1 ? 8 : (NT == 2 ? 6 : 4);        // chunks of one wave in flight together
   __shared__ __attribute__((aligned(16))) float red[KS * T * 64 * 4];
@@ -471,6 +472,9 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
       }
       if (f32io) {
         *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else if (h16out) {
+        u32x2 pk; pk.x = cp_pack2<true>(v[0], v[1]); pk.y = cp_pack2<true>(v[2], v[3]);
+        *(u32x2*)((uint16_t*)p.out + o) = pk;
       } else {
         u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
         *(u32x2*)((uint16_t*)p.out + o) = pk;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(KS * 64) void conv_igemm_splitk_kernel(const ConvPa
 // split-K plan: bf16, a K walk worth splitting, and a tiled grid that would leave most CUs idle.  Channel tiles per
 // workgroup: as many (<= 3: the pixel fragments are then read once for 48 channels) as still leave a workgroup per CU.
 static int splitk_plan(int dtype, long long M, int KC, int n_tiles, int* NTs) {
-  if (dtype != CP_BF16 || KC < 6 || cp_knob("CP_NO_SPLITK")) return 0;
+  if ((dtype != CP_BF16 && dtype != CP_F16) || KC < 6 || cp_knob("CP_NO_SPLITK")) return 0;
   int NT = 1, best = 1 << 30;
   for (int nt = 5; nt >= 1; --nt) {
     const int padded = (n_tiles + nt - 1) / nt * nt;
@@ -511,17 +515,18 @@ static int splitk_plan(int dtype, long long M, int KC, int n_tiles, int* NTs) {
 }
 
 template <int NT, int KS>
-static void launch_splitk(ConvParams p, hipStream_t st) {
+static void launch_splitk(ConvParams p, hipStream_t st, bool half_in) {
   p.m_blocks = (p.M + 31) / 32;
   p.n_blocks = (p.n_tiles + NT - 1) / NT;
-  cp_mark_kernel("conv_igemm_splitk_kernel<BF16Tag, %d, %d>", NT, KS);
-  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BF16Tag, NT, KS>), dim3((unsigned)(p.m_blocks * p.n_blocks)), dim3(KS * 64), 0, st, p);
+  cp_mark_kernel("conv_igemm_splitk_kernel<%s, %d, %d>", half_in ? "F16Tag" : "BF16Tag", NT, KS);
+  if (half_in) hipLaunchKernelGGL((conv_igemm_splitk_kernel<F16Tag, NT, KS>), dim3((unsigned)(p.m_blocks * p.n_blocks)), dim3(KS * 64), 0, st, p);
+  else hipLaunchKernelGGL((conv_igemm_splitk_kernel<BF16Tag, NT, KS>), dim3((unsigned)(p.m_blocks * p.n_blocks)), dim3(KS * 64), 0, st, p);
 }
 
 // 0, or the number of waves the K walk of this conv would be split over (the engine then routes 3x3 / 1x1 convs that have
 // faster large-batch kernels to cp_conv2d_igemm with the generic weight pack)
 extern "C" int cp_conv2d_igemm_splitk(int dtype, long long M, int K, int Cout) {
-  if (M <= 0 || K <= 0 || Cout <= 0 || (dtype != CP_F32 && dtype != CP_BF16)) return 0;
+  if (M <= 0 || K <= 0 || Cout <= 0 || (dtype != CP_F32 && dtype != CP_BF16 && dtype != CP_F16)) return 0;
   const int KCH = 4 * cp_chan_align(dtype);
   int nts = 1;
   return splitk_plan(dtype, M, (K + KCH - 1) / KCH, (Cout + 15) / 16, &nts);
@@ -588,10 +593,11 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
   p.o_base = d->o_base; p.o_sb = d->o_sb; p.o_sy = d->o_sy; p.o_sx = d->o_sx; p.o_sc = d->o_sc;
 
   int nts = 1;
-  if (const int ks = (d->ksplit == -1 || halfish) ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles, &nts)) {
+  if (const int ks = d->ksplit == -1 ? 0 : splitk_plan(d->dtype, M, p.KC, p.n_tiles, &nts)) {
     hipStream_t st_ = (hipStream_t)stream;
-    if (ks == 8) { if (nts == 3) launch_splitk<3, 8>(p, st_); else if (nts == 2) launch_splitk<2, 8>(p, st_); else launch_splitk<1, 8>(p, st_); }
-    else         { if (nts == 3) launch_splitk<3, 4>(p, st_); else if (nts == 2) launch_splitk<2, 4>(p, st_); else launch_splitk<1, 4>(p, st_); }
+    const bool hin = d->dtype == CP_F16;
+    if (ks == 8) { if (nts == 3) launch_splitk<3, 8>(p, st_, hin); else if (nts == 2) launch_splitk<2, 8>(p, st_, hin); else launch_splitk<1, 8>(p, st_, hin); }
+    else         { if (nts == 3) launch_splitk<3, 4>(p, st_, hin); else if (nts == 2) launch_splitk<2, 4>(p, st_, hin); else launch_splitk<1, 4>(p, st_, hin); }
     return cp_check_launch();
   }
   // tile choice: NT minimises padded channel tiles (ties -> wider), MT=4 (256 pixels/block) unless the
@@ -614,7 +620,7 @@ extern "C" int cp_conv2d_igemm(cp_stream_t stream, const CpConvDesc* d, const vo
                (!residual || ((uintptr_t)residual % 16) == 0) && !cp_knob("CP_NO_EPI_LDS")) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CP_F32) { if (MT == 4) dispatch_nt<F32Tag, 4>(p, NT, st); else dispatch_nt<F32Tag, 2>(p, NT, st); }
-  else if (d->dtype == CP_F16) dispatch_nt<F16Tag, 2>(p, NT, st);      // (small per-keypoint Linears: the light tile only)
+  else if (d->dtype == CP_F16) { if (MT == 4) dispatch_nt<F16Tag, 4>(p, NT, st); else dispatch_nt<F16Tag, 2>(p, NT, st); }
   else                    { if (MT == 4) dispatch_nt<BF16Tag, 4>(p, NT, st); else dispatch_nt<BF16Tag, 2>(p, NT, st); }
   return cp_check_launch();
 }

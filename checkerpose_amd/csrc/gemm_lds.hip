@@ -41,8 +41,14 @@ template <> struct MmaG<BF16Tag> {
   }
 };
 
+template <> struct MmaG<F16Tag> {
+  static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) { acc = cp_mma16<true>(w, a, acc); }
+};
+
 template <typename Tag, bool HAS_RES>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmParams p) {
+  constexpr bool HF = Tag::dtype == CP_F16;                        // IEEE-half rows and weights (keypoint side, no residual)
+  if constexpr (HF) cp_f16_saturate_on();
   constexpr int E = Tag::E;
   constexpr int KCH = 4 * E;
   constexpr int ES = 16 / E;
@@ -211,11 +217,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmParams p) {
       *(f32x4*)((float*)p.out + o[mt]) = f32x4{v[0], v[1], v[2], v[3]};
       if (hi_ok) *(f32x4*)((float*)p.out + o[mt] + 4) = f32x4{v[4], v[5], v[6], v[7]};
     } else if (hi_ok) {
-      u32x4 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+      const u32x4 pk = cp_pack8<HF>(v);
       if ((((uintptr_t)((uint16_t*)p.out + o[mt])) & 15u) == 0) *(u32x4*)((uint16_t*)p.out + o[mt]) = pk;
       else { *(u32x2*)((uint16_t*)p.out + o[mt]) = u32x2{pk.x, pk.y}; *(u32x2*)((uint16_t*)p.out + o[mt] + 4) = u32x2{pk.z, pk.w}; }
     } else {
-      u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+      u32x2 pk; pk.x = cp_pack2<HF>(v[0], v[1]); pk.y = cp_pack2<HF>(v[2], v[3]);
       *(u32x2*)((uint16_t*)p.out + o[mt]) = pk;
     }
   }
@@ -236,8 +242,9 @@ constexpr int WS_ROWS = 64;
 constexpr int WS_PITCH = WS_ROWS * 16 + 16;                 // plane [row][16 B]; +16: consecutive planes shift one slot
 constexpr int ws_buf(int NCH) { return NCH * 4 * WS_PITCH; }   // 33 280 B (K <= 256) / 66 560 B (K <= 512)
 
-template <int NCH, int NG>                                   // K chunks resident per wave, 32-channel groups per wave
+template <int NCH, int NG, bool HF = false>                  // K chunks resident per wave, 32-channel groups per wave; HF: IEEE half
 __global__ __launch_bounds__(512 / NG, NG) void gemm_rows_ws_kernel(const GemmParams p, const int ncg, const int n_rt) {
+  if constexpr (HF) cp_f16_saturate_on();
   constexpr int NT = 2 * NG;                                 // MFMA tiles per wave
   constexpr int NWAVE = 8 / NG, THREADS = 64 * NWAVE;
   constexpr int PPR = NCH * 4;                               // 16-byte pieces per row
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(512 / NG, NG) void gemm_rows_ws_kernel(const GemmPa
         for (int mt = 0; mt < MTP; ++mt) {
           const u32x4 a = *(const u32x4*)(ab + kc * 4 * WS_PITCH + mt * 256);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) MmaG<BF16Tag>::run(W[kc][t], a, acc[mt][t]);
+          for (int t = 0; t < NT; ++t) acc[mt][t] = cp_mma16<HF>(W[kc][t], a, acc[mt][t]);
         }
       }
     }
@@ -344,11 +351,11 @@ __global__ __launch_bounds__(512 / NG, NG) void gemm_rows_ws_kernel(const GemmPa
           v[j] = cp_act_apply(v[j], cp_act_slope(p.act, p.slope));
         }
         if (hi_ok) {
-          u32x4 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+          const u32x4 pk = cp_pack8<HF>(v);
           if ((((uintptr_t)op) & 15u) == 0) *(u32x4*)op = pk;
           else { *(u32x2*)op = u32x2{pk.x, pk.y}; *(u32x2*)(op + 4) = u32x2{pk.z, pk.w}; }
         } else {
-          u32x2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+          u32x2 pk; pk.x = cp_pack2<HF>(v[0], v[1]); pk.y = cp_pack2<HF>(v[2], v[3]);
           *(u32x2*)op = pk;
         }
       }
@@ -418,9 +425,10 @@ extern "C" int cp_pack_item_gemm(int dtype, const float* w, int Cout, int Cin, i
 extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void* in, const void* packed_w,
                             const float* scale, const float* shift, const void* residual, void* out) {
   if (!d || !in || !packed_w || !scale || !shift || !out) return CP_ERR_INVALID;
-  if ((d->dtype != CP_F32 && d->dtype != CP_BF16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
+  if ((d->dtype != CP_F32 && d->dtype != CP_BF16 && d->dtype != CP_F16) || !cp_act_ok(d->act, d->slope)) return CP_ERR_INVALID;
   if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->Ho != d->H || d->Wo != d->W || d->out_f32 || d->o_sc != 1)
     return CP_ERR_INVALID;
+  if (d->dtype == CP_F16 && residual) return CP_ERR_INVALID;          // IEEE-half rows (keypoint side): in, weights and out in half, no residual
   const int E = cp_chan_align(d->dtype), es = cp_elem_size(d->dtype);
   if (d->B <= 0 || d->H <= 0 || d->W <= 0) return CP_ERR_INVALID;
   if (d->Cin <= 0 || d->Cin % E || d->in_coff % E || d->in_cstride % E || d->in_coff + d->Cin > d->in_cstride) return CP_ERR_ALIGN;
@@ -448,11 +456,13 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
   p.dense = (d->o_sy == (long long)d->Wo * d->o_sx && d->o_sb == (long long)d->Ho * d->Wo * d->o_sx) ? 1 : 0;
   const unsigned grid = (unsigned)(((p.m_blocks + 7) / 8) * 8 * p.NB);
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CP_BF16 && !residual && p.nchunk <= 16 && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {
+  if ((d->dtype == CP_BF16 || d->dtype == CP_F16) && !residual && p.nchunk <= 16 && M >= 16384 && !cp_knob("CP_NO_GEMM_WS")) {
     static CpDeviceOnce once;
     const int dev = cp_current_device();
     CP_LDS_ATTR_ONCE(once, dev, cp_set_max_lds((const void*)gemm_rows_ws_kernel<8, 2>, 2 * ws_buf(8)) &&
-                                    cp_set_max_lds((const void*)gemm_rows_ws_kernel<16, 1>, 2 * ws_buf(16)));
+                                    cp_set_max_lds((const void*)gemm_rows_ws_kernel<16, 1>, 2 * ws_buf(16)) &&
+                                    cp_set_max_lds((const void*)gemm_rows_ws_kernel<8, 2, true>, 2 * ws_buf(8)) &&
+                                    cp_set_max_lds((const void*)gemm_rows_ws_kernel<16, 1, true>, 2 * ws_buf(16)));
     const int n_cu = cp_num_cus();
     if (n_cu <= 0) return CP_ERR_HIP;
     const bool deep = p.nchunk > 8;                           // 256 < K <= 512: 8-wave blocks, one per CU
@@ -462,13 +472,18 @@ extern "C" int cp_gemm_rows(cp_stream_t stream, const CpConvDesc* d, const void*
     int nstreams = per_xcd / ncg > 0 ? per_xcd / ncg : 1;
     const int need = (n_rt + 7) / 8;                          // row tiles one XCD label owns
     if (nstreams > need) nstreams = need;
-    if (deep) CP_LAUNCH((gemm_rows_ws_kernel<16, 1>), dim3((unsigned)(8 * nstreams * ncg)), dim3(512), 2 * ws_buf(16), st, p, ncg, n_rt);
+    if (d->dtype == CP_F16) {
+      if (deep) CP_LAUNCH((gemm_rows_ws_kernel<16, 1, true>), dim3((unsigned)(8 * nstreams * ncg)), dim3(512), 2 * ws_buf(16), st, p, ncg, n_rt);
+      else CP_LAUNCH((gemm_rows_ws_kernel<8, 2, true>), dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * ws_buf(8), st, p, ncg, n_rt);
+    } else if (deep) CP_LAUNCH((gemm_rows_ws_kernel<16, 1>), dim3((unsigned)(8 * nstreams * ncg)), dim3(512), 2 * ws_buf(16), st, p, ncg, n_rt);
     else CP_LAUNCH((gemm_rows_ws_kernel<8, 2>), dim3((unsigned)(8 * nstreams * ncg)), dim3(256), 2 * ws_buf(8), st, p, ncg, n_rt);
     return cp_check_launch();
   }
   if (d->dtype == CP_F32) {
     if (residual) CP_LAUNCH((gemm_rows_kernel<F32Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
     else CP_LAUNCH((gemm_rows_kernel<F32Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
+  } else if (d->dtype == CP_F16) {
+    CP_LAUNCH((gemm_rows_kernel<F16Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);
   } else {
     if (residual) CP_LAUNCH((gemm_rows_kernel<BF16Tag, true>), dim3(grid), dim3(256), 2 * GBUF, st, p);
     else CP_LAUNCH((gemm_rows_kernel<BF16Tag, false>), dim3(grid), dim3(256), 2 * GBUF, st, p);

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void edgeconv_gather_max_kernel(
     const void* __restrict__ pq, const int32_t* __restrict__ idx, const int32_t* __restrict__ graph_ids,
     void* __restrict__ out, int B, int N, int K, int chunks, int out_cs, int out_coff, float slope) {
   constexpr int E = Tag::E;
+  if constexpr (Tag::dtype == CP_F16) cp_f16_saturate_on();
   constexpr int KPB = 256 / TPK;             // keypoints per block
   constexpr int C = TPK * E;
   extern __shared__ __attribute__((aligned(16))) int32_t s_idx[];   // KPB * K
@@ -87,7 +88,7 @@ static int launch_edge(hipStream_t st, const void* pq, const int32_t* idx, const
   constexpr int KPB = 256 / TPK;
   const int chunks = (N + KPB - 1) / KPB;
   const int grid = 8 * ((B + 7) / 8) * chunks;
-  cp_mark_kernel("edgeconv_gather_max_kernel<%s, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : "F32Tag", TPK);
+  cp_mark_kernel("edgeconv_gather_max_kernel<%s, %d>", Tag::dtype == CP_BF16 ? "BF16Tag" : (Tag::dtype == CP_F16 ? "F16Tag" : "F32Tag"), TPK);
   hipLaunchKernelGGL((edgeconv_gather_max_kernel<Tag, TPK>), dim3(grid), dim3(256), KPB * K * sizeof(int32_t), st, pq, idx,
                      gids, out, B, N, K, chunks, out_cs, out_coff, slope);
   return cp_check_launch();
@@ -97,7 +98,7 @@ extern "C" int cp_edgeconv_gather_max(cp_stream_t stream, int dtype, const void*
                                       const int32_t* graph_ids, void* out, int B, int N, int K, int C, int G,
                                       int out_cstride, int out_coff, float slope) {
   if (!pq || !idx || !out || B <= 0 || N <= 0 || K <= 0 || K > 64 || C <= 0 || G <= 0) return CP_ERR_INVALID;
-  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype);
   if (C % E || out_cstride % E || out_coff % E || out_coff + C > out_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(pq) || !cp_aligned16(out)) return CP_ERR_ALIGN;
@@ -106,6 +107,8 @@ extern "C" int cp_edgeconv_gather_max(cp_stream_t stream, int dtype, const void*
 #define CP_EDGE(TAG, T) case T: return launch_edge<TAG, T>(st, pq, idx, graph_ids, out, B, N, K, out_cstride, out_coff, slope);
   if (dtype == CP_F32) {
     switch (tpk) { CP_EDGE(F32Tag, 8) CP_EDGE(F32Tag, 16) CP_EDGE(F32Tag, 32) CP_EDGE(F32Tag, 64) CP_EDGE(F32Tag, 128) default: return CP_ERR_INVALID; }
+  } else if (dtype == CP_F16) {
+    switch (tpk) { CP_EDGE(F16Tag, 4) CP_EDGE(F16Tag, 8) CP_EDGE(F16Tag, 16) CP_EDGE(F16Tag, 32) CP_EDGE(F16Tag, 64) default: return CP_ERR_INVALID; }
   } else {
     switch (tpk) { CP_EDGE(BF16Tag, 4) CP_EDGE(BF16Tag, 8) CP_EDGE(BF16Tag, 16) CP_EDGE(BF16Tag, 32) CP_EDGE(BF16Tag, 64) default: return CP_ERR_INVALID; }
   }
@@ -121,6 +124,7 @@ __global__ void index2feat_kernel(const void* __restrict__ patches, const int32_
                                   const int32_t* __restrict__ y_id, const float* __restrict__ mask, void* __restrict__ out,
                                   int N, int Hp, int Wp, int EG, int k, int out_cs, int out_coff, size_t total) {
   constexpr int E = Tag::E;
+  if constexpr (Tag::dtype == CP_F16) cp_f16_saturate_on();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*N*4*EG
   if (i >= total) return;
   const int g = (int)(i % EG);
@@ -145,7 +149,7 @@ extern "C" int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* p
                                     int E_ch, int k, int out_cstride, int out_coff) {
   if (!patches || !x_id || !y_id || !mask || !out || B <= 0 || N <= 0 || Hp <= 0 || Wp <= 0 || E_ch <= 0 || k <= 0)
     return CP_ERR_INVALID;
-  if (dtype != CP_F32 && dtype != CP_BF16) return CP_ERR_INVALID;
+  if (dtype != CP_F32 && dtype != CP_BF16 && dtype != CP_F16) return CP_ERR_INVALID;
   const int E = cp_chan_align(dtype);
   if (E_ch % E || out_cstride % E || out_coff % E || out_coff + 4 * E_ch > out_cstride) return CP_ERR_ALIGN;
   if (!cp_aligned16(patches) || !cp_aligned16(out)) return CP_ERR_ALIGN;
@@ -154,6 +158,9 @@ extern "C" int cp_index2feat_gather(cp_stream_t stream, int dtype, const void* p
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CP_F32)
     CP_LAUNCH(index2feat_kernel<F32Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,
+                       out, N, Hp, Wp, EG, k, out_cstride, out_coff, total);
+  else if (dtype == CP_F16)
+    CP_LAUNCH(index2feat_kernel<F16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,
                        out, N, Hp, Wp, EG, k, out_cstride, out_coff, total);
   else
     CP_LAUNCH(index2feat_kernel<BF16Tag>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, x_id, y_id, mask,

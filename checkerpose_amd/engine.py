@@ -242,13 +242,9 @@ class Program:
         return CP_F16 if self.gnn_half else self.dtype
 
     def wants_gnn_half(self, N, K, tiled_hpad=None):
-        """every op of the keypoint side would take its fused per-crop kernel at this batch: the group can run in half"""
-        if not (USE_GNN_F16 and self.dtype == CP_BF16 and USE_MLP_FUSED and self.mlp_min_rows <= self.B * N):
-            return False
-        if N == 512:
-            return self.can_fuse_edgeconv(N, K, 64, 64) and self.can_fuse_edgeconv(N, K, 256, 256)
-        return (tiled_hpad is not None and self.can_tile_edgeconv(N, K, 64, 64, tiled_hpad)
-                and self.can_tile_edgeconv(N, K, 256, 256, tiled_hpad))
+        """bf16 programs run their keypoint side in half at every batch size and kernel selection: the fused per-crop kernels and the
+        generic ones (cp_conv2d_igemm incl. split-K, cp_gemm_rows, cp_edgeconv_gather_max, cp_index2feat_gather) all take CP_F16"""
+        return bool(USE_GNN_F16 and self.dtype == CP_BF16)
 
     # ---- tensors
     def tensor(self, nelem, es=None):
@@ -343,6 +339,7 @@ class Program:
             raise RuntimeError("conv %s: weight expects %d input channels, activation has %d" % (wkey, wCin, x.C))
         halo = (USE_HALO and R == 3 and S == 3 and stride == 1 and pad == 1 and ostr is None and not out_f32
                 and not transposed and row_map is None and x.W >= 16 and x.H >= 8 and not (out_half or in_half))
+        cdt = CP_F16 if in_half else self.dtype          # the launch's dtype: half rows + half weights for a keypoint-side layer
         if halo and wCout <= 80 and self.dtype == CP_F32:
             # small-Cout variant pads Cin to 64-byte chunks PER TAP: in fp32 (MFMA-bound) that only pays when the
             # padding waste is small (measured: 18/36-channel convs are faster on the generic kernel in fp32)
@@ -351,7 +348,7 @@ class Program:
         # also pays at K = 64 .. 127 (incre conv3 + shortcut of the 32^2 branch: 98 -> 72 us)
         kmin = 16 * self.E if not (self.dtype == CP_BF16 and residual is None and x.B * x.H * x.W >= 16384 and GEMM_WS_SMALL_K) else 64
         gemm = (USE_GEMM and R == 1 and S == 1 and stride == 1 and pad == 0 and ostr is None and not out_f32
-                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= kmin and not (out_half or in_half))
+                and not transposed and row_map is None and wCout >= 96 and x.Cphys >= kmin and not out_half)
         s2small = (USE_S2_SMALL and self.dtype == CP_BF16 and R == 3 and S == 3 and stride == 2 and pad == 1 and ostr is None and not out_f32
                    and not transposed and row_map is None and residual is None and x.H % 2 == 0 and x.W % 2 == 0 and x.B >= self.chain_min
                    and not (out_half or in_half) and bool(self.lib.cp_conv3x3_s2_small_supported(x.H, x.W, x.Cphys, _rup(wCout, self.E))))
@@ -360,8 +357,8 @@ class Program:
                  and not transposed and row_map is None and not in_half and not self.ws.repacks_every_step   # (eval programs:
                  # the training program repacks its weights every step through the pack-item tables, which have no entry for this image)
                  and bool(self.lib.cp_conv2x2_halo_supported(self.dtype, x.H, x.W, _rup(wCout, self.E))))
-        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small or halo2) and not (out_half or in_half)
-                and self.lib.cp_conv2d_igemm_splitk(self.dtype, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
+        if (self.splitk and not transposed and row_map is None and (halo or gemm or s2small or halo2)
+                and self.lib.cp_conv2d_igemm_splitk(cdt, x.B * ((x.H + 2 * pad - R) // stride + 1) * ((x.W + 2 * pad - S) // stride + 1),
                                                     R * S * x.Cphys, _rup(wCout, self.E))):
             halo = gemm = s2small = halo2 = False      # small batch: the generic kernel's split-K variant beats the tiled specialists
         if s2small:
@@ -390,7 +387,7 @@ class Program:
         elif halo:
             packed = self.ws.pack_halo(wkey, w, wCout, wCin, x.Cphys)
         elif gemm:
-            packed = self.ws.pack_gemm(wkey, w, wCout, wCin, x.Cphys)
+            packed = self.ws.pack_gemm(wkey, w, wCout, wCin, x.Cphys, **({"dtype": CP_F16} if in_half else {}))
         else:
             packed = self.ws.pack(wkey, w, wCout, wCin, R, S, x.Cphys, rows, transposed, phase, row_map, **({"dtype": CP_F16} if in_half else {}))
         sc, sh = self.ws.affine(wkey + "#" + str(phase), scale, shift, rows)
@@ -401,7 +398,7 @@ class Program:
         d.Cin, d.in_cstride, d.in_coff = x.Cphys, x.cstride, x.coff
         d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = R, S, stride, pad, Ho, Wo
         d.act, d.slope = act, slope
-        d.ksplit = 0 if (self.splitk and not (out_half or in_half)) else -1
+        d.ksplit = 0 if self.splitk else -1
         if ostr is None:
             if out is None:
                 out = self.act(Ho, Wo, Cout)
@@ -923,13 +920,13 @@ class Program:
         return out
 
     def edge_gather(self, pq: Act, idx_t, gids_t, out: Act, K, C_, G, slope):
-        assert not self.gnn_half, "keypoint side in half: every EdgeConv layer must take a fused kernel"
+        gdt = self.gdt
         fn = self.lib.cp_edgeconv_gather_max
         pt, ot = pq.tbuf, out.tbuf
         ip = idx_t.data_ptr()
         gp = gids_t.data_ptr() if gids_t is not None else None
         N = pq.W
-        self._add(fn, lambda P: (self.dtype, P(pt), ip, gp, P(ot), pq.B, N, K, C_, G, out.cstride, out.coff, slope),
+        self._add(fn, lambda P: (gdt, P(pt), ip, gp, P(ot), pq.B, N, K, C_, G, out.cstride, out.coff, slope),
                   "edge_gather:%d" % C_, [pt], [ot])
         return out
 
@@ -1166,12 +1163,12 @@ class Program:
         return out
 
     def index2feat(self, patches: Act, xid_t, yid_t, mask_t, out: Act, N, E_ch, k):
-        assert not self.gnn_half, "keypoint side in half: Index2Feat's gather must ride in a fused kernel"
+        gdt = self.gdt
         fn = self.lib.cp_index2feat_gather
         pt, ot = patches.tbuf, out.tbuf
         args = (xid_t.data_ptr(), yid_t.data_ptr(), mask_t.data_ptr())
         tail = (patches.B, N, patches.H, patches.W, E_ch, k, out.cstride, out.coff)
-        self._add(fn, lambda P: (self.dtype, P(pt)) + args + (P(ot),) + tail, "index2feat", [pt, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
+        self._add(fn, lambda P: (gdt, P(pt)) + args + (P(ot),) + tail, "index2feat", [pt, self.raw(xid_t), self.raw(yid_t), self.raw(mask_t)], [ot])
         return out
 
     def decode(self, bits_t, stage, mask_t, xid_t, yid_t, x64_t, y64_t, N):

@@ -556,7 +556,7 @@ class NetEmitter:
         tl = graph.get("tiled")
         if tl is not None and x.C == Cc and self.p.can_tile_edgeconv(x.W, graph["K"], Cc, Co, tl["HPAD"]):
             return self.p.edge_tiled(x, ck, wpq, sc, sh, tl, graph["gids"], out, graph["K"], graph["G"], slope)
-        pq = self.p.conv(x, ck, wpq, sc, sh, 1, 1, 1, 0, 2 * Co)
+        pq = self.p.conv(x, ck, wpq, sc, sh, 1, 1, 1, 0, 2 * Co, in_half=self.p.gnn_half)     # (half in -> half out: the whole layer in the group's type)
         return self.p.edge_gather(pq, graph["idx"], graph["gids"], out, graph["K"], Co, graph["G"], slope)
 
 
@@ -864,9 +864,9 @@ def emit_posenet(em: NetEmitter, cfg, io):
         elif tp is None and p.can_fuse_mlp_pair(L, pws[0], pws[1]):
             h = p.mlp_pair_fused(L, pkeys, pws, [em.W(k_ + ".bias") for k_ in pkeys], slope)     # csrc/mlp_fused.hip
         else:
-            assert not p.gnn_half, "keypoint side in half: pre_graph_module must take the fused pair kernel"
-            h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope)
-            h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope)
+            hk = {"in_half": True} if (tp is None and p.gnn_half) else {}
+            h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope, **hk)
+            h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope, **hk)
         Lnext = local_buf(i + 1) if i + 1 < active else None
         for gi in range(ngs[i]):
             last = gi == ngs[i] - 1
@@ -884,13 +884,13 @@ def emit_posenet(em: NetEmitter, cfg, io):
                               ((4 + i) * N, 13 * N, 0, 1, 6 * N))
             q = None
         else:
-            assert not p.gnn_half, "keypoint side in half: MLP_QueryNet must take the fused kernel"
-            q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope)
-            q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope)
+            hk = {"in_half": True} if (tp is None and p.gnn_half) else {}
+            q = em.linear(h, rp + ".query_block.mlps.0", ACT_LEAKY, slope, **hk)
+            q = em.linear(q, rp + ".query_block.mlps.2", ACT_LEAKY, slope, **hk)
         if q is None:
             pass
         elif tp is None:
-            em.linear(q, qk, ACT_NONE, 0.0, out_f32=True, ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"])
+            em.linear(q, qk, ACT_NONE, 0.0, out_f32=True, ostr=((4 + i) * N, 13 * N, 0, 1, 6 * N), out_tbuf=io["bits_tb"], in_half=p.gnn_half)
         else:
             wq = em.W(qk + ".weight")
             wq4 = wq.view(wq.shape[0], wq.shape[1], 1, 1)

@@ -358,3 +358,122 @@ def test_edgeconv_tiled_half_vs_torch(lib, N, Cc):
     for i in range(B):
         got[i][sc["perm"][gsel[i]].astype(np.int64)] = got_int[i]        # internal row r holds original keypoint perm[r]
     close(got, ref, TOL_H)
+
+
+# ---- the generic kernels in half: what the small-batch programs (below the per-crop crossovers) run the keypoint side on
+@pytest.mark.parametrize("B,N,Cin,Cout,act", [(2, 512, 256, 512, 0), (64, 512, 256, 512, 0), (3, 200, 64, 128, 2), (1, 512, 320, 256, 2)])
+def test_gemm_rows_half_vs_torch(lib, B, N, Cin, Cout, act):
+    """cp_gemm_rows with CpConvDesc.dtype = CP_F16 (rows, weights and output in half; the weight-stationary variant from 16 384 rows
+    on): the EdgeConv node GEMM 256 -> 512 and the per-keypoint Linears of a small-batch program"""
+    x = rnd(det_tensor("hgx%d_%d_%d" % (B, N, Cin), (B, N, Cin)), CP_F16)
+    w = det_tensor("hgw%d_%d" % (Cin, Cout), (Cout, Cin), (2.0 / Cin) ** 0.5 * 1.7)
+    scale = 1.0 + 0.3 * det_tensor("hgs%d" % Cout, (Cout,))
+    shift = 0.2 * det_tensor("hgt%d" % Cout, (Cout,))
+    ref = (x @ rnd(w, CP_F16).t()) * scale + shift
+    ref = F.leaky_relu(ref, 0.01) if act == 2 else ref
+    xin = x.to(torch.float16).contiguous().to(dev())
+    pw = _gemm_pack(lib, CP_F16, w, Cout, Cin)
+    sc, sh = scale.to(dev()), shift.to(dev())
+    d = _desc(CP_F16, 0, B, 1, N, Cin, Cout, 1, 0, 1, N)
+    d.act, d.slope = act, 0.01
+    d.ksplit = 0
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, N * Cout, N * Cout, Cout, 1
+    out = torch.full((B, N, Cout), float("nan"), dtype=torch.float16, device=dev())
+    _abi.check(lib.cp_gemm_rows(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()))
+    torch.cuda.synchronize()
+    close(out.float().cpu(), ref, TOL_H)
+    res = torch.zeros_like(out)
+    assert lib.cp_gemm_rows(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), out.data_ptr()) == -1
+
+
+@pytest.mark.parametrize("B,N,Cin,Cout,ksplit", [(1, 512, 256, 512, 0), (1, 512, 256, 512, -1), (40, 512, 64, 128, 0), (2, 100, 256, 64, 0)])
+def test_conv_igemm_half_rows_tiled_and_splitk(lib, B, N, Cin, Cout, ksplit):
+    """cp_conv2d_igemm with dtype = CP_F16 and out_f32 = 0: half rows in, half weights, half rows out -- the tiled kernel (ksplit -1 /
+    large M) and the split-K variant the small-batch programs take (ksplit 0, small M)"""
+    x = rnd(det_tensor("hix%d_%d_%d" % (B, N, Cin), (B, N, Cin)), CP_F16)
+    w = det_tensor("hiw%d_%d" % (Cin, Cout), (Cout, Cin), (2.0 / Cin) ** 0.5 * 1.7)
+    shift = 0.2 * det_tensor("hit%d" % Cout, (Cout,))
+    ref = F.leaky_relu(x @ rnd(w, CP_F16).t() + shift, 0.2)
+    xin = x.to(torch.float16).contiguous().to(dev())
+    pw = torch.empty(lib.cp_packed_weight_bytes(CP_F16, Cout, Cin, 1, 1), dtype=torch.uint8, device=dev())
+    wd = w.contiguous().to(dev())
+    _abi.check(lib.cp_pack_conv_weight(st(), CP_F16, wd.data_ptr(), Cout, Cin, 1, 1, Cin, 0, 0, None, Cout, pw.data_ptr()))
+    sc, sh = torch.ones(Cout, device=dev()), shift.to(dev())
+    d = _desc(CP_F16, 0, B, 1, N, Cin, Cout, 1, 0, 1, N)
+    d.act, d.slope, d.ksplit = 2, 0.2, ksplit
+    d.o_base, d.o_sb, d.o_sy, d.o_sx, d.o_sc = 0, N * Cout, N * Cout, Cout, 1
+    out = torch.full((B, N, Cout), float("nan"), dtype=torch.float16, device=dev())
+    _abi.check(lib.cp_conv2d_igemm(st(), C.byref(d), xin.data_ptr(), pw.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, out.data_ptr()))
+    torch.cuda.synchronize()
+    sym = lib.cp_last_kernel().decode()
+    assert "F16Tag" in sym and (("splitk" in sym) == bool(ksplit == 0 and lib.cp_conv2d_igemm_splitk(CP_F16, B * N, Cin, Cout))), sym
+    close(out.float().cpu(), ref, TOL_H)
+
+
+@pytest.mark.parametrize("Cc", [64, 256])
+def test_edgeconv_gather_max_half_vs_torch(lib, Cc):
+    """cp_edgeconv_gather_max(CP_F16): out = leaky(max_k P'[j(k)] + Q'[i]) over a half [P' | Q'] table (the L2 gather of the small-batch
+    programs), real `ape` graph, channel-sliced output"""
+    B, N, K = 3, 512, 20
+    idx = O.knn(ape_p3d(512), K)
+    pq = rnd(det_tensor("hgm%d" % Cc, (B, N, 2 * Cc)), CP_F16)
+    ref = F.leaky_relu(pq[:, idx[0], :Cc].max(dim=2)[0] + pq[..., Cc:], 0.2)
+    pd = pq.to(torch.float16).contiguous().to(dev())
+    idx_d = idx.to(torch.int32).contiguous().to(dev())
+    wide = torch.full((B, N, Cc + 64), 7.0, dtype=torch.float16, device=dev())
+    _abi.check(lib.cp_edgeconv_gather_max(st(), CP_F16, pd.data_ptr(), idx_d.data_ptr(), None, wide.data_ptr(), B, N, K, Cc, 1, Cc + 64, 64, 0.2))
+    torch.cuda.synchronize()
+    got = wide.float().cpu()
+    assert float((got[..., :64] - 7.0).abs().max()) == 0.0
+    close(got[..., 64:], ref, 1e-3)                                       # one half rounding of the sum
+
+
+def test_index2feat_gather_half_is_a_byte_exact_gather(lib):
+    """cp_index2feat_gather(CP_F16): taps x {0, 1} RoI bit of a half patch map == the torch gather, bit for bit"""
+    B, N, E, k, H = 2, 512, 64, 2, 32
+    Hp = H + 1
+    patches = det_tensor("hig_p", (B, Hp, Hp, E)).to(torch.float16)
+    g_ = torch.Generator().manual_seed(9)
+    xid = torch.randint(0, H // 2, (B, N), generator=g_, dtype=torch.int32)
+    yid = torch.randint(0, H // 2, (B, N), generator=g_, dtype=torch.int32)
+    mask = (torch.rand(B, N, generator=g_) > 0.3).float()
+    taps = []
+    for t in range(4):
+        yy = 2 * yid.long() + (k if (t & 1) else 0)
+        xx = 2 * xid.long() + (k if (t & 2) else 0)
+        taps.append(patches[torch.arange(B)[:, None], yy, xx])
+    ref = torch.cat(taps, -1) * mask[..., None].to(torch.float16)
+    out = torch.full((B, N, 320), 5.0, dtype=torch.float16, device=dev())
+    pd, xd, yd, md = patches.contiguous().to(dev()), xid.to(dev()), yid.to(dev()), mask.to(dev())
+    _abi.check(lib.cp_index2feat_gather(st(), CP_F16, pd.data_ptr(), xd.data_ptr(), yd.data_ptr(), md.data_ptr(), out.data_ptr(), B, N, Hp, Hp, E, k, 320, 64))
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., 64:].cpu().view(torch.int16), ref.view(torch.int16).where(ref != 0, torch.zeros((), dtype=torch.int16)))
+    assert float((out[..., :64].float() - 5.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("selection", ["tiled", "auto"])
+def test_small_batch_program_runs_the_keypoint_side_in_half_too(monkeypatch, selection):
+    """the generic-kernel programs (small batches; `set_kernel_selection("tiled")`) run the keypoint side in half as well: closer to the
+    fp32 path than with the flag off, and the launch list shows half kernels on the keypoint side"""
+    from checkerpose_amd import engine
+    B = 2
+    img = det_image(B, seed=4).cuda()
+    net = build_net(seed=1).cuda().eval()
+    net.set_kernel_selection(selection)
+    net.set_compute_dtype("fp32")
+    ref = [t.clone() for t in net(img, None)]
+    t = torch.zeros(B, 13, 512, device=img.device)
+    t[:, 0:1], t[:, 1:7], t[:, 7:13] = ref[0], ref[1], ref[2]
+    err = {}
+    for half in (True, False):
+        monkeypatch.setattr(engine, "USE_GNN_F16", half)
+        net.set_compute_dtype("bf16")
+        out = net.forward_teacher_forced(img, t)
+        z, zr = torch.cat(out[:3], 1), torch.cat(ref[:3], 1)
+        err[half] = float((z - zr).abs().mean())
+        pr = [p for k, p in net._programs.items() if k[3] == "bf16"][-1]["prog"].progs[0]
+        assert pr.gnn_half is half
+        names = [c[2].split(":")[0] for c in pr.calls]
+        assert "edge_gather" in names and "edge_fused" not in names          # the small-batch EdgeConv path
+    print("%s selection, B = %d: teacher-forced mean |dlogit| vs fp32: half %.5f, bf16 %.5f" % (selection, B, err[True], err[False]))
+    assert err[True] < 0.9 * err[False], err
