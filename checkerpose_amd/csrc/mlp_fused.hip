@@ -334,21 +334,23 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
   // gathering loader: the keypoint ids / RoI bits of the wave's four rows of the tile whose DMA is issued NEXT (scalar registers)
   i32x4 gxi = {0, 0, 0, 0}, gyi = {0, 0, 0, 0}, gmk = {0, 0, 0, 0};
   long long gm0 = 0;
+  // The three id arrays are read-only for the whole launch and the addresses are wave-uniform: loaded through CONSTANT-address-space
+  // pointers the compiler emits s_load_dwordx4 itself and owns the wait (round 5 issued the loads in one inline-asm statement and waited in
+  // another: between the two the register allocator believed the destination SGPRs defined and was free to copy or spill them before
+  // the data had landed).  ids_issue() sits in front of the tile barrier, the first use behind it: the barrier's skew hides the scalar-cache
+  // miss as before.
+  typedef const __attribute__((address_space(4))) i32x4 c_i32x4;
   auto ids_issue = [&](int rt) {
     if constexpr (GATHER) {
       long long m0 = (long long)rt * MP_ROWS + wave * 4;
       if (m0 > p.M - 4) m0 = p.M - 4;                          // rows past the end: valid rows, never stored
       gm0 = m0;
-      const int32_t* px = p.x_id + m0;
-      const int32_t* py = p.y_id + m0;
-      const float* pm = p.mask + m0;
-      asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %5, 0x0"
-                   : "=&s"(gxi), "=&s"(gyi), "=&s"(gmk) : "s"(px), "s"(py), "s"(pm) : "memory");
+      gxi = *(c_i32x4*)(p.x_id + m0);
+      gyi = *(c_i32x4*)(p.y_id + m0);
+      gmk = *(c_i32x4*)((const int32_t*)p.mask + m0);
     }
   };
-  auto ids_wait = [&]() {                                      // the registers are tied through the wait: no use can move above it
-    if constexpr (GATHER) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gxi), "+s"(gyi), "+s"(gmk) : : "memory");
-  };
+  auto ids_wait = [&]() {};
   auto dma_tile = [&](int rt, int buf) {
     // The lane's piece offsets are loop invariants: hipcc hoisted them out of the tile loop as NI 64-bit pairs, spilled them (the
     // layer-1 waves hold 128 weight registers) and reloaded them in front of every DMA -- and a scratch reload is a VMEM load:
@@ -425,6 +427,7 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
     if (l1) {
       const int nb = xb >= 1 ? xb - 1 : 2;                    // (it + 2) % 3
       dma_tile(dma_target(rt), nb);                           // always ND pieces: the vmcnt arithmetic below counts them
+      ids_issue(dma_target(rt + step));                       // the next iteration's DMA target: its ids travel under this tile's MFMAs
       MP_MARK(0);                                             // DMA issue
       if (rt < p.n_rt) {
         // (lane geometry from an opaque copy of the lane id, per iteration: hoisted out of the loop these few values were spilled
@@ -479,7 +482,6 @@ __global__ __launch_bounds__(768) void mlp_pair_fused_kernel(const MlpPairParams
       MP_MARK(2);                                             // layer-1 epilogue
       __builtin_amdgcn_s_waitcnt(0x0070 | ND);                // vmcnt(ND), lgkmcnt(0): the tile of the NEXT iteration has landed
       MP_MARK(3);                                             // DMA wait
-      ids_issue(dma_target(rt + step));                       // the next iteration's DMA target: its ids fly across the tile barrier
     } else {
       if (it > 0) {
         int ln = mp_lane<GATHER>(lane);
