@@ -207,3 +207,22 @@ def test_struct_epoch_reaches_every_model_that_shares_a_submodule():
     del b
     gc.collect()
     assert not RT._HOOKS and not len(RT._TRACKED)
+
+
+def test_committed_sq_counters_cover_the_bench_lines_kernels():
+    """profiles/summarize.py `check`: every kernel symbol the newest committed default bench line spends its time in has a row in the
+    newest committed SQ counter file (round 5 committed counters of a build that was no longer the launched one: its file fails this
+    check for `hr_chain0p_kernel` and the chain tails)."""
+    import glob
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("summarize", os.path.join(root, "profiles", "summarize.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bench = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_bf16_b256.json")))[-1]
+    sq = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_sq_counters.csv")))[-1]
+    assert mod.sq_missing(bench, sq) == [], (bench, sq, mod.sq_missing(bench, sq))
+    stale = os.path.join(root, "profiles", "r05_sq_counters_PRE_FINAL_BUILD.csv")
+    if os.path.exists(stale):
+        assert "hr_chain0p_kernel" in mod.sq_missing(bench, stale)
