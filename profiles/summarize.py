@@ -15,14 +15,20 @@ def short(name):
     return name.split("(")[0][:70]
 
 
+def newest(pattern):
+    """gpurun merges a call's outputs INTO gpurun_out/ (older runs of the same tag stay beside them): take the newest file"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
 def main(stats_dir, fetch_dir, write_dir, out_prefix):
-    rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0])))
+    rows = list(csv.DictReader(open(newest(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0])))
     ours = [r for r in rows if not r["Name"].startswith(("void at::", "__amd_rocclr"))]
     tot = sum(float(r["TotalDurationNs"]) for r in ours)
     pmc = {}
     for key, d, mult in (("fetch", fetch_dir, 2.0), ("write", write_dir, 1.0)):
         acc = defaultdict(lambda: [0.0, 0])
-        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+        f = newest(os.path.join(d, "*", "*counter_collection.csv"))
         if f:
             for r in csv.DictReader(open(f[0])):
                 a = acc[r["Kernel_Name"]]
