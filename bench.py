@@ -818,7 +818,10 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": wl["name"] + ", PoseNet_GNNskip forward, deterministic random-init weights",
                       "crops_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d (no forward collective)" % world,
-                      "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls)},
+                      "launch": "hipGraph replay of %d kernel launches" % len(net.program_for(B).calls),
+                      "precision": ("bf16 storage + MFMA inputs on the image side (backbone, decoder), IEEE half (f16 storage + f16 MFMA, same bytes and "
+                                    "rate) on the per-keypoint side (EdgeConv, Index2Feat rows, MLP stacks); fp32 accumulation and epilogues"
+                                    if (a.dtype == "bf16" and net.program_for(B).progs[0].gnn_half) else a.dtype)},
            "ranks_seen": seen, "per_rank_ms": per_rank, "backend": rk.backend if world > 1 else None,
            "cpu_affinity": rk.cpu_affinity}
     if a.workload == "ycbv_rr21":
