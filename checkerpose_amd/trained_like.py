@@ -84,7 +84,7 @@ def train_net(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, device=None, log
             loss.backward()
             opt.step()
             if it % 25 == 0 or it == steps - 1:
-                losses.append(round(float(loss), 4))
+                losses.append(round(float(loss.detach()), 4))
                 if log:
                     log("trained_like step %d loss %.4f" % (it, losses[-1]))
     finally:
