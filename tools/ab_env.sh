@@ -1,4 +1,5 @@
 # interleaved A/B of bench.py under different environments (the boxes drift by +-2 % within minutes: single runs cannot rank variants)
+# AB_SCRIPT / AB_ARGS: another bench script and its fixed arguments (bench_train.py: AB_ARGS="--no-breakdown --no-cpu-baseline --no-deterministic-cost")
 # usage: bash tools/ab_env.sh <reps> "<ENV=.. ENV=..>" "<ENV=..>" ... [-- bench args]     ("-" = no extra environment)
 cd $GRAFT_REPO_ROOT
 reps=$1; shift
@@ -9,7 +10,7 @@ for i in $(seq $reps); do
   k=0
   for v in "${vars[@]}"; do
     e="$v"; [ "$v" = "-" ] && e=""
-    env $e python bench.py --no-extras --no-cpu-baseline --no-breakdown --steps 60 --warmup 5 "$@" 2>/dev/null | python -c "
+    env $e python ${AB_SCRIPT:-bench.py} ${AB_ARGS:---no-extras --no-cpu-baseline --no-breakdown --steps 60 --warmup 5} "$@" 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
