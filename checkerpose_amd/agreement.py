@@ -77,11 +77,27 @@ def _margin_stats(zo, zr, tau):
         buckets["%g-%s" % (lo, ("%g" % hi) if hi != float("inf") else "inf")] = {
             "n": n, "flips": f, "flip_rate": round(f / max(n, 1), 6), "worst_row_flip_rate": round(max(per_row), 6)}
     above = flip & (m > tau)
-    return {"flip_rate_by_margin": buckets,
-            "flips": int(flip.sum()),
-            "flips_above_margin": int(above.sum()),
-            "max_flip_margin": round(float(m[flip].max()) if bool(flip.any()) else 0.0, 6),
-            "flip_margin_over_dlogit_max": round(float((m[flip] / (zo - zr).abs()[flip].clamp_min(1e-30)).max()) if bool(flip.any()) else 0.0, 4)}
+    res = {"flip_rate_by_margin": buckets,
+           "flips": int(flip.sum()),
+           "flips_above_margin": int(above.sum()),
+           "max_flip_margin": round(float(m[flip].max()) if bool(flip.any()) else 0.0, 6),
+           "flip_margin_over_dlogit_max": round(float((m[flip] / (zo - zr).abs()[flip].clamp_min(1e-30)).max()) if bool(flip.any()) else 0.0, 4)}
+    # the same two tail statistics against the error scale of the flip's OWN logit row / refinement stage (each row is another output
+    # head at another depth: pooled, the rows' error scales differ by 2-3x and the pooled mean under-states the deeper heads')
+    d = (zo - zr).abs()
+    R = zr.shape[1]
+    row_mean = d.mean(dim=(0, 2))                                              # (R,)
+    if R == 13:
+        st = torch.tensor(row_stages(6, 6))
+        stage_mean = torch.stack([d[:, st == s_].mean() for s_ in range(int(st.max()) + 1)])[st]     # (R,) the row's stage mean
+    else:
+        stage_mean = row_mean
+    for name, scale in (("row", row_mean), ("stage", stage_mean)):
+        rel = m / scale.clamp_min(1e-30)[None, :, None]
+        res["max_flip_margin_over_%s_mean" % name] = round(float(rel[flip].max()) if bool(flip.any()) else 0.0, 3)
+        res["flips_above_4x_%s_mean" % name] = int((flip & (rel > 4.0)).sum())
+    res["row_mean_abs_dlogit"] = [round(float(v), 6) for v in row_mean]
+    return res
 
 
 def row_stages(nx, ny, init_bits=3):

@@ -119,7 +119,8 @@ def train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=1, held_ou
     keep = ("bit_agreement_min_row", "bit_agreement_all_rows", "xy_id_equal", "id_abs_err_mean_px", "seg_agreement", "max_abs_dlogit",
             "mean_abs_dlogit", "logit_rms", "mean_abs_dlogit_over_rms", "tau", "tau_cap", "flips", "flips_above_margin", "max_flip_margin",
             "flip_rate_by_margin", "id_mismatches", "id_mismatches_explained_frac", "id_mismatches_self_subtau_frac",
-            "perturbed_coverage_by_stage")
+            "perturbed_coverage_by_stage", "max_flip_margin_over_row_mean", "flips_above_4x_row_mean", "max_flip_margin_over_stage_mean",
+            "flips_above_4x_stage_mean", "row_mean_abs_dlogit")
     absz = z.abs()
     return {"weights": "random init (seed %d) + %d steps of the HIP training program (bf16, B = %d, Adam lr %g) on the synthetic translation "
                        "task of checkerpose_amd/trained_like.py" % (seed, steps, batch, lr),

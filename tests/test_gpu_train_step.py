@@ -305,7 +305,8 @@ def test_bf16_contract_on_trained_like_weights(seed):
     Asserted with the contract's OWN clauses (agreement.margin_contract_violations == [], no slack) and its floors: teacher-forced
     rows >= 98 %, seg >= 99 %, mean |dlogit| <= 2 % of the logit RMS; free-running rows >= 95 %, final id pairs >= 90 %.  Recorded:
     profiles/r06_trained_like_*.json (seeds 1-5 at 300 steps and seed 1 at 3 000 steps: no violation in any; seed 4 is the run
-    with the lowest free-running agreement)."""
+    with the lowest free-running agreement).  Seeds 6-15 were run afterwards: three of them miss a tail clause by one flip -- see
+    test_bf16_contract_known_marginal_seed below and DESIGN.md section 7."""
     import checkerpose_amd
     from checkerpose_amd.trained_like import train_then_measure
     checkerpose_amd.set_deterministic(True)
@@ -324,6 +325,29 @@ def test_bf16_contract_on_trained_like_weights(seed):
     assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99 and tf["mean_abs_dlogit_over_rms"] <= 0.02, tf
     assert tf["max_abs_dlogit"] <= 0.5 and tf["flip_rate_by_margin"]["0.2-1"]["flips"] == 0 and tf["flip_rate_by_margin"]["1-inf"]["flips"] == 0, tf
     assert fr["bit_agreement_min_row"] >= 0.95 and fr["xy_id_equal"] >= 0.90 and fr["id_abs_err_mean_px"] <= 0.5, fr
+
+
+def test_bf16_contract_known_marginal_seed():
+    """The tail clauses (b) / (c) of the contract are statistical at this error level: of 15 training seeds
+    (profiles/r06_trained_like_300steps_seeds1-15.json) three miss one of them by ONE flip.  This pins the worst of the three, seed 10
+    -- deterministic training, so the same network on every box: exactly one violated clause, (b), a flip at 6.83 x the mean |dlogit|
+    (margin 0.084, clause (a)'s bound is 0.2); every floor of the contract holds.  A build whose error grows shows up here as a
+    second violation or a larger excess; one whose error shrinks makes this test fail on the `== 1`, which is the cue to retire it."""
+    import checkerpose_amd
+    from checkerpose_amd.trained_like import train_then_measure
+    checkerpose_amd.set_deterministic(True)
+    try:
+        r = train_then_measure(npoint=512, steps=300, batch=32, lr=5e-4, seed=10, held_out=8)
+    finally:
+        checkerpose_amd.set_deterministic(False)
+    tf, fr = r["teacher_forced"], r["free_running"]
+    v = r["margin_contract_violations"]
+    print("trained-like seed 10:", v, "per-row ratio %.2f" % tf["max_flip_margin_over_row_mean"])
+    assert len(v) == 1 and v[0].startswith("teacher-forced: a flip at margin") and "6 x mean" in v[0], v
+    assert tf["max_flip_margin"] <= 7.5 * tf["mean_abs_dlogit"] and tf["max_flip_margin"] < 0.2 and tf["flips_above_margin"] <= 2, tf
+    assert tf["bit_agreement_min_row"] >= 0.98 and tf["seg_agreement"] >= 0.99 and tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, tf
+    assert fr["bit_agreement_min_row"] >= 0.95 and fr["xy_id_equal"] >= 0.90 and fr["id_abs_err_mean_px"] <= 0.5, fr
+    assert fr["id_mismatches_explained_frac"] >= 0.95 and fr["id_mismatches_self_subtau_frac"] >= 0.60, fr
 
 
 def _train_steps(steps, deterministic, seed=1, batch=8):

@@ -27,10 +27,11 @@ if __name__ == "__main__":
         res.append(r)
         tf, fr = r["teacher_forced"], r["free_running"]
         print("seed %d steps %d: loss %s->%s roi_acc %.3f | tf mean %.5f (%.4f of rms %.2f) max %.4f flips %d max flip margin %.4f (%.2f x mean) "
-              "above tau %d minrow %.4f | fr minrow %.4f ideq %.4f px %.3f expl %.3f self %.3f | viol %s" % (
+              "above tau %d | per row: %.2f x, %d above 4x | per stage: %.2f x, %d above 4x | minrow %.4f | fr minrow %.4f ideq %.4f px %.3f expl %.3f self %.3f | viol %s" % (
                   seed, a.steps, r["loss_every_25_steps"][0], r["loss_every_25_steps"][-1], r["held_out"]["roi_bit_accuracy_vs_gt"],
                   tf["mean_abs_dlogit"], tf["mean_abs_dlogit_over_rms"], tf["logit_rms"], tf["max_abs_dlogit"], tf["flips"], tf["max_flip_margin"],
-                  tf["max_flip_margin"] / max(tf["mean_abs_dlogit"], 1e-30), tf["flips_above_margin"], tf["bit_agreement_min_row"],
+                  tf["max_flip_margin"] / max(tf["mean_abs_dlogit"], 1e-30), tf["flips_above_margin"], tf["max_flip_margin_over_row_mean"], tf["flips_above_4x_row_mean"],
+                  tf["max_flip_margin_over_stage_mean"], tf["flips_above_4x_stage_mean"], tf["bit_agreement_min_row"],
                   fr["bit_agreement_min_row"], fr["xy_id_equal"], fr["id_abs_err_mean_px"], fr["id_mismatches_explained_frac"],
                   fr.get("id_mismatches_self_subtau_frac", 1.0), r["margin_contract_violations"]), flush=True)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
