@@ -199,7 +199,7 @@ def test_training_loop_like_train_py_reduces_the_loss(dt, optim):
                 + seg_loss(seg[:, 0:1], m_vis) + seg_loss(seg[:, 1:2], m_full)
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
     print(dt, optim, "losses", ["%.4f" % v for v in losses])
     assert all(v == v for v in losses), "NaN loss"
     assert losses[-1] < 0.9 * losses[0], losses
@@ -254,7 +254,7 @@ def test_lm_twin_training_loop_per_sample_graphs():
                 + MaskedCodeLoss("BCE")(yb, x_gt[:, :yb.shape[1]], roi_gt)
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
     print("lm losses", ["%.4f" % v for v in losses])
     assert all(v == v for v in losses) and losses[-1] < 0.9 * losses[0], losses
 
