@@ -18,11 +18,16 @@ def lib():
     return _abi.load()
 
 
+DP_TEST_MAX_RANKS = int(os.environ.get("CHECKERPOSE_DP_TEST_MAX_RANKS", "4"))
+
+
 def dp_child_plan(ndev):
     """(backend, ranks) of the data-parallel child job: a node with several GPUs runs one rank per GPU over RCCL ("nccl" IS RCCL on
-    ROCm: the gradient all-reduce over xGMI that BASELINE config #3 names), up to 8; a 1-GPU box rehearses the same code with two
-    ranks sharing the GPU over gloo"""
-    return ("nccl", min(int(ndev), 8)) if int(ndev) >= 2 else ("gloo", 2)
+    ROCm: the gradient all-reduce over xGMI that BASELINE config #3 names), up to DP_TEST_MAX_RANKS = 4 -- the pool's process guard
+    allows a job six GPU processes at once (the ranks + this pytest process), and the 8-rank case is the driver's to launch
+    (`CHECKERPOSE_DP_TEST_MAX_RANKS=8` on a node without that guard); a 1-GPU box rehearses the same code with two ranks sharing the
+    GPU over gloo"""
+    return ("nccl", min(int(ndev), DP_TEST_MAX_RANKS)) if int(ndev) >= 2 else ("gloo", 2)
 
 
 def pytest_sessionstart(session):

@@ -152,12 +152,12 @@ def test_bench_rejects_world_size_mismatch():
 
 def test_dp_child_plan_picks_rccl_when_the_node_has_several_gpus():
     """tests/conftest.py: the GPU-side data-parallel job (tests/dp_step_child.py + `bench.py --gpus N`) runs one rank per GPU over
-    RCCL as soon as the box shows two or more (config #3's gradient all-reduce over xGMI: never exercised on the 1-GPU boxes), up to 8;
-    a 1-GPU box keeps the two-rank gloo rehearsal"""
+    RCCL as soon as the box shows two or more (config #3's gradient all-reduce over xGMI: never exercised on the 1-GPU boxes), up to 4
+    (six GPU processes per job on this pool; the 8-rank case is the driver's); a 1-GPU box keeps the two-rank gloo rehearsal"""
     from tests.conftest import dp_child_plan
     assert dp_child_plan(1) == ("gloo", 2)
-    assert dp_child_plan(2) == ("nccl", 2) and dp_child_plan(4) == ("nccl", 4) and dp_child_plan(8) == ("nccl", 8)
-    assert dp_child_plan(16) == ("nccl", 8)
+    assert dp_child_plan(2) == ("nccl", 2) and dp_child_plan(4) == ("nccl", 4) and dp_child_plan(8) == ("nccl", 4)
+    assert dp_child_plan(16) == ("nccl", 4)
 
 
 def test_gpu_local_cpus_reads_the_pci_devices_numa_cores(tmp_path):
