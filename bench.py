@@ -15,7 +15,7 @@ forward has no collective), so scaling is weak and value = N*B*K / max-over-rank
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the
 MFMA implicit-GEMM conv) and `cpu_baseline` (oracle restatement timed on the host cores).  Extra keys of the default
 N=1 run (`--no-extras` skips them): `fp32_exact` (the path north_star's 1e-4 applies to, at its best
-batch), `by_batch` (bf16 at B = 1 / 8 / 32: the reference's test.py:198 runs batch 1, its configs train at 32),
+batch), `by_batch` (bf16 at B = 1 / 8 / 32 / 64 / 128: the reference's test.py:198 runs batch 1, its configs train at 32),
 `b1_latency_ms`, `bf16_agreement` (the bf16 path's accuracy contract, checkerpose_amd/agreement.py, measured against the
 fp32 HIP path on the same crops) and `host_u8` (crops start as uint8 in pinned HOST memory and are double-buffered over
 PCIe on a copy stream: the PCIe-inclusive rate, never `value`) `device_crop` (the data loader's RoI crop + resize done on the
@@ -206,7 +206,7 @@ def side_measurements(net_bf16, npoint, dev, B_main, img_main):
     ex = {}
     # ---- bf16 at the small batches the reference itself uses (test.py:198 batch 1; config batch 32)
     by = {}
-    for b in (1, 8, 32):
+    for b in (1, 8, 32, 64, 128):     # 64 / 128: the per-crop launches (from 40 crops), low-resolution chains one / two crops per workgroup
         img = det_image(b, seed=200 + b).to(dev)
         net_bf16(img, None)
         buf = net_bf16.input_buffer(b); buf.copy_(img)

@@ -78,6 +78,11 @@ struct ChainCfg {
 using CfgB1 = ChainCfg<36, 32, 32, 1, 1, 3, 4>;
 using CfgB2 = ChainCfg<72, 16, 16, 2, 1, 3, 0>;
 using CfgB3 = ChainCfg<144, 8, 8, 4, 2, 2, 0>;      // 4 crops per workgroup: a conv's 378 KB of weights are streamed per workgroup
+// mid-size batches (40 .. ~190 crops): with 2 / 4 crops per workgroup the low-resolution chains launch 10-48 workgroups on 256 CUs and
+// bound the module; fewer crops per workgroup (the same arithmetic per crop, bit-identical) fill the chip instead
+using CfgB2m = ChainCfg<72, 16, 16, 1, 1, 3, 0>;
+using CfgB3h = ChainCfg<144, 8, 8, 2, 2, 2, 0>;
+using CfgB3m = ChainCfg<144, 8, 8, 1, 2, 2, 0>;
 
 // a fuse-layer conv that reads this branch's finished map, run in the launch's tail off the map in LDS (cp_hr_branch_chain_tails):
 // kind 0 = the 1x1 conv towards a higher-resolution branch, kind 1 = the first 3x3 / stride-2 conv towards a lower-resolution one
@@ -539,6 +544,8 @@ __global__ void pack_chain_weight_kernel(const float* __restrict__ w, const floa
   out[i] = (uint16_t)f32_to_bf16_bits(v);
 }
 
+constexpr int CHAIN_CPW_FULL_B = 192;       // crops from which the low-resolution chains take their full crops-per-workgroup packing
+
 template <typename Cfg>
 int launch_chain(hipStream_t st, const ChainParams& p) {
   static CpDeviceOnce once;                  // per template instance, per device
@@ -682,6 +689,7 @@ static int branch_chain(cp_stream_t stream, int B, int C, int H, int W, int nsrc
   p.ntail = ntail;
   hipStream_t st = (hipStream_t)stream;
   if (C == CfgB1::C) return launch_chain<CfgB1>(st, p);
-  if (C == CfgB2::C) return launch_chain<CfgB2>(st, p);
-  return launch_chain<CfgB3>(st, p);
+  if (C == CfgB2::C) return B >= CHAIN_CPW_FULL_B ? launch_chain<CfgB2>(st, p) : launch_chain<CfgB2m>(st, p);
+  if (B >= CHAIN_CPW_FULL_B) return launch_chain<CfgB3>(st, p);
+  return B >= CHAIN_CPW_FULL_B / 2 ? launch_chain<CfgB3h>(st, p) : launch_chain<CfgB3m>(st, p);
 }

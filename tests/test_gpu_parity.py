@@ -574,12 +574,15 @@ def test_hr_fuse_out_vs_torch_cpu(lib, case):
 
 
 @pytest.mark.parametrize("nsrc", [1, 3])
-@pytest.mark.parametrize("cfg", [(36, 32, 32, 3), (72, 16, 16, 5), (144, 8, 8, 3), (36, 32, 32, 1), (18, 64, 64, 3)])
+@pytest.mark.parametrize("cfg", [(36, 32, 32, 3), (72, 16, 16, 5), (144, 8, 8, 3), (36, 32, 32, 1), (18, 64, 64, 3),
+                                 (72, 16, 16, 193), (144, 8, 8, 99), (144, 8, 8, 195)])      # crops per workgroup by batch: 2 | 2 | 4, ragged last group
 def test_hr_branch_chain_vs_torch_cpu(lib, cfg, nsrc):
     """cp_hr_branch_chain (one launch, map resident in LDS, K packed across taps) == the previous module's fuse sum
     (nearest-upsampled terms, ReLU) followed by the 4 BasicBlocks of an HRNet branch, every stored tensor rounded to bf16
     (timm HighResolutionModule.branches[j], restated oracle _hr_module).  Odd batches (two crops per workgroup on the
-    72/144-channel branches), pad channels exactly zero, in-place refused."""
+    72/144-channel branches), pad channels exactly zero, in-place refused.  The low-resolution chains pack 1 crop per workgroup below 96
+    crops (144 channels: 2 from 96, 4 from 192; 72 channels: 2 from 192 -- hr_chain.hip CHAIN_CPW_FULL_B): the last three cases run the
+    packed forms with a ragged last group."""
     Cc, H, W, B = cfg
     assert lib.cp_hr_chain_supported(Cc, H, W) == 1 and lib.cp_hr_chain_supported(18, 32, 32) == 0
     dtype = CP_BF16
@@ -707,8 +710,11 @@ def test_hr_branch_chain_tail_vs_fuse_out_and_torch(lib, tconvs):
 @pytest.mark.parametrize("Cc,H,W,B,tconvs", [
     (36, 32, 32, 3, [(0, 18, False), (1, 72, False), (1, 36, True)]),      # stage 4, branch 1: 1x1 -> 0, s2 -> 2, s2 (+ReLU) towards 3
     (36, 32, 32, 2, [(0, 18, False)]),                                     # stage 2
-    (72, 16, 16, 5, [(0, 18, False), (0, 36, False), (1, 144, False)]),    # stage 4, branch 2 (two crops per workgroup, ragged batch)
-    (144, 8, 8, 6, [(0, 18, False), (0, 36, False), (0, 72, False)]),      # stage 4, branch 3 (four crops per workgroup, ragged batch)
+    (72, 16, 16, 5, [(0, 18, False), (0, 36, False), (1, 144, False)]),    # stage 4, branch 2 (one crop per workgroup at this batch)
+    (144, 8, 8, 6, [(0, 18, False), (0, 36, False), (0, 72, False)]),      # stage 4, branch 3 (one crop per workgroup at this batch)
+    (72, 16, 16, 193, [(0, 18, False), (0, 36, False), (1, 144, False)]),  # ... two crops per workgroup (from 192 crops), ragged batch
+    (144, 8, 8, 98, [(0, 18, False), (0, 36, False), (0, 72, False)]),     # ... two crops per workgroup (96 .. 191 crops)
+    (144, 8, 8, 194, [(0, 18, False), (0, 36, False), (0, 72, False)]),    # ... four crops per workgroup, ragged batch
 ])
 def test_hr_branch_chain_tails_vs_torch(lib, Cc, H, W, B, tconvs):
     """cp_hr_branch_chain_tails (round 5): the 36 / 72 / 144-channel chain launches also produce the first-level fuse-layer convs that read
