@@ -58,7 +58,10 @@ def sq_missing(bench_json, sq_csv):
     have = [r["kernel"] for r in csv.DictReader(open(sq_csv))]
 
     def covered(sym):
-        for part in sym.split(" + "):                                  # a call that issues several launches
+        for part in sym.split(" + "):                                  # a call that issues several launches: "(a<..>) + (b<..>)"
+            part = part.strip()
+            if part.startswith("(") and part.endswith(")"):
+                part = part[1:-1]
             base = part.split("<")[0]
             if "<Cfg" in part:
                 tail = part.split("<Cfg", 1)[1]                          # e.g. ", true>"

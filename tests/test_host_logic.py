@@ -223,6 +223,9 @@ def test_committed_sq_counters_cover_the_bench_lines_kernels():
     bench = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_bf16_b256.json")))[-1]
     sq = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_sq_counters.csv")))[-1]
     assert mod.sq_missing(bench, sq) == [], (bench, sq, mod.sq_missing(bench, sq))
+    bench5 = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_lm13_n4096_bf16_b256.json")))[-1]     # config #5: a composite symbol
+    sq5 = sorted(glob.glob(os.path.join(root, "profiles", "r*_sq_counters_lm13_n4096.csv")))[-1]            # "(ptable) + (gather)"
+    assert mod.sq_missing(bench5, sq5) == [], (bench5, sq5, mod.sq_missing(bench5, sq5))
     stale = os.path.join(root, "profiles", "r05_sq_counters_PRE_FINAL_BUILD.csv")
     if os.path.exists(stale):
         assert "hr_chain0p_kernel" in mod.sq_missing(bench, stale)
