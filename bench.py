@@ -543,7 +543,7 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def make_workload(workload, npoint, B, dtype, dev, rank=0, streams=1):
+def make_workload(workload, npoint, B, dtype, dev, rank=0, streams=1, backbone="hrnet_w18"):
     """Networks + resident inputs + the step closure of one BASELINE config.  Returns dict(net, step, name, img, nets)."""
     from checkerpose_amd.synthetic import LM_OBJ_IDS, det_image, ycbv_p3d
     img = det_image(B, seed=100 + rank).to(dev)      # this rank's shard, resident in HBM before timing
@@ -576,7 +576,7 @@ def make_workload(workload, npoint, B, dtype, dev, rank=0, streams=1):
         name = "YCB-V all 21 objects, one hr18GNN2_res6_gnn3Skip_mlpQuery network per object (round-robin), npt=%d" % npoint
         return {"net": nets[0], "nets": nets, "step": step, "name": name, "img": bufs[0]}
     lm = workload == "lm13_n4096"
-    net = build(npoint, lm=lm).to(dev).set_compute_dtype(dtype)
+    net = build(npoint, lm=lm, backbone=backbone).to(dev).set_compute_dtype(dtype)
     net.clone_outputs = False            # outputs stay in the program's persistent buffers (no per-step clones)
     obj = torch.tensor([LM_OBJ_IDS[(i + rank) % 13] for i in range(B)], device=dev) if lm else None
     net(img, None, obj) if lm else net(img, None)      # builds the launch program for B
@@ -587,6 +587,8 @@ def make_workload(workload, npoint, B, dtype, dev, rank=0, streams=1):
         return net(buf, None, obj) if lm else net(buf, None)
     name = ("LM 13-object shared estimator (pipeline_lm), npt=%d dense keypoints, obj_ids uniform over the 13 LM ids" % npoint
             if lm else "LMO 'ape' hr18GNN2_res6_gnn3Skip_mlpQuery npt=%d" % npoint)
+    if backbone != "hrnet_w18":
+        name += " with backbone %s (NOT BASELINE's config)" % backbone
     return {"net": net, "nets": [net], "step": step, "name": name, "img": buf}
 
 
@@ -784,6 +786,8 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--dump-convs", default=None, help="write per-conv-launch timings (json) to this path")
     ap.add_argument("--workload", default="lmo_ape", choices=["lmo_ape", "ycbv_rr21", "lm13_n4096"])
+    ap.add_argument("--backbone", default="hrnet_w18", choices=["hrnet_w18", "hrnet_w18_small", "hrnet_w30", "resnet34"],
+                    help="lmo_ape only: another of the reference's backbone names (not BASELINE's config; --no-extras --no-breakdown implied)")
     ap.add_argument("--no-extras", action="store_true", help="skip fp32_exact / by_batch / bf16_agreement / host_u8 / the sub-configs")
     ap.add_argument("--streams", type=int, default=1, help="ycbv_rr21: HIP streams the independent per-object networks' steps rotate over")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing collectives only, no GPU call (CPU test of --gpus N)")
@@ -805,7 +809,10 @@ def main():
     world, rank, dev = rk.world, rk.rank, rk.dev
     torch.set_grad_enabled(False)
     B = a.batch
-    wl = make_workload(a.workload, a.npoint, B, a.dtype, dev, rank, a.streams)
+    if a.backbone != "hrnet_w18":
+        assert a.workload == "lmo_ape", "--backbone applies to the lmo_ape workload"
+        a.no_extras = a.no_breakdown = True
+    wl = make_workload(a.workload, a.npoint, B, a.dtype, dev, rank, a.streams, a.backbone)
     net, step, img = wl["net"], wl["step"], wl["img"]
     for _ in range(max(a.warmup, 2)):    # >= 2: eager run, then hipGraph capture
         step()

@@ -264,7 +264,10 @@ extern "C" size_t cp_hr_fuse_out_weight_bytes(int cin_phys, int out_cphys, int k
   return (size_t)fo_mt(out_cphys) * fo_nchunk(cin_phys, kind) * 1024;
 }
 
-extern "C" int cp_hr_fuse_out_affine_floats(int out_cphys) { return fo_mt(out_cphys) * 16; }
+// 0: a conv with that many (padded) output channels is not supported (more than FO_AFF = 160: e.g. hrnet_w30's 240-channel branch)
+extern "C" int cp_hr_fuse_out_affine_floats(int out_cphys) {
+  return (out_cphys <= 0 || out_cphys % 8 || out_cphys > FO_AFF) ? 0 : fo_mt(out_cphys) * 16;
+}
 
 extern "C" int cp_pack_hr_fuse_out_weight(cp_stream_t stream, const float* w, int Cout, int Cin, int cin_phys, int out_cphys,
                                           int kind, void* packed) {

@@ -794,9 +794,11 @@ class Program:
         self.conv_log.append((name, self.B * H * W, C_, 9 * C_, fl, "hr_chain", (n + 1) * nb + 8 * 9 * C_ * C_ * self.es + nbt))
         return out, touts
 
-    def can_fuse_out(self, x: Act):
+    def can_fuse_out(self, x: Act, couts=()):
+        """couts: output channels of the convs the launch would run (each must fit the kernel's epilogue table: <= 160 padded)"""
         return (USE_FUSE_OUT and self.dtype == CP_BF16 and self.B >= self.fuse_out_min and x.coff == 0 and x.cstride == x.Cphys
-                and bool(self.lib.cp_hr_fuse_out_supported(x.H, x.W, x.Cphys)))
+                and bool(self.lib.cp_hr_fuse_out_supported(x.H, x.W, x.Cphys))
+                and all(self.lib.cp_hr_fuse_out_affine_floats(_rup(int(c), self.E)) > 0 for c in couts))
 
     def hr_fuse_out(self, x: Act, convs):
         """Every first-level fuse-layer conv fed by one branch output `x` in ONE launch (cp_hr_fuse_out).  convs: list of

@@ -3,8 +3,8 @@
 Mirrors reference checkerpose/model/backbone.py:39-50 (`get_timm_backbone`), which obtains
 `timm.create_model(name, features_only=True, out_indices=(1,2,3,4))`.  timm is a third-party
 dependency absent from the reference tree, so the layouts below restate timm's published
-`HighResolutionNetFeatures(hrnet_w18, feature_location="incre")` and ResNet-34 (SURVEY.md
-Appendix A); the state-dict keys follow timm's so released checkpoints load unchanged.
+`HighResolutionNetFeatures(hrnet_w18 | hrnet_w18_small | hrnet_w30, feature_location="incre")` and ResNet-34
+(SURVEY.md Appendix A); the state-dict keys follow timm's so released checkpoints load unchanged.
 
 These classes only HOLD parameters (nn.Conv2d / nn.BatchNorm2d children are never called);
 the arithmetic runs in the HIP engine (checkerpose_amd/engine.py).  Calling forward() directly
@@ -78,35 +78,60 @@ class HighResolutionModule(nn.Module):
         self.fuse_layers = nn.ModuleList(fuse)
 
 
-class HRNetW18Features(nn.Module):
-    """hrnet_w18 features_only: outputs [128@64^2, 256@32^2, 512@16^2, 1024@8^2] for a 256^2 crop."""
-    name = "hrnet_w18"
-    out_channels = (128, 256, 512, 1024)
-    STAGES = (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144)))
+# timm `hrnet.cfg_cls` (published layouts) of the HRNet names the reference accepts (backbone.py:43, init.py:15-24):
+#   layer1 = (Bottleneck blocks, planes) ; stages 2..4 = (modules, BasicBlocks per branch, branch channels).  stem_width 64 and the
+#   "incre" head channels (32, 64, 128, 256) x Bottleneck expansion 4 are the same for all of them.
+HRNET_CFGS = {
+    "hrnet_w18": dict(layer1=(4, 64), stages=((1, 4, (18, 36)), (4, 4, (18, 36, 72)), (3, 4, (18, 36, 72, 144)))),
+    "hrnet_w30": dict(layer1=(4, 64), stages=((1, 4, (30, 60)), (4, 4, (30, 60, 120)), (3, 4, (30, 60, 120, 240)))),
+    "hrnet_w18_small": dict(layer1=(1, 32), stages=((1, 2, (16, 32)), (1, 2, (16, 32, 64)), (1, 2, (16, 32, 64, 128)))),
+}
 
-    def __init__(self):
+
+class HRNetFeatures(nn.Module):
+    """timm HighResolutionNetFeatures(<name>, feature_location="incre"), out_indices (1, 2, 3, 4):
+    outputs [128@64^2, 256@32^2, 512@16^2, 1024@8^2] for a 256^2 crop, whatever the body's widths."""
+    out_channels = (128, 256, 512, 1024)
+
+    def __init__(self, name="hrnet_w18"):
         super().__init__()
+        cfg = HRNET_CFGS[name]
+        self.name = name
+        self.cfg = cfg
+        n1, p1 = cfg["layer1"]
         self.conv1 = _conv(3, 64, 3, 2, 1)
         self.bn1 = nn.BatchNorm2d(64)
         self.conv2 = _conv(64, 64, 3, 2, 1)
         self.bn2 = nn.BatchNorm2d(64)
-        self.layer1 = nn.Sequential(Bottleneck(64, 64, _down(64, 256)), *[Bottleneck(256, 64) for _ in range(3)])
-        self.transition1 = nn.ModuleList([
-            nn.Sequential(_conv(256, 18, 3, 1, 1), nn.BatchNorm2d(18), nn.ReLU(False)),
-            nn.Sequential(nn.Sequential(_conv(256, 36, 3, 2, 1), nn.BatchNorm2d(36), nn.ReLU(False)))])
-        self.stage2 = nn.Sequential(HighResolutionModule((18, 36)))
-        self.transition2 = nn.ModuleList([nn.Identity(), nn.Identity(), nn.Sequential(
-            nn.Sequential(_conv(36, 72, 3, 2, 1), nn.BatchNorm2d(72), nn.ReLU(False)))])
-        self.stage3 = nn.Sequential(*[HighResolutionModule((18, 36, 72)) for _ in range(4)])
-        self.transition3 = nn.ModuleList([nn.Identity(), nn.Identity(), nn.Identity(), nn.Sequential(
-            nn.Sequential(_conv(72, 144, 3, 2, 1), nn.BatchNorm2d(144), nn.ReLU(False)))])
-        self.stage4 = nn.Sequential(*[HighResolutionModule((18, 36, 72, 144)) for _ in range(3)])
+        self.layer1 = nn.Sequential(Bottleneck(64, p1, _down(64, 4 * p1)), *[Bottleneck(4 * p1, p1) for _ in range(n1 - 1)])
+        pre = (4 * p1,)
+        for si, (nmod, nblk, chans) in enumerate(cfg["stages"]):
+            # timm _make_transition_layer: a kept branch whose width changes gets conv3x3 + BN + ReLU (only transition1's branch 0
+            # here), an unchanged one nn.Identity; every NEW branch is a stride-2 conv3x3 + BN + ReLU from the previous LAST branch
+            tr = []
+            for i, c in enumerate(chans):
+                if i < len(pre):
+                    tr.append(nn.Identity() if pre[i] == c else nn.Sequential(_conv(pre[i], c, 3, 1, 1), nn.BatchNorm2d(c), nn.ReLU(False)))
+                else:
+                    assert i == len(pre), "one new branch per stage"
+                    tr.append(nn.Sequential(nn.Sequential(_conv(pre[-1], c, 3, 2, 1), nn.BatchNorm2d(c), nn.ReLU(False))))
+            setattr(self, "transition%d" % (si + 1), nn.ModuleList(tr))
+            setattr(self, "stage%d" % (si + 2), nn.Sequential(*[HighResolutionModule(chans, nblk) for _ in range(nmod)]))
+            pre = chans
         self.incre_modules = nn.ModuleList(
-            nn.Sequential(Bottleneck(c, p, _down(c, p * 4))) for c, p in zip((18, 36, 72, 144), (32, 64, 128, 256)))
+            nn.Sequential(Bottleneck(c, p, _down(c, p * 4))) for c, p in zip(pre, (32, 64, 128, 256)))
 
     def forward(self, x):
         raise RuntimeError("checkerpose_amd backbones are parameter containers; run them through InitNet_GNN "
                            "(HIP engine). There is no PyTorch fallback path.")
+
+
+class HRNetW18Features(HRNetFeatures):
+    """hrnet_w18 (the shipped configs' backbone)"""
+    STAGES = (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144)))
+
+    def __init__(self):
+        super().__init__("hrnet_w18")
 
 
 class ResNet34Features(nn.Module):
@@ -189,8 +214,8 @@ def _load_pretrained_(m, model_name):
 def get_timm_backbone(model_name="resnet34", concat_decoder=True, pretrained=True):
     """Same name/arguments as reference backbone.py:39.  pretrained=True loads a local timm checkpoint (see
     _load_pretrained_) or warns; either way a from-scratch backbone gets timm's init, not PyTorch's default."""
-    if model_name == "hrnet_w18":
-        m = HRNetW18Features()
+    if model_name in HRNET_CFGS:                  # hrnet_w18 | hrnet_w18_small | hrnet_w30 (backbone.py:43)
+        m = HRNetFeatures(model_name)
     elif model_name == "resnet34":
         m = ResNet34Features()
     else:

@@ -10,7 +10,7 @@ import torch.nn as nn
 from .backbone import get_timm_backbone
 from ._runtime import HipForwardMixin
 
-CONV1X1_IN_CHANS = {"resnet34": 512, "hrnet_w18": 1024}   # init.py:15-24 (supported backbones)
+CONV1X1_IN_CHANS = {"resnet34": 512, "hrnet_w18": 1024, "hrnet_w18_small": 1024, "hrnet_w30": 1024}   # init.py:15-24 (supported backbones)
 
 
 def knn(x, k):

@@ -8,7 +8,8 @@ import torch.nn as nn
 from ._runtime import HipForwardMixin
 from .init import StaticGraph_module, knn  # noqa: F401  (re-exported like the reference module does)
 
-IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024]}   # pipeline.py:6-15
+IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024], "hrnet_w18_small": [128, 256, 512, 1024],
+                  "hrnet_w30": [128, 256, 512, 1024]}   # pipeline.py:6-15
 
 
 def get_MLP_leakyReLU_layers(dims, doLastAct, negative_slope=0.1):

@@ -10,8 +10,9 @@ import torch
 from ._abi import ACT_LEAKY, ACT_NONE, ACT_RELU
 from .engine import Act, Program, _rup
 
-HR_STAGES = (("stage2", 1, (18, 36)), ("stage3", 4, (18, 36, 72)), ("stage4", 3, (18, 36, 72, 144)))
-IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024]}   # pipeline.py:6-15
+from .model.backbone import HRNET_CFGS     # layer1 = (blocks, planes), stages = ((modules, blocks per branch, branch channels), ...)
+IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024], "hrnet_w18_small": [128, 256, 512, 1024],
+                  "hrnet_w30": [128, 256, 512, 1024]}   # pipeline.py:6-15
 
 
 FUSE_OUT_DEEP = os.environ.get("CHECKERPOSE_AMD_FUSE_OUT_DEEP", "1") != "0"   # A/B: 2nd / 3rd convs of the stride-2 fuse chains through cp_hr_fuse_out
@@ -124,12 +125,12 @@ class NetEmitter:
         tp.tape.append(bwd)
         return ys
 
-    def _hr_module_train(self, pfx, xs):
+    def _hr_module_train(self, pfx, xs, nblocks=4):
         """hr_module for the training program, emitted DEPTH-major: block k / conv c of every branch, then ONE grouped launch per
         BatchNorm pass for all of them (the branches are independent until the fuse layers); likewise the fuse convs level by level"""
         nb = len(xs)
         xs = [self._materialize(x) for x in xs]
-        for k in range(4):
+        for k in range(nblocks):
             bp = ["%s.branches.%d.%d" % (pfx, j, k) for j in range(nb)]
             assert not any((q + ".downsample.0.weight") in self.sd for q in bp)
             ys = self.conv_bn_group([(xs[j], bp[j] + ".conv1", bp[j] + ".bn1", 3, 1, 1, True, None) for j in range(nb)])
@@ -266,7 +267,7 @@ class NetEmitter:
             return t
         a = t.act
         for ck, bk, relu in t.convs:
-            if FUSE_OUT_DEEP and self.p.can_fuse_out(a):
+            if FUSE_OUT_DEEP and self.p.can_fuse_out(a, [self.W(ck + ".weight").shape[0]]):
                 a = self.p.hr_fuse_out(a, [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (3, relu)])[0]
             else:
                 a = self.conv_bn(a, ck, bk, 3, 2, 1, relu=relu)
@@ -302,14 +303,14 @@ class NetEmitter:
         wm, shift = self.ws.cache[ck]
         return self.p.conv(cat, ck, wm, self._unit(wm.shape[0]), shift, 1, 1, 1, 0, wm.shape[0], ACT_RELU, out=out)
 
-    def hr_module(self, pfx, xs, lazy=False, defer=False):
+    def hr_module(self, pfx, xs, lazy=False, defer=False, nblocks=4):
         """One timm HighResolutionModule.  xs[j]: an Act, or (terms, shifts) = the previous module's fuse terms of branch j
         still un-summed.  With lazy=True the outputs are returned in that un-summed form too: a branch that runs as ONE
         chain launch (engine.hr_chain, bf16) sums + ReLUs them while staging its map into LDS, other consumers
         materialise them (fuse_sum launch)."""
         nb = len(xs)
         if self.tp is not None and self.tp.bn_grouped and nb > 1:
-            return self._hr_module_train(pfx, xs)
+            return self._hr_module_train(pfx, xs, nblocks)
         xs = list(xs)
         p = self.p
         # lane j: branch j's four BasicBlocks; then lane i runs the fuse-layer conv chains INTO branch i (it waits for the
@@ -327,7 +328,7 @@ class NetEmitter:
             else:
                 t0, sh0 = xs[j][0][0], xs[j][1][0]
                 C_, H, W = t0.C, t0.H << sh0, t0.W << sh0
-            if self.tp is None and p.can_chain(C_, H, W):
+            if self.tp is None and nblocks == 4 and p.can_chain(C_, H, W):      # (the chain launches are 4 BasicBlocks = 8 convs long)
                 srcs, shifts = ([xs[j]], [0]) if isinstance(xs[j], Act) else xs[j]
                 bp = "%s.branches.%d" % (pfx, j)
                 ws = [self.W("%s.%d.conv%d.weight" % (bp, k, c)) for k in range(4) for c in (1, 2)]
@@ -359,18 +360,18 @@ class NetEmitter:
                 xs[j] = p.hr_chain(bp, srcs, shifts, not isinstance(xs[j], Act), ws, affs, C_, H, W)
             else:
                 xs[j] = self._materialize(xs[j])
-                for k in range(4):
+                for k in range(nblocks):
                     xs[j] = self.basic_block("%s.branches.%d.%d" % (pfx, j, k), xs[j])
-            if self.tp is None and nb > 1 and p.can_fuse_out(xs[j]):
-                # the same lane goes on with ONE launch for every first-level fuse conv that reads branch j (its map staged
-                # in LDS once); the second region keeps only the 2nd / 3rd convs of the long stride-2 chains
-                lst = []
-                for i in range(nb):
-                    q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
-                    if j > i:
-                        lst.append((i, q + ".0", q + ".1", 1, False))
-                    elif j < i:
-                        lst.append((i, q + ".0.0", q + ".0.1", 3, i - j > 1))
+            lst = []                     # every first-level fuse conv that reads branch j
+            for i in range(nb):
+                q = "%s.fuse_layers.%d.%d" % (pfx, i, j)
+                if j > i:
+                    lst.append((i, q + ".0", q + ".1", 1, False))
+                elif j < i:
+                    lst.append((i, q + ".0.0", q + ".0.1", 3, i - j > 1))
+            if self.tp is None and nb > 1 and p.can_fuse_out(xs[j], [self.W(ck + ".weight").shape[0] for (_, ck, _, _, _) in lst]):
+                # the same lane goes on with ONE launch for all of them (its map staged in LDS once); the second region keeps only the
+                # 2nd / 3rd convs of the long stride-2 chains
                 outs = p.hr_fuse_out(xs[j], [(ck, self.W(ck + ".weight")) + tuple(self.ws.bn_fold(bk)) + (k, relu)
                                              for (_, ck, bk, k, relu) in lst])
                 for (i, _, _, _, _), o in zip(lst, outs):
@@ -447,11 +448,13 @@ class NetEmitter:
                 tp.fuse_sum_bwd(go, out, tp.grad_of(s_), sh, True)
         tp.tape.append(bwd)
 
-    def hrnet(self, pfx, x, feat_outs=None, stem_done=False):
+    def hrnet(self, pfx, x, feat_outs=None, stem_done=False, name="hrnet_w18"):
+        hcfg = HRNET_CFGS[name]
+        stages = [("stage%d" % (si + 2),) + tuple(st) for si, st in enumerate(hcfg["stages"])]      # (stage, modules, blocks per branch, channels)
         if not stem_done:
             x = self.conv_bn(x, pfx + "conv1", pfx + "bn1", 3, 2, 1)
             x = self.conv_bn(x, pfx + "conv2", pfx + "bn2", 3, 2, 1)
-        for k in range(4):
+        for k in range(hcfg["layer1"][0]):
             x = self.bottleneck("%slayer1.%d" % (pfx, k), x)
         if self.tp is None:                  # the two transition convs are independent: two lanes
             self.p.par_begin(2)
@@ -462,14 +465,14 @@ class NetEmitter:
         else:
             xs = [self.conv_bn(x, pfx + "transition1.0.0", pfx + "transition1.0.1", 3, 1, 1),
                   self.conv_bn(x, pfx + "transition1.1.0.0", pfx + "transition1.1.0.1", 3, 2, 1)]
-        for si, (stage, nmod, chans) in enumerate(HR_STAGES):
+        for si, (stage, nmod, nblk, chans) in enumerate(stages):
             if si > 0:
                 t = "%stransition%d.%d.0" % (pfx, si + 1, len(chans) - 1)
                 xs = xs + [self.conv_bn(xs[-1], t + ".0", t + ".1", 3, 2, 1)]
-            last_stage = si == len(HR_STAGES) - 1
+            last_stage = si == len(stages) - 1
             for m in range(nmod):           # inside a stage the fuse sums stay un-summed for the next module's chain launches
                 xs = self.hr_module("%s%s.%d" % (pfx, stage, m), xs, lazy=(m + 1 < nmod) or (last_stage and self.tp is None),
-                                    defer=FUSE_DEFER and m + 1 < nmod)
+                                    defer=FUSE_DEFER and m + 1 < nmod, nblocks=nblk)
         feats = []
         self.p.par_begin(len(xs))            # the four incre bottlenecks are independent
         for i, f in enumerate(xs):
@@ -583,7 +586,7 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_o
         if defer_head:
             return feats, (lambda: _emit_init_head(em, cfg, io, pfx, graph_out, feats))
         return feats, _emit_init_head(em, cfg, io, pfx, graph_out, feats)
-    fused_stem = (tp is None and cfg["backbone"] == "hrnet_w18" and not cfg.get("uint8_input") and p.can_fuse_stem(cfg["img_size"]))
+    fused_stem = (tp is None and cfg["backbone"] in HRNET_CFGS and not cfg.get("uint8_input") and p.can_fuse_stem(cfg["img_size"]))    # stem_width 64 in all of them
     if fused_stem:                 # layout change + conv1 + conv2 of the HRNet stem in one launch, straight from the NCHW image
         s1, t1 = em.ws.bn_fold(bb + "bn1")
         s2, t2 = em.ws.bn_fold(bb + "bn2")
@@ -594,7 +597,7 @@ def emit_init_net(em: NetEmitter, cfg, io, pfx="", graph_out: Act = None, feat_o
         x = p.nchw_to_nhwc(io["img"], 3, cfg["img_size"], cfg["img_size"])
     if tp is not None:
         tp.nograd.add(id(x.tbuf))                           # the image needs no gradient
-    feats = em.hrnet(bb, x, feat_outs=feat_outs, stem_done=fused_stem) if cfg["backbone"] == "hrnet_w18" else em.resnet34(bb, x)
+    feats = em.hrnet(bb, x, feat_outs=feat_outs, stem_done=fused_stem, name=cfg["backbone"]) if cfg["backbone"] in HRNET_CFGS else em.resnet34(bb, x)
     if defer_head:
         return feats, (lambda: _emit_init_head(em, cfg, io, pfx, graph_out, feats))
     return feats, _emit_init_head(em, cfg, io, pfx, graph_out, feats)
@@ -735,7 +738,7 @@ def emit_posenet(em: NetEmitter, cfg, io):
     # (engine.conv_up2x); its input is the LOW-resolution concat buffer, filled in place by its two producers -- the previous
     # stage's last conv (channels [0, nf)) and the backbone's incre module (the skip feature, channels [nf, ..))
     lowcats, feat_outs = {}, None
-    if tp is None and cfg["backbone"] == "hrnet_w18":
+    if tp is None and cfg["backbone"] in HRNET_CFGS:
         feat_outs = [None] * 4
         for i in range(1, active):
             j = 3 - i

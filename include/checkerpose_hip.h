@@ -416,7 +416,7 @@ typedef struct CpFuseConv {
 } CpFuseConv;
 int cp_hr_fuse_out_supported(int H, int W, int cin_phys);
 size_t cp_hr_fuse_out_weight_bytes(int cin_phys, int out_cphys, int kind);
-int cp_hr_fuse_out_affine_floats(int out_cphys);
+int cp_hr_fuse_out_affine_floats(int out_cphys);   /* 0: that many (padded) output channels are not supported (> 160) */
 int cp_pack_hr_fuse_out_weight(cp_stream_t stream, const float* w, int Cout, int Cin, int cin_phys, int out_cphys, int kind,
                                void* packed);
 int cp_hr_fuse_out(cp_stream_t stream, const void* src, int B, int H, int W, int cin_phys, int nconv, const CpFuseConv* convs);

@@ -39,8 +39,9 @@ import torch
 import torch.nn.functional as F
 
 # pipeline.py:6-15 / init.py:15-24
-IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024]}
-CONV1X1_IN_CHANS = {"resnet34": 512, "hrnet_w18": 1024}
+IMG_FEATS_DIMS = {"resnet34": [64, 128, 256, 512], "hrnet_w18": [128, 256, 512, 1024], "hrnet_w18_small": [128, 256, 512, 1024],
+                  "hrnet_w30": [128, 256, 512, 1024]}
+CONV1X1_IN_CHANS = {"resnet34": 512, "hrnet_w18": 1024, "hrnet_w18_small": 1024, "hrnet_w30": 1024}
 
 
 # --------------------------------------------------------------------------- generic pieces
@@ -222,6 +223,14 @@ def _bottleneck(sd, p, x):
 HRNET_W18 = dict(stage2=(1, (18, 36)), stage3=(4, (18, 36, 72)), stage4=(3, (18, 36, 72, 144)), blocks=4)
 
 
+def _count(sd, fmt):
+    """number of consecutive indices k = 0, 1, .. for which the key fmt % k exists in the state dict"""
+    k = 0
+    while (fmt % k) in sd:
+        k += 1
+    return k
+
+
 def _hr_module(sd, p, xs, nblocks=4):
     """timm HighResolutionModule.forward: per-branch BasicBlocks, then fuse (sum over j, ReLU)."""
     nb = len(xs)
@@ -249,21 +258,24 @@ def _hr_module(sd, p, xs, nblocks=4):
 
 
 def hrnet_features(sd, p, x):
-    """timm HighResolutionNetFeatures(hrnet_w18, features_only, out_indices=(1,2,3,4)) as called from
-    backbone.py:48-49: returns [128@/4, 256@/8, 512@/16, 1024@/32]."""
+    """timm HighResolutionNetFeatures(hrnet_w18 | hrnet_w18_small | hrnet_w30, features_only, out_indices=(1,2,3,4)) as called from
+    backbone.py:48-49: returns [128@/4, 256@/8, 512@/16, 1024@/32].  The variants differ in widths and COUNTS only (timm cfg_cls:
+    layer1 blocks, modules per stage, BasicBlocks per branch); the counts are read off the state dict's keys, the widths off its
+    shapes (hrnet_w18: HRNET_W18 above)."""
     x = _conv_bn(sd, p + "conv1", p + "bn1", x, 2, 1)
     x = _conv_bn(sd, p + "conv2", p + "bn2", x, 2, 1)
-    for k in range(4):
+    for k in range(_count(sd, p + "layer1.%d.conv1.weight")):
         x = _bottleneck(sd, "%slayer1.%d" % (p, k), x)
     xs = [_conv_bn(sd, p + "transition1.0.0", p + "transition1.0.1", x, 1, 1),
           _conv_bn(sd, p + "transition1.1.0.0", p + "transition1.1.0.1", x, 2, 1)]
     for si, stage in enumerate(("stage2", "stage3", "stage4")):
-        nmod, chans = HRNET_W18[stage]
+        nmod = _count(sd, p + stage + ".%d.branches.0.0.conv1.weight")
+        nblk = _count(sd, p + stage + ".0.branches.0.%d.conv1.weight")
         if si > 0:  # transition{2,3}: new branch from the LAST branch of the previous stage
-            t = "%stransition%d.%d.0" % (p, si + 1, len(chans) - 1)
+            t = "%stransition%d.%d.0" % (p, si + 1, si + 1)
             xs = xs + [_conv_bn(sd, t + ".0", t + ".1", xs[-1], 2, 1)]
         for m in range(nmod):
-            xs = _hr_module(sd, "%s%s.%d" % (p, stage, m), xs, HRNET_W18["blocks"])
+            xs = _hr_module(sd, "%s%s.%d" % (p, stage, m), xs, nblk)
     return [_bottleneck(sd, "%sincre_modules.%d.0" % (p, i), f) for i, f in enumerate(xs)]
 
 
@@ -279,7 +291,7 @@ def resnet34_features(sd, p, x):
     return feats
 
 
-BACKBONES = {"hrnet_w18": hrnet_features, "resnet34": resnet34_features}
+BACKBONES = {"hrnet_w18": hrnet_features, "hrnet_w18_small": hrnet_features, "hrnet_w30": hrnet_features, "resnet34": resnet34_features}
 
 
 # --------------------------------------------------------------------------- the two nets

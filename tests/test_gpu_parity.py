@@ -1766,6 +1766,34 @@ def test_e2e_resnet34_backbone(lib):
     _cmp_e2e(net(img.to(dev()), None), ref)
 
 
+@pytest.mark.parametrize("backbone", ["hrnet_w18_small", "hrnet_w30"])
+def test_e2e_other_hrnet_backbones(lib, backbone):
+    """The reference's other HRNet names (backbone.py:43, init.py:15-24; no shipped config uses them): hrnet_w18_small (one 32-plane
+    Bottleneck in layer1, ONE module per stage, two BasicBlocks per branch, widths 16 / 32 / 64 / 128) and hrnet_w30 (hrnet_w18's
+    layout at widths 30 / 60 / 120 / 240) -- timm's published layouts (checkerpose_amd/model/backbone.py: HRNET_CFGS; their parameter
+    counts reproduce timm's model-zoo figures: tests/test_oracle.py), same "incre" heads, same four pyramid features.  fp32 <= 1e-4 vs
+    the oracle (teacher-forced always, free-running when every decision has a margin), two batch sizes through the per-crop and the
+    per-conv launches; bf16 (keypoint side half): the teacher-forced floors of the contract."""
+    from checkerpose_amd.agreement import logit_agreement
+    net = build_net(seed=6, backbone=backbone)
+    img = det_image(2, seed=11)
+    kw = dict(oracle_kwargs(), backbone=backbone)
+    ref, _ = O.posenet_forward(net.state_dict(), img, net.init_net.knn_idx, 512, **kw)
+    net = net.to(dev())
+    tb = _teacher_bits(ref).to(dev())
+    _cmp_e2e(net.forward_teacher_forced(img.to(dev()), tb), ref)
+    z = torch.cat([ref[0], ref[1][:, :-1], ref[2][:, :-1]], 1)
+    if float(z.abs().min()) > 4e-5:                     # free-running parity is only well-posed with a decision margin
+        _cmp_e2e(net(img.to(dev()), None), ref)
+    net.set_kernel_selection("per_crop")                # the launches of the 256-crop step (fused stem, Bottleneck / chains where they fit)
+    _cmp_e2e(net.forward_teacher_forced(img.to(dev()), tb), ref)
+    net.set_kernel_selection("auto")
+    net.set_compute_dtype("bf16")
+    tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), tb), ref)
+    assert tf["bit_agreement_all_rows"] >= 0.99 and tf["bit_agreement_min_row"] >= 0.96 and tf["seg_agreement"] >= 0.99, (backbone, tf)
+    assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, (backbone, tf)
+
+
 def test_batch_buckets_and_inplace_weight_edit(lib):
     """(a) Ragged batches run in the next cached program size (1, 2, 3, 4, 6, 8, 12, 16, ...) instead of building a program per
     size: B=5 and B=6 share ONE program, the 5 crops' outputs equal the first rows of the 6-crop forward bit for bit and the

@@ -107,6 +107,26 @@ def test_e2e_lm_matches_reference():
     _check_e2e(o, g)
 
 
+def test_hrnet_variants_reproduce_timms_published_parameter_counts():
+    """checkerpose_amd/model/backbone.py: HRNET_CFGS restates timm's cfg_cls for hrnet_w18 / hrnet_w18_small / hrnet_w30 (timm is absent:
+    unpinned).  A cross-check that needs no timm: body + "incre" heads as built here, plus the classification head timm's full model
+    adds on top (three stride-2 3x3 down-sampling convs 128 -> 256 -> 512 -> 1024 with bias + BN, the 1x1 final layer 1024 -> 2048 with
+    bias + BN, Linear 2048 -> 1000: 10 350 824 parameters, the same for every width), must give timm's model-zoo parameter counts:
+    21.30 M / 13.19 M / 37.71 M.  Then the features contract of the two new names through the oracle."""
+    from checkerpose_amd.model.backbone import HRNetFeatures
+    from checkerpose_amd.detweights import fill_state_dict_
+    head = sum(ci * co * 9 + co + 2 * co for ci, co in ((128, 256), (256, 512), (512, 1024))) + 1024 * 2048 + 2048 + 2 * 2048 + 2048 * 1000 + 1000
+    assert head == 10350824
+    for name, published in (("hrnet_w18", 21.30e6), ("hrnet_w18_small", 13.19e6), ("hrnet_w30", 37.71e6)):
+        m = HRNetFeatures(name)
+        n = sum(p.numel() for p in m.parameters())
+        assert abs(n + head - published) < 0.01e6, (name, n, n + head)
+    for name in ("hrnet_w18_small", "hrnet_w30"):
+        sd = fill_state_dict_(HRNetFeatures(name).state_dict())
+        f = O.hrnet_features(sd, "", det_image(1))
+        assert [tuple(t.shape[1:]) for t in f] == [(128, 64, 64), (256, 32, 32), (512, 16, 16), (1024, 8, 8)]   # pipeline.py:12-14
+
+
 def test_resnet34_contract():
     from checkerpose_amd.model.backbone import ResNet34Features
     from checkerpose_amd.detweights import fill_state_dict_
