@@ -613,14 +613,21 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
     for j in range(nc1 - 1):     # init.py:87-95: Conv2d -> [LeakyReLU(0.01) -> Conv2d(N -> N)]*: the activation rides in the producer
         f = em.linear(f, pfx + "conv1x1.%d" % (2 * j), ACT_LEAKY, 0.01)
     w = em.W(c1key + ".weight")
-    g0 = p.act(1, N, 64)
+    ng = cfg["init_num_graph_module"]
+    tiled = tp is None and io["graph"].get("tiled") is not None
+    # init_network_num_graph_module = 0 (config/lm/*woEdgeConv*, init_gnn0_*): the reinterpreted conv1x1 rows ARE the graph feature
+    # (init.py:112-118 with an empty pre_query_block) -- inside PoseNet they go straight into their slice of stage 0's input rows
+    direct = ng == 0 and graph_out is not None and not tiled
+    g0 = graph_out if direct else p.act(1, N, 64)
     npix = f.H * f.W
+    assert npix == g0.C, "conv1x1's response map is the keypoint's feature vector (init.py:114)"
+    ostr = (g0.coff, N * g0.cstride, f.W, 1, g0.cstride)      # element (b, pixel, n) -> row n of crop b, channel = pixel
     if tp is None:      # (p.gnn_half: from here to the logits the rows are IEEE half -- engine.USE_GNN_F16)
         p.conv(f, c1key, w, em._unit(N), em.W(c1key + ".bias"), 1, 1, 1, 0, N,
-               ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf, out_half=p.gnn_half)
+               ostr=ostr, out_tbuf=g0.tbuf, out_half=p.gnn_half)
     else:
         p.conv(f, c1key, w, tp.const_vec(N, True), em._bias_vec(c1key, N), 1, 1, 1, 0, N,
-               ostr=(0, N * npix, f.W, 1, npix), out_tbuf=g0.tbuf)
+               ostr=ostr, out_tbuf=g0.tbuf)
         f_in = f
 
         def bwd_conv1x1():
@@ -634,18 +641,17 @@ def _emit_init_head(em: NetEmitter, cfg, io, pfx, graph_out, feats):
             tp.conv_backward(c1key, w, f_in, gy, 1, 1, 1, 0)
         tp.tape.append(bwd_conv1x1)
     g = g0
-    if tp is None and io["graph"].get("tiled") is not None:
+    if tiled:
         # large graphs (N > 512): from here on the rows follow the INTERNAL keypoint numbering in which 512 consecutive rows are a
         # compact patch of the kNN graph (graph_sched.tile_schedule); every op between here and the logits is per keypoint or
         # goes through the (renumbered) graph, and the runtime un-permutes the logit block / ids behind the last launch
         g = p.permute_rows(g0, p.act(1, N, 64), io["graph"]["tiled"]["perm"], io["graph"]["gids"])
-    ng = cfg["init_num_graph_module"]
     for i in range(ng):
         last = i == ng - 1
         g = em.edgeconv("%spre_query_block.%d" % (pfx, i), g, io["graph"], cfg["init_graph_slope"],
                         out=graph_out if (last and graph_out is not None) else None)
-    if ng == 0 and graph_out is not None:
-        raise RuntimeError("init_network_num_graph_module == 0 is not supported by the fused program")
+    if ng == 0 and graph_out is not None and not direct:
+        raise RuntimeError("init_network_num_graph_module == 0 with more than 512 keypoints (patch-ordered rows) is not supported")
     # Linear(64 -> 1 + 2r) (init.py:107,120-122) into the (B,13,N) logit block: r = 3 -> rows [roi | x2 x1 x0 | . . . | y2 y1 y0]
     # (the layout PoseNet appends its refinement bits to); an InitNet used alone with another res_log2 writes rows [0, 1 + 2r)
     wl = em.W(pfx + "mlp.weight")
@@ -849,6 +855,11 @@ def emit_posenet(em: NetEmitter, cfg, io):
             patches = p.conv(f, rp + ".patch", wpg, em._unit(Ech), em.W(pgk + ".bias"), k, k, 1, k - 1, Ech, out_half=p.gnn_half)
         else:
             patches = p.conv(f, rp + ".patch", wpg, tp.const_vec(Ech, True), em._bias_vec(pgk, Ech), k, k, 1, k - 1, Ech)
+        Lnext = local_buf(i + 1) if i + 1 < active else None
+        # network_num_graph_module = 0 (config/lm/hr18GNN2_res6_gnn3Skip_mlpQuery_lm_woEdgeConv.txt): the pre-graph MLP's rows are the
+        # stage's graph feature (pipeline.py:288-297 with an empty pre_query_block) -> they land in the next stage's input rows
+        carry = Lnext.slice(qd[0], qd[0]) if (ngs[i] == 0 and Lnext is not None) else None
+        carried = False
         pkeys = [rp + ".pre_graph_module.0", rp + ".pre_graph_module.2"]
         pws = [em.W(k_ + ".weight") for k_ in pkeys]
         gather_in_pair = tp is None and p.can_fuse_mlp_pair_gather(L, patches, pws[0], pws[1], Ech, k)
@@ -869,14 +880,14 @@ def emit_posenet(em: NetEmitter, cfg, io):
         else:
             hk = {"in_half": True} if (tp is None and p.gnn_half) else {}
             h = em.linear(L, rp + ".pre_graph_module.0", ACT_LEAKY, slope, **hk)
-            h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope, **hk)
-        Lnext = local_buf(i + 1) if i + 1 < active else None
+            h = em.linear(h, rp + ".pre_graph_module.2", ACT_LEAKY, slope, out=carry, **hk)
+            carried = carry is not None
+        if carry is not None and not carried:      # (the fused pair launches write a dense tensor) one term, no ReLU: cp_fuse_sum_act is a
+            p.fuse_sum([h], [0], carry, relu=False)    # copy -- bit-exact for 16-bit rows of either format
         for gi in range(ngs[i]):
             last = gi == ngs[i] - 1
             h = em.edgeconv("%s.pre_query_block.%d" % (rp, gi), h, io["graph"], cfg["graph_slope"],
                             out=Lnext.slice(qd[0], qd[0]) if (last and Lnext is not None) else None)
-        if ngs[i] == 0 and Lnext is not None:
-            raise RuntimeError("num_graph_module == 0 is not supported by the fused program")
         # Linear(64 -> 2): channel 0 = new x bit -> row 4+i, channel 1 = new y bit -> row 10+i  (pipeline.py:375-378)
         qk = rp + ".query_block.mlps.4"
         qkeys = [rp + ".query_block.mlps.%d" % j for j in (0, 2, 4)]

@@ -57,7 +57,7 @@ def apply_overrides(sd, overrides):
     return n
 
 
-def build_net(npoint=512, p3d=None, seed=0, lm=False, backbone="hrnet_w18", full=True, overrides=None):
+def build_net(npoint=512, p3d=None, seed=0, lm=False, backbone="hrnet_w18", full=True, overrides=None, init_graph=2, graph=3):
     """The drop-in modules with the config of hr18GNN2_res6_gnn3Skip_mlpQuery(.txt), deterministic weights (+ a fixture's
     recorded parameter overrides)."""
     if lm:
@@ -69,12 +69,12 @@ def build_net(npoint=512, p3d=None, seed=0, lm=False, backbone="hrnet_w18", full
     if p3d is None:
         p3d = lm_p3d(npoint) if lm else ape_p3d(npoint)
     init_net = InitNet_GNN(npoint=npoint, p3d_normed=p3d, res_log2=3, backbone_name=backbone, pretrain_backbone=False,
-                           max_batch_size=8, num_graph_module=2, graph_k=20, graph_leaky_slope=0.2)
+                           max_batch_size=8, num_graph_module=init_graph, graph_k=20, graph_leaky_slope=0.2)
     if not full:
         fill_state_dict_(init_net.state_dict(), seed=seed)
         return init_net.eval()
     net = PoseNet_GNNskip(init_net=init_net, npoint=npoint, p3d_normed=p3d, res_log2=6, num_filters=256, max_batch_size=8,
-                          query_dims=None, local_k=2, leaky_slope=0.01, num_graph_module=3, graph_k=20,
+                          query_dims=None, local_k=2, leaky_slope=0.01, num_graph_module=graph, graph_k=20,
                           graph_leaky_slope=0.2, query_type="mlp")
     fill_state_dict_(net.state_dict(), seed=seed)
     apply_overrides(net.state_dict(), overrides)

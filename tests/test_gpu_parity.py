@@ -1794,6 +1794,46 @@ def test_e2e_other_hrnet_backbones(lib, backbone):
     assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, (backbone, tf)
 
 
+@pytest.mark.parametrize("case", ["woEdgeConv", "woEdgeConv_lm", "stage1_without", "init_only"])
+def test_e2e_without_graph_modules(lib, case):
+    """`num_graph_module = 0` (shipped: config/lm/hr18GNN2_res6_gnn3Skip_mlpQuery_lm_woEdgeConv.txt -- init_network_num_graph_module = 0
+    AND network_num_graph_module = 0 -- and config/lm/init_gnn0_hrnetw18_npt512_lm.txt): with an empty `pre_query_block` the
+    reinterpreted conv1x1 rows are InitNet's graph feature (init.py:112-118) and a refinement stage's pre-graph MLP rows are the feature
+    it hands to the next stage (pipeline.py:288-297).  The plain and the LM twin, a per-stage tuple with one empty stage
+    (pipeline.py:335), and InitNet alone: fp32 <= 1e-4 vs the oracle on both kernel selections, bf16 floors."""
+    from checkerpose_amd.agreement import logit_agreement
+    lm = case == "woEdgeConv_lm"
+    ig, gr = {"woEdgeConv": (0, 0), "woEdgeConv_lm": (0, 0), "stage1_without": (2, (3, 0, 3)), "init_only": (0, 3)}[case]
+    net = build_net(seed=4, lm=lm, init_graph=ig, graph=gr)
+    img = det_image(2, seed=13)
+    obj = torch.tensor([2, 9]) if lm else None
+    knn_idx = net.init_net.knn_idx[obj - 1] if lm else net.init_net.knn_idx
+    if case == "init_only":                             # InitNet_GNN alone (config init_gnn0_*: the pretraining network)
+        sd_i = {k[len("init_net."):]: v for k, v in net.state_dict().items() if k.startswith("init_net.")}
+        ref_i, _, _ = O.init_net_forward(sd_i, "", img, knn_idx, 512, "hrnet_w18", 0, 0.2)
+        init = net.init_net.to(dev())
+        out_i = init(img.to(dev()))
+        assert float((out_i.cpu() - ref_i).abs().max()) <= 1e-4
+        init.set_kernel_selection("per_crop")
+        assert float((init(img.to(dev())).cpu() - ref_i).abs().max()) <= 1e-4
+        return
+    kw = dict(oracle_kwargs(), init_n_graph=ig, n_graph=gr)
+    ref, _ = O.posenet_forward(net.state_dict(), img, knn_idx, 512, **kw)
+    net = net.to(dev())
+    tb = _teacher_bits(ref).to(dev())
+    okw = dict(obj_ids=obj.to(dev())) if lm else {}
+    for sel in ("auto", "per_crop"):
+        net.set_kernel_selection(sel)
+        _cmp_e2e(net.forward_teacher_forced(img.to(dev()), tb, **okw), ref)
+    z = torch.cat([ref[0], ref[1][:, :-1], ref[2][:, :-1]], 1)
+    if float(z.abs().min()) > 4e-5:                     # free-running parity is only well-posed with a decision margin
+        _cmp_e2e(net(img.to(dev()), None, obj.to(dev())) if lm else net(img.to(dev()), None), ref)
+    net.set_compute_dtype("bf16")
+    tf = logit_agreement(net.forward_teacher_forced(img.to(dev()), tb, **okw), ref)
+    assert tf["bit_agreement_all_rows"] >= 0.99 and tf["bit_agreement_min_row"] >= 0.96 and tf["seg_agreement"] >= 0.99, (case, tf)
+    assert tf["mean_abs_dlogit_over_rms"] <= 0.02 and tf["max_abs_dlogit"] <= 0.5, (case, tf)
+
+
 def test_batch_buckets_and_inplace_weight_edit(lib):
     """(a) Ragged batches run in the next cached program size (1, 2, 3, 4, 6, 8, 12, 16, ...) instead of building a program per
     size: B=5 and B=6 share ONE program, the 5 crops' outputs equal the first rows of the 6-crop forward bit for bit and the

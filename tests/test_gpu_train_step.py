@@ -48,19 +48,19 @@ def _device_masks(net, prefix=""):
     return out
 
 
-def _oracle_step(net, img, seeds, stage=None, init_only=False, kstar=None, masks=None, backbone="hrnet_w18"):
+def _oracle_step(net, img, seeds, stage=None, init_only=False, kstar=None, masks=None, backbone="hrnet_w18", okw=None):
     O.FORCE_KSTAR.clear()
     O.FORCE_KSTAR.update(kstar or {})
     O.FORCE_MASK.clear()
     O.FORCE_MASK.update(masks or {})
     try:
-        return _oracle_step_(net, img, seeds, stage, init_only, backbone)
+        return _oracle_step_(net, img, seeds, stage, init_only, backbone, okw)
     finally:
         O.FORCE_KSTAR.clear()
         O.FORCE_MASK.clear()
 
 
-def _oracle_step_(net, img, seeds, stage=None, init_only=False, backbone="hrnet_w18"):
+def _oracle_step_(net, img, seeds, stage=None, init_only=False, backbone="hrnet_w18", okw=None):
     sd = {}
     for k, v in net.state_dict().items():
         sd[k] = v.detach().clone()
@@ -73,7 +73,8 @@ def _oracle_step_(net, img, seeds, stage=None, init_only=False, backbone="hrnet_
             outs = [out]
             ids = None
         else:
-            (roi, xb, yb, seg, x_id, y_id), _ = O.posenet_forward(sd, img, net.init_net.knn_idx, net.npoint, stage=stage, **oracle_kwargs())
+            (roi, xb, yb, seg, x_id, y_id), _ = O.posenet_forward(sd, img, net.init_net.knn_idx, net.npoint, stage=stage,
+                                                                  **dict(oracle_kwargs(), **(okw or {})))
             outs = [roi, xb, yb, seg]
             ids = (x_id, y_id)
         grads = torch.autograd.grad(outs, [sd[k] for k in params], seeds, allow_unused=True)
@@ -143,6 +144,29 @@ def test_posenet_train_step_vs_oracle_autograd(stage):
         ref_ev, _ = O.posenet_forward(sd_eval, img, net.init_net.knn_idx, net.npoint, stage=stage, **oracle_kwargs())
     for a, b in zip(ev[:4], ref_ev[:4]):
         assert float((a.cpu() - b).abs().max()) <= 2e-4
+
+
+def test_posenet_train_step_without_graph_modules_vs_oracle_autograd():
+    """`num_graph_module = 0` in InitNet and in every refinement stage (config/lm/*_woEdgeConv.txt) through the TRAINING program: the
+    conv1x1 rows / the pre-graph MLP rows are written straight into the next stage's input rows, and their gradients come back
+    through those slices.  Seeds searched on the CPU oracle for a train-mode decision margin (1.35e-4)."""
+    B = 2
+    net = build_net(seed=10, init_graph=0, graph=0).train()
+    net_cpu = build_net(seed=10, init_graph=0, graph=0).train()
+    img = det_image(B, seed=5)
+    seeds = [det_tensor("g_roi", (B, 1, 512)), det_tensor("g_x", (B, 6, 512)), det_tensor("g_y", (B, 6, 512)), det_tensor("g_seg", (B, 2, 64, 64), 0.05)]
+    net = net.cuda()
+    with torch.enable_grad():
+        res = net(img.cuda(), None, None)
+        torch.cuda.synchronize()
+        masks = _device_masks(net)
+        torch.autograd.backward(list(res[:4]), [s.cuda() for s in seeds])
+    torch.cuda.synchronize()
+    outs, ids, ref_grads, sd_ref = _oracle_step(net_cpu, img, seeds, kstar=_device_kstar(net), masks=masks, okw=dict(init_n_graph=0, n_graph=0))
+    for a, b in zip(res[:4], outs):
+        assert float((a.detach().cpu() - b.detach()).abs().max()) <= 2e-4
+    assert torch.equal(res[4].cpu(), ids[0]) and torch.equal(res[5].cpu(), ids[1]), "discrete ids differ: comparison void"
+    _compare(net, ref_grads, sd_ref)
 
 
 def test_initnet_train_step_vs_oracle_autograd():
